@@ -1,0 +1,141 @@
+/*
+ * pyfocusr_hip.h — C-ABI of libpyfocusr_hip.so: the MI355X (gfx950) implementation of
+ * pyfocusr's spectral-embedding hot path.
+ *
+ * The reference (gattia/pyfocusr) is pure Python with no FFI layer of its own; its boundary
+ * for this path is the Python class API (Graph / eigsort / Focusr).  The entry points below
+ * are what a ctypes binding of that path needs; each one names the reference code it
+ * replaces (file:line in /root/reference/pyfocusr).  The Python mirror of the reference
+ * classes that calls them lives in pyfocusr_amd/{graph,eigsort,focusr}.py; INTEGRATION.md
+ * shows the stub a reference maintainer would add.
+ *
+ * Conventions
+ *  - plain C: pointers + sizes, no C++/torch types; all functions return 0 on success or a
+ *    negative PF_E_* code (message via pf_last_error()); nothing throws.
+ *  - host arrays are caller-owned, C-contiguous; the library never keeps a host pointer.
+ *  - one pf_ctx per (device, HIP stream); a pf_graph belongs to the ctx that built it.  Calls
+ *    on one ctx must not overlap in time; distinct ctxs are independent.
+ *  - "slot" = one length-n float64 vector in the graph's device workspace.
+ */
+#ifndef PYFOCUSR_HIP_H
+#define PYFOCUSR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PF_VERSION 1
+
+#define PF_OK 0
+#define PF_E_ARG (-1)        /* bad argument (null pointer, size, slot range, face index out of range) */
+#define PF_E_HIP (-2)        /* HIP runtime error (allocation, launch, copy); see pf_last_error() */
+#define PF_E_DEGENERATE (-3) /* a face repeats a vertex: the reference would store W_ii = inf */
+#define PF_E_STATE (-4)      /* call order violated (e.g. knn run before upload) */
+
+/* operator selector for the eigensolver kernels */
+#define PF_OP_RW 0  /* L = G (D - W), G = diag(1/(deg+1e-8))   graph.py:216-226 (as stored by the reference) */
+#define PF_OP_SYM 1 /* S = G^1/2 (D - W) G^1/2: same spectrum, only when W is symmetric */
+
+typedef struct pf_ctx pf_ctx;
+typedef struct pf_graph pf_graph;
+
+typedef struct pf_graph_info {
+    int64_t n;             /* vertices */
+    int64_t n_faces;
+    int64_t nnz_w;         /* unique directed edges = nnz(W)                       graph.py:178 */
+    int64_t nnz_l;         /* nnz of scipy's L = nnz_w + #(vertices with deg>0)     graph.py:226 */
+    int32_t is_symmetric;  /* W == W^T (structure; values then agree bit for bit)  */
+    int32_t n_isolated;    /* vertices referenced by no face (deg == 0)            */
+    int32_t n_components;  /* weakly connected components with >= 2 vertices       */
+    int32_t max_degree;    /* longest row of W                                      */
+    int64_t sell_entries;  /* stored off-diagonal slots incl. padding (SELL-64)     */
+    int64_t n_pad;         /* workspace slot stride in elements                     */
+} pf_graph_info;
+
+typedef struct pf_timing {
+    double op_ms;        /* accumulated device time of fused SpMV/Chebyshev launches (HIP events) */
+    int64_t op_launches; /* number of those launches                                              */
+    double knn_ms;       /* device time of the last pf_knn_run                                    */
+    double build_ms;     /* device time of the last pf_graph_build (kernels only)                 */
+} pf_timing;
+
+/* ---- context -------------------------------------------------------------------------- */
+int pf_version(void);
+const char* pf_last_error(void);
+int pf_device_count(void);
+int pf_create(int device, pf_ctx** out);
+void pf_destroy(pf_ctx* ctx);
+int pf_sync(pf_ctx* ctx);
+int pf_timing_enable(pf_ctx* ctx, int on);            /* time operator launches with HIP events on the ctx stream */
+int pf_timing_get(pf_ctx* ctx, pf_timing* out, int reset);
+
+/* ---- Laplacian assembly --------------------------------------------------------------- */
+/* Replaces Graph.get_weighted_adjacency_matrix / get_degree_matrix / get_G_matrix (no
+ * features) / get_laplacian_matrix   (graph.py:148-178, 216-219, 213-214, 221-226).
+ * pts: n x 3 float64; faces: F x verts_per_face int32 (VTK polygon edge order
+ * (0,1),(1,2),...,(v-1,0)).  Directed "set" semantics: W[i,j] = 1/||xi-xj|| once per unique
+ * directed edge.  Builds, on the device: CSR(W) with sorted columns, deg (row sums, left to
+ * right in column order), the SELL-64 operator storage for L (and S when W is symmetric), and
+ * connected-component labels. */
+int pf_graph_build(pf_ctx* ctx, const double* pts, int64_t n, const int32_t* faces, int64_t n_faces,
+                   int32_t verts_per_face, pf_graph** out);
+void pf_graph_free(pf_graph* g);
+int pf_graph_get_info(pf_graph* g, pf_graph_info* out);
+/* CSR(W): rowptr[n+1], colidx[nnz_w], w[nnz_w]; l_offdiag[nnz_w] = -w/(deg_i+1e-8);
+ * per-vertex deg[n], l_diag[n] = deg/(deg+1e-8).  Any output may be NULL. */
+int pf_graph_download(pf_graph* g, int32_t* rowptr, int32_t* colidx, double* w, double* l_offdiag,
+                      double* deg, double* l_diag, int32_t* component_label);
+
+/* ---- device workspace ------------------------------------------------------------------ */
+int pf_ws_ensure(pf_graph* g, int32_t n_slots);
+int pf_ws_upload(pf_graph* g, int32_t slot, const double* x);            /* x[n]            */
+int pf_ws_download(pf_graph* g, int32_t first, int32_t count, double* out); /* out[count][n]  */
+int pf_ws_copy(pf_graph* g, int32_t src, int32_t dst, int32_t count);
+int pf_mask_isolated(pf_graph* g, int32_t slot);                          /* x[i] = 0 where deg_i == 0 */
+/* unit-norm null vectors of `op`, one per component with >= 2 vertices, into slots
+ * [0, n_components): 1_C for PF_OP_RW, sqrt(deg+1e-8) on C for PF_OP_SYM. */
+int pf_lock_null_vectors(pf_graph* g, int32_t op, int32_t* n_locked);
+
+/* ---- eigensolver kernels (replace scipy eigs/ARPACK+SuperLU at graph.py:372) ------------- */
+int pf_spmv(pf_graph* g, int32_t op, int32_t src, int32_t dst);           /* dst = A src     */
+/* dst = T_degree((c I - A)/e) src : `degree` launches of the fused SpMV + three-term
+ * recurrence kernel.  src is preserved; dst != src. */
+int pf_cheb(pf_graph* g, int32_t op, int32_t src, int32_t dst, int32_t degree, double c, double e);
+int pf_dots(pf_graph* g, int32_t w, int32_t first, int32_t count, double* out);  /* out[b] = <slot first+b, slot w> */
+/* classical Gram-Schmidt twice of slot w against slots [first, first+count): h[count] = summed
+ * coefficients, *nrm = ||w|| afterwards (w is left un-normalised). */
+int pf_orth(pf_graph* g, int32_t w, int32_t first, int32_t count, double* h, double* nrm);
+int pf_scale(pf_graph* g, int32_t slot, double alpha);
+/* slots [dst_first, dst_first+k) = slots [src_first, src_first+m) * Y, Y row-major m x k; ranges must not overlap */
+int pf_combine(pf_graph* g, int32_t src_first, int32_t m, const double* Y, int32_t k, int32_t dst_first);
+int pf_resnorm(pf_graph* g, int32_t ax, int32_t x, double lam, double* out);     /* ||ax - lam x||_2 */
+/* Eigenvector post-processing (graph.py:254-257 + the sign/scale convention): for each of
+ * `count` slots from `first`: x <- sqrt(g) .* x if from_sym; scale to unit 2-norm; flip so the
+ * largest-|entry| (lowest index on ties) is positive; if minmax: (v - min)/(max - min) - 0.5.
+ * out: host n x count row-major (numpy (n, count) C-order). */
+int pf_finalize_vectors(pf_graph* g, int32_t first, int32_t count, int32_t from_sym, int32_t minmax,
+                        double* out);
+/* y = A x on host vectors (tests / roofline probes) */
+int pf_spmv_host(pf_graph* g, int32_t op, const double* x, double* y);
+/* Repeated mean filter out = (D+I)^-1 (W+I) applied `iterations` times to values[n][ncols]
+ * (row-major), graph.py:320-354. */
+int pf_mean_filter(pf_graph* g, const double* values, int32_t ncols, int32_t iterations, double* out);
+
+/* ---- nearest neighbour (replaces scipy KDTree(ref).query(qry), k=1, p=2) ------------------ */
+/* focusr.py:351-353 (spectral coordinates, d = n_spectral_features) and eigsort.py:203-204
+ * (d = 3).  Exhaustive search, squared distance accumulated left to right over the d
+ * coordinates without FMA contraction, lowest reference index wins ties.
+ * ref: n_ref x d, qry: n_qry x d row-major float64; idx_out[n_qry] int64; d2_out nullable. */
+int pf_knn1(pf_ctx* ctx, const double* ref, int64_t n_ref, const double* qry, int64_t n_qry, int32_t d,
+            int64_t* idx_out, double* d2_out);
+/* split form (inputs resident in HBM across the timed region) */
+int pf_knn_upload(pf_ctx* ctx, const double* ref, int64_t n_ref, const double* qry, int64_t n_qry, int32_t d);
+int pf_knn_run(pf_ctx* ctx);
+int pf_knn_download(pf_ctx* ctx, int64_t* idx_out, double* d2_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PYFOCUSR_HIP_H */

@@ -1,0 +1,337 @@
+"""ctypes binding of libpyfocusr_hip.so (C-ABI in include/pyfocusr_hip.h).
+
+There is no CPU fallback: if the shared library is missing, or no MI355X is
+visible, the product path raises.  The library is built in-tree by
+`__graft_entry__.build()` (hipcc --offload-arch=gfx950).
+"""
+import atexit
+import ctypes as C
+import os
+import threading
+import weakref
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libpyfocusr_hip.so")
+
+PF_OP_RW = 0
+PF_OP_SYM = 1
+
+_f64p = C.POINTER(C.c_double)
+_i32p = C.POINTER(C.c_int32)
+_i64p = C.POINTER(C.c_int64)
+
+
+class HipUnavailable(RuntimeError):
+    pass
+
+
+class PfError(RuntimeError):
+    def __init__(self, code, msg):
+        RuntimeError.__init__(self, "libpyfocusr_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+class GraphInfo(C.Structure):
+    _fields_ = [("n", C.c_int64), ("n_faces", C.c_int64), ("nnz_w", C.c_int64), ("nnz_l", C.c_int64),
+                ("is_symmetric", C.c_int32), ("n_isolated", C.c_int32), ("n_components", C.c_int32),
+                ("max_degree", C.c_int32), ("sell_entries", C.c_int64), ("n_pad", C.c_int64)]
+
+
+class Timing(C.Structure):
+    _fields_ = [("op_ms", C.c_double), ("op_launches", C.c_int64), ("knn_ms", C.c_double), ("build_ms", C.c_double)]
+
+
+# name -> (restype, argtypes): every symbol include/pyfocusr_hip.h declares.
+SIGNATURES = {
+    "pf_version": (C.c_int, []),
+    "pf_last_error": (C.c_char_p, []),
+    "pf_device_count": (C.c_int, []),
+    "pf_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "pf_destroy": (None, [C.c_void_p]),
+    "pf_sync": (C.c_int, [C.c_void_p]),
+    "pf_timing_enable": (C.c_int, [C.c_void_p, C.c_int]),
+    "pf_timing_get": (C.c_int, [C.c_void_p, C.POINTER(Timing), C.c_int]),
+    "pf_graph_build": (C.c_int, [C.c_void_p, _f64p, C.c_int64, _i32p, C.c_int64, C.c_int32, C.POINTER(C.c_void_p)]),
+    "pf_graph_free": (None, [C.c_void_p]),
+    "pf_graph_get_info": (C.c_int, [C.c_void_p, C.POINTER(GraphInfo)]),
+    "pf_graph_download": (C.c_int, [C.c_void_p, _i32p, _i32p, _f64p, _f64p, _f64p, _f64p, _i32p]),
+    "pf_ws_ensure": (C.c_int, [C.c_void_p, C.c_int32]),
+    "pf_ws_upload": (C.c_int, [C.c_void_p, C.c_int32, _f64p]),
+    "pf_ws_download": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _f64p]),
+    "pf_ws_copy": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
+    "pf_mask_isolated": (C.c_int, [C.c_void_p, C.c_int32]),
+    "pf_lock_null_vectors": (C.c_int, [C.c_void_p, C.c_int32, _i32p]),
+    "pf_spmv": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
+    "pf_cheb": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double]),
+    "pf_dots": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, _f64p]),
+    "pf_orth": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, _f64p, _f64p]),
+    "pf_scale": (C.c_int, [C.c_void_p, C.c_int32, C.c_double]),
+    "pf_combine": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _f64p, C.c_int32, C.c_int32]),
+    "pf_resnorm": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_double, _f64p]),
+    "pf_finalize_vectors": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _f64p]),
+    "pf_spmv_host": (C.c_int, [C.c_void_p, C.c_int32, _f64p, _f64p]),
+    "pf_mean_filter": (C.c_int, [C.c_void_p, _f64p, C.c_int32, C.c_int32, _f64p]),
+    "pf_knn1": (C.c_int, [C.c_void_p, _f64p, C.c_int64, _f64p, C.c_int64, C.c_int32, _i64p, _f64p]),
+    "pf_knn_upload": (C.c_int, [C.c_void_p, _f64p, C.c_int64, _f64p, C.c_int64, C.c_int32]),
+    "pf_knn_run": (C.c_int, [C.c_void_p]),
+    "pf_knn_download": (C.c_int, [C.c_void_p, _i64p, _f64p]),
+}
+
+_lib = None
+_lib_lock = threading.Lock()
+_live_graphs = weakref.WeakSet()
+_live_contexts = weakref.WeakSet()
+
+
+@atexit.register
+def _shutdown():
+    """Release device objects while the HIP runtime is still alive (its own static
+    destructors run after Python's, and freeing into a torn-down runtime aborts)."""
+    for g in list(_live_graphs):
+        g.close()
+    for c in list(_live_contexts):
+        c.close()
+
+
+def load_library():
+    """dlopen the in-tree library and bind every declared symbol (no GPU needed)."""
+    global _lib
+    with _lib_lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise HipUnavailable(
+                "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+        return lib
+
+
+def _check(code):
+    if code != 0:
+        raise PfError(code, load_library().pf_last_error().decode("utf-8", "replace"))
+
+
+def _f64(a):
+    return a.ctypes.data_as(_f64p)
+
+
+def _c_f64(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None and a.shape != shape:
+        raise ValueError("expected shape %r, got %r" % (shape, a.shape))
+    return a
+
+
+class Context(object):
+    """One HIP stream on one device."""
+
+    def __init__(self, device=0):
+        lib = load_library()
+        if lib.pf_device_count() <= 0:
+            raise HipUnavailable("no HIP device visible: the pyfocusr_amd hot path needs an MI355X (no CPU fallback)")
+        h = C.c_void_p()
+        _check(lib.pf_create(int(device), C.byref(h)))
+        self._lib = lib
+        self._h = h
+        self.device = int(device)
+        _live_contexts.add(self)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.pf_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+    def sync(self):
+        _check(self._lib.pf_sync(self._h))
+
+    def timing_enable(self, on=True):
+        _check(self._lib.pf_timing_enable(self._h, int(bool(on))))
+
+    def timing(self, reset=False):
+        t = Timing()
+        _check(self._lib.pf_timing_get(self._h, C.byref(t), int(bool(reset))))
+        return dict(op_ms=t.op_ms, op_launches=int(t.op_launches), knn_ms=t.knn_ms, build_ms=t.build_ms)
+
+    # ---- nearest neighbour -------------------------------------------------------------
+    def knn1(self, ref, qry, return_d2=False):
+        """Index (int64) of the nearest `ref` row for every `qry` row."""
+        ref, qry = _c_f64(ref), _c_f64(qry)
+        if ref.ndim != 2 or qry.ndim != 2 or ref.shape[1] != qry.shape[1]:
+            raise ValueError("ref and qry must be (n, d) arrays with equal d")
+        idx = np.empty(qry.shape[0], dtype=np.int64)
+        d2 = np.empty(qry.shape[0], dtype=np.float64) if return_d2 else None
+        _check(self._lib.pf_knn1(self._h, _f64(ref), ref.shape[0], _f64(qry), qry.shape[0], ref.shape[1],
+                                 idx.ctypes.data_as(_i64p), _f64(d2) if return_d2 else None))
+        return (idx, d2) if return_d2 else idx
+
+    def knn_upload(self, ref, qry):
+        ref, qry = _c_f64(ref), _c_f64(qry)
+        _check(self._lib.pf_knn_upload(self._h, _f64(ref), ref.shape[0], _f64(qry), qry.shape[0], ref.shape[1]))
+        self._knn_nq = qry.shape[0]
+
+    def knn_run(self):
+        _check(self._lib.pf_knn_run(self._h))
+
+    def knn_download(self):
+        idx = np.empty(self._knn_nq, dtype=np.int64)
+        d2 = np.empty(self._knn_nq, dtype=np.float64)
+        _check(self._lib.pf_knn_download(self._h, idx.ctypes.data_as(_i64p), _f64(d2)))
+        return idx, d2
+
+
+_default_ctx = {}
+
+
+def default_context(device=None):
+    """Process-wide context per device (LOCAL_RANK selects the device under torchrun)."""
+    if device is None:
+        device = int(os.environ.get("PYFOCUSR_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+        n = load_library().pf_device_count()
+        if n > 0:
+            device %= n
+    if device not in _default_ctx:
+        _default_ctx[device] = Context(device)
+    return _default_ctx[device]
+
+
+class DeviceLaplacian(object):
+    """Device-resident graph of one mesh: CSR(W), deg, SELL-64 operators, workspace.
+    Also the `ops` object the Krylov driver (`_krylov.filtered_eigs`) drives."""
+
+    def __init__(self, points, faces, ctx=None):
+        self.ctx = ctx if ctx is not None else default_context()
+        self._lib = self.ctx._lib
+        pts = _c_f64(points).reshape(-1, 3)
+        f = np.ascontiguousarray(faces, dtype=np.int32)
+        if f.ndim != 2:
+            raise ValueError("faces must be (F, verts_per_face)")
+        h = C.c_void_p()
+        _check(self._lib.pf_graph_build(self.ctx._h, _f64(pts), pts.shape[0], f.ctypes.data_as(_i32p), f.shape[0],
+                                        f.shape[1] if f.shape[0] else 3, C.byref(h)))
+        self._h = h
+        _live_graphs.add(self)
+        info = GraphInfo()
+        _check(self._lib.pf_graph_get_info(h, C.byref(info)))
+        self.info = info
+        self.n = int(info.n)
+        self.nnz_w = int(info.nnz_w)
+        self.nnz_l = int(info.nnz_l)
+        self.symmetric = bool(info.is_symmetric)
+        self.n_isolated = int(info.n_isolated)
+        self.n_components = int(info.n_components)
+        self.max_degree = int(info.max_degree)
+        self.op = PF_OP_SYM if self.symmetric else PF_OP_RW
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.pf_graph_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+    # ---- matrices back to the host (scipy views for the reference-style attributes) ----------
+    def download(self, labels=False):
+        n, nnz = self.n, self.nnz_w
+        out = dict(rowptr=np.empty(n + 1, np.int32), colidx=np.empty(nnz, np.int32), w=np.empty(nnz),
+                   l_offdiag=np.empty(nnz), deg=np.empty(n), l_diag=np.empty(n))
+        lab = np.empty(n, np.int32) if labels else None
+        _check(self._lib.pf_graph_download(self._h, out["rowptr"].ctypes.data_as(_i32p),
+                                           out["colidx"].ctypes.data_as(_i32p), _f64(out["w"]), _f64(out["l_offdiag"]),
+                                           _f64(out["deg"]), _f64(out["l_diag"]),
+                                           lab.ctypes.data_as(_i32p) if labels else None))
+        if labels:
+            out["labels"] = lab
+        return out
+
+    # ---- ops interface ------------------------------------------------------------------------
+    def ws_ensure(self, n_slots):
+        _check(self._lib.pf_ws_ensure(self._h, int(n_slots)))
+
+    def upload(self, slot, x):
+        x = _c_f64(x, (self.n,))
+        _check(self._lib.pf_ws_upload(self._h, int(slot), _f64(x)))
+
+    def download_slots(self, first, count):
+        out = np.empty((int(count), self.n), dtype=np.float64)
+        _check(self._lib.pf_ws_download(self._h, int(first), int(count), _f64(out)))
+        return out.T
+
+    def copy(self, src, dst, count):
+        _check(self._lib.pf_ws_copy(self._h, int(src), int(dst), int(count)))
+
+    def mask_isolated(self, slot):
+        _check(self._lib.pf_mask_isolated(self._h, int(slot)))
+
+    def lock_null_vectors(self):
+        k = C.c_int32()
+        _check(self._lib.pf_lock_null_vectors(self._h, self.op, C.byref(k)))
+        return int(k.value)
+
+    def spmv(self, src, dst):
+        _check(self._lib.pf_spmv(self._h, self.op, int(src), int(dst)))
+
+    def cheb(self, src, dst, degree, c, e):
+        _check(self._lib.pf_cheb(self._h, self.op, int(src), int(dst), int(degree), float(c), float(e)))
+
+    def dots(self, w, first, count):
+        out = np.empty(int(count), dtype=np.float64)
+        _check(self._lib.pf_dots(self._h, int(w), int(first), int(count), _f64(out)))
+        return out
+
+    def orth(self, w, first, count):
+        h = np.empty(max(int(count), 1), dtype=np.float64)
+        nrm = C.c_double()
+        _check(self._lib.pf_orth(self._h, int(w), int(first), int(count), _f64(h), C.byref(nrm)))
+        return h[: int(count)], float(nrm.value)
+
+    def scale(self, slot, alpha):
+        _check(self._lib.pf_scale(self._h, int(slot), float(alpha)))
+
+    def combine(self, src_first, m, Y, dst_first):
+        Y = _c_f64(Y)
+        if Y.ndim != 2 or Y.shape[0] != m:
+            raise ValueError("Y must be (m, k)")
+        _check(self._lib.pf_combine(self._h, int(src_first), int(m), _f64(Y), Y.shape[1], int(dst_first)))
+
+    def resnorm(self, ax, x, lam):
+        out = C.c_double()
+        _check(self._lib.pf_resnorm(self._h, int(ax), int(x), float(lam), C.byref(out)))
+        return float(out.value)
+
+    def finalize_vectors(self, first, count, minmax):
+        out = np.empty((self.n, int(count)), dtype=np.float64)
+        _check(self._lib.pf_finalize_vectors(self._h, int(first), int(count), int(self.op == PF_OP_SYM), int(bool(minmax)),
+                                             _f64(out)))
+        return out
+
+    def spmv_host(self, x, op=None):
+        x = _c_f64(x, (self.n,))
+        y = np.empty(self.n, dtype=np.float64)
+        _check(self._lib.pf_spmv_host(self._h, self.op if op is None else int(op), _f64(x), _f64(y)))
+        return y
+
+    def mean_filter(self, values, iterations):
+        v = _c_f64(values)
+        one_d = v.ndim == 1
+        v2 = v.reshape(self.n, -1)
+        out = np.empty_like(v2)
+        _check(self._lib.pf_mean_filter(self._h, _f64(v2), v2.shape[1], int(iterations), _f64(out)))
+        return out[:, 0] if one_d else out

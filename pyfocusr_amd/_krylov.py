@@ -1,0 +1,280 @@
+"""Host driver of the GPU eigensolver: Chebyshev-filtered Krylov-Schur.
+
+Replaces the reference's `scipy.sparse.linalg.eigs(L, k, sigma=1e-10, which="LM",
+ncv=4k)` call (`/root/reference/pyfocusr/graph.py:372`, ARPACK shift-invert on a
+SuperLU factorisation) with an SpMV-only method that suits the GPU:
+
+* the operator is either the symmetrised Laplacian `S = G^1/2 (D-W) G^1/2`
+  (when W is symmetric; same eigenvalues as `L = G (D-W)`, `x_L = G^1/2 x_S`) or
+  `L` itself (one-way edges make W asymmetric on the bundled 15k meshes);
+* `B = T_p((c I - A)/e)` — a degree-p Chebyshev polynomial that maps the unwanted
+  spectrum [a, 2] into [-1, 1] and the wanted low end to cosh-sized values — is
+  applied by p fused SpMV+recurrence kernel launches;
+* a Krylov-Schur (thick-restart Lanczos when A is symmetric, restarted Arnoldi
+  otherwise) iteration on B with full CGS2 re-orthogonalisation finds the
+  dominant invariant subspace of B in a few tens of steps;
+* null vectors are known analytically per connected component (1_C for L,
+  G^-1/2 1_C for S) and are locked in the basis from the start; isolated vertices
+  (all-zero rows) are masked out and only counted;
+* a final Rayleigh-Ritz step on A itself over the converged subspace yields the
+  eigenvalues of A and the reference's `> 1e-10` null filter is applied to them.
+
+Everything O(n) runs on the device through the `ops` object (the ctypes wrapper of
+the C-ABI, `pyfocusr_amd/_hip.py`); this module only does the O(m^2)..O(m^3) dense
+algebra on the small projected matrices and the control flow.
+"""
+import math
+
+import numpy as np
+import scipy.linalg as sla
+
+MIN_EIG_VAL = 1e-10  # graph.py:369
+
+
+class EigsStats(object):
+    def __init__(self):
+        self.matvecs = 0  # SpMV-equivalent launches of the fused Chebyshev/SpMV kernel
+        self.outer_steps = 0
+        self.restarts = 0
+        self.filter_resets = 0
+        self.degree = 0
+        self.cut = 0.0
+        self.residuals = None  # ||A x - lambda x||_2 of the returned pairs (operator actually iterated)
+        self.n_null = 0
+
+    def as_dict(self):
+        return dict(self.__dict__)
+
+
+def _cheb_value(lam, c, e, p):
+    """T_p((c - lam)/e) for real lam."""
+    t = (c - lam) / e
+    if abs(t) <= 1.0:
+        return math.cos(p * math.acos(t))
+    s = 1.0 if t > 0 or p % 2 == 0 else -1.0
+    return s * math.cosh(p * math.acosh(abs(t)))
+
+
+def _cheb_inverse(theta, c, e, p):
+    """lam < a with T_p((c-lam)/e) = theta > 1."""
+    return c - e * math.cosh(math.acosh(max(theta, 1.0)) / p)
+
+
+def choose_filter(cut, hi=2.0, strength=5.5, min_degree=8, max_degree=4000):
+    """Damped interval [cut, hi]; degree such that eigenvalues <= cut/2 are
+    amplified by >= cosh(strength) relative to the damped part."""
+    cut = min(max(cut, 1e-12), 0.5 * hi)
+    c = 0.5 * (hi + cut)
+    e = 0.5 * (hi - cut)
+    growth_rate = math.acosh((c - 0.5 * cut) / e)  # acosh of the map of cut/2
+    p = int(math.ceil(strength / growth_rate))
+    p = max(min_degree, min(max_degree, p))
+    return c, e, p
+
+
+def _ordered_schur(H, symmetric, n_real, n_extra=0):
+    """Orthogonal U, (quasi-)triangular T with H = U T U^T, ordered so that the
+    leading q columns span the dominant (largest-modulus) invariant subspace of
+    the filtered operator that contains `n_real` real positive Ritz values — the
+    images of the wanted low eigenvalues — plus `n_extra` more Ritz values.
+
+    With a symmetric operator every Ritz value is real and q = n_real + n_extra.
+    One-way mesh edges make L non-normal with a few genuinely complex eigenvalues
+    (|Im| ~ 0.1) which the real Chebyshev polynomial amplifies even more than the
+    wanted ones: they are dominant eigenvalues of B, must be carried (and
+    converged) in the kept subspace, and are discarded after the final
+    Rayleigh-Ritz step.  Returns (theta, U, T, q, n_real_found)."""
+    m = H.shape[0]
+    if symmetric:
+        w, U = np.linalg.eigh(0.5 * (H + H.T))
+        order = np.argsort(-w)
+        q = min(n_real + n_extra, m)
+        return w[order].astype(np.complex128), U[:, order], np.diag(w[order]), q, min(n_real, m)
+    ev = np.linalg.eigvals(H)
+    order = np.argsort(-np.abs(ev), kind="stable")
+    ev = ev[order]
+    is_real = (np.abs(ev.imag) <= 1e-9 * np.abs(ev)) & (ev.real > 0)
+    cnt = np.cumsum(is_real)
+    hit = np.nonzero(cnt >= n_real)[0]
+    q = int(hit[0]) + 1 if len(hit) else m
+    extra = 0
+    while q < m and extra < n_extra:
+        # extend without splitting a conjugate pair
+        step = 1 if is_real[q] or abs(ev[q].imag) <= 1e-9 * abs(ev[q]) else 2
+        if q + step > m:
+            break
+        q += step
+        extra += step
+    if q < m:
+        thr = 0.5 * (abs(ev[q - 1]) + abs(ev[q]))
+        if abs(ev[q - 1]) == abs(ev[q]):  # conjugate pair straddling the cut
+            q += 1
+            thr = 0.5 * (abs(ev[q - 1]) + abs(ev[q])) if q < m else -1.0
+    else:
+        thr = -1.0
+    T, U, sdim = sla.schur(H, output="real", sort=lambda r, i: math.hypot(r, i) > thr)
+    theta = np.diag(T).astype(np.complex128)
+    i = 0
+    while i < m - 1:  # 2x2 blocks -> complex pair
+        if T[i + 1, i] != 0.0:
+            ev2 = np.linalg.eigvals(T[i:i + 2, i:i + 2])
+            theta[i], theta[i + 1] = ev2[0], ev2[1]
+            i += 2
+        else:
+            i += 1
+    return theta, U, T, int(sdim), int(min(cnt[-1], n_real))
+
+
+def filtered_eigs(ops, n_wanted, symmetric, null_slots=0, cut=None, tol=1e-12, m_max=None,
+                  max_restarts=60, max_filter_resets=8, seed=0, strength=5.5, hi=2.0,
+                  nonsym_degree_cap=128, verbose=False):
+    """Smallest `n_wanted` non-null eigenpairs of the Laplacian held by `ops`.
+
+    `ops` must already hold `null_slots` orthonormal null vectors of the operator
+    in workspace slots [0, null_slots) (one per non-trivial connected component).
+    Returns (eig_vals ascending, first_slot, stats): eigenvalues > 1e-10 (the
+    reference's null filter, graph.py:381), at least `n_wanted` of them unless the
+    graph has fewer; the matching eigenvectors of the ITERATED operator (S if
+    symmetric else L) sit in workspace slots [first_slot, first_slot+len(vals)).
+    """
+    n = ops.n
+    n_active = n - ops.n_isolated
+    stats = EigsStats()
+    c0 = int(null_slots)
+    n_wanted = int(min(n_wanted, max(n_active - c0, 0)))
+    if n_wanted <= 0:
+        return np.zeros(0), 0, stats
+    q_target = c0 + n_wanted  # real dominant Ritz values to converge (locked nulls included)
+    if m_max is None:
+        m_max = max(3 * q_target + 24, 48)
+    m_max = int(min(m_max, n_active))
+    reg = m_max + 1  # region A: Krylov basis + residual vector; region B: restart / Ritz products
+    ops.ws_ensure(2 * reg)
+    A0, B0 = 0, reg
+    if cut is None:
+        cut = 8.0 * (n_wanted + 1) / max(n_active, 1)
+    degree_cap = 4000 if symmetric else int(nonsym_degree_cap)
+    rng = np.random.default_rng(seed)
+
+    def start_vector(slot, nbasis):
+        ops.upload(slot, rng.standard_normal(n))
+        ops.mask_isolated(slot)
+        _, nrm = ops.orth(slot, A0, nbasis)
+        ops.scale(slot, 1.0 / nrm)
+
+    def ritz(j, n_extra=0):
+        theta, U, T, q, n_real = _ordered_schur(H[:j, :j], symmetric, q_target, n_extra)
+        res = np.abs(b[:j] @ U[:, :q])
+        lead = theta[:q]
+        real_lead = lead[(np.abs(lead.imag) <= 1e-9 * np.abs(lead)) & (lead.real > 0)].real
+        theta_min = float(np.min(real_lead)) if len(real_lead) else 0.0
+        return theta, U, T, q, n_real, res, theta_min
+
+    while True:
+        c, e, p = choose_filter(cut, hi=hi, strength=strength, max_degree=degree_cap)
+        stats.degree, stats.cut = p, cut
+        theta0 = _cheb_value(0.0, c, e, p)
+        # Krylov-Schur state  B V_j = V_j H + v_j b^T ;  null vectors are locked exact Ritz pairs.
+        j = c0
+        H = np.zeros((m_max, m_max))
+        H[:c0, :c0] = theta0 * np.eye(c0)
+        b = np.zeros(m_max)
+        start_vector(A0 + j, j)
+        outcome = None  # "converged" | "cut" | "range"
+        restarts = 0
+        while outcome is None:
+            while j < m_max and outcome is None:  # ---- expand
+                ops.cheb(A0 + j, A0 + j + 1, p, c, e)
+                stats.matvecs += p
+                stats.outer_steps += 1
+                h, beta = ops.orth(A0 + j + 1, A0, j + 1)
+                H[:j + 1, j] = h
+                H[j, :j] = b[:j]
+                j += 1
+                b[:] = 0.0
+                b[j - 1] = beta
+                exhausted = beta <= 1e-14 * max(abs(theta0), 1.0) or j >= n_active
+                if not exhausted:
+                    ops.scale(A0 + j, 1.0 / beta)
+                if exhausted or (j >= q_target + 2 and ((j - q_target) % 4 == 0 or j == m_max)):
+                    theta, U, T, q, n_real, res, theta_min = ritz(j)
+                    if verbose:
+                        print("  j=%d q=%d theta_min=%.4g |theta|max=%.3g max res=%.3e" % (
+                            j, q, theta_min, np.max(np.abs(theta)), np.max(res)))
+                    if n_real >= q_target and np.all(res <= tol * max(theta_min, 1.0)) and theta_min > 1.5:
+                        outcome = "converged"
+                    elif not symmetric and np.max(np.abs(theta)) > 1e7 * max(theta_min, 1.0) and p > 16:
+                        outcome = "range"  # complex outliers eat the dynamic range: lower the degree
+                    elif (j >= q + 12 or exhausted) and theta_min < 1.5:
+                        outcome = "cut"  # wanted eigenvalues sit inside the damped band
+                    elif exhausted:
+                        outcome = "converged"
+            if outcome is not None:
+                break
+            if restarts >= max_restarts:
+                raise RuntimeError("filtered Krylov-Schur did not converge (max residual %.3e)" % np.max(res))
+            # ---- thick restart: keep the dominant Schur vectors + a buffer
+            theta, U, T, n_keep, _, _, _ = ritz(j, n_extra=max(4, q_target // 2))
+            n_keep = min(n_keep, j - 1)
+            if not symmetric and n_keep < j and T[n_keep, n_keep - 1] != 0.0:
+                n_keep -= 1  # never split a 2x2 block
+            ops.combine(A0, j, U[:, :n_keep], B0)
+            ops.copy(A0 + j, B0 + n_keep, 1)  # the residual vector follows the kept block
+            ops.copy(B0, A0, n_keep + 1)
+            Hn = np.zeros((m_max, m_max))
+            Hn[:n_keep, :n_keep] = T[:n_keep, :n_keep]
+            bn = np.zeros(m_max)
+            bn[:n_keep] = U[:, :n_keep].T @ b[:j]
+            H, b, j = Hn, bn, n_keep
+            restarts += 1
+            stats.restarts += 1
+        if outcome == "converged":
+            break
+        stats.filter_resets += 1
+        if stats.filter_resets > max_filter_resets:
+            raise RuntimeError("could not place the Chebyshev filter (cut %g, degree %d)" % (cut, p))
+        if outcome == "range":
+            degree_cap = max(16, p // 2)
+        else:
+            lead = theta[:q]
+            lam_est = sorted(_cheb_inverse(t.real, c, e, p) for t in lead
+                             if abs(t.imag) <= 1e-9 * abs(t) and t.real > 1.5)[c0:]
+            if len(lam_est) >= 2:
+                cut = max(4.0 * cut, 2.5 * lam_est[-1] * (n_wanted + 1) / len(lam_est))
+            else:
+                cut = 8.0 * cut
+        if verbose:
+            print("  filter reset (%s): cut %.3e degree cap %d" % (outcome, cut, degree_cap))
+
+    # ---- Rayleigh-Ritz on A itself over the converged orthonormal Schur vectors Z
+    if 2 * q + 1 > reg:
+        raise RuntimeError("workspace too small for Ritz extraction (q=%d, m_max=%d)" % (q, m_max))
+    ops.combine(A0, j, U[:, :q], B0)  # Z -> region B
+    HA = np.zeros((q, q))
+    for i in range(q):
+        ops.spmv(B0 + i, A0 + i)  # A z_i -> region A (Krylov basis no longer needed)
+        stats.matvecs += 1
+    for i in range(q):
+        HA[:, i] = ops.dots(A0 + i, B0, q)
+    if symmetric:
+        lam, R = np.linalg.eigh(0.5 * (HA + HA.T))
+    else:
+        lam_c, R_c = np.linalg.eig(HA)
+        order = np.argsort(lam_c.real, kind="stable")[:q_target]  # complex outliers have Re ~ 1
+        if np.max(np.abs(lam_c.imag[order])) > 1e-9:
+            raise RuntimeError("wanted eigenvalues of the asymmetric Laplacian are not real")
+        lam = lam_c.real[order]
+        R = np.real(R_c[:, order])
+        R /= np.linalg.norm(R, axis=0, keepdims=True)
+    keep = np.where(lam > MIN_EIG_VAL)[0]
+    stats.n_null = int(min(q_target, len(lam)) - len(keep)) if not symmetric else int(np.sum(lam <= MIN_EIG_VAL))
+    lam = lam[keep]
+    R = R[:, keep]
+    nk = len(keep)
+    X0, AX0 = B0 + q, A0 + q
+    if X0 + nk > 2 * reg or AX0 + nk > reg:
+        raise RuntimeError("workspace too small for Ritz extraction")
+    ops.combine(B0, q, R, X0)  # X = Z R
+    ops.combine(A0, q, R, AX0)  # A X = (A Z) R
+    stats.residuals = np.array([ops.resnorm(AX0 + i, X0 + i, lam[i]) for i in range(nk)])
+    return lam, X0, stats

@@ -1,0 +1,493 @@
+// Laplacian assembly on the device.
+//
+// Replaces the per-edge Python loop of Graph.get_weighted_adjacency_matrix and the scipy
+// sparse algebra of get_degree_matrix / get_G_matrix / get_laplacian_matrix
+// (/root/reference/pyfocusr/graph.py:148-178, 216-226).  Semantics reproduced:
+//   * W[i,j] = 1/sqrt((xi-xj)^2 summed left to right), ASSIGNED per directed polygon edge
+//     (set semantics: duplicates collapse, one-way edges make W asymmetric);
+//   * deg_i = sum_j W_ij accumulated left to right in column order (what lil.sum(axis=1) does);
+//   * G = diag(1/(deg+1e-8)); L = G (D - W): L_ij = -(g_i W_ij), L_ii = g_i deg_i.
+// This file is compiled with -ffp-contract=off so every product/sum rounds as numpy's does:
+// W, deg, L come out bit-identical to the reference's matrices (tests/golden).
+//
+// Pipeline (all on the ctx stream): count directed edges per source vertex (coalesced sweep of
+// the face list, one int atomic per edge) -> scan -> scatter (col, w) into per-vertex segments
+// -> per-vertex sort + unique -> scan -> compact into CSR and reduce deg -> symmetry probe ->
+// union-find components -> SELL-64 operator storage.
+#include <algorithm>
+
+#include "pf_internal.h"
+
+namespace {
+
+__global__ __launch_bounds__(PF_BLOCK) void k_count_edges(const int32_t* __restrict__ faces, int64_t n_edges,
+                                                          int32_t vpf, int64_t n, int32_t* __restrict__ cnt,
+                                                          int32_t* __restrict__ flags) {
+    const int64_t e = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
+    if (e >= n_edges) return;
+    const int64_t f = e / vpf;
+    const int32_t k = (int32_t)(e - f * vpf);
+    const int32_t src = faces[e];
+    const int32_t dst = faces[f * vpf + (k + 1 == vpf ? 0 : k + 1)];
+    if (src < 0 || src >= n || dst < 0 || dst >= n) {
+        atomicOr(flags, 1);
+        return;
+    }
+    if (src == dst) {
+        atomicOr(flags, 2);
+        return;
+    }
+    atomicAdd(&cnt[src], 1);
+}
+
+__global__ __launch_bounds__(PF_BLOCK) void k_scatter_edges(const int32_t* __restrict__ faces,
+                                                            const double* __restrict__ pts, int64_t n_edges,
+                                                            int32_t vpf, const int32_t* __restrict__ start,
+                                                            int32_t* __restrict__ cursor, int32_t* __restrict__ rcol,
+                                                            double* __restrict__ rw) {
+    const int64_t e = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
+    if (e >= n_edges) return;
+    const int64_t f = e / vpf;
+    const int32_t k = (int32_t)(e - f * vpf);
+    const int32_t src = faces[e];
+    const int32_t dst = faces[f * vpf + (k + 1 == vpf ? 0 : k + 1)];
+    const double dx = pts[3 * (int64_t)src + 0] - pts[3 * (int64_t)dst + 0];
+    const double dy = pts[3 * (int64_t)src + 1] - pts[3 * (int64_t)dst + 1];
+    const double dz = pts[3 * (int64_t)src + 2] - pts[3 * (int64_t)dst + 2];
+    const double d2 = (dx * dx + dy * dy) + dz * dz;  // np.sum(np.square(.)): left to right
+    const double wv = 1.0 / sqrt(d2);                 // graph.py:177-178
+    const int32_t slot = start[src] + atomicAdd(&cursor[src], 1);
+    rcol[slot] = dst;
+    rw[slot] = wv;
+}
+
+// one thread per vertex: insertion-sort its (col, w) segment by column, drop duplicate columns
+// (a directed edge listed by two faces carries the same weight), report the unique count.
+__global__ __launch_bounds__(PF_BLOCK) void k_sort_unique_rows(const int32_t* __restrict__ start, int64_t n,
+                                                               int32_t* __restrict__ rcol, double* __restrict__ rw,
+                                                               int32_t* __restrict__ ucnt) {
+    const int64_t i = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const int32_t b = start[i], e = start[i + 1];
+    for (int32_t a = b + 1; a < e; ++a) {
+        const int32_t c = rcol[a];
+        const double v = rw[a];
+        int32_t p = a - 1;
+        while (p >= b && rcol[p] > c) {
+            rcol[p + 1] = rcol[p];
+            rw[p + 1] = rw[p];
+            --p;
+        }
+        rcol[p + 1] = c;
+        rw[p + 1] = v;
+    }
+    int32_t u = 0;
+    for (int32_t a = b; a < e; ++a) {
+        if (a == b || rcol[a] != rcol[b + u - 1]) {
+            rcol[b + u] = rcol[a];
+            rw[b + u] = rw[a];
+            ++u;
+        }
+    }
+    ucnt[i] = u;
+}
+
+__global__ __launch_bounds__(PF_BLOCK) void k_compact_rows(const int32_t* __restrict__ start,
+                                                           const int32_t* __restrict__ rowptr, int64_t n,
+                                                           const int32_t* __restrict__ rcol,
+                                                           const double* __restrict__ rw, int32_t* __restrict__ col,
+                                                           double* __restrict__ w, double* __restrict__ deg,
+                                                           double* __restrict__ g, double* __restrict__ sg,
+                                                           int32_t* __restrict__ stats /* [0]=n_isolated [1]=max_degree */) {
+    const int64_t i = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const int32_t src = start[i];
+    const int32_t b = rowptr[i], cntu = rowptr[i + 1] - b;
+    double d = 0.0;
+    for (int32_t a = 0; a < cntu; ++a) {
+        const double v = rw[src + a];
+        col[b + a] = rcol[src + a];
+        w[b + a] = v;
+        d += v;  // left to right in column order: lil_matrix.sum(axis=1)
+    }
+    deg[i] = d;
+    const double gi = 1.0 / (d + 1e-8);  // graph.py:219
+    g[i] = gi;
+    sg[i] = sqrt(gi);
+    if (cntu == 0) atomicAdd(&stats[0], 1);
+    atomicMax(&stats[1], cntu);
+}
+
+__global__ __launch_bounds__(PF_BLOCK) void k_symmetry_probe(const int32_t* __restrict__ rowptr,
+                                                             const int32_t* __restrict__ col, int64_t n,
+                                                             int32_t* __restrict__ asym) {
+    const int64_t i = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    for (int32_t a = rowptr[i]; a < rowptr[i + 1]; ++a) {
+        const int32_t j = col[a];
+        int32_t lo = rowptr[j], hi = rowptr[j + 1] - 1;
+        bool found = false;
+        while (lo <= hi) {
+            const int32_t mid = (lo + hi) >> 1;
+            const int32_t c = col[mid];
+            if (c == (int32_t)i) {
+                found = true;
+                break;
+            }
+            if (c < (int32_t)i) lo = mid + 1; else hi = mid - 1;
+        }
+        if (!found) {
+            atomicOr(asym, 1);
+            return;
+        }
+    }
+}
+
+// ---- weakly connected components: union-find with atomic hooking, labels only decrease --------
+__device__ __forceinline__ int32_t uf_find(const int32_t* label, int32_t x) {
+    int32_t p = label[x];
+    while (p != x) {
+        x = p;
+        p = label[x];
+    }
+    return x;
+}
+
+__global__ __launch_bounds__(PF_BLOCK) void k_label_init(int32_t* label, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
+    if (i < n) label[i] = (int32_t)i;
+}
+
+__global__ __launch_bounds__(PF_BLOCK) void k_label_hook(const int32_t* __restrict__ rowptr,
+                                                         const int32_t* __restrict__ col, int64_t n, int32_t* label,
+                                                         int32_t* changed) {
+    const int64_t i = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    for (int32_t a = rowptr[i]; a < rowptr[i + 1]; ++a) {
+        int32_t ri = uf_find(label, (int32_t)i);
+        int32_t rj = uf_find(label, col[a]);
+        if (ri != rj) {
+            const int32_t lo = ri < rj ? ri : rj, hi = ri < rj ? rj : ri;
+            atomicMin(&label[hi], lo);
+            *changed = 1;
+        }
+    }
+}
+
+__global__ __launch_bounds__(PF_BLOCK) void k_label_compress(int32_t* label, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
+    if (i < n) label[i] = uf_find(label, (int32_t)i);
+}
+
+__global__ __launch_bounds__(PF_BLOCK) void k_collect_roots(const int32_t* __restrict__ label,
+                                                            const int32_t* __restrict__ rowptr, int64_t n,
+                                                            int32_t* __restrict__ roots, int32_t* __restrict__ n_roots) {
+    const int64_t i = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    if (label[i] == (int32_t)i && rowptr[i + 1] > rowptr[i]) {
+        const int32_t k = atomicAdd(n_roots, 1);
+        if (k < PF_MAX_ROOTS) roots[k] = (int32_t)i;
+    }
+}
+
+// ---- SELL-64 ----------------------------------------------------------------------------------
+__global__ __launch_bounds__(PF_BLOCK) void k_slice_widths(const int32_t* __restrict__ rowptr, int64_t n,
+                                                           int64_t n_slices, int64_t* __restrict__ width64) {
+    const int64_t row = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
+    int32_t c = 0;
+    if (row < n) c = rowptr[row + 1] - rowptr[row];
+#pragma unroll
+    for (int off = PF_WAVE / 2; off > 0; off >>= 1) c = max(c, __shfl_xor(c, off, PF_WAVE));
+    const int64_t s = row / PF_WAVE;
+    if ((threadIdx.x & (PF_WAVE - 1)) == 0 && s < n_slices) width64[s] = (int64_t)c * PF_WAVE;
+}
+
+__global__ __launch_bounds__(PF_BLOCK) void k_fill_sell(const int32_t* __restrict__ rowptr,
+                                                        const int32_t* __restrict__ col, const double* __restrict__ w,
+                                                        const double* __restrict__ deg, const double* __restrict__ g,
+                                                        const double* __restrict__ sg, int64_t n, int64_t n_pad,
+                                                        const int64_t* __restrict__ slice_ptr, int32_t* __restrict__ scol,
+                                                        double* __restrict__ sval_rw, double* __restrict__ sval_sym,
+                                                        double* __restrict__ diag) {
+    const int64_t row = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
+    if (row >= n_pad) return;
+    const int64_t s = row / PF_WAVE;
+    const int lane = (int)(row & (PF_WAVE - 1));
+    const int64_t base = slice_ptr[s];
+    const int32_t width = (int32_t)((slice_ptr[s + 1] - base) / PF_WAVE);
+    int32_t b = 0, cnt = 0;
+    double gi = 0.0, si = 0.0;
+    if (row < n) {
+        b = rowptr[row];
+        cnt = rowptr[row + 1] - b;
+        gi = g[row];
+        si = sg[row];
+        diag[row] = gi * deg[row];  // L_ii = g_i deg_i  (graph.py:226)
+    } else {
+        diag[row] = 0.0;
+    }
+    for (int32_t j = 0; j < width; ++j) {
+        const int64_t idx = base + (int64_t)j * PF_WAVE + lane;
+        if (j < cnt) {
+            const int32_t c = col[b + j];
+            const double wv = w[b + j];
+            scol[idx] = c;
+            sval_rw[idx] = -(gi * wv);  // L_ij = g_i * (0 - W_ij)
+            if (sval_sym) sval_sym[idx] = -(wv * (si * sg[c]));
+        } else {
+            scol[idx] = (int32_t)(row < n ? row : 0);  // padding: zero weight on an in-range, cached column
+            sval_rw[idx] = 0.0;
+            if (sval_sym) sval_sym[idx] = 0.0;
+        }
+    }
+}
+
+__global__ __launch_bounds__(PF_BLOCK) void k_l_offdiag(const int32_t* __restrict__ rowptr, const double* __restrict__ w,
+                                                        const double* __restrict__ g, int64_t n, double* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const double gi = g[i];
+    for (int32_t a = rowptr[i]; a < rowptr[i + 1]; ++a) out[a] = -(gi * w[a]);
+}
+
+inline unsigned nblk(int64_t n) { return (unsigned)((n + PF_BLOCK - 1) / PF_BLOCK); }
+
+template <typename T>
+int dev_alloc(T** p, int64_t count) {
+    *p = nullptr;
+    PF_HIP(hipMalloc((void**)p, sizeof(T) * (size_t)std::max<int64_t>(count, 1)));
+    return PF_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void pf_graph_free(pf_graph* g) {
+    if (!g) return;
+    if (g->ctx) {
+        hipSetDevice(g->ctx->device);
+        hipStreamSynchronize(g->ctx->stream);
+    }
+    hipFree(g->rowptr);
+    hipFree(g->col);
+    hipFree(g->w);
+    hipFree(g->deg);
+    hipFree(g->g);
+    hipFree(g->sg);
+    hipFree(g->label);
+    hipFree(g->slice_ptr);
+    hipFree(g->scol);
+    hipFree(g->sval_rw);
+    hipFree(g->sval_sym);
+    hipFree(g->diag);
+    hipFree(g->ws);
+    hipFree(g->partials);
+    hipFree(g->coef);
+    delete g;
+}
+
+int pf_graph_build(pf_ctx* ctx, const double* pts, int64_t n, const int32_t* faces, int64_t n_faces,
+                   int32_t vpf, pf_graph** out) {
+    PF_CHECK(ctx && pts && out && (faces || n_faces == 0), PF_E_ARG, "pf_graph_build: NULL argument");
+    PF_CHECK(n > 0 && n < (int64_t)1 << 31, PF_E_ARG, "pf_graph_build: n = %lld out of range", (long long)n);
+    PF_CHECK(n_faces >= 0 && vpf >= 2 && n_faces * vpf < (int64_t)1 << 31, PF_E_ARG,
+             "pf_graph_build: faces %lld x %d out of range", (long long)n_faces, vpf);
+    *out = nullptr;
+    PF_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const int64_t n_edges = n_faces * vpf;
+
+    pf_graph* g = new pf_graph();
+    g->ctx = ctx;
+    g->n = n;
+    g->n_faces = n_faces;
+    g->vpf = vpf;
+    g->n_pad = (n + PF_BLOCK - 1) / PF_BLOCK * PF_BLOCK;  // multiple of 256: no tails in vector kernels
+    g->n_slices = g->n_pad / PF_WAVE;
+    g->n_chunks = (g->n_pad + PF_DOT_CHUNK - 1) / PF_DOT_CHUNK;
+
+    struct Guard {
+        pf_graph* g;
+        std::vector<void*> tmp;
+        bool ok = false;
+        ~Guard() {
+            for (void* p : tmp) hipFree(p);
+            if (!ok) pf_graph_free(g);
+        }
+    } guard{g};
+    auto scratch = [&](auto** p, int64_t count) -> int {
+        int r = dev_alloc(p, count);
+        if (r == PF_OK) guard.tmp.push_back((void*)*p);
+        return r;
+    };
+
+    double* d_pts = nullptr;
+    int32_t* d_faces = nullptr;
+    int32_t *cnt = nullptr, *start = nullptr, *cursor = nullptr, *rcol = nullptr, *ucnt = nullptr, *flags = nullptr;
+    double* rw = nullptr;
+    int64_t* width64 = nullptr;
+    int32_t* d_roots = nullptr;
+    PF_TRY(scratch(&d_pts, 3 * n));
+    PF_TRY(scratch(&d_faces, n_edges));
+    PF_TRY(scratch(&cnt, n + 1));
+    PF_TRY(scratch(&start, n + 1));
+    PF_TRY(scratch(&cursor, n + 1));
+    PF_TRY(scratch(&ucnt, n + 1));
+    PF_TRY(scratch(&rcol, n_edges));
+    PF_TRY(scratch(&rw, n_edges));
+    PF_TRY(scratch(&flags, 8));
+    PF_TRY(scratch(&width64, g->n_slices + 1));
+    PF_TRY(scratch(&d_roots, PF_MAX_ROOTS));
+    PF_TRY(dev_alloc(&g->rowptr, n + 1));
+    PF_TRY(dev_alloc(&g->deg, g->n_pad));
+    PF_TRY(dev_alloc(&g->g, g->n_pad));
+    PF_TRY(dev_alloc(&g->sg, g->n_pad));
+    PF_TRY(dev_alloc(&g->diag, g->n_pad));
+    PF_TRY(dev_alloc(&g->label, g->n_pad));
+    PF_TRY(dev_alloc(&g->slice_ptr, g->n_slices + 1));
+
+    PF_HIP(hipMemcpyAsync(d_pts, pts, sizeof(double) * 3 * n, hipMemcpyHostToDevice, st));
+    if (n_edges) PF_HIP(hipMemcpyAsync(d_faces, faces, sizeof(int32_t) * n_edges, hipMemcpyHostToDevice, st));
+    PF_HIP(hipMemsetAsync(cnt, 0, sizeof(int32_t) * (n + 1), st));
+    PF_HIP(hipMemsetAsync(cursor, 0, sizeof(int32_t) * (n + 1), st));
+    PF_HIP(hipMemsetAsync(ucnt, 0, sizeof(int32_t) * (n + 1), st));
+    PF_HIP(hipMemsetAsync(flags, 0, sizeof(int32_t) * 8, st));
+    PF_HIP(hipMemsetAsync(g->deg, 0, sizeof(double) * g->n_pad, st));
+    PF_HIP(hipMemsetAsync(g->g, 0, sizeof(double) * g->n_pad, st));
+    PF_HIP(hipMemsetAsync(g->sg, 0, sizeof(double) * g->n_pad, st));
+    PF_HIP(hipEventRecord(ctx->ev0, st));
+
+    if (n_edges) {
+        k_count_edges<<<nblk(n_edges), PF_BLOCK, 0, st>>>(d_faces, n_edges, vpf, n, cnt, flags);
+        PF_HIP(hipGetLastError());
+    }
+    int32_t h_flags[8];
+    PF_HIP(hipMemcpyAsync(h_flags, flags, sizeof(h_flags), hipMemcpyDeviceToHost, st));
+    PF_HIP(hipStreamSynchronize(st));
+    PF_CHECK(!(h_flags[0] & 1), PF_E_ARG, "pf_graph_build: face index out of range [0,%lld)", (long long)n);
+    PF_CHECK(!(h_flags[0] & 2), PF_E_DEGENERATE, "pf_graph_build: a face repeats a vertex on one edge");
+
+    PF_TRY(pf_exclusive_scan_i32(st, cnt, start, n + 1));
+    if (n_edges) {
+        k_scatter_edges<<<nblk(n_edges), PF_BLOCK, 0, st>>>(d_faces, d_pts, n_edges, vpf, start, cursor, rcol, rw);
+        PF_HIP(hipGetLastError());
+    }
+    k_sort_unique_rows<<<nblk(n), PF_BLOCK, 0, st>>>(start, n, rcol, rw, ucnt);
+    PF_HIP(hipGetLastError());
+    PF_TRY(pf_exclusive_scan_i32(st, ucnt, g->rowptr, n + 1));
+    int32_t nnz32 = 0;
+    PF_HIP(hipMemcpyAsync(&nnz32, g->rowptr + n, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    PF_HIP(hipStreamSynchronize(st));
+    g->nnz_w = nnz32;
+    PF_TRY(dev_alloc(&g->col, g->nnz_w));
+    PF_TRY(dev_alloc(&g->w, g->nnz_w));
+
+    int32_t* stats = flags + 2;  // [0] isolated, [1] max degree, [2] asym, [3] changed, [4] n_roots
+    k_compact_rows<<<nblk(n), PF_BLOCK, 0, st>>>(start, g->rowptr, n, rcol, rw, g->col, g->w, g->deg, g->g, g->sg, stats);
+    PF_HIP(hipGetLastError());
+    k_symmetry_probe<<<nblk(n), PF_BLOCK, 0, st>>>(g->rowptr, g->col, n, stats + 2);
+    PF_HIP(hipGetLastError());
+
+    // components
+    k_label_init<<<nblk(g->n_pad), PF_BLOCK, 0, st>>>(g->label, g->n_pad);
+    PF_HIP(hipGetLastError());
+    for (int round = 0; round < 64; ++round) {
+        PF_HIP(hipMemsetAsync(stats + 3, 0, sizeof(int32_t), st));
+        k_label_hook<<<nblk(n), PF_BLOCK, 0, st>>>(g->rowptr, g->col, n, g->label, stats + 3);
+        PF_HIP(hipGetLastError());
+        k_label_compress<<<nblk(n), PF_BLOCK, 0, st>>>(g->label, n);
+        PF_HIP(hipGetLastError());
+        int32_t changed = 0;
+        PF_HIP(hipMemcpyAsync(&changed, stats + 3, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        PF_HIP(hipStreamSynchronize(st));
+        if (!changed) break;
+        PF_CHECK(round < 63, PF_E_HIP, "pf_graph_build: component labelling did not converge");
+    }
+    k_collect_roots<<<nblk(n), PF_BLOCK, 0, st>>>(g->label, g->rowptr, n, d_roots, stats + 4);
+    PF_HIP(hipGetLastError());
+
+    // SELL-64
+    k_slice_widths<<<nblk(g->n_pad), PF_BLOCK, 0, st>>>(g->rowptr, n, g->n_slices, width64);
+    PF_HIP(hipGetLastError());
+    PF_HIP(hipMemsetAsync(width64 + g->n_slices, 0, sizeof(int64_t), st));
+    PF_TRY(pf_exclusive_scan_i64(st, width64, g->slice_ptr, g->n_slices + 1));
+    int32_t h_stats[6];
+    PF_HIP(hipMemcpyAsync(h_stats, stats, sizeof(int32_t) * 5, hipMemcpyDeviceToHost, st));
+    PF_HIP(hipMemcpyAsync(&g->sell_entries, g->slice_ptr + g->n_slices, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    PF_HIP(hipStreamSynchronize(st));
+    g->n_isolated = h_stats[0];
+    g->max_degree = h_stats[1];
+    g->is_symmetric = h_stats[2] ? 0 : 1;
+    const int32_t n_roots = h_stats[4];
+    PF_CHECK(n_roots <= PF_MAX_ROOTS, PF_E_ARG, "pf_graph_build: %d connected components exceed the supported %d",
+             n_roots, PF_MAX_ROOTS);
+    g->n_components = n_roots;
+    g->roots.resize(n_roots);
+    if (n_roots) {
+        PF_HIP(hipMemcpyAsync(g->roots.data(), d_roots, sizeof(int32_t) * n_roots, hipMemcpyDeviceToHost, st));
+        PF_HIP(hipStreamSynchronize(st));
+        std::sort(g->roots.begin(), g->roots.end());
+    }
+    PF_TRY(dev_alloc(&g->scol, g->sell_entries));
+    PF_TRY(dev_alloc(&g->sval_rw, g->sell_entries));
+    if (g->is_symmetric) PF_TRY(dev_alloc(&g->sval_sym, g->sell_entries));
+    k_fill_sell<<<nblk(g->n_pad), PF_BLOCK, 0, st>>>(g->rowptr, g->col, g->w, g->deg, g->g, g->sg, n, g->n_pad,
+                                                     g->slice_ptr, g->scol, g->sval_rw, g->sval_sym, g->diag);
+    PF_HIP(hipGetLastError());
+    PF_HIP(hipEventRecord(ctx->ev1, st));
+    PF_HIP(hipStreamSynchronize(st));
+    float ms = 0.f;
+    PF_HIP(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    ctx->build_ms = ms;
+    guard.ok = true;
+    *out = g;
+    return PF_OK;
+}
+
+int pf_graph_get_info(pf_graph* g, pf_graph_info* o) {
+    PF_CHECK(g && o, PF_E_ARG, "pf_graph_get_info: NULL argument");
+    o->n = g->n;
+    o->n_faces = g->n_faces;
+    o->nnz_w = g->nnz_w;
+    o->nnz_l = g->nnz_w + (g->n - g->n_isolated);
+    o->is_symmetric = g->is_symmetric;
+    o->n_isolated = g->n_isolated;
+    o->n_components = g->n_components;
+    o->max_degree = g->max_degree;
+    o->sell_entries = g->sell_entries;
+    o->n_pad = g->n_pad;
+    return PF_OK;
+}
+
+int pf_graph_download(pf_graph* g, int32_t* rowptr, int32_t* colidx, double* w, double* l_offdiag, double* deg,
+                      double* l_diag, int32_t* component_label) {
+    PF_CHECK(g, PF_E_ARG, "pf_graph_download: graph is NULL");
+    PF_HIP(hipSetDevice(g->ctx->device));
+    hipStream_t st = g->ctx->stream;
+    double* tmp = nullptr;
+    if (rowptr) PF_HIP(hipMemcpyAsync(rowptr, g->rowptr, sizeof(int32_t) * (g->n + 1), hipMemcpyDeviceToHost, st));
+    if (colidx && g->nnz_w) PF_HIP(hipMemcpyAsync(colidx, g->col, sizeof(int32_t) * g->nnz_w, hipMemcpyDeviceToHost, st));
+    if (w && g->nnz_w) PF_HIP(hipMemcpyAsync(w, g->w, sizeof(double) * g->nnz_w, hipMemcpyDeviceToHost, st));
+    if (deg) PF_HIP(hipMemcpyAsync(deg, g->deg, sizeof(double) * g->n, hipMemcpyDeviceToHost, st));
+    if (l_diag) PF_HIP(hipMemcpyAsync(l_diag, g->diag, sizeof(double) * g->n, hipMemcpyDeviceToHost, st));
+    if (component_label) PF_HIP(hipMemcpyAsync(component_label, g->label, sizeof(int32_t) * g->n, hipMemcpyDeviceToHost, st));
+    if (l_offdiag && g->nnz_w) {
+        PF_HIP(hipMalloc((void**)&tmp, sizeof(double) * g->nnz_w));
+        k_l_offdiag<<<nblk(g->n), PF_BLOCK, 0, st>>>(g->rowptr, g->w, g->g, g->n, tmp);
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(l_offdiag, tmp, sizeof(double) * g->nnz_w, hipMemcpyDeviceToHost, st);
+        if (e != hipSuccess) {
+            hipStreamSynchronize(st);
+            hipFree(tmp);
+            pf_set_error("pf_graph_download: %s", hipGetErrorString(e));
+            return PF_E_HIP;
+        }
+    }
+    hipError_t e = hipStreamSynchronize(st);
+    if (tmp) hipFree(tmp);
+    PF_HIP(e);
+    return PF_OK;
+}
+
+}  // extern "C"

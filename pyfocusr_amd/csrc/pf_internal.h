@@ -1,0 +1,102 @@
+// Internal declarations shared by the HIP translation units of libpyfocusr_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <vector>
+
+#include "../../include/pyfocusr_hip.h"
+
+void pf_set_error(const char* fmt, ...);
+
+#define PF_HIP(call)                                                                          \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            pf_set_error("%s:%d %s: %s", __FILE__, __LINE__, #call, hipGetErrorString(e_));   \
+            return PF_E_HIP;                                                                  \
+        }                                                                                     \
+    } while (0)
+
+#define PF_CHECK(cond, code, ...)        \
+    do {                                 \
+        if (!(cond)) {                   \
+            pf_set_error(__VA_ARGS__);   \
+            return (code);               \
+        }                                \
+    } while (0)
+
+#define PF_TRY(call)            \
+    do {                        \
+        int r_ = (call);        \
+        if (r_ != PF_OK) return r_; \
+    } while (0)
+
+constexpr int PF_WAVE = 64;        // gfx950 wavefront
+constexpr int PF_BLOCK = 256;      // 4 waves: one per SIMD of a CU
+constexpr int PF_DOT_CHUNK = 4096; // rows per block in the reduction kernels
+constexpr int PF_MAX_ROOTS = 4096; // components tracked explicitly
+
+struct pf_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timing = false;
+    double op_ms = 0.0;
+    int64_t op_launches = 0;
+    double knn_ms = 0.0;
+    double build_ms = 0.0;
+    // nearest-neighbour state (pf_knn_upload / run / download)
+    double* knn_ref = nullptr;
+    double* knn_qry = nullptr;
+    int64_t knn_nref = 0, knn_nqry = 0, knn_cap_ref = 0, knn_cap_qry = 0;
+    int32_t knn_d = 0;
+    int32_t knn_splits = 0, knn_cap_part = 0;
+    double* knn_part_d2 = nullptr;   // [splits][n_qry]
+    int32_t* knn_part_idx = nullptr; // [splits][n_qry]
+    int64_t* knn_idx = nullptr;      // [n_qry]
+    double* knn_d2 = nullptr;        // [n_qry]
+    bool knn_ready = false, knn_done = false;
+};
+
+struct pf_graph {
+    pf_ctx* ctx = nullptr;
+    int64_t n = 0, n_pad = 0, n_faces = 0;
+    int32_t vpf = 0;
+    // CSR(W), sorted columns, unique directed edges
+    int32_t* rowptr = nullptr; // [n+1]
+    int32_t* col = nullptr;    // [nnz_w]
+    double* w = nullptr;       // [nnz_w]
+    int64_t nnz_w = 0;
+    double* deg = nullptr;  // [n_pad]
+    double* g = nullptr;    // 1/(deg+1e-8)
+    double* sg = nullptr;   // sqrt(g)
+    int32_t* label = nullptr; // component root per vertex
+    // SELL-64 operator storage (off-diagonals) + dense diagonal
+    int64_t n_slices = 0, sell_entries = 0;
+    int64_t* slice_ptr = nullptr; // [n_slices+1]
+    int32_t* scol = nullptr;      // [sell_entries]
+    double* sval_rw = nullptr;    // -g_i W_ij
+    double* sval_sym = nullptr;   // -W_ij sqrt(g_i g_j)   (only when symmetric)
+    double* diag = nullptr;       // deg_i g_i  (both operators)
+    int32_t is_symmetric = 0, n_isolated = 0, n_components = 0, max_degree = 0;
+    std::vector<int32_t> roots; // roots of components with >= 2 vertices, ascending
+    // workspace: n_slots vectors + 2 Chebyshev temporaries, stride n_pad
+    double* ws = nullptr;
+    int32_t n_slots = 0;
+    // reduction scratch
+    double* partials = nullptr; // [max_count][n_chunks] (+ stats)
+    int32_t partial_cap = 0;    // in vectors
+    double* coef = nullptr;     // device coefficients: [3][coef_cap]
+    int32_t coef_cap = 0;
+    int64_t n_chunks = 0;
+};
+
+static inline double* pf_slot(pf_graph* g, int32_t s) { return g->ws + (int64_t)s * g->n_pad; }
+static inline double* pf_tmp(pf_graph* g, int which) { return g->ws + (int64_t)(g->n_slots + which) * g->n_pad; }
+
+// pf_scan.hip
+int pf_exclusive_scan_i32(hipStream_t st, const int32_t* in, int32_t* out, int64_t n);
+int pf_exclusive_scan_i64(hipStream_t st, const int64_t* in, int64_t* out, int64_t n);
+
+// pf_operator.hip
+int pf_reduce_ensure(pf_graph* g, int32_t count);

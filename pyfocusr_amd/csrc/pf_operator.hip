@@ -1,0 +1,653 @@
+// Eigensolver kernels: the fused SpMV + Chebyshev three-term recurrence over the SELL-64
+// operator storage, and the dense-vector kernels of the Krylov-Schur driver (multi-dot,
+// multi-axpy, basis rotation, residual norm, eigenvector post-processing).
+//
+// These replace the ARPACK/SuperLU machinery behind `scipy.sparse.linalg.eigs(L, k,
+// sigma=1e-10, which="LM", ncv=4k)` (/root/reference/pyfocusr/graph.py:372).  Everything here
+// is HBM/L2-bandwidth-bound: one thread per matrix row, 64 consecutive rows per wave reading
+// 64 consecutive SELL entries per step (512 B of values + 256 B of column indices per wave
+// instruction), x gathered through L2.  Reductions are two-stage and atomic-free, so results
+// are bitwise reproducible run to run.
+#include <math.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "pf_internal.h"
+
+namespace {
+
+inline unsigned nblk(int64_t n) { return (unsigned)((n + PF_BLOCK - 1) / PF_BLOCK); }
+
+// out = alpha * (shift * x - A x) - beta * prev          (A = diag + SELL off-diagonals)
+//   SpMV:            alpha = -1, shift = 0, beta = 0      -> out = A x
+//   Chebyshev k = 1: alpha = 1/e, shift = c, beta = 0
+//   Chebyshev k > 1: alpha = 2/e, shift = c, beta = 1     (out may alias prev)
+template <bool HAS_PREV>
+__global__ __launch_bounds__(PF_BLOCK) void k_sell_op(const int64_t* __restrict__ slice_ptr,
+                                                      const int32_t* __restrict__ scol,
+                                                      const double* __restrict__ sval,
+                                                      const double* __restrict__ diag, const double* __restrict__ x,
+                                                      const double* prev, double* out, double alpha, double shift,
+                                                      double beta) {
+#pragma clang fp contract(fast)
+    const int64_t row = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
+    const int64_t s = row >> 6;
+    const int lane = threadIdx.x & (PF_WAVE - 1);
+    const int64_t base = slice_ptr[s];
+    const int width = (int)((slice_ptr[s + 1] - base) >> 6);
+    const double xi = x[row];
+    double acc = diag[row] * xi;
+    const int32_t* cp = scol + base + lane;
+    const double* vp = sval + base + lane;
+    int j = 0;
+    for (; j + 4 <= width; j += 4) {
+        const int32_t c0 = cp[(int64_t)(j + 0) * PF_WAVE], c1 = cp[(int64_t)(j + 1) * PF_WAVE];
+        const int32_t c2 = cp[(int64_t)(j + 2) * PF_WAVE], c3 = cp[(int64_t)(j + 3) * PF_WAVE];
+        const double v0 = vp[(int64_t)(j + 0) * PF_WAVE], v1 = vp[(int64_t)(j + 1) * PF_WAVE];
+        const double v2 = vp[(int64_t)(j + 2) * PF_WAVE], v3 = vp[(int64_t)(j + 3) * PF_WAVE];
+        const double x0 = x[c0], x1 = x[c1], x2 = x[c2], x3 = x[c3];
+        acc += v0 * x0;
+        acc += v1 * x1;
+        acc += v2 * x2;
+        acc += v3 * x3;
+    }
+    for (; j < width; ++j) acc += vp[(int64_t)j * PF_WAVE] * x[cp[(int64_t)j * PF_WAVE]];
+    double r = alpha * (shift * xi - acc);
+    if (HAS_PREV) r -= beta * prev[row];
+    out[row] = r;
+}
+
+// partial[b][chunk] = sum over the chunk's rows of V_b[i] * w[i]   (fixed order -> deterministic)
+__global__ __launch_bounds__(PF_BLOCK) void k_dot_partial(const double* __restrict__ ws, int64_t n_pad, int32_t first,
+                                                          int32_t wslot, int64_t n_chunks, double* __restrict__ partial) {
+    __shared__ double red[PF_BLOCK / PF_WAVE];
+    const int b = blockIdx.y;
+    const int64_t chunk = blockIdx.x;
+    const double* v = ws + (int64_t)(first + b) * n_pad;
+    const double* w = ws + (int64_t)wslot * n_pad;
+    const int64_t lo = chunk * PF_DOT_CHUNK;
+    const int64_t hi = lo + PF_DOT_CHUNK < n_pad ? lo + PF_DOT_CHUNK : n_pad;
+    double s = 0.0;
+    for (int64_t i = lo + 2 * threadIdx.x; i < hi; i += 2 * PF_BLOCK) {
+        const double2 a = *reinterpret_cast<const double2*>(v + i);
+        const double2 c = *reinterpret_cast<const double2*>(w + i);
+        s += a.x * c.x;
+        s += a.y * c.y;
+    }
+#pragma unroll
+    for (int off = PF_WAVE / 2; off > 0; off >>= 1) s += __shfl_down(s, off, PF_WAVE);
+    if ((threadIdx.x & (PF_WAVE - 1)) == 0) red[threadIdx.x / PF_WAVE] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[(int64_t)b * n_chunks + chunk] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// out[b] = sum_chunks partial[b][chunk];  acc[b] (+)= out[b]
+__global__ __launch_bounds__(PF_WAVE) void k_dot_finish(const double* __restrict__ partial, int64_t n_chunks,
+                                                        double* __restrict__ out, double* __restrict__ acc, int accumulate) {
+    const int b = blockIdx.x;
+    double s = 0.0;
+    for (int64_t k = threadIdx.x; k < n_chunks; k += PF_WAVE) s += partial[(int64_t)b * n_chunks + k];
+#pragma unroll
+    for (int off = PF_WAVE / 2; off > 0; off >>= 1) s += __shfl_down(s, off, PF_WAVE);
+    if (threadIdx.x == 0) {
+        out[b] = s;
+        if (acc) acc[b] = accumulate ? acc[b] + s : s;
+    }
+}
+
+// w -= sum_b h[b] V_b
+__global__ __launch_bounds__(PF_BLOCK) void k_multi_axpy(double* __restrict__ ws, int64_t n_pad, int32_t first,
+                                                         int32_t count, int32_t wslot, const double* __restrict__ h) {
+    const int64_t i = 2 * ((int64_t)blockIdx.x * PF_BLOCK + threadIdx.x);
+    if (i >= n_pad) return;
+    double2 acc = *reinterpret_cast<double2*>(ws + (int64_t)wslot * n_pad + i);
+    for (int b = 0; b < count; ++b) {
+        const double hb = h[b];
+        const double2 v = *reinterpret_cast<const double2*>(ws + (int64_t)(first + b) * n_pad + i);
+        acc.x -= hb * v.x;
+        acc.y -= hb * v.y;
+    }
+    *reinterpret_cast<double2*>(ws + (int64_t)wslot * n_pad + i) = acc;
+}
+
+__global__ __launch_bounds__(PF_BLOCK) void k_scale(double* __restrict__ x, int64_t n_pad, double alpha) {
+    const int64_t i = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
+    if (i < n_pad) x[i] *= alpha;
+}
+
+__global__ __launch_bounds__(PF_BLOCK) void k_mask_isolated(double* __restrict__ x, const int32_t* __restrict__ rowptr,
+                                                            int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
+    if (i < n && rowptr[i + 1] == rowptr[i]) x[i] = 0.0;
+}
+
+__global__ __launch_bounds__(PF_BLOCK) void k_null_vector(double* __restrict__ x, const int32_t* __restrict__ label,
+                                                          const int32_t* __restrict__ rowptr,
+                                                          const double* __restrict__ deg, int64_t n, int64_t n_pad,
+                                                          int32_t root, int32_t sym) {
+    const int64_t i = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
+    if (i >= n_pad) return;
+    double v = 0.0;
+    if (i < n && label[i] == root && rowptr[i + 1] > rowptr[i]) v = sym ? sqrt(deg[i] + 1e-8) : 1.0;
+    x[i] = v;
+}
+
+// dst_c = sum_b src_b Y[b][c] for up to 8 output columns per launch (Y row-major m x k, in device memory)
+constexpr int COMBINE_COLS = 8;
+__global__ __launch_bounds__(PF_BLOCK) void k_combine(double* __restrict__ ws, int64_t n_pad, int32_t src_first, int32_t m,
+                                                      const double* __restrict__ Y, int32_t k, int32_t c0, int32_t ncols,
+                                                      int32_t dst_first) {
+    const int64_t i = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
+    if (i >= n_pad) return;
+    double acc[COMBINE_COLS];
+#pragma unroll
+    for (int c = 0; c < COMBINE_COLS; ++c) acc[c] = 0.0;
+    for (int b = 0; b < m; ++b) {
+        const double v = ws[(int64_t)(src_first + b) * n_pad + i];
+        const double* yr = Y + (int64_t)b * k + c0;
+#pragma unroll
+        for (int c = 0; c < COMBINE_COLS; ++c)
+            if (c < ncols) acc[c] += v * yr[c];
+    }
+#pragma unroll
+    for (int c = 0; c < COMBINE_COLS; ++c)
+        if (c < ncols) ws[(int64_t)(dst_first + c0 + c) * n_pad + i] = acc[c];
+}
+
+// partial sums of (ax - lam x)^2
+__global__ __launch_bounds__(PF_BLOCK) void k_resnorm_partial(const double* __restrict__ ax, const double* __restrict__ x,
+                                                              double lam, int64_t n_pad, int64_t n_chunks,
+                                                              double* __restrict__ partial) {
+    __shared__ double red[PF_BLOCK / PF_WAVE];
+    const int64_t lo = (int64_t)blockIdx.x * PF_DOT_CHUNK;
+    const int64_t hi = lo + PF_DOT_CHUNK < n_pad ? lo + PF_DOT_CHUNK : n_pad;
+    double s = 0.0;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += PF_BLOCK) {
+        const double r = ax[i] - lam * x[i];
+        s += r * r;
+    }
+#pragma unroll
+    for (int off = PF_WAVE / 2; off > 0; off >>= 1) s += __shfl_down(s, off, PF_WAVE);
+    if ((threadIdx.x & (PF_WAVE - 1)) == 0) red[threadIdx.x / PF_WAVE] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// ---- eigenvector post-processing -----------------------------------------------------------------
+struct VecStats {
+    double sumsq, vmin, vmax, absmax, at_absmax;
+    int64_t arg;
+};
+
+__device__ __forceinline__ void stats_merge(VecStats& a, const VecStats& b) {
+    a.sumsq += b.sumsq;
+    a.vmin = fmin(a.vmin, b.vmin);
+    a.vmax = fmax(a.vmax, b.vmax);
+    if (b.absmax > a.absmax || (b.absmax == a.absmax && b.arg < a.arg)) {
+        a.absmax = b.absmax;
+        a.at_absmax = b.at_absmax;
+        a.arg = b.arg;
+    }
+}
+
+__device__ __forceinline__ VecStats stats_shfl(const VecStats& v, int off) {
+    VecStats o;
+    o.sumsq = __shfl_down(v.sumsq, off, PF_WAVE);
+    o.vmin = __shfl_down(v.vmin, off, PF_WAVE);
+    o.vmax = __shfl_down(v.vmax, off, PF_WAVE);
+    o.absmax = __shfl_down(v.absmax, off, PF_WAVE);
+    o.at_absmax = __shfl_down(v.at_absmax, off, PF_WAVE);
+    o.arg = __shfl_down(v.arg, off, PF_WAVE);
+    return o;
+}
+
+__global__ __launch_bounds__(PF_BLOCK) void k_vec_stats_partial(const double* __restrict__ ws, int64_t n_pad, int64_t n,
+                                                                int32_t first, const double* __restrict__ sg,
+                                                                int32_t from_sym, int64_t n_chunks,
+                                                                VecStats* __restrict__ partial) {
+    __shared__ VecStats red[PF_BLOCK / PF_WAVE];
+    const int b = blockIdx.y;
+    const double* x = ws + (int64_t)(first + b) * n_pad;
+    const int64_t lo = (int64_t)blockIdx.x * PF_DOT_CHUNK;
+    const int64_t hi0 = lo + PF_DOT_CHUNK;
+    const int64_t hi = hi0 < n ? hi0 : n;
+    VecStats st{0.0, INFINITY, -INFINITY, -1.0, 0.0, (int64_t)1 << 62};
+    for (int64_t i = lo + threadIdx.x; i < hi; i += PF_BLOCK) {
+        double v = x[i];
+        if (from_sym) v *= sg[i];
+        VecStats e{v * v, v, v, fabs(v), v, i};
+        stats_merge(st, e);
+    }
+#pragma unroll
+    for (int off = PF_WAVE / 2; off > 0; off >>= 1) {
+        VecStats o = stats_shfl(st, off);
+        stats_merge(st, o);
+    }
+    if ((threadIdx.x & (PF_WAVE - 1)) == 0) red[threadIdx.x / PF_WAVE] = st;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        VecStats t = red[0];
+        stats_merge(t, red[1]);
+        stats_merge(t, red[2]);
+        stats_merge(t, red[3]);
+        partial[(int64_t)b * n_chunks + blockIdx.x] = t;
+    }
+}
+
+__global__ __launch_bounds__(PF_WAVE) void k_vec_stats_finish(const VecStats* __restrict__ partial, int64_t n_chunks,
+                                                              VecStats* __restrict__ out) {
+    const int b = blockIdx.x;
+    VecStats st{0.0, INFINITY, -INFINITY, -1.0, 0.0, (int64_t)1 << 62};
+    for (int64_t k = threadIdx.x; k < n_chunks; k += PF_WAVE) stats_merge(st, partial[(int64_t)b * n_chunks + k]);
+#pragma unroll
+    for (int off = PF_WAVE / 2; off > 0; off >>= 1) {
+        VecStats o = stats_shfl(st, off);
+        stats_merge(st, o);
+    }
+    if (threadIdx.x == 0) out[b] = st;
+}
+
+// out[i][c] = (x_c[i] * scale_c - off_c) * inv_c - half_c       (row-major n x count)
+__global__ __launch_bounds__(PF_BLOCK) void k_vec_apply(const double* __restrict__ ws, int64_t n_pad, int64_t n,
+                                                        int32_t first, int32_t count, const double* __restrict__ sg,
+                                                        int32_t from_sym, const double* __restrict__ params,
+                                                        double* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const double s = from_sym ? sg[i] : 1.0;
+    for (int c = 0; c < count; ++c) {
+        const double scale = params[4 * c + 0], off = params[4 * c + 1], ptp = params[4 * c + 2], half = params[4 * c + 3];
+        double v = (ws[(int64_t)(first + c) * n_pad + i] * s) * scale;
+        if (ptp != 0.0) v = (v - off) / ptp - half;  // graph.py:254-257
+        out[i * count + c] = v;
+    }
+}
+
+// out = (W x + x) * dinv1   per column; values row-major n x ncols   (graph.py:349-353)
+__global__ __launch_bounds__(PF_BLOCK) void k_mean_filter(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                          const double* __restrict__ w, const double* __restrict__ deg,
+                                                          int64_t n, int32_t ncols, const double* __restrict__ in,
+                                                          double* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const double dinv = 1.0 / (1.0 + deg[i]);
+    for (int c = 0; c < ncols; ++c) {
+        // scipy: average_mat = D_inv @ (W + I) is a sparse-sparse product whose rows come out in
+        // DESCENDING column order (SMMP linked list); average_mat @ v then sums in that order.
+        double acc = 0.0;
+        bool diag_done = false;
+        for (int32_t a = rowptr[i + 1] - 1; a >= rowptr[i]; --a) {
+            const int32_t j = col[a];
+            if (!diag_done && j < (int32_t)i) {
+                acc += dinv * in[i * ncols + c];
+                diag_done = true;
+            }
+            acc += (dinv * w[a]) * in[(int64_t)j * ncols + c];
+        }
+        if (!diag_done) acc += dinv * in[i * ncols + c];
+        out[i * ncols + c] = acc;
+    }
+}
+
+int check_slots(pf_graph* g, int32_t first, int32_t count, const char* who) {
+    PF_CHECK(g != nullptr, PF_E_ARG, "%s: graph is NULL", who);
+    PF_CHECK(first >= 0 && count >= 0 && first + count <= g->n_slots, PF_E_ARG, "%s: slots [%d,%d) outside workspace of %d",
+             who, first, first + count, g->n_slots);
+    return PF_OK;
+}
+
+const double* op_values(pf_graph* g, int32_t op) {
+    if (op == PF_OP_RW) return g->sval_rw;
+    if (op == PF_OP_SYM) return g->sval_sym;
+    return nullptr;
+}
+
+int launch_op(pf_graph* g, const double* vals, const double* x, const double* prev, double* out, double alpha, double shift,
+              double beta) {
+    hipStream_t st = g->ctx->stream;
+    if (prev)
+        k_sell_op<true><<<nblk(g->n_pad), PF_BLOCK, 0, st>>>(g->slice_ptr, g->scol, vals, g->diag, x, prev, out, alpha, shift, beta);
+    else
+        k_sell_op<false><<<nblk(g->n_pad), PF_BLOCK, 0, st>>>(g->slice_ptr, g->scol, vals, g->diag, x, nullptr, out, alpha, shift, beta);
+    PF_HIP(hipGetLastError());
+    return PF_OK;
+}
+
+struct OpTimer {
+    pf_ctx* c;
+    int64_t launches;
+    bool on;
+    OpTimer(pf_ctx* ctx, int64_t n) : c(ctx), launches(n), on(ctx->timing) {
+        if (on) hipEventRecord(c->ev0, c->stream);
+    }
+    int finish() {
+        if (!on) return PF_OK;
+        PF_HIP(hipEventRecord(c->ev1, c->stream));
+        PF_HIP(hipEventSynchronize(c->ev1));
+        float ms = 0.f;
+        PF_HIP(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+        c->op_ms += ms;
+        c->op_launches += launches;
+        return PF_OK;
+    }
+};
+
+int dots_device(pf_graph* g, int32_t w, int32_t first, int32_t count, double* d_out, double* d_acc, int accumulate) {
+    hipStream_t st = g->ctx->stream;
+    PF_TRY(pf_reduce_ensure(g, count));
+    dim3 grid((unsigned)g->n_chunks, (unsigned)count);
+    k_dot_partial<<<grid, PF_BLOCK, 0, st>>>(g->ws, g->n_pad, first, w, g->n_chunks, g->partials);
+    PF_HIP(hipGetLastError());
+    k_dot_finish<<<(unsigned)count, PF_WAVE, 0, st>>>(g->partials, g->n_chunks, d_out, d_acc, accumulate);
+    PF_HIP(hipGetLastError());
+    return PF_OK;
+}
+
+}  // namespace
+
+int pf_reduce_ensure(pf_graph* g, int32_t count) {
+    if (count > g->partial_cap) {
+        PF_HIP(hipStreamSynchronize(g->ctx->stream));
+        hipFree(g->partials);
+        g->partials = nullptr;
+        const int32_t cap = std::max(count, 64);
+        // sized for VecStats partials (48 B) as well as plain doubles
+        PF_HIP(hipMalloc((void**)&g->partials, sizeof(VecStats) * (size_t)cap * (size_t)(g->n_chunks + 1)));
+        g->partial_cap = cap;
+    }
+    if (count > g->coef_cap) {
+        PF_HIP(hipStreamSynchronize(g->ctx->stream));
+        hipFree(g->coef);
+        g->coef = nullptr;
+        const int32_t cap = std::max(count, 64);
+        PF_HIP(hipMalloc((void**)&g->coef, sizeof(double) * 8 * (size_t)cap));
+        g->coef_cap = cap;
+    }
+    return PF_OK;
+}
+
+extern "C" {
+
+int pf_ws_ensure(pf_graph* g, int32_t n_slots) {
+    PF_CHECK(g != nullptr && n_slots > 0, PF_E_ARG, "pf_ws_ensure: bad argument");
+    if (n_slots <= g->n_slots) return PF_OK;
+    PF_HIP(hipSetDevice(g->ctx->device));
+    hipStream_t st = g->ctx->stream;
+    double* nw = nullptr;
+    const size_t bytes = sizeof(double) * (size_t)(n_slots + 2) * (size_t)g->n_pad;
+    PF_HIP(hipMalloc((void**)&nw, bytes));
+    PF_HIP(hipMemsetAsync(nw, 0, bytes, st));
+    if (g->ws && g->n_slots > 0)
+        PF_HIP(hipMemcpyAsync(nw, g->ws, sizeof(double) * (size_t)g->n_slots * g->n_pad, hipMemcpyDeviceToDevice, st));
+    PF_HIP(hipStreamSynchronize(st));
+    hipFree(g->ws);
+    g->ws = nw;
+    g->n_slots = n_slots;
+    return PF_OK;
+}
+
+int pf_ws_upload(pf_graph* g, int32_t slot, const double* x) {
+    PF_TRY(check_slots(g, slot, 1, "pf_ws_upload"));
+    PF_CHECK(x != nullptr, PF_E_ARG, "pf_ws_upload: x is NULL");
+    hipStream_t st = g->ctx->stream;
+    PF_HIP(hipMemcpyAsync(pf_slot(g, slot), x, sizeof(double) * g->n, hipMemcpyHostToDevice, st));
+    if (g->n_pad > g->n) PF_HIP(hipMemsetAsync(pf_slot(g, slot) + g->n, 0, sizeof(double) * (g->n_pad - g->n), st));
+    PF_HIP(hipStreamSynchronize(st));  // x may be a temporary on the host side
+    return PF_OK;
+}
+
+int pf_ws_download(pf_graph* g, int32_t first, int32_t count, double* out) {
+    PF_TRY(check_slots(g, first, count, "pf_ws_download"));
+    PF_CHECK(out != nullptr, PF_E_ARG, "pf_ws_download: out is NULL");
+    hipStream_t st = g->ctx->stream;
+    PF_HIP(hipMemcpy2DAsync(out, sizeof(double) * g->n, pf_slot(g, first), sizeof(double) * g->n_pad, sizeof(double) * g->n,
+                            (size_t)count, hipMemcpyDeviceToHost, st));
+    PF_HIP(hipStreamSynchronize(st));
+    return PF_OK;
+}
+
+int pf_ws_copy(pf_graph* g, int32_t src, int32_t dst, int32_t count) {
+    PF_TRY(check_slots(g, src, count, "pf_ws_copy"));
+    PF_TRY(check_slots(g, dst, count, "pf_ws_copy"));
+    PF_CHECK(src + count <= dst || dst + count <= src || src == dst, PF_E_ARG, "pf_ws_copy: overlapping ranges");
+    if (src == dst || count == 0) return PF_OK;
+    PF_HIP(hipMemcpyAsync(pf_slot(g, dst), pf_slot(g, src), sizeof(double) * (size_t)count * g->n_pad,
+                          hipMemcpyDeviceToDevice, g->ctx->stream));
+    return PF_OK;
+}
+
+int pf_mask_isolated(pf_graph* g, int32_t slot) {
+    PF_TRY(check_slots(g, slot, 1, "pf_mask_isolated"));
+    if (g->n_isolated == 0) return PF_OK;
+    k_mask_isolated<<<nblk(g->n), PF_BLOCK, 0, g->ctx->stream>>>(pf_slot(g, slot), g->rowptr, g->n);
+    PF_HIP(hipGetLastError());
+    return PF_OK;
+}
+
+int pf_lock_null_vectors(pf_graph* g, int32_t op, int32_t* n_locked) {
+    PF_CHECK(g != nullptr && n_locked != nullptr, PF_E_ARG, "pf_lock_null_vectors: NULL argument");
+    PF_CHECK(op == PF_OP_RW || (op == PF_OP_SYM && g->is_symmetric), PF_E_ARG,
+             "pf_lock_null_vectors: operator %d not available (W symmetric: %d)", op, g->is_symmetric);
+    const int32_t nc = g->n_components;
+    PF_TRY(pf_ws_ensure(g, nc + 1));
+    hipStream_t st = g->ctx->stream;
+    PF_TRY(pf_reduce_ensure(g, 1));
+    for (int32_t c = 0; c < nc; ++c) {
+        k_null_vector<<<nblk(g->n_pad), PF_BLOCK, 0, st>>>(pf_slot(g, c), g->label, g->rowptr, g->deg, g->n, g->n_pad,
+                                                          g->roots[c], op == PF_OP_SYM);
+        PF_HIP(hipGetLastError());
+        PF_TRY(dots_device(g, c, c, 1, g->coef, nullptr, 0));
+        double nrm2 = 0.0;
+        PF_HIP(hipMemcpyAsync(&nrm2, g->coef, sizeof(double), hipMemcpyDeviceToHost, st));
+        PF_HIP(hipStreamSynchronize(st));
+        PF_CHECK(nrm2 > 0.0, PF_E_STATE, "pf_lock_null_vectors: empty component %d", c);
+        k_scale<<<nblk(g->n_pad), PF_BLOCK, 0, st>>>(pf_slot(g, c), g->n_pad, 1.0 / sqrt(nrm2));
+        PF_HIP(hipGetLastError());
+    }
+    *n_locked = nc;
+    return PF_OK;
+}
+
+int pf_spmv(pf_graph* g, int32_t op, int32_t src, int32_t dst) {
+    PF_TRY(check_slots(g, src, 1, "pf_spmv"));
+    PF_TRY(check_slots(g, dst, 1, "pf_spmv"));
+    const double* vals = op_values(g, op);
+    PF_CHECK(vals != nullptr && src != dst, PF_E_ARG, "pf_spmv: operator %d unavailable or src == dst", op);
+    OpTimer t(g->ctx, 1);
+    PF_TRY(launch_op(g, vals, pf_slot(g, src), nullptr, pf_slot(g, dst), -1.0, 0.0, 0.0));
+    return t.finish();
+}
+
+int pf_cheb(pf_graph* g, int32_t op, int32_t src, int32_t dst, int32_t degree, double c, double e) {
+    PF_TRY(check_slots(g, src, 1, "pf_cheb"));
+    PF_TRY(check_slots(g, dst, 1, "pf_cheb"));
+    const double* vals = op_values(g, op);
+    PF_CHECK(vals != nullptr && src != dst, PF_E_ARG, "pf_cheb: operator %d unavailable or src == dst", op);
+    PF_CHECK(degree >= 1 && e > 0.0, PF_E_ARG, "pf_cheb: degree %d / half-width %g invalid", degree, e);
+    OpTimer t(g->ctx, degree);
+    // y0 = src; y1 = (c y0 - A y0)/e; y_{k+1} = (2/e)(c y_k - A y_k) - y_{k-1}.
+    // y_{k+1} overwrites y_{k-1} element-wise (thread i reads prev[i] then writes out[i]); the last step lands in dst.
+    const double* y_prev = pf_slot(g, src);
+    double* bufs[2] = {pf_tmp(g, 0), pf_tmp(g, 1)};
+    double* d = pf_slot(g, dst);
+    double* y1 = degree == 1 ? d : bufs[0];
+    PF_TRY(launch_op(g, vals, y_prev, nullptr, y1, 1.0 / e, c, 0.0));
+    const double* y_cur = y1;
+    for (int32_t k = 2; k <= degree; ++k) {
+        double* target;
+        if (k == degree) target = d;
+        else if (k == 2) target = bufs[1];          // y0 is the caller's src: never overwrite it
+        else target = const_cast<double*>(y_prev);  // recycle y_{k-2}'s buffer
+        PF_TRY(launch_op(g, vals, y_cur, y_prev, target, 2.0 / e, c, 1.0));
+        y_prev = y_cur;
+        y_cur = target;
+    }
+    return t.finish();
+}
+
+int pf_dots(pf_graph* g, int32_t w, int32_t first, int32_t count, double* out) {
+    PF_TRY(check_slots(g, w, 1, "pf_dots"));
+    PF_TRY(check_slots(g, first, count, "pf_dots"));
+    PF_CHECK(out != nullptr, PF_E_ARG, "pf_dots: out is NULL");
+    if (count == 0) return PF_OK;
+    PF_TRY(pf_reduce_ensure(g, count));  // g->coef must exist before its address is taken
+    PF_TRY(dots_device(g, w, first, count, g->coef, nullptr, 0));
+    PF_HIP(hipMemcpyAsync(out, g->coef, sizeof(double) * count, hipMemcpyDeviceToHost, g->ctx->stream));
+    PF_HIP(hipStreamSynchronize(g->ctx->stream));
+    return PF_OK;
+}
+
+int pf_orth(pf_graph* g, int32_t w, int32_t first, int32_t count, double* h, double* nrm) {
+    PF_TRY(check_slots(g, w, 1, "pf_orth"));
+    PF_TRY(check_slots(g, first, count, "pf_orth"));
+    PF_CHECK(nrm != nullptr && (h != nullptr || count == 0), PF_E_ARG, "pf_orth: NULL output");
+    PF_CHECK(w < first || w >= first + count, PF_E_ARG, "pf_orth: w inside the basis range");
+    hipStream_t st = g->ctx->stream;
+    PF_TRY(pf_reduce_ensure(g, std::max(count, 1)));
+    const int32_t cap = g->coef_cap;
+    double* hpass = g->coef;            // coefficients of the current pass
+    double* hsum = g->coef + cap;       // h1 + h2
+    double* nrm2 = g->coef + 2 * cap;   // ||w||^2
+    if (count > 0) {
+        for (int pass = 0; pass < 2; ++pass) {
+            PF_TRY(dots_device(g, w, first, count, hpass, hsum, pass));
+            k_multi_axpy<<<nblk(g->n_pad / 2), PF_BLOCK, 0, st>>>(g->ws, g->n_pad, first, count, w, hpass);
+            PF_HIP(hipGetLastError());
+        }
+    }
+    PF_TRY(dots_device(g, w, w, 1, nrm2, nullptr, 0));
+    std::vector<double> host((size_t)count + 1);
+    if (count > 0) PF_HIP(hipMemcpyAsync(host.data(), hsum, sizeof(double) * count, hipMemcpyDeviceToHost, st));
+    PF_HIP(hipMemcpyAsync(host.data() + count, nrm2, sizeof(double), hipMemcpyDeviceToHost, st));
+    PF_HIP(hipStreamSynchronize(st));
+    for (int32_t b = 0; b < count; ++b) h[b] = host[b];
+    *nrm = sqrt(host[count] > 0.0 ? host[count] : 0.0);
+    return PF_OK;
+}
+
+int pf_scale(pf_graph* g, int32_t slot, double alpha) {
+    PF_TRY(check_slots(g, slot, 1, "pf_scale"));
+    k_scale<<<nblk(g->n_pad), PF_BLOCK, 0, g->ctx->stream>>>(pf_slot(g, slot), g->n_pad, alpha);
+    PF_HIP(hipGetLastError());
+    return PF_OK;
+}
+
+int pf_combine(pf_graph* g, int32_t src_first, int32_t m, const double* Y, int32_t k, int32_t dst_first) {
+    PF_TRY(check_slots(g, src_first, m, "pf_combine"));
+    PF_TRY(check_slots(g, dst_first, k, "pf_combine"));
+    PF_CHECK(Y != nullptr && m > 0 && k > 0, PF_E_ARG, "pf_combine: bad argument");
+    PF_CHECK(src_first + m <= dst_first || dst_first + k <= src_first, PF_E_ARG, "pf_combine: overlapping ranges");
+    hipStream_t st = g->ctx->stream;
+    double* dY = nullptr;
+    PF_HIP(hipMalloc((void**)&dY, sizeof(double) * (size_t)m * k));
+    hipError_t e = hipMemcpyAsync(dY, Y, sizeof(double) * (size_t)m * k, hipMemcpyHostToDevice, st);
+    for (int32_t c0 = 0; c0 < k && e == hipSuccess; c0 += COMBINE_COLS) {
+        const int32_t nc = std::min(COMBINE_COLS, k - c0);
+        k_combine<<<nblk(g->n_pad), PF_BLOCK, 0, st>>>(g->ws, g->n_pad, src_first, m, dY, k, c0, nc, dst_first);
+        e = hipGetLastError();
+    }
+    hipError_t e2 = hipStreamSynchronize(st);
+    hipFree(dY);
+    PF_HIP(e);
+    PF_HIP(e2);
+    return PF_OK;
+}
+
+int pf_resnorm(pf_graph* g, int32_t ax, int32_t x, double lam, double* out) {
+    PF_TRY(check_slots(g, ax, 1, "pf_resnorm"));
+    PF_TRY(check_slots(g, x, 1, "pf_resnorm"));
+    PF_CHECK(out != nullptr, PF_E_ARG, "pf_resnorm: out is NULL");
+    hipStream_t st = g->ctx->stream;
+    PF_TRY(pf_reduce_ensure(g, 1));
+    k_resnorm_partial<<<(unsigned)g->n_chunks, PF_BLOCK, 0, st>>>(pf_slot(g, ax), pf_slot(g, x), lam, g->n_pad, g->n_chunks, g->partials);
+    PF_HIP(hipGetLastError());
+    k_dot_finish<<<1, PF_WAVE, 0, st>>>(g->partials, g->n_chunks, g->coef, nullptr, 0);
+    PF_HIP(hipGetLastError());
+    double r2 = 0.0;
+    PF_HIP(hipMemcpyAsync(&r2, g->coef, sizeof(double), hipMemcpyDeviceToHost, st));
+    PF_HIP(hipStreamSynchronize(st));
+    *out = sqrt(r2 > 0.0 ? r2 : 0.0);
+    return PF_OK;
+}
+
+int pf_finalize_vectors(pf_graph* g, int32_t first, int32_t count, int32_t from_sym, int32_t minmax, double* out) {
+    PF_TRY(check_slots(g, first, count, "pf_finalize_vectors"));
+    PF_CHECK(out != nullptr && count > 0, PF_E_ARG, "pf_finalize_vectors: bad argument");
+    PF_CHECK(!from_sym || g->is_symmetric, PF_E_ARG, "pf_finalize_vectors: from_sym on an asymmetric graph");
+    hipStream_t st = g->ctx->stream;
+    PF_TRY(pf_reduce_ensure(g, count));
+    VecStats* part = reinterpret_cast<VecStats*>(g->partials);
+    VecStats* fin = part + (size_t)count * g->n_chunks;
+    dim3 grid((unsigned)g->n_chunks, (unsigned)count);
+    k_vec_stats_partial<<<grid, PF_BLOCK, 0, st>>>(g->ws, g->n_pad, g->n, first, g->sg, from_sym, g->n_chunks, part);
+    PF_HIP(hipGetLastError());
+    k_vec_stats_finish<<<(unsigned)count, PF_WAVE, 0, st>>>(part, g->n_chunks, fin);
+    PF_HIP(hipGetLastError());
+    std::vector<VecStats> hs((size_t)count);
+    PF_HIP(hipMemcpyAsync(hs.data(), fin, sizeof(VecStats) * count, hipMemcpyDeviceToHost, st));
+    PF_HIP(hipStreamSynchronize(st));
+    std::vector<double> params(4 * (size_t)count);
+    for (int32_t c = 0; c < count; ++c) {
+        const VecStats& s = hs[c];
+        PF_CHECK(s.sumsq > 0.0 && isfinite(s.sumsq), PF_E_STATE, "pf_finalize_vectors: vector %d has norm^2 %g", c, s.sumsq);
+        const double sgn = s.at_absmax < 0.0 ? -1.0 : 1.0;
+        const double scale = sgn / sqrt(s.sumsq);
+        const double vmin = (sgn > 0 ? s.vmin : s.vmax) * scale;  // monotone map: exact min/max of the scaled vector
+        const double vmax = (sgn > 0 ? s.vmax : s.vmin) * scale;
+        params[4 * c + 0] = scale;
+        params[4 * c + 1] = minmax ? vmin : 0.0;
+        params[4 * c + 2] = minmax ? (vmax - vmin) : 0.0;
+        params[4 * c + 3] = minmax ? 0.5 : 0.0;
+    }
+    double *d_params = nullptr, *d_out = nullptr;
+    PF_HIP(hipMalloc((void**)&d_params, sizeof(double) * params.size()));
+    hipError_t e = hipMalloc((void**)&d_out, sizeof(double) * (size_t)g->n * count);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_params, params.data(), sizeof(double) * params.size(), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) {
+        k_vec_apply<<<nblk(g->n), PF_BLOCK, 0, st>>>(g->ws, g->n_pad, g->n, first, count, g->sg, from_sym, d_params, d_out);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, sizeof(double) * (size_t)g->n * count, hipMemcpyDeviceToHost, st);
+    hipError_t e2 = hipStreamSynchronize(st);
+    hipFree(d_params);
+    hipFree(d_out);
+    PF_HIP(e);
+    PF_HIP(e2);
+    return PF_OK;
+}
+
+int pf_spmv_host(pf_graph* g, int32_t op, const double* x, double* y) {
+    PF_CHECK(g != nullptr && x != nullptr && y != nullptr, PF_E_ARG, "pf_spmv_host: NULL argument");
+    const double* vals = op_values(g, op);
+    PF_CHECK(vals != nullptr, PF_E_ARG, "pf_spmv_host: operator %d unavailable", op);
+    PF_TRY(pf_ws_ensure(g, 2));
+    PF_TRY(pf_ws_upload(g, 0, x));
+    PF_TRY(launch_op(g, vals, pf_slot(g, 0), nullptr, pf_slot(g, 1), -1.0, 0.0, 0.0));
+    return pf_ws_download(g, 1, 1, y);
+}
+
+int pf_mean_filter(pf_graph* g, const double* values, int32_t ncols, int32_t iterations, double* out) {
+    PF_CHECK(g != nullptr && values != nullptr && out != nullptr && ncols > 0 && iterations >= 0, PF_E_ARG,
+             "pf_mean_filter: bad argument");
+    hipStream_t st = g->ctx->stream;
+    const size_t bytes = sizeof(double) * (size_t)g->n * ncols;
+    double *a = nullptr, *b = nullptr;
+    PF_HIP(hipMalloc((void**)&a, bytes));
+    hipError_t e = hipMalloc((void**)&b, bytes);
+    if (e == hipSuccess) e = hipMemcpyAsync(a, values, bytes, hipMemcpyHostToDevice, st);
+    for (int32_t it = 0; it < iterations && e == hipSuccess; ++it) {
+        k_mean_filter<<<nblk(g->n), PF_BLOCK, 0, st>>>(g->rowptr, g->col, g->w, g->deg, g->n, ncols, a, b);
+        e = hipGetLastError();
+        std::swap(a, b);
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out, a, bytes, hipMemcpyDeviceToHost, st);
+    hipError_t e2 = hipStreamSynchronize(st);
+    hipFree(a);
+    hipFree(b);
+    PF_HIP(e);
+    PF_HIP(e2);
+    return PF_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,109 @@
+// Exclusive prefix sums (int32 / int64) used by the Laplacian assembler: row pointers from
+// per-vertex edge counts, SELL slice offsets from slice widths.  Three-phase scan: per-block
+// totals -> (recursive) scan of the totals -> per-block rescan with its offset.  Wave-level
+// scans use 64-lane shuffles; the four waves of a block meet through LDS.
+#include "pf_internal.h"
+
+namespace {
+
+constexpr int SCAN_ITEMS = 8;
+constexpr int SCAN_TILE = PF_BLOCK * SCAN_ITEMS;  // 2048 elements per block
+
+template <typename T>
+__device__ __forceinline__ T wave_inclusive_scan(T v, int lane) {
+#pragma unroll
+    for (int off = 1; off < PF_WAVE; off <<= 1) {
+        T up = __shfl_up(v, off, PF_WAVE);
+        if (lane >= off) v += up;
+    }
+    return v;
+}
+
+// exclusive scan of one value per thread over the 256-thread block; returns the block total via `total`
+template <typename T>
+__device__ __forceinline__ T block_exclusive_scan(T v, T* total) {
+    __shared__ T wave_sum[PF_BLOCK / PF_WAVE];
+    const int lane = threadIdx.x & (PF_WAVE - 1);
+    const int wid = threadIdx.x / PF_WAVE;
+    T inc = wave_inclusive_scan(v, lane);
+    if (lane == PF_WAVE - 1) wave_sum[wid] = inc;
+    __syncthreads();
+    T offset = 0, all = 0;
+#pragma unroll
+    for (int wv = 0; wv < PF_BLOCK / PF_WAVE; ++wv) {
+        T s = wave_sum[wv];
+        if (wv < wid) offset += s;
+        all += s;
+    }
+    __syncthreads();
+    *total = all;
+    return offset + inc - v;
+}
+
+template <typename T>
+__global__ __launch_bounds__(PF_BLOCK) void scan_block_totals(const T* __restrict__ in, T* __restrict__ totals, int64_t n) {
+    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+    T s = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        int64_t i = base + k;
+        if (i < n) s += in[i];
+    }
+    T total;
+    (void)block_exclusive_scan(s, &total);
+    if (threadIdx.x == 0) totals[blockIdx.x] = total;
+}
+
+template <typename T>
+__global__ __launch_bounds__(PF_BLOCK) void scan_block_apply(const T* __restrict__ in, T* __restrict__ out,
+                                                             const T* __restrict__ block_offset, int64_t n) {
+    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+    T v[SCAN_ITEMS];
+    T s = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        int64_t i = base + k;
+        v[k] = (i < n) ? in[i] : T(0);
+        s += v[k];
+    }
+    T total;
+    T run = block_exclusive_scan(s, &total) + (block_offset ? block_offset[blockIdx.x] : T(0));
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        int64_t i = base + k;
+        if (i < n) out[i] = run;
+        run += v[k];
+    }
+}
+
+template <typename T>
+int exclusive_scan(hipStream_t st, const T* in, T* out, int64_t n) {
+    if (n <= 0) return PF_OK;
+    const int64_t blocks = (n + SCAN_TILE - 1) / SCAN_TILE;
+    if (blocks == 1) {
+        scan_block_apply<T><<<1, PF_BLOCK, 0, st>>>(in, out, nullptr, n);
+        PF_HIP(hipGetLastError());
+        return PF_OK;
+    }
+    T* totals = nullptr;
+    PF_HIP(hipMalloc(&totals, sizeof(T) * blocks));
+    scan_block_totals<T><<<(unsigned)blocks, PF_BLOCK, 0, st>>>(in, totals, n);
+    PF_HIP(hipGetLastError());
+    int r = exclusive_scan<T>(st, totals, totals, blocks);
+    if (r == PF_OK) {
+        scan_block_apply<T><<<(unsigned)blocks, PF_BLOCK, 0, st>>>(in, out, totals, n);
+        if (hipGetLastError() != hipSuccess) r = PF_E_HIP;
+    }
+    hipStreamSynchronize(st);
+    hipFree(totals);
+    return r;
+}
+
+}  // namespace
+
+int pf_exclusive_scan_i32(hipStream_t st, const int32_t* in, int32_t* out, int64_t n) {
+    return exclusive_scan<int32_t>(st, in, out, n);
+}
+int pf_exclusive_scan_i64(hipStream_t st, const int64_t* in, int64_t* out, int64_t n) {
+    return exclusive_scan<int64_t>(st, in, out, n);
+}

@@ -1,0 +1,147 @@
+"""`eigsort` — order and sign-flip the eigenmaps of two graphs so they correspond.
+
+Drop-in mirror of `/root/reference/pyfocusr/eigsort.py` (`class eigsort` :9-249):
+same constructor, public cost matrices (`c_lambda`, `c_hist`, `c_hist_f`,
+`c_spatial`, `c_spatial_f`, `Q`) and in-place mutation of the non-reference
+graph's `eig_vecs` (its `eig_vals` are never permuted).
+
+Device work: the 3-D nearest-neighbour query of `calc_c_spatial`
+(eigsort.py:203-204, scipy KDTree in the reference) runs through `pf_knn1`.
+Everything else is k x k bookkeeping on <= n_rand_samples rows — eigenvalue
+costs, 2k^2 one-dimensional Wasserstein distances (sorts of m values; scipy, as
+in the reference), the Hungarian assignment on a k x k matrix — and stays on the
+host, as SURVEY.md §7 plans.
+"""
+import numpy as np
+from scipy.optimize import linear_sum_assignment
+from scipy.stats import wasserstein_distance
+
+from . import _hip
+from .main import print_header
+
+
+class eigsort(object):
+    def __init__(self, graph_target, graph_source, n_features, target_as_reference=True):
+        self.graph_target = graph_target
+        self.graph_source = graph_source
+        self.n_features = n_features
+        self.target_as_reference = target_as_reference
+
+        # eigsort.py:34-41
+        self.rand_target_points = self.graph_target.get_rand_normalized_points()
+        self.rand_source_points = self.graph_source.get_rand_normalized_points()
+        self.rand_target_eig_vecs = self.graph_target.get_rand_eig_vecs()
+        self.rand_source_eig_vecs = self.graph_source.get_rand_eig_vecs()
+
+        self.c_lambda = np.zeros((self.n_features, self.n_features))
+        self.c_hist = np.zeros_like(self.c_lambda)
+        self.c_hist_f = np.zeros_like(self.c_lambda)
+        self.c_spatial = np.zeros_like(self.c_lambda)
+        self.c_spatial_f = np.zeros_like(self.c_lambda)
+
+        self.Q = None
+        self.target_matches = None
+        self.source_matches = None
+        self.flipped_pairs = None
+        self.idx_source_for_each_target_pt = None
+        self.verbose = getattr(graph_target, "verbose", True)
+
+    def _ctx(self):
+        ctx = getattr(self.graph_target, "_ctx", None)
+        return ctx if ctx is not None else _hip.default_context()
+
+    def eigen_sort(self):
+        """eigsort.py:54-140."""
+        c = self.c_spatial * self.c_lambda * self.c_hist
+        c_f = self.c_spatial_f * self.c_lambda * self.c_hist_f
+        self.Q = np.min((c, c_f), axis=0)
+        S = c > c_f  # True where the FLIPPED pairing is cheaper
+        (target_flipped, source_flipped) = np.where(S == True)  # noqa: E712
+
+        if self.target_as_reference is True:
+            target_matches, source_matches = linear_sum_assignment(self.Q)
+        elif self.target_as_reference is False:
+            source_matches, target_matches = linear_sum_assignment(self.Q.T)
+        self.Q = self.Q[target_matches, source_matches]
+
+        flipped_pairs = [
+            p2
+            for p1 in zip(target_flipped, source_flipped)
+            for p2 in zip(target_matches, source_matches)
+            if p2 == p1
+        ]
+        for mode_0, mode_1 in flipped_pairs:
+            if self.target_as_reference is True:
+                self.graph_source.eig_vecs[:, mode_1] = self.graph_source.eig_vecs[:, mode_1] * -1
+            elif self.target_as_reference is False:
+                self.graph_target.eig_vecs[:, mode_0] = self.graph_target.eig_vecs[:, mode_0] * -1
+        if self.target_as_reference is True:
+            self.graph_source.eig_vecs[:, target_matches] = self.graph_source.eig_vecs[:, source_matches]
+        elif self.target_as_reference is False:
+            self.graph_target.eig_vecs[:, source_matches] = self.graph_target.eig_vecs[:, target_matches]
+        self.target_matches, self.source_matches = np.asarray(target_matches), np.asarray(source_matches)
+        self.flipped_pairs = flipped_pairs
+
+        if self.verbose:
+            print_header("Eigenvector Sorting Results")
+            if self.target_as_reference is True:
+                print("Using target eigenmaps as the reference")
+            elif self.target_as_reference is False:
+                print("Using source eigenmaps as the reference")
+            print("The matches for eigenvectors were as follows:")
+            print("Target\t|  Source")
+            for matched_pair in zip(target_matches, source_matches):
+                source_value = str(matched_pair[1])
+                target_value = str(matched_pair[0])
+                if matched_pair in flipped_pairs:
+                    if self.target_as_reference is True:
+                        source_value = "-" + source_value
+                    elif self.target_as_reference is False:
+                        target_value = "-" + target_value
+                print("{:6}\t|  {:6}".format(target_value, source_value))
+            print("*Negative source values means those eigenvectors were flipped*\n ")
+
+    def calc_c_lambda(self):
+        """eigsort.py:142-160."""
+        for graph in [self.graph_source, self.graph_target]:
+            if graph.eig_val_gap is None:
+                graph.get_eig_val_gap()
+        eigen_gap = (self.graph_target.eig_val_gap + self.graph_source.eig_val_gap) / 2
+        for i in range(self.n_features):
+            for j in range(self.n_features):
+                self.c_lambda[i, j] = np.exp(
+                    (self.graph_target.eig_vals[i] - self.graph_source.eig_vals[j]) ** 2 / (2 * eigen_gap**2)
+                )
+
+    def calc_c_hist(self):
+        """eigsort.py:162-189."""
+        eps = np.finfo(float).eps
+        log_t = [np.log(self.rand_target_eig_vecs[:, i] + 0.5 + eps) for i in range(self.n_features)]
+        log_s = [np.log(self.rand_source_eig_vecs[:, j] + 0.5 + eps) for j in range(self.n_features)]
+        log_sf = [np.log(-self.rand_source_eig_vecs[:, j] + 0.5 + eps) for j in range(self.n_features)]
+        for i in range(self.n_features):
+            for j in range(self.n_features):
+                self.c_hist[i, j] = wasserstein_distance(log_t[i], log_s[j])
+                self.c_hist_f[i, j] = wasserstein_distance(log_t[i], log_sf[j])
+
+    def calc_c_spatial(self):
+        """eigsort.py:191-233; the KDTree query runs on the GPU."""
+        idx = self._ctx().knn1(self.rand_source_points, self.rand_target_points)
+        self.idx_source_for_each_target_pt = idx
+        m = self.rand_target_eig_vecs.shape[0]
+        for i in range(self.n_features):
+            for j in range(self.n_features):
+                self.c_spatial[i, j] = (
+                    np.sqrt(np.sum((self.rand_source_eig_vecs[idx, j] - self.rand_target_eig_vecs[:, i]) ** 2)) / m
+                )
+                self.c_spatial_f[i, j] = (
+                    np.sqrt(np.sum((-self.rand_source_eig_vecs[idx, j] - self.rand_target_eig_vecs[:, i]) ** 2)) / m
+                )
+
+    def sort_eigenmaps(self):
+        """eigsort.py:235-249."""
+        self.calc_c_lambda()
+        self.calc_c_hist()
+        self.calc_c_spatial()
+        self.eigen_sort()
+        return self.Q

@@ -1,0 +1,317 @@
+"""`Focusr` — orchestration shell around the MI355X spectral hot path.
+
+Mirror of `/root/reference/pyfocusr/focusr.py` (`class Focusr` :22-807): the
+constructor takes the same arguments in the same order (target mesh first) with
+the same defaults, builds both graphs and their spectra eagerly (:134-170), and
+`align_maps()` (:514-568) runs eigenmap sorting -> spectral coordinates ->
+[CPD registration] -> nearest-neighbour correspondence -> [smoothing].
+
+On the device: Laplacian assembly + eigensolve (`Graph`), the 3-D NN of `eigsort`,
+`get_kd_correspondence` (focusr.py:351-353 -> `pf_knn1`) and the graph mean
+filter behind `get_smoothed_correspondences` (focusr.py:368-396).
+
+Outside the hot path, kept as thin shells:
+* ICP pre-alignment (:110-131) and VTK mesh outputs need the `vtk` package;
+* CPD registration (:297-334) is the third-party `cycpd` package: used when
+  importable, otherwise `registration` may be injected as a callable
+  `(source_coords, target_coords, kind) -> new_target_coords`, and when neither
+  is available the step is skipped with a notice;
+* Hungarian point correspondence (:340-349, O(N^3)) and the 3-NN weighted final
+  locations (:401-426) are not implemented.
+"""
+import numpy as np
+
+from . import _hip
+from .eigsort import eigsort
+from .graph import Graph
+from .main import print_header
+from .vtk_functions import PolyMesh, apply_transform, icp_transform, vtk_deep_copy
+
+try:  # pragma: no cover - not installed in the build image
+    import cycpd
+except Exception:  # noqa: BLE001
+    cycpd = None
+
+__all__ = ["Focusr"]
+
+
+class Focusr(object):
+    def __init__(
+        self,
+        vtk_mesh_target,
+        vtk_mesh_source,
+        icp_register_first=True,
+        icp_registration_mode="rigid",
+        icp_reg_target_to_source=False,
+        n_spectral_features=3,
+        n_extra_spectral=3,
+        target_eigenmap_as_reference=True,
+        norm_physical_and_spectral=True,
+        n_coords_spectral_ordering=5000,
+        n_coords_spectral_registration=5000,
+        rigid_before_non_rigid_reg=True,
+        rigid_reg_max_iterations=100,
+        rigid_tolerance=1e-8,
+        non_rigid_max_iterations=1000,
+        non_rigid_tolerance=1e-8,
+        non_rigid_alpha=0.5,
+        non_rigid_beta=3.0,
+        non_rigid_n_eigens=100,
+        include_points_as_features=False,
+        get_weighted_spectral_coords=True,
+        graph_smoothing_iterations=300,
+        feature_smoothing_iterations=40,
+        smooth_correspondences=True,
+        return_average_final_points=True,
+        return_nearest_final_points=True,
+        return_transformed_mesh=True,
+        projection_smooth_iterations=40,
+        feature_weights=None,
+        initial_correspondence_type="kd",
+        final_correspondence_type="kd",
+        list_features_to_calc=["curvature"],
+        list_features_to_get_from_mesh=[],
+        use_features_as_coords=False,
+        use_features_in_graph=False,
+        include_features_in_adj_matrix=False,
+        G_matrix_p_function="exp",
+        norm_node_features_std=True,
+        norm_node_features_cap_std=3,
+        norm_node_features_0_1=True,
+        verbose=False,
+        registration=None,
+        ctx=None,
+    ):
+        self.verbose = verbose
+        self._ctx = ctx if ctx is not None else _hip.default_context()
+        self.registration = registration
+        print("Starting Focusr")
+        self.n_spectral_features = n_spectral_features
+        self.n_extra_spectral = n_extra_spectral
+        self.n_total_spectral_features = self.n_spectral_features + self.n_extra_spectral
+        self.target_eigenmap_as_reference = target_eigenmap_as_reference
+
+        self.norm_physical_and_spectral = norm_physical_and_spectral
+        self.include_points_as_features = include_points_as_features
+        self.get_weighted_spectral_coords = get_weighted_spectral_coords
+        self.feature_smoothing_iterations = feature_smoothing_iterations
+        self.n_coords_spectral_registration = n_coords_spectral_registration
+        self.rigid_before_non_rigid_reg = rigid_before_non_rigid_reg
+        self.rigid_reg_max_iterations = rigid_reg_max_iterations
+        self.rigid_tolerance = rigid_tolerance
+        self.non_rigid_max_iterations = non_rigid_max_iterations
+        self.non_rigid_tolerance = non_rigid_tolerance
+        self.non_rigid_alpha = non_rigid_alpha
+        self.non_rigid_beta = non_rigid_beta
+        self.non_rigid_n_eigens = non_rigid_n_eigens
+        self.initial_correspondence_type = initial_correspondence_type
+        self.smooth_correspondences = smooth_correspondences
+        self.return_average_final_points = return_average_final_points
+        self.return_nearest_final_points = return_nearest_final_points
+        self.graph_smoothing_iterations = graph_smoothing_iterations
+        self.projection_smooth_iterations = projection_smooth_iterations
+        self.final_correspondence_type = final_correspondence_type
+        self.return_transformed_mesh = return_transformed_mesh
+
+        for kind in (initial_correspondence_type, final_correspondence_type):
+            if kind == "hungarian":
+                raise NotImplementedError("Hungarian point correspondence (focusr.py:340-349) is O(N^3) on the host "
+                                          "and outside the MI355X hot path; use 'kd'")
+            if kind != "kd":
+                raise ValueError("correspondence type must be 'kd'")
+        if return_average_final_points:
+            raise NotImplementedError("3-NN weighted final locations (focusr.py:401-426) are not implemented yet; "
+                                      "pass return_average_final_points=False")
+
+        print("Starting ICP")
+        self._icp_transform = None
+        if icp_register_first is True:  # focusr.py:110-131 (VTK C++)
+            if icp_reg_target_to_source is True:
+                icp = icp_transform(target=vtk_mesh_source, source=vtk_mesh_target, transform_mode=icp_registration_mode)
+                vtk_mesh_target = apply_transform(source=vtk_mesh_target, transform=icp)
+            else:
+                icp = icp_transform(target=vtk_mesh_target, source=vtk_mesh_source, transform_mode=icp_registration_mode)
+                vtk_mesh_source = apply_transform(source=vtk_mesh_source, transform=icp)
+            self._icp_transform = icp
+
+        graph_kw = dict(
+            n_spectral_features=self.n_total_spectral_features,
+            n_rand_samples=n_coords_spectral_ordering,
+            list_features_to_calc=list_features_to_calc,
+            list_features_to_get_from_mesh=list_features_to_get_from_mesh,
+            feature_weights=feature_weights,
+            include_features_in_G_matrix=use_features_in_graph,
+            include_features_in_adj_matrix=include_features_in_adj_matrix,
+            G_matrix_p_function=G_matrix_p_function,
+            norm_node_features_std=norm_node_features_std,
+            norm_node_features_cap_std=norm_node_features_cap_std,
+            norm_node_features_0_1=norm_node_features_0_1,
+            ctx=self._ctx,
+        )
+        print("Starting to build first graph")
+        self.graph_target = Graph(vtk_mesh_target, **graph_kw)
+        print("Loaded Mesh 1")
+        self.graph_target.get_graph_spectrum()
+        print("Computed spectrum 1")
+        self.graph_source = Graph(vtk_mesh_source, **graph_kw)
+        print("Loaded Mesh 2")
+        self.graph_source.get_graph_spectrum()
+        print("Computed spectrum 2")
+
+        self.Q = None
+        self.spec_weights = None
+        self.spectral_weights = None
+        self.source_spectral_coords = None
+        self.target_spectral_coords = None
+        self.source_extra_features = None
+        self.target_extra_features = None
+        self.use_features_as_coords = use_features_as_coords
+        self.source_spectral_coords_after_rigid = None
+        self.source_spectral_coords_b4_reg = None
+        self.rigid_params = None
+        self.non_rigid_params = None
+        self.smoothed_target_coords = None
+        self.source_projected_on_target = None
+        self.weighted_avg_transformed_mesh = None
+        self.nearest_neighbour_transformed_mesh = None
+        self.corresponding_target_idx_for_each_source_pt = None
+        self.nearest_neighbor_transformed_points = None
+        self.weighted_avg_transformed_points = None
+        self.average_mesh = None
+
+    # ------------------------------------------------------------------ point sets
+    def append_pts_to_spectral_coords(self):
+        """focusr.py:271-295."""
+        if self.norm_physical_and_spectral is True:
+            self.source_spectral_coords = np.concatenate(
+                (self.source_spectral_coords, self.graph_source.normed_points), axis=1)
+            self.target_spectral_coords = np.concatenate(
+                (self.target_spectral_coords, self.graph_target.normed_points), axis=1)
+        elif self.norm_physical_and_spectral is False:
+            self.source_spectral_coords = np.concatenate(
+                (self.source_spectral_coords * self.graph_source.mean_pts_scale_range, self.graph_source.points), axis=1)
+            self.target_spectral_coords = np.concatenate(
+                (self.target_spectral_coords * self.graph_target.mean_pts_scale_range, self.graph_target.points), axis=1)
+
+    def register_target_to_source(self, reg_type="deformable"):
+        """focusr.py:297-334: CPD moves the TARGET cloud onto the source (X=source, Y=target)."""
+        X = self.source_spectral_coords[self.graph_source.get_list_rand_idxs(self.n_coords_spectral_registration), :]
+        Y = self.target_spectral_coords[self.graph_target.get_list_rand_idxs(self.n_coords_spectral_registration), :]
+        if self.registration is not None:
+            self.target_spectral_coords = np.asarray(
+                self.registration(self.source_spectral_coords, self.target_spectral_coords, reg_type))
+            return
+        if cycpd is None:
+            print("cycpd is not installed: skipping the %s CPD registration of spectral coordinates" % reg_type)
+            return
+        if reg_type == "deformable":
+            reg = cycpd.deformable_registration(
+                **{"X": X, "Y": Y, "num_eig": self.non_rigid_n_eigens, "max_iterations": self.non_rigid_max_iterations,
+                   "tolerance": self.non_rigid_tolerance, "alpha": self.non_rigid_alpha, "beta": self.non_rigid_beta,
+                   "verbose": self.verbose})
+            _, self.non_rigid_params = reg.register()
+        elif reg_type == "affine":
+            reg = cycpd.affine_registration(
+                **{"X": X, "Y": Y, "max_iterations": self.rigid_reg_max_iterations, "tolerance": self.rigid_tolerance})
+            _, self.rigid_params = reg.register()
+        self.target_spectral_coords = reg.transform_point_cloud(self.target_spectral_coords)
+
+    # ------------------------------------------------------------------ correspondences
+    def get_kd_correspondence(self, target_pts, spectral_pts):
+        """focusr.py:351-353: nearest target point of every source point, on the GPU."""
+        self.corresponding_target_idx_for_each_source_pt = self._ctx.knn1(target_pts, spectral_pts)
+
+    def get_initial_correspondences(self):
+        """focusr.py:355-366."""
+        self.get_kd_correspondence(self.target_spectral_coords, self.source_spectral_coords)
+
+    def get_smoothed_correspondences(self):
+        """focusr.py:368-396 (mean filters and the second NN query on the device)."""
+        self.smoothed_target_coords = self.graph_target.mean_filter_graph(
+            self.graph_target.points, iterations=self.graph_smoothing_iterations)
+        self.source_projected_on_target = self.graph_source.mean_filter_graph(
+            self.smoothed_target_coords[self.corresponding_target_idx_for_each_source_pt, :],
+            iterations=self.projection_smooth_iterations)
+        self.get_kd_correspondence(self.smoothed_target_coords, self.source_projected_on_target)
+
+    def get_nearest_neighbour_final_node_locations(self):
+        """focusr.py:428-431."""
+        self.nearest_neighbor_transformed_points = self.graph_target.points[
+            self.corresponding_target_idx_for_each_source_pt, :]
+
+    def get_source_mesh_transformed_nearest_neighbour(self):
+        """focusr.py:615-625 for `PolyMesh` inputs (VTK inputs go through `vtk_deep_copy`)."""
+        mesh = self.graph_source.vtk_mesh
+        if isinstance(mesh, PolyMesh):
+            self.nearest_neighbour_transformed_mesh = PolyMesh(
+                self.nearest_neighbor_transformed_points, mesh.faces.copy(), list(mesh.point_data))
+            return
+        self.nearest_neighbour_transformed_mesh = vtk_deep_copy(mesh)
+        points = self.nearest_neighbour_transformed_mesh.GetPoints()
+        for i in range(self.graph_source.n_points):
+            points.SetPoint(i, self.nearest_neighbor_transformed_points[i])
+
+    # ------------------------------------------------------------------ spectral weighting (focusr.py:459-508)
+    def calc_c_weighting_spectral(self):
+        self.spectral_weights = self.Q[: self.n_spectral_features] * np.max(
+            (self.graph_source.eig_vals[: self.n_spectral_features],
+             self.graph_target.eig_vals[: self.n_spectral_features]), axis=0)
+        sigma = np.mean(self.spectral_weights)
+        self.spectral_weights = np.exp(-(self.spectral_weights**2) / (2 * sigma**2))
+        self.spec_weights = self.spectral_weights  # the reference initialises this name
+
+    def calc_weighted_spectral_coords(self):
+        self.calc_c_weighting_spectral()
+        self.source_spectral_coords = (
+            self.graph_source.eig_vecs[:, : self.n_spectral_features] * self.spectral_weights[None, :])
+        self.target_spectral_coords = (
+            self.graph_target.eig_vecs[:, : self.n_spectral_features] * self.spectral_weights[None, :])
+
+    def calc_spectral_coords(self):
+        if self.get_weighted_spectral_coords is True:
+            self.calc_weighted_spectral_coords()
+        elif self.get_weighted_spectral_coords is False:
+            self.source_spectral_coords = self.graph_source.eig_vecs[:, : self.n_spectral_features]
+            self.target_spectral_coords = self.graph_target.eig_vecs[:, : self.n_spectral_features]
+
+    # ------------------------------------------------------------------ align_maps (focusr.py:514-568)
+    def align_maps(self):
+        eig_map_sorter = eigsort(
+            graph_target=self.graph_target,
+            graph_source=self.graph_source,
+            n_features=self.n_total_spectral_features,
+            target_as_reference=self.target_eigenmap_as_reference,
+        )
+        self.Q = eig_map_sorter.sort_eigenmaps()
+        self.calc_spectral_coords()
+
+        if self.include_points_as_features is True:
+            self.append_pts_to_spectral_coords()
+
+        self.source_spectral_coords_b4_reg = np.copy(self.source_spectral_coords)
+        print("Number of features (including spectral) used for registartion: {}".format(
+            self.target_spectral_coords.shape[1]))
+
+        if self.rigid_before_non_rigid_reg is True:
+            print_header("Rigid Registration Beginning!")
+            self.register_target_to_source(reg_type="affine")
+            self.source_spectral_coords_after_rigid = np.copy(self.source_spectral_coords)
+        print_header("Non-Rigid (Deformable) Registration Beginning")
+        self.register_target_to_source("deformable")
+
+        self.get_initial_correspondences()
+        print("Number of unique correspondences: {}".format(
+            len(np.unique(self.corresponding_target_idx_for_each_source_pt))))
+        if self.smooth_correspondences is True:
+            self.get_smoothed_correspondences()
+            print("Number of unique correspondences after smoothing: {}".format(
+                len(np.unique(self.corresponding_target_idx_for_each_source_pt))))
+        if self.return_nearest_final_points is True:
+            self.get_nearest_neighbour_final_node_locations()
+            if self.return_transformed_mesh is True:
+                self.get_source_mesh_transformed_nearest_neighbour()
+
+    @property
+    def icp_transform(self):
+        """focusr.py:797-807."""
+        return self._icp_transform

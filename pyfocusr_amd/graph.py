@@ -1,0 +1,280 @@
+"""`Graph` — mesh -> weighted adjacency -> degree -> random-walk Laplacian ->
+lowest-k non-null eigenpairs -> min-max-normalised spectral coordinates.
+
+Drop-in mirror of `/root/reference/pyfocusr/graph.py` (`class Graph` :18-354,
+`recursive_eig` :357-389): same constructor arguments, methods and attribute
+names, so `eigsort` / `Focusr` / user code written against the reference keep
+working.  The arithmetic runs on an MI355X through `libpyfocusr_hip.so`:
+
+* `get_weighted_adjacency_matrix / get_degree_matrix / get_G_matrix /
+  get_laplacian_matrix` (graph.py:148-226)  -> `pf_graph_build` (one call builds
+  all of them on the device; the scipy attributes are host views of its output,
+  bit-identical to the reference's matrices);
+* `recursive_eig` -> scipy `eigs` ARPACK shift-invert (graph.py:372)  ->
+  Chebyshev-filtered Krylov-Schur on the device (`_krylov.filtered_eigs`), with
+  the reference's `> 1e-10` null filter and `k += k_buffer + n_k_needed` widening
+  rule reproduced from the number of connected components;
+* eigenvector normalisation (graph.py:254-257) -> `pf_finalize_vectors`;
+* `mean_filter_graph` (graph.py:320-354) -> `pf_mean_filter`.
+
+Deliberate strengthenings: `feature_weights=None` works
+(A1); eigenpairs are returned sorted ascending with a deterministic sign —
+largest-|entry| positive (A5); `get_list_rand_idxs(force_randomization=True)`
+uses `np.random.shuffle` (A7).  Extra node features (curvature, point-data
+arrays; graph.py:85-119,166-175,191-210) need VTK and are outside the hot path:
+non-empty feature lists raise `NotImplementedError`.
+"""
+import numpy as np
+from scipy import sparse
+
+from . import _hip
+from ._krylov import MIN_EIG_VAL, filtered_eigs
+from .vtk_functions import mesh_arrays, vtk_deep_copy  # noqa: F401
+
+__all__ = ["Graph", "recursive_eig"]
+
+
+class _DeviceBackedCSR(sparse.csr_matrix):
+    """scipy CSR view of the device Laplacian that remembers the device graph, so
+    `recursive_eig(graph.laplacian_matrix, ...)` can run on the GPU."""
+
+    _pf_device = None
+
+
+def _widened_k(k, n_k_needed, k_buffer, n_null, n_max):
+    """graph.py:374-379: ARPACK is asked for k pairs; those <= 1e-10 are dropped;
+    while fewer than n_k_needed remain, k += k_buffer + n_k_needed."""
+    retries = 0
+    while k - n_null < n_k_needed and k + k_buffer + n_k_needed < n_max:
+        k += k_buffer + n_k_needed
+        retries += 1
+    return k, retries
+
+
+class Graph(object):
+    def __init__(
+        self,
+        vtk_mesh,
+        n_spectral_features=3,
+        norm_eig_vecs=True,
+        n_rand_samples=10000,
+        list_features_to_calc=[],
+        list_features_to_get_from_mesh=[],
+        feature_weights=None,
+        include_features_in_adj_matrix=False,
+        include_features_in_G_matrix=False,
+        G_matrix_p_function="exp",
+        norm_node_features_std=True,
+        norm_node_features_cap_std=3,
+        norm_node_features_0_1=True,
+        ctx=None,
+        verbose=True,
+    ):
+        # Inputs (graph.py:36-55)
+        self.vtk_mesh = vtk_mesh
+        self.n_spectral_features = n_spectral_features
+        self.norm_eig_vecs = norm_eig_vecs
+        self.include_features_in_adj_matrix = include_features_in_adj_matrix
+        self.include_features_in_G_matrix = include_features_in_G_matrix
+        self.G_matrix_p_function = G_matrix_p_function
+        self.norm_node_features_std = norm_node_features_std
+        self.norm_node_features_cap_std = norm_node_features_cap_std
+        self.norm_node_features_0_1 = norm_node_features_0_1
+        self.verbose = verbose
+        self._ctx = ctx
+
+        if len(list_features_to_calc) or len(list_features_to_get_from_mesh):
+            raise NotImplementedError(
+                "extra node features (graph.py:85-119) need VTK and are outside the MI355X hot path; "
+                "pass list_features_to_calc=[] and list_features_to_get_from_mesh=[]")
+        self.node_features = []
+        self.n_extra_features = 0
+        self.mean_xyz_range_scaled_features = []
+        self.feature_weights = np.eye(self.n_extra_features) if feature_weights is None else feature_weights
+
+        # Mesh/points characteristics (graph.py:58-67)
+        self.points, self._faces = mesh_arrays(vtk_mesh)
+        self.n_points = int(self.points.shape[0])
+        self.pts_scale_range = np.ptp(self.points, axis=0)
+        self.max_pts_scale_range = np.max(self.pts_scale_range)
+        self.mean_pts_scale_range = np.mean(self.pts_scale_range)
+        self.normed_points = (self.points - np.min(self.points, axis=0)) / self.mean_pts_scale_range
+
+        # Matrices (graph.py:70-76): filled from the device graph on demand.
+        self._device = None
+        self._host = None
+        self._adjacency_matrix = None
+        self.degree_matrix = None
+        self.degree_matrix_inv = None
+        self.laplacian_matrix = None
+        self.G = None
+
+        self.eig_vals = None
+        self.eig_vecs = None
+        self.eig_val_gap = None
+        self.eigs_stats = None
+        self.rand_idxs = self.get_list_rand_idxs(n_rand_samples)
+
+    # ------------------------------------------------------------------ device graph
+    @property
+    def device(self):
+        """The `DeviceLaplacian` of this mesh (built on first use)."""
+        if self._device is None:
+            self._device = _hip.DeviceLaplacian(self.points, self._faces, ctx=self._ctx)
+        return self._device
+
+    def _host_arrays(self):
+        if self._host is None:
+            self._host = self.device.download()
+        return self._host
+
+    @property
+    def adjacency_matrix(self):
+        if self._adjacency_matrix is None:
+            return sparse.lil_matrix((self.n_points, self.n_points))  # graph.py:70-72 (empty until computed)
+        return self._adjacency_matrix
+
+    @adjacency_matrix.setter
+    def adjacency_matrix(self, value):
+        self._adjacency_matrix = value
+
+    def norm_node_features(self, norm_using_std=True, norm_range_0_to_1=True, cap_std=3):
+        """graph.py:121-142 (no features on the hot path: nothing to do)."""
+        return None
+
+    # ------------------------------------------------------------------ matrices (graph.py:148-226)
+    def get_weighted_adjacency_matrix(self):
+        h = self._host_arrays()
+        n = self.n_points
+        self._adjacency_matrix = sparse.csr_matrix((h["w"], h["colidx"], h["rowptr"]), shape=(n, n))
+
+    def get_degree_matrix(self):
+        h = self._host_arrays()
+        self.degree_matrix = sparse.diags(h["deg"])
+        self.degree_matrix_inv = sparse.diags((h["deg"] + 1e-8) ** -1)
+
+    def get_G_matrix(self, p_function="exp"):
+        if self.degree_matrix_inv is None:
+            self.get_degree_matrix()
+        self.G = self.degree_matrix_inv  # graph.py:213-214 (no extra features)
+
+    def get_laplacian_matrix(self):
+        if self.G is None:
+            self.get_G_matrix()
+        h = self._host_arrays()
+        n = self.n_points
+        rowptr = h["rowptr"].astype(np.int64)
+        cnt = np.diff(rowptr)
+        has_diag = cnt > 0  # scipy drops the explicit zero diagonal of isolated vertices
+        rows = np.repeat(np.arange(n), cnt)
+        below = np.zeros(n + 1, dtype=np.int64)  # entries of row i with column < i
+        np.add.at(below, rows[h["colidx"] < rows] + 1, 1)
+        new_ptr = rowptr + np.concatenate([[0], np.cumsum(has_diag)])
+        nnz = int(new_ptr[-1])
+        data = np.empty(nnz)
+        idx = np.empty(nnz, dtype=np.int32)
+        diag_pos = new_ptr[:-1] + below[1:]
+        pos_in_row = np.arange(len(rows)) - rowptr[rows]
+        shift = (h["colidx"] > rows).astype(np.int64)
+        dest = new_ptr[rows] + pos_in_row + shift
+        data[dest] = h["l_offdiag"]
+        idx[dest] = h["colidx"]
+        data[diag_pos[has_diag]] = h["l_diag"][has_diag]
+        idx[diag_pos[has_diag]] = np.arange(n, dtype=np.int32)[has_diag]
+        L = _DeviceBackedCSR((data, idx, new_ptr.astype(np.int32)), shape=(n, n))
+        L._pf_device = self.device
+        self.laplacian_matrix = L
+
+    # ------------------------------------------------------------------ spectrum (graph.py:228-257)
+    def get_graph_spectrum(self):
+        dev = self.device
+        if self.verbose:
+            print("Beginning Eigen Decomposition")
+        self.eig_vals, self.eig_vecs, self.eigs_stats = _device_eigs(
+            dev,
+            k=self.n_spectral_features + 1,
+            n_k_needed=self.n_spectral_features,
+            k_buffer=1,
+            minmax=self.norm_eig_vecs is True,
+            verbose=self.verbose,
+        )
+        if self.verbose:
+            print("All final eigenvalues are: \n{}".format(self.eig_vals))
+            print("-" * 72)
+            print("Final eigenvalues of interest are: \n{}".format(self.eig_vals))
+
+    # ------------------------------------------------------------------ samplers (graph.py:263-290)
+    def get_eig_val_gap(self):
+        self.eig_val_gap = np.mean(np.diff(self.eig_vals))
+
+    def get_rand_eig_vecs(self):
+        return self.eig_vecs[self.rand_idxs, :]
+
+    def get_rand_normalized_points(self):
+        return (
+            self.points[self.rand_idxs, :] - np.min(self.points[self.rand_idxs, :], axis=0)
+        ) / np.ptp(self.points[self.rand_idxs, :], axis=0)
+
+    def get_list_rand_idxs(self, n_rand_samples, replace=False, force_randomization=False):
+        if n_rand_samples > self.n_points:
+            list_points = np.arange(self.n_points)
+            if force_randomization is True:
+                np.random.shuffle(list_points)
+            return list_points
+        return np.random.choice(self.n_points, size=n_rand_samples, replace=replace)
+
+    # ------------------------------------------------------------------ viewers (graph.py:296-314)
+    def _no_viewer(self, *a, **k):
+        raise ImportError("itkwidgets viewers are not part of the MI355X hot path")
+
+    view_mesh_existing_scalars = view_mesh_eig_vec = view_mesh_features = _no_viewer
+
+    # ------------------------------------------------------------------ graph filter (graph.py:320-354)
+    def mean_filter_graph(self, values, iterations=300):
+        """out = ((D+I)^-1 (W+I))^iterations values, on the device."""
+        return self.device.mean_filter(np.asarray(values, dtype=np.float64), iterations)
+
+
+def _device_eigs(dev, k, n_k_needed, k_buffer=1, minmax=False, verbose=False, **solver_kw):
+    """`recursive_eig` on a device graph.  Returns (eig_vals ascending, eig_vecs
+    (n, m), stats) with m = k_final - (#null eigenvalues) >= n_k_needed, exactly
+    the column count the reference's widen-and-retry loop ends with."""
+    n = dev.n
+    n_null = dev.n_components + dev.n_isolated
+    if verbose:
+        print("Starting!")
+    while True:
+        k_final, retries = _widened_k(k, n_k_needed, k_buffer, n_null, n)
+        if verbose:
+            for _ in range(retries):
+                print("Not enough eigenvalues found, trying again with more eigenvalues!")
+                print("Starting!")
+        m_out = max(min(k_final - n_null, n - n_null), 0)
+        if m_out == 0:
+            return np.zeros(0), np.zeros((n, 0)), None
+        c0 = dev.lock_null_vectors()
+        lam, first, stats = filtered_eigs(dev, m_out, dev.symmetric, null_slots=c0, **solver_kw)
+        extra_null = stats.n_null - c0
+        if extra_null > 0 and len(lam) < m_out:  # a null vector the component count did not predict
+            n_null += extra_null
+            continue
+        break
+    vecs = dev.finalize_vectors(first, len(lam), minmax)
+    return lam, vecs, stats
+
+
+def recursive_eig(matrix, k, n_k_needed, k_buffer=1, sigma=1e-10, which="LM"):
+    """graph.py:357-389 for a Laplacian produced by `Graph.get_laplacian_matrix()`.
+
+    The reference hands a scipy matrix to ARPACK; here the matrix must carry its
+    device graph (`Graph.laplacian_matrix` does).  `sigma`/`which` select ARPACK's
+    shift-invert mode in the reference and have no counterpart here: the
+    eigenvalues nearest zero are always the ones computed.  Returns raw
+    (un-normalised, unit-2-norm) eigenvectors, sorted ascending."""
+    dev = getattr(matrix, "_pf_device", None)
+    if dev is None:
+        raise NotImplementedError(
+            "recursive_eig needs a Laplacian built by pyfocusr_amd.Graph (device-resident); "
+            "arbitrary scipy matrices are not uploaded")
+    vals, vecs, _ = _device_eigs(dev, k, n_k_needed, k_buffer, minmax=False, verbose=True)
+    return vals, vecs

@@ -1,0 +1,103 @@
+"""TEST DOUBLE (CPU) for the device-ops object the Krylov driver talks to.
+
+Implements the same method surface as `pyfocusr_amd._hip.DeviceLaplacian` with
+numpy/scipy so that the host logic in `pyfocusr_amd/_krylov.py` can be exercised
+by `-m "not gpu"` tests in a container without a GPU.  Lives under `tests/` and is
+never imported by the product package (the product fails loudly without the HIP
+library)."""
+import numpy as np
+from scipy import sparse
+from scipy.sparse.csgraph import connected_components
+
+
+class NumpyOps(object):
+    def __init__(self, W):
+        """W: scipy CSR weighted adjacency (directed set semantics)."""
+        n = W.shape[0]
+        self.n = n
+        self.W = W.tocsr()
+        deg = np.asarray(self.W @ np.ones((n, 1)))[:, 0]
+        self.deg = deg
+        g = 1.0 / (deg + 1e-8)
+        self.g = g
+        self.isolated = deg == 0
+        self.n_isolated = int(self.isolated.sum())
+        self.symmetric = abs(self.W - self.W.T).nnz == 0
+        K = sparse.diags(deg) - self.W
+        self.L = (sparse.diags(g) @ K).tocsr()
+        s = np.sqrt(g)
+        self.s = s
+        self.S = (sparse.diags(s) @ K @ sparse.diags(s)).tocsr() if self.symmetric else None
+        self.A = self.S if self.symmetric else self.L
+        self.ws = np.zeros((n, 0), order="F")
+        ncomp, labels = connected_components(self.W + self.W.T, directed=False)
+        self.labels = labels
+        self.launches = 0
+
+    # -- workspace
+    def ws_ensure(self, nslots):
+        if self.ws.shape[1] < nslots:
+            new = np.zeros((self.n, nslots), order="F")
+            new[:, : self.ws.shape[1]] = self.ws
+            self.ws = new
+
+    def upload(self, slot, x):
+        self.ws[:, slot] = x
+
+    def download(self, first, count):
+        return np.array(self.ws[:, first : first + count])
+
+    def copy(self, src, dst, count):
+        self.ws[:, dst : dst + count] = self.ws[:, src : src + count].copy()
+
+    def mask_isolated(self, slot):
+        self.ws[self.isolated, slot] = 0.0
+
+    # -- null vectors of the iterated operator, one per non-trivial component
+    def lock_null_vectors(self):
+        comps = [c for c in np.unique(self.labels) if np.sum(self.labels == c) > 1]
+        self.ws_ensure(len(comps) + 1)
+        for i, c in enumerate(comps):
+            v = (self.labels == c).astype(np.float64)
+            if self.symmetric:
+                v = v * np.sqrt(self.deg + 1e-8)
+            self.ws[:, i] = v / np.linalg.norm(v)
+        return len(comps)
+
+    # -- operator applications
+    def spmv(self, src, dst):
+        self.ws[:, dst] = self.A @ self.ws[:, src]
+        self.launches += 1
+
+    def cheb(self, src, dst, p, c, e):
+        A = self.A
+        y0 = self.ws[:, src]
+        y1 = (c * y0 - A @ y0) / e
+        for _ in range(p - 1):
+            y0, y1 = y1, (2.0 / e) * (c * y1 - A @ y1) - y0
+        self.ws[:, dst] = y1
+        self.launches += p
+
+    # -- vector kernels
+    def dots(self, w, first, count):
+        return self.ws[:, first : first + count].T @ self.ws[:, w]
+
+    def orth(self, w, first, count):
+        V = self.ws[:, first : first + count]
+        x = self.ws[:, w]
+        h1 = V.T @ x
+        x = x - V @ h1
+        h2 = V.T @ x
+        x = x - V @ h2
+        self.ws[:, w] = x
+        return h1 + h2, float(np.linalg.norm(x))
+
+    def scale(self, slot, alpha):
+        self.ws[:, slot] *= alpha
+
+    def combine(self, src_first, m, Y, dst_first):
+        Y = np.asarray(Y, dtype=np.float64)
+        self.ws[:, dst_first : dst_first + Y.shape[1]] = self.ws[:, src_first : src_first + m] @ Y
+
+    def resnorm(self, ax, x, lam):
+        return float(np.linalg.norm(self.ws[:, ax] - lam * self.ws[:, x]))
