@@ -1,0 +1,260 @@
+#!/usr/bin/env python3
+"""Benchmark of the spectral hot path on MI355X (contract: see the build brief).
+
+One "step" = one pass of the hot path over one synthetic mesh pair (BASELINE.json config C3:
+250k-vertex closed-manifold blobs, seeds 2r / 2r+1 on rank r, k = 5):
+    for target and source:  Laplacian assembly (inputs resident in HBM)  ->  lowest-k non-null
+                            eigenpairs (Chebyshev-filtered Krylov-Schur)  ->  normalised eigenvectors
+    eigsort (sign/order, 3-D NN on 5000 samples)  ->  weighted spectral coordinates
+    1-NN of every source vertex among the target vertices (d = k)
+metric value = eigenpairs per second = (2 k) / step time, whole job (sum over ranks).
+
+N > 1 ranks: every rank owns an independent mesh pair (the unit that shards with no data-path
+collective: template-to-many-targets pipelines) -> weak scaling.  With exactly 2 ranks the C4
+layout is measured in addition (one pair split target/source over the two GPUs, RCCL all-gather
+of the spectral coordinates, query-sharded KNN) and reported under "split_pair".
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+METRIC = "lowest-k eigenpairs/sec + KNN-correspondence wall-clock, 250k-vertex mesh pair k=5"
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md)
+
+
+def spmv_algorithmic_bytes(n, nnz_l):
+    """y = L x moves 12*nnz + 20*n + 4 bytes (f64 values, i32 columns,
+    row pointers, x once, y once), nnz counted with the diagonal."""
+    return 12 * nnz_l + 20 * n + 4
+
+
+def hot_path_step(ctx, mesh_t, mesh_s, k, n_samples, timers):
+    """Same calls as Focusr.__init__ + align_maps (focusr.py:134-170, 514-545) without ICP/CPD."""
+    from pyfocusr_amd import Graph, eigsort
+
+    graphs = []
+    for mesh in (mesh_t, mesh_s):
+        t0 = time.perf_counter()
+        g = Graph(mesh, n_spectral_features=k, n_rand_samples=n_samples, ctx=ctx, verbose=False)
+        _ = g.device  # assembly from the resident mesh
+        ctx.sync()
+        t1 = time.perf_counter()
+        g.get_graph_spectrum()
+        t2 = time.perf_counter()
+        timers["assembly"] += t1 - t0
+        timers["eigensolve"] += t2 - t1
+        graphs.append(g)
+    gt, gs = graphs
+    t0 = time.perf_counter()
+    Q = eigsort(gt, gs, k, target_as_reference=True).sort_eigenmaps()
+    w = Q[:k] * np.max((gs.eig_vals[:k], gt.eig_vals[:k]), axis=0)  # focusr.py:481-490
+    w = np.exp(-(w**2) / (2 * np.mean(w) ** 2))
+    src, tgt = gs.eig_vecs[:, :k] * w[None, :], gt.eig_vecs[:, :k] * w[None, :]
+    t1 = time.perf_counter()
+    idx = ctx.knn1(tgt, src)  # focusr.py:351-353
+    t2 = time.perf_counter()
+    timers["eigsort"] += t1 - t0
+    timers["knn"] += t2 - t1
+    timers["matvecs"] += gt.eigs_stats.matvecs + gs.eigs_stats.matvecs
+    res = max(gt.eigs_stats.residuals.max(), gs.eigs_stats.residuals.max())
+    for g in graphs:
+        g.device.close()
+    return idx, res, (gt.device.nnz_l, gs.device.nnz_l)
+
+
+def cpu_baseline(mesh_t, mesh_s, k, n_samples, knn_sample):
+    """The oracle (reference calls restated: scipy eigs shift-invert + KDTree, 1 thread, exactly as
+    the reference issues them) on a bounded sample of the same workload: ONE of the two
+    eigensolves and `knn_sample` of the n queries, scaled to the pair."""
+    from oracle import reference_port as orc
+
+    t0 = time.perf_counter()
+    W, deg, d_inv, L = orc.graph_matrices(mesh_t.points, mesh_t.faces)
+    t_asm = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    vals, vecs = orc.recursive_eig(L, k + 1, k)
+    t_eigs = time.perf_counter() - t0
+    vals, vecs = orc.canonicalize(vals, vecs)
+    coords = orc.minmax_normalize(vecs)[:, :k]
+    rng = np.random.default_rng(0)
+    q = coords[rng.choice(len(coords), knn_sample, replace=False)] + 1e-3 * rng.standard_normal((knn_sample, k))
+    from scipy.spatial import KDTree
+
+    t0 = time.perf_counter()
+    tree = KDTree(coords)
+    t_tree = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    tree.query(q)
+    t_query = time.perf_counter() - t0
+    n = len(coords)
+    t_pair = 2 * (t_asm + t_eigs) + t_tree + t_query * (n / knn_sample)
+    return dict(value=2 * k / t_pair, unit="eigenpairs/s", cores=1, kind="port",
+                sample="1 of 2 meshes: vectorised assembly %.2fs + scipy eigs(sigma=1e-10, ncv=4(k+1)) %.2fs; KDTree build "
+                       "%.2fs + query of %d/%d source points %.2fs (scaled x%.0f); pair estimate %.1fs"
+                       % (t_asm, t_eigs, t_tree, knn_sample, n, t_query, n / knn_sample, t_pair),
+                pair_seconds=t_pair)
+
+
+def split_pair_step(ctx, dist, torch, rank, mesh, k, n_samples):
+    """BASELINE config C4: rank 0 = target, rank 1 = source; all-gather of the normalised
+    eigenvectors (n x k f64) over RCCL/xGMI; eigsort replicated (k x k work); KNN sharded by
+    source rows; indices gathered on rank 0."""
+    from pyfocusr_amd import Graph, eigsort
+    from pyfocusr_amd.parallel import gather_spectral, shard_rows
+
+    g = Graph(mesh, n_spectral_features=k, n_rand_samples=n_samples, ctx=ctx, verbose=False)
+    g.get_graph_spectrum()
+    vals, vecs, pts = gather_spectral(dist, torch, g.eig_vals, g.eig_vecs, g.points)
+    graphs = []
+    for r in range(2):
+        h = Graph.__new__(Graph)
+        h.points, h.n_points, h.eig_vals, h.eig_vecs = pts[r], len(pts[r]), vals[r], vecs[r].copy()
+        h.eig_val_gap, h.verbose, h._ctx = None, False, ctx
+        np.random.seed(1234)  # identical sample on both ranks
+        h.rand_idxs = h.get_list_rand_idxs(n_samples)
+        graphs.append(h)
+    gt, gs = graphs
+    Q = eigsort(gt, gs, k, target_as_reference=True).sort_eigenmaps()
+    w = Q[:k] * np.max((gs.eig_vals[:k], gt.eig_vals[:k]), axis=0)
+    w = np.exp(-(w**2) / (2 * np.mean(w) ** 2))
+    src, tgt = gs.eig_vecs[:, :k] * w[None, :], gt.eig_vecs[:, :k] * w[None, :]
+    lo, hi = shard_rows(len(src), 2, rank)
+    part = ctx.knn1(tgt, src[lo:hi])
+    out = [torch.empty(shard_rows(len(src), 2, r)[1] - shard_rows(len(src), 2, r)[0], dtype=torch.int64, device="cuda")
+           for r in range(2)]
+    dist.all_gather(out, torch.from_numpy(part).cuda())
+    g.device.close()
+    return torch.cat(out).cpu().numpy()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n", type=int, default=250000, help="vertices per mesh")
+    ap.add_argument("--k", type=int, default=5)
+    ap.add_argument("--samples", type=int, default=5000, help="n_coords_spectral_ordering (focusr.py:37)")
+    ap.add_argument("--cpu-knn-sample", type=int, default=25000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+
+    import torch
+
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    from pyfocusr_amd import _hip
+    from pyfocusr_amd.meshgen import blob_mesh
+
+    ctx = _hip.Context(local)
+    ctx.timing_enable(True)
+    mesh_t, mesh_s = blob_mesh(args.n, seed=2 * rank), blob_mesh(args.n, seed=2 * rank + 1)
+    for m in (mesh_t, mesh_s):
+        m._pf_device_mesh = _hip.DeviceMesh(m.points, m.faces, ctx=ctx)  # inputs resident in HBM
+
+    def barrier():
+        ctx.sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    timers = dict(assembly=0.0, eigensolve=0.0, eigsort=0.0, knn=0.0, matvecs=0)
+    np.random.seed(1234 + rank)
+    for _ in range(args.warmup):
+        hot_path_step(ctx, mesh_t, mesh_s, args.k, args.samples, timers)
+    for key in timers:
+        timers[key] = 0
+    ctx.timing(reset=True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        idx, max_res, nnz = hot_path_step(ctx, mesh_t, mesh_s, args.k, args.samples, timers)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    tm = ctx.timing()
+
+    split = None
+    if world == 2:
+        for it in range(2):  # one warm-up, one timed
+            barrier()
+            s0 = time.perf_counter()
+            split_pair_step(ctx, dist, torch, rank, mesh_t if rank == 0 else mesh_s, args.k, args.samples)
+            barrier()
+            split_s = time.perf_counter() - s0
+        t = torch.tensor([split_s], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        split = dict(workload="C4: one %d-vertex pair, target on GPU0 / source on GPU1, RCCL all-gather of spectral "
+                              "coordinates, query-sharded KNN" % args.n, ms=1e3 * float(t.item()),
+                     eigenpairs_per_s=2 * args.k / float(t.item()), scaling="strong")
+
+    if rank == 0:
+        n = args.n
+        kernel_us = 1e3 * tm["op_ms"] / max(tm["op_launches"], 1)
+        alg_bytes = spmv_algorithmic_bytes(n, nnz[0])
+        achieved = alg_bytes / (kernel_us * 1e-6) / 1e9
+        traffic = None
+        pmc = os.path.join(REPO, "profiles", "pmc_summary.json")
+        if os.path.exists(pmc):
+            with open(pmc) as fh:
+                traffic = json.load(fh).get("k_sell_op_hbm_bytes_per_launch")
+        out = {
+            "metric": METRIC,
+            "value": world * 2 * args.k * args.steps / elapsed,
+            "unit": "eigenpairs/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "C3: synthetic %d-vertex closed-manifold blob mesh pair per GPU (seeds 2r/2r+1), k=%d: "
+                                   "assembly + eigensolve x2, eigsort, 1-NN correspondence" % (n, args.k),
+                       "n_vertices": n, "n_faces": 2 * n - 4, "k": args.k, "parallelism": "%d independent pair(s)" % world},
+            "breakdown_ms_per_step": {key: 1e3 * timers[key] / args.steps
+                                      for key in ("assembly", "eigensolve", "eigsort", "knn")},
+            "matvecs_per_step": timers["matvecs"] / args.steps,
+            "knn_kernel_ms": tm["knn_ms"],
+            "max_eig_residual": float(max_res),
+            "roofline": {"bound": "hbm", "kernel": "k_sell_op (fused SpMV + Chebyshev recurrence, SELL-64, f64)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
+                         "avg_launch_us_hip_events": kernel_us, "launches": tm["op_launches"]},
+        }
+        if split is not None:
+            out["split_pair"] = split
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(mesh_t, mesh_s, args.k, args.samples, min(args.cpu_knn_sample, n))
+            out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

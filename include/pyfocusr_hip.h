@@ -40,6 +40,7 @@ extern "C" {
 
 typedef struct pf_ctx pf_ctx;
 typedef struct pf_graph pf_graph;
+typedef struct pf_mesh pf_mesh; /* points + faces resident in HBM */
 
 typedef struct pf_graph_info {
     int64_t n;             /* vertices */
@@ -81,6 +82,11 @@ int pf_timing_get(pf_ctx* ctx, pf_timing* out, int reset);
  * connected-component labels. */
 int pf_graph_build(pf_ctx* ctx, const double* pts, int64_t n, const int32_t* faces, int64_t n_faces,
                    int32_t verts_per_face, pf_graph** out);
+/* the same in two steps: host -> HBM copy of the mesh, then assembly from resident inputs */
+int pf_mesh_upload(pf_ctx* ctx, const double* pts, int64_t n, const int32_t* faces, int64_t n_faces,
+                   int32_t verts_per_face, pf_mesh** out);
+void pf_mesh_free(pf_mesh* mesh);
+int pf_graph_build_device(pf_mesh* mesh, pf_graph** out);
 void pf_graph_free(pf_graph* g);
 int pf_graph_get_info(pf_graph* g, pf_graph_info* out);
 /* CSR(W): rowptr[n+1], colidx[nnz_w], w[nnz_w]; l_offdiag[nnz_w] = -w/(deg_i+1e-8);

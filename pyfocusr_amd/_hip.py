@@ -54,6 +54,9 @@ SIGNATURES = {
     "pf_timing_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "pf_timing_get": (C.c_int, [C.c_void_p, C.POINTER(Timing), C.c_int]),
     "pf_graph_build": (C.c_int, [C.c_void_p, _f64p, C.c_int64, _i32p, C.c_int64, C.c_int32, C.POINTER(C.c_void_p)]),
+    "pf_mesh_upload": (C.c_int, [C.c_void_p, _f64p, C.c_int64, _i32p, C.c_int64, C.c_int32, C.POINTER(C.c_void_p)]),
+    "pf_mesh_free": (None, [C.c_void_p]),
+    "pf_graph_build_device": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "pf_graph_free": (None, [C.c_void_p]),
     "pf_graph_get_info": (C.c_int, [C.c_void_p, C.POINTER(GraphInfo)]),
     "pf_graph_download": (C.c_int, [C.c_void_p, _i32p, _i32p, _f64p, _f64p, _f64p, _f64p, _i32p]),
@@ -208,9 +211,8 @@ def default_context(device=None):
     return _default_ctx[device]
 
 
-class DeviceLaplacian(object):
-    """Device-resident graph of one mesh: CSR(W), deg, SELL-64 operators, workspace.
-    Also the `ops` object the Krylov driver (`_krylov.filtered_eigs`) drives."""
+class DeviceMesh(object):
+    """points (n,3) f64 + faces (F,v) i32 resident in HBM (input side of the assembler)."""
 
     def __init__(self, points, faces, ctx=None):
         self.ctx = ctx if ctx is not None else default_context()
@@ -220,8 +222,43 @@ class DeviceLaplacian(object):
         if f.ndim != 2:
             raise ValueError("faces must be (F, verts_per_face)")
         h = C.c_void_p()
-        _check(self._lib.pf_graph_build(self.ctx._h, _f64(pts), pts.shape[0], f.ctypes.data_as(_i32p), f.shape[0],
+        _check(self._lib.pf_mesh_upload(self.ctx._h, _f64(pts), pts.shape[0], f.ctypes.data_as(_i32p), f.shape[0],
                                         f.shape[1] if f.shape[0] else 3, C.byref(h)))
+        self._h = h
+        self.n, self.n_faces = pts.shape[0], f.shape[0]
+        _live_graphs.add(self)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.pf_mesh_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+
+class DeviceLaplacian(object):
+    """Device-resident graph of one mesh: CSR(W), deg, SELL-64 operators, workspace.
+    Also the `ops` object the Krylov driver (`_krylov.filtered_eigs`) drives."""
+
+    def __init__(self, points=None, faces=None, ctx=None, device_mesh=None):
+        h = C.c_void_p()
+        if device_mesh is not None:
+            self.ctx = device_mesh.ctx
+            self._lib = self.ctx._lib
+            _check(self._lib.pf_graph_build_device(device_mesh._h, C.byref(h)))
+        else:
+            self.ctx = ctx if ctx is not None else default_context()
+            self._lib = self.ctx._lib
+            pts = _c_f64(points).reshape(-1, 3)
+            f = np.ascontiguousarray(faces, dtype=np.int32)
+            if f.ndim != 2:
+                raise ValueError("faces must be (F, verts_per_face)")
+            _check(self._lib.pf_graph_build(self.ctx._h, _f64(pts), pts.shape[0], f.ctypes.data_as(_i32p), f.shape[0],
+                                            f.shape[1] if f.shape[0] else 3, C.byref(h)))
         self._h = h
         _live_graphs.add(self)
         info = GraphInfo()

@@ -287,12 +287,66 @@ void pf_graph_free(pf_graph* g) {
     delete g;
 }
 
+struct pf_mesh {
+    pf_ctx* ctx = nullptr;
+    double* pts = nullptr;    // [n][3]
+    int32_t* faces = nullptr; // [n_faces][vpf]
+    int64_t n = 0, n_faces = 0;
+    int32_t vpf = 0;
+};
+
+int pf_mesh_upload(pf_ctx* ctx, const double* pts, int64_t n, const int32_t* faces, int64_t n_faces, int32_t vpf,
+                   pf_mesh** out) {
+    PF_CHECK(ctx && pts && out && (faces || n_faces == 0), PF_E_ARG, "pf_mesh_upload: NULL argument");
+    PF_CHECK(n > 0 && n < (int64_t)1 << 31, PF_E_ARG, "pf_mesh_upload: n = %lld out of range", (long long)n);
+    PF_CHECK(n_faces >= 0 && vpf >= 2 && n_faces * vpf < (int64_t)1 << 31, PF_E_ARG,
+             "pf_mesh_upload: faces %lld x %d out of range", (long long)n_faces, vpf);
+    *out = nullptr;
+    PF_HIP(hipSetDevice(ctx->device));
+    pf_mesh* m = new pf_mesh();
+    m->ctx = ctx;
+    m->n = n;
+    m->n_faces = n_faces;
+    m->vpf = vpf;
+    int r = dev_alloc(&m->pts, 3 * n);
+    if (r == PF_OK) r = dev_alloc(&m->faces, n_faces * vpf);
+    hipError_t e = hipSuccess;
+    if (r == PF_OK) e = hipMemcpyAsync(m->pts, pts, sizeof(double) * 3 * n, hipMemcpyHostToDevice, ctx->stream);
+    if (r == PF_OK && e == hipSuccess && n_faces)
+        e = hipMemcpyAsync(m->faces, faces, sizeof(int32_t) * n_faces * vpf, hipMemcpyHostToDevice, ctx->stream);
+    if (r == PF_OK && e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (r != PF_OK || e != hipSuccess) {
+        if (e != hipSuccess) pf_set_error("pf_mesh_upload: %s", hipGetErrorString(e));
+        pf_mesh_free(m);
+        return r != PF_OK ? r : PF_E_HIP;
+    }
+    *out = m;
+    return PF_OK;
+}
+
+void pf_mesh_free(pf_mesh* m) {
+    if (!m) return;
+    hipFree(m->pts);
+    hipFree(m->faces);
+    delete m;
+}
+
 int pf_graph_build(pf_ctx* ctx, const double* pts, int64_t n, const int32_t* faces, int64_t n_faces,
                    int32_t vpf, pf_graph** out) {
-    PF_CHECK(ctx && pts && out && (faces || n_faces == 0), PF_E_ARG, "pf_graph_build: NULL argument");
-    PF_CHECK(n > 0 && n < (int64_t)1 << 31, PF_E_ARG, "pf_graph_build: n = %lld out of range", (long long)n);
-    PF_CHECK(n_faces >= 0 && vpf >= 2 && n_faces * vpf < (int64_t)1 << 31, PF_E_ARG,
-             "pf_graph_build: faces %lld x %d out of range", (long long)n_faces, vpf);
+    PF_CHECK(out != nullptr, PF_E_ARG, "pf_graph_build: out is NULL");
+    *out = nullptr;
+    pf_mesh* m = nullptr;
+    PF_TRY(pf_mesh_upload(ctx, pts, n, faces, n_faces, vpf, &m));
+    int r = pf_graph_build_device(m, out);
+    pf_mesh_free(m);
+    return r;
+}
+
+int pf_graph_build_device(pf_mesh* mesh, pf_graph** out) {
+    PF_CHECK(mesh && out, PF_E_ARG, "pf_graph_build_device: NULL argument");
+    pf_ctx* ctx = mesh->ctx;
+    const int64_t n = mesh->n, n_faces = mesh->n_faces;
+    const int32_t vpf = mesh->vpf;
     *out = nullptr;
     PF_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
@@ -322,14 +376,12 @@ int pf_graph_build(pf_ctx* ctx, const double* pts, int64_t n, const int32_t* fac
         return r;
     };
 
-    double* d_pts = nullptr;
-    int32_t* d_faces = nullptr;
+    const double* d_pts = mesh->pts;
+    const int32_t* d_faces = mesh->faces;
     int32_t *cnt = nullptr, *start = nullptr, *cursor = nullptr, *rcol = nullptr, *ucnt = nullptr, *flags = nullptr;
     double* rw = nullptr;
     int64_t* width64 = nullptr;
     int32_t* d_roots = nullptr;
-    PF_TRY(scratch(&d_pts, 3 * n));
-    PF_TRY(scratch(&d_faces, n_edges));
     PF_TRY(scratch(&cnt, n + 1));
     PF_TRY(scratch(&start, n + 1));
     PF_TRY(scratch(&cursor, n + 1));
@@ -347,8 +399,6 @@ int pf_graph_build(pf_ctx* ctx, const double* pts, int64_t n, const int32_t* fac
     PF_TRY(dev_alloc(&g->label, g->n_pad));
     PF_TRY(dev_alloc(&g->slice_ptr, g->n_slices + 1));
 
-    PF_HIP(hipMemcpyAsync(d_pts, pts, sizeof(double) * 3 * n, hipMemcpyHostToDevice, st));
-    if (n_edges) PF_HIP(hipMemcpyAsync(d_faces, faces, sizeof(int32_t) * n_edges, hipMemcpyHostToDevice, st));
     PF_HIP(hipMemsetAsync(cnt, 0, sizeof(int32_t) * (n + 1), st));
     PF_HIP(hipMemsetAsync(cursor, 0, sizeof(int32_t) * (n + 1), st));
     PF_HIP(hipMemsetAsync(ucnt, 0, sizeof(int32_t) * (n + 1), st));

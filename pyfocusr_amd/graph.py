@@ -120,7 +120,11 @@ class Graph(object):
     def device(self):
         """The `DeviceLaplacian` of this mesh (built on first use)."""
         if self._device is None:
-            self._device = _hip.DeviceLaplacian(self.points, self._faces, ctx=self._ctx)
+            resident = getattr(self.vtk_mesh, "_pf_device_mesh", None)  # inputs already in HBM (bench, pipelines)
+            if resident is not None:
+                self._device = _hip.DeviceLaplacian(device_mesh=resident)
+            else:
+                self._device = _hip.DeviceLaplacian(self.points, self._faces, ctx=self._ctx)
         return self._device
 
     def _host_arrays(self):
