@@ -191,11 +191,15 @@ __global__ __launch_bounds__(PF_BLOCK) void k_collect_roots(const int32_t* __res
 }
 
 // ---- SELL-64 ----------------------------------------------------------------------------------
-__global__ __launch_bounds__(PF_BLOCK) void k_slice_widths(const int32_t* __restrict__ rowptr, int64_t n,
+__global__ __launch_bounds__(PF_BLOCK) void k_slice_widths(const int32_t* __restrict__ rowptr,
+                                                           const int32_t* __restrict__ perm, int64_t n,
                                                            int64_t n_slices, int64_t* __restrict__ width64) {
-    const int64_t row = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
+    const int64_t row = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;  // renumbered row
     int32_t c = 0;
-    if (row < n) c = rowptr[row + 1] - rowptr[row];
+    if (row < n) {
+        const int32_t old = perm[row];
+        c = rowptr[old + 1] - rowptr[old];
+    }
 #pragma unroll
     for (int off = PF_WAVE / 2; off > 0; off >>= 1) c = max(c, __shfl_xor(c, off, PF_WAVE));
     const int64_t s = row / PF_WAVE;
@@ -205,7 +209,8 @@ __global__ __launch_bounds__(PF_BLOCK) void k_slice_widths(const int32_t* __rest
 __global__ __launch_bounds__(PF_BLOCK) void k_fill_sell(const int32_t* __restrict__ rowptr,
                                                         const int32_t* __restrict__ col, const double* __restrict__ w,
                                                         const double* __restrict__ deg, const double* __restrict__ g,
-                                                        const double* __restrict__ sg, int64_t n, int64_t n_pad,
+                                                        const double* __restrict__ sg, const int32_t* __restrict__ perm,
+                                                        const int32_t* __restrict__ iperm, int64_t n, int64_t n_pad,
                                                         const int64_t* __restrict__ slice_ptr, int32_t* __restrict__ scol,
                                                         double* __restrict__ sval_rw, double* __restrict__ sval_sym,
                                                         double* __restrict__ diag) {
@@ -218,11 +223,12 @@ __global__ __launch_bounds__(PF_BLOCK) void k_fill_sell(const int32_t* __restric
     int32_t b = 0, cnt = 0;
     double gi = 0.0, si = 0.0;
     if (row < n) {
-        b = rowptr[row];
-        cnt = rowptr[row + 1] - b;
-        gi = g[row];
-        si = sg[row];
-        diag[row] = gi * deg[row];  // L_ii = g_i deg_i  (graph.py:226)
+        const int32_t old = perm[row];
+        b = rowptr[old];
+        cnt = rowptr[old + 1] - b;
+        gi = g[old];
+        si = sg[old];
+        diag[row] = gi * deg[old];  // L_ii = g_i deg_i  (graph.py:226)
     } else {
         diag[row] = 0.0;
     }
@@ -231,7 +237,7 @@ __global__ __launch_bounds__(PF_BLOCK) void k_fill_sell(const int32_t* __restric
         if (j < cnt) {
             const int32_t c = col[b + j];
             const double wv = w[b + j];
-            scol[idx] = c;
+            scol[idx] = iperm[c];
             sval_rw[idx] = -(gi * wv);  // L_ij = g_i * (0 - W_ij)
             if (sval_sym) sval_sym[idx] = -(wv * (si * sg[c]));
         } else {
@@ -248,6 +254,12 @@ __global__ __launch_bounds__(PF_BLOCK) void k_l_offdiag(const int32_t* __restric
     if (i >= n) return;
     const double gi = g[i];
     for (int32_t a = rowptr[i]; a < rowptr[i + 1]; ++a) out[a] = -(gi * w[a]);
+}
+
+__global__ __launch_bounds__(PF_BLOCK) void k_l_diag(const double* __restrict__ deg, const double* __restrict__ g, int64_t n,
+                                                     double* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
+    if (i < n) out[i] = g[i] * deg[i];
 }
 
 inline unsigned nblk(int64_t n) { return (unsigned)((n + PF_BLOCK - 1) / PF_BLOCK); }
@@ -276,6 +288,9 @@ void pf_graph_free(pf_graph* g) {
     hipFree(g->g);
     hipFree(g->sg);
     hipFree(g->label);
+    hipFree(g->perm);
+    hipFree(g->iperm);
+    hipFree(g->stage);
     hipFree(g->slice_ptr);
     hipFree(g->scol);
     hipFree(g->sval_rw);
@@ -397,6 +412,8 @@ int pf_graph_build_device(pf_mesh* mesh, pf_graph** out) {
     PF_TRY(dev_alloc(&g->sg, g->n_pad));
     PF_TRY(dev_alloc(&g->diag, g->n_pad));
     PF_TRY(dev_alloc(&g->label, g->n_pad));
+    PF_TRY(dev_alloc(&g->perm, g->n_pad));
+    PF_TRY(dev_alloc(&g->iperm, g->n_pad));
     PF_TRY(dev_alloc(&g->slice_ptr, g->n_slices + 1));
 
     PF_HIP(hipMemsetAsync(cnt, 0, sizeof(int32_t) * (n + 1), st));
@@ -457,8 +474,9 @@ int pf_graph_build_device(pf_mesh* mesh, pf_graph** out) {
     k_collect_roots<<<nblk(n), PF_BLOCK, 0, st>>>(g->label, g->rowptr, n, d_roots, stats + 4);
     PF_HIP(hipGetLastError());
 
-    // SELL-64
-    k_slice_widths<<<nblk(g->n_pad), PF_BLOCK, 0, st>>>(g->rowptr, n, g->n_slices, width64);
+    // solver-internal renumbering (Morton order, degree-sorted windows), then SELL-64 in that order
+    PF_TRY(pf_compute_order(g, d_pts));
+    k_slice_widths<<<nblk(g->n_pad), PF_BLOCK, 0, st>>>(g->rowptr, g->perm, n, g->n_slices, width64);
     PF_HIP(hipGetLastError());
     PF_HIP(hipMemsetAsync(width64 + g->n_slices, 0, sizeof(int64_t), st));
     PF_TRY(pf_exclusive_scan_i64(st, width64, g->slice_ptr, g->n_slices + 1));
@@ -482,7 +500,7 @@ int pf_graph_build_device(pf_mesh* mesh, pf_graph** out) {
     PF_TRY(dev_alloc(&g->scol, g->sell_entries));
     PF_TRY(dev_alloc(&g->sval_rw, g->sell_entries));
     if (g->is_symmetric) PF_TRY(dev_alloc(&g->sval_sym, g->sell_entries));
-    k_fill_sell<<<nblk(g->n_pad), PF_BLOCK, 0, st>>>(g->rowptr, g->col, g->w, g->deg, g->g, g->sg, n, g->n_pad,
+    k_fill_sell<<<nblk(g->n_pad), PF_BLOCK, 0, st>>>(g->rowptr, g->col, g->w, g->deg, g->g, g->sg, g->perm, g->iperm, n, g->n_pad,
                                                      g->slice_ptr, g->scol, g->sval_rw, g->sval_sym, g->diag);
     PF_HIP(hipGetLastError());
     PF_HIP(hipEventRecord(ctx->ev1, st));
@@ -520,7 +538,19 @@ int pf_graph_download(pf_graph* g, int32_t* rowptr, int32_t* colidx, double* w, 
     if (colidx && g->nnz_w) PF_HIP(hipMemcpyAsync(colidx, g->col, sizeof(int32_t) * g->nnz_w, hipMemcpyDeviceToHost, st));
     if (w && g->nnz_w) PF_HIP(hipMemcpyAsync(w, g->w, sizeof(double) * g->nnz_w, hipMemcpyDeviceToHost, st));
     if (deg) PF_HIP(hipMemcpyAsync(deg, g->deg, sizeof(double) * g->n, hipMemcpyDeviceToHost, st));
-    if (l_diag) PF_HIP(hipMemcpyAsync(l_diag, g->diag, sizeof(double) * g->n, hipMemcpyDeviceToHost, st));
+    double* tmp_diag = nullptr;
+    if (l_diag) {  // g->diag is stored in solver order: rebuild g_i deg_i in mesh order
+        PF_HIP(hipMalloc((void**)&tmp_diag, sizeof(double) * g->n));
+        k_l_diag<<<nblk(g->n), PF_BLOCK, 0, st>>>(g->deg, g->g, g->n, tmp_diag);
+        hipError_t ed = hipGetLastError();
+        if (ed == hipSuccess) ed = hipMemcpyAsync(l_diag, tmp_diag, sizeof(double) * g->n, hipMemcpyDeviceToHost, st);
+        if (ed != hipSuccess) {
+            hipStreamSynchronize(st);
+            hipFree(tmp_diag);
+            pf_set_error("pf_graph_download: %s", hipGetErrorString(ed));
+            return PF_E_HIP;
+        }
+    }
     if (component_label) PF_HIP(hipMemcpyAsync(component_label, g->label, sizeof(int32_t) * g->n, hipMemcpyDeviceToHost, st));
     if (l_offdiag && g->nnz_w) {
         PF_HIP(hipMalloc((void**)&tmp, sizeof(double) * g->nnz_w));
@@ -536,6 +566,7 @@ int pf_graph_download(pf_graph* g, int32_t* rowptr, int32_t* colidx, double* w, 
     }
     hipError_t e = hipStreamSynchronize(st);
     if (tmp) hipFree(tmp);
+    if (tmp_diag) hipFree(tmp_diag);
     PF_HIP(e);
     return PF_OK;
 }

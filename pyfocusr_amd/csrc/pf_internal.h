@@ -71,6 +71,12 @@ struct pf_graph {
     double* g = nullptr;    // 1/(deg+1e-8)
     double* sg = nullptr;   // sqrt(g)
     int32_t* label = nullptr; // component root per vertex
+    // solver-internal renumbering (pf_reorder.hip): operator storage and workspace vectors live in
+    // "new" order; everything that crosses the C-ABI is in the mesh's own ("old") order.
+    int32_t* perm = nullptr;  // [n_pad] new -> old, -1 on padding rows
+    int32_t* iperm = nullptr; // [n]     old -> new
+    double* stage = nullptr;  // [stage_cap] staging for permuted uploads/downloads
+    int64_t stage_cap = 0;
     // SELL-64 operator storage (off-diagonals) + dense diagonal
     int64_t n_slices = 0, sell_entries = 0;
     int64_t* slice_ptr = nullptr; // [n_slices+1]
@@ -100,3 +106,6 @@ int pf_exclusive_scan_i64(hipStream_t st, const int64_t* in, int64_t* out, int64
 
 // pf_operator.hip
 int pf_reduce_ensure(pf_graph* g, int32_t count);
+
+// pf_reorder.hip
+int pf_compute_order(pf_graph* g, const double* d_pts);

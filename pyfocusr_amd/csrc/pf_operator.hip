@@ -117,20 +117,41 @@ __global__ __launch_bounds__(PF_BLOCK) void k_scale(double* __restrict__ x, int6
 }
 
 __global__ __launch_bounds__(PF_BLOCK) void k_mask_isolated(double* __restrict__ x, const int32_t* __restrict__ rowptr,
-                                                            int64_t n) {
+                                                            const int32_t* __restrict__ perm, int64_t n) {
+    const int64_t r = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
+    if (r >= n) return;
+    const int32_t i = perm[r];
+    if (rowptr[i + 1] == rowptr[i]) x[r] = 0.0;
+}
+
+// host order <-> solver order
+__global__ __launch_bounds__(PF_BLOCK) void k_permute_in(const double* __restrict__ src_old, const int32_t* __restrict__ perm,
+                                                         int64_t n_pad, double* __restrict__ dst_new) {
+    const int64_t r = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
+    if (r >= n_pad) return;
+    const int32_t i = perm[r];
+    dst_new[r] = i >= 0 ? src_old[i] : 0.0;
+}
+
+__global__ __launch_bounds__(PF_BLOCK) void k_permute_out(const double* __restrict__ ws, int64_t n_pad, int32_t first,
+                                                          int32_t count, const int32_t* __restrict__ iperm, int64_t n,
+                                                          double* __restrict__ dst_old /* [count][n] */) {
     const int64_t i = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
-    if (i < n && rowptr[i + 1] == rowptr[i]) x[i] = 0.0;
+    if (i >= n) return;
+    const int64_t r = iperm[i];
+    for (int c = 0; c < count; ++c) dst_old[(int64_t)c * n + i] = ws[(int64_t)(first + c) * n_pad + r];
 }
 
 __global__ __launch_bounds__(PF_BLOCK) void k_null_vector(double* __restrict__ x, const int32_t* __restrict__ label,
                                                           const int32_t* __restrict__ rowptr,
-                                                          const double* __restrict__ deg, int64_t n, int64_t n_pad,
-                                                          int32_t root, int32_t sym) {
-    const int64_t i = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
-    if (i >= n_pad) return;
+                                                          const double* __restrict__ deg, const int32_t* __restrict__ perm,
+                                                          int64_t n_pad, int32_t root, int32_t sym) {
+    const int64_t r = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
+    if (r >= n_pad) return;
+    const int32_t i = perm[r];
     double v = 0.0;
-    if (i < n && label[i] == root && rowptr[i + 1] > rowptr[i]) v = sym ? sqrt(deg[i] + 1e-8) : 1.0;
-    x[i] = v;
+    if (i >= 0 && label[i] == root && rowptr[i + 1] > rowptr[i]) v = sym ? sqrt(deg[i] + 1e-8) : 1.0;
+    x[r] = v;
 }
 
 // dst_c = sum_b src_b Y[b][c] for up to 8 output columns per launch (Y row-major m x k, in device memory)
@@ -204,8 +225,8 @@ __device__ __forceinline__ VecStats stats_shfl(const VecStats& v, int off) {
 
 __global__ __launch_bounds__(PF_BLOCK) void k_vec_stats_partial(const double* __restrict__ ws, int64_t n_pad, int64_t n,
                                                                 int32_t first, const double* __restrict__ sg,
-                                                                int32_t from_sym, int64_t n_chunks,
-                                                                VecStats* __restrict__ partial) {
+                                                                const int32_t* __restrict__ perm, int32_t from_sym,
+                                                                int64_t n_chunks, VecStats* __restrict__ partial) {
     __shared__ VecStats red[PF_BLOCK / PF_WAVE];
     const int b = blockIdx.y;
     const double* x = ws + (int64_t)(first + b) * n_pad;
@@ -213,8 +234,9 @@ __global__ __launch_bounds__(PF_BLOCK) void k_vec_stats_partial(const double* __
     const int64_t hi0 = lo + PF_DOT_CHUNK;
     const int64_t hi = hi0 < n ? hi0 : n;
     VecStats st{0.0, INFINITY, -INFINITY, -1.0, 0.0, (int64_t)1 << 62};
-    for (int64_t i = lo + threadIdx.x; i < hi; i += PF_BLOCK) {
-        double v = x[i];
+    for (int64_t r = lo + threadIdx.x; r < hi; r += PF_BLOCK) {
+        const int64_t i = perm[r];  // mesh-order index: the tie-break key of the sign convention
+        double v = x[r];
         if (from_sym) v *= sg[i];
         VecStats e{v * v, v, v, fabs(v), v, i};
         stats_merge(st, e);
@@ -251,14 +273,15 @@ __global__ __launch_bounds__(PF_WAVE) void k_vec_stats_finish(const VecStats* __
 // out[i][c] = (x_c[i] * scale_c - off_c) * inv_c - half_c       (row-major n x count)
 __global__ __launch_bounds__(PF_BLOCK) void k_vec_apply(const double* __restrict__ ws, int64_t n_pad, int64_t n,
                                                         int32_t first, int32_t count, const double* __restrict__ sg,
-                                                        int32_t from_sym, const double* __restrict__ params,
-                                                        double* __restrict__ out) {
+                                                        const int32_t* __restrict__ iperm, int32_t from_sym,
+                                                        const double* __restrict__ params, double* __restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
     if (i >= n) return;
+    const int64_t r = iperm[i];
     const double s = from_sym ? sg[i] : 1.0;
     for (int c = 0; c < count; ++c) {
         const double scale = params[4 * c + 0], off = params[4 * c + 1], ptp = params[4 * c + 2], half = params[4 * c + 3];
-        double v = (ws[(int64_t)(first + c) * n_pad + i] * s) * scale;
+        double v = (ws[(int64_t)(first + c) * n_pad + r] * s) * scale;
         if (ptp != 0.0) v = (v - off) / ptp - half;  // graph.py:254-257
         out[i * count + c] = v;
     }
@@ -288,6 +311,17 @@ __global__ __launch_bounds__(PF_BLOCK) void k_mean_filter(const int32_t* __restr
         if (!diag_done) acc += dinv * in[i * ncols + c];
         out[i * ncols + c] = acc;
     }
+}
+
+int stage_ensure(pf_graph* g, int64_t elems) {
+    if (elems <= g->stage_cap) return PF_OK;
+    PF_HIP(hipStreamSynchronize(g->ctx->stream));
+    hipFree(g->stage);
+    g->stage = nullptr;
+    g->stage_cap = 0;
+    PF_HIP(hipMalloc((void**)&g->stage, sizeof(double) * (size_t)elems));
+    g->stage_cap = elems;
+    return PF_OK;
 }
 
 int check_slots(pf_graph* g, int32_t first, int32_t count, const char* who) {
@@ -391,8 +425,10 @@ int pf_ws_upload(pf_graph* g, int32_t slot, const double* x) {
     PF_TRY(check_slots(g, slot, 1, "pf_ws_upload"));
     PF_CHECK(x != nullptr, PF_E_ARG, "pf_ws_upload: x is NULL");
     hipStream_t st = g->ctx->stream;
-    PF_HIP(hipMemcpyAsync(pf_slot(g, slot), x, sizeof(double) * g->n, hipMemcpyHostToDevice, st));
-    if (g->n_pad > g->n) PF_HIP(hipMemsetAsync(pf_slot(g, slot) + g->n, 0, sizeof(double) * (g->n_pad - g->n), st));
+    PF_TRY(stage_ensure(g, g->n));
+    PF_HIP(hipMemcpyAsync(g->stage, x, sizeof(double) * g->n, hipMemcpyHostToDevice, st));
+    k_permute_in<<<nblk(g->n_pad), PF_BLOCK, 0, st>>>(g->stage, g->perm, g->n_pad, pf_slot(g, slot));
+    PF_HIP(hipGetLastError());
     PF_HIP(hipStreamSynchronize(st));  // x may be a temporary on the host side
     return PF_OK;
 }
@@ -400,9 +436,12 @@ int pf_ws_upload(pf_graph* g, int32_t slot, const double* x) {
 int pf_ws_download(pf_graph* g, int32_t first, int32_t count, double* out) {
     PF_TRY(check_slots(g, first, count, "pf_ws_download"));
     PF_CHECK(out != nullptr, PF_E_ARG, "pf_ws_download: out is NULL");
+    if (count == 0) return PF_OK;
     hipStream_t st = g->ctx->stream;
-    PF_HIP(hipMemcpy2DAsync(out, sizeof(double) * g->n, pf_slot(g, first), sizeof(double) * g->n_pad, sizeof(double) * g->n,
-                            (size_t)count, hipMemcpyDeviceToHost, st));
+    PF_TRY(stage_ensure(g, (int64_t)count * g->n));
+    k_permute_out<<<nblk(g->n), PF_BLOCK, 0, st>>>(g->ws, g->n_pad, first, count, g->iperm, g->n, g->stage);
+    PF_HIP(hipGetLastError());
+    PF_HIP(hipMemcpyAsync(out, g->stage, sizeof(double) * (size_t)count * g->n, hipMemcpyDeviceToHost, st));
     PF_HIP(hipStreamSynchronize(st));
     return PF_OK;
 }
@@ -420,7 +459,7 @@ int pf_ws_copy(pf_graph* g, int32_t src, int32_t dst, int32_t count) {
 int pf_mask_isolated(pf_graph* g, int32_t slot) {
     PF_TRY(check_slots(g, slot, 1, "pf_mask_isolated"));
     if (g->n_isolated == 0) return PF_OK;
-    k_mask_isolated<<<nblk(g->n), PF_BLOCK, 0, g->ctx->stream>>>(pf_slot(g, slot), g->rowptr, g->n);
+    k_mask_isolated<<<nblk(g->n), PF_BLOCK, 0, g->ctx->stream>>>(pf_slot(g, slot), g->rowptr, g->perm, g->n);
     PF_HIP(hipGetLastError());
     return PF_OK;
 }
@@ -434,7 +473,7 @@ int pf_lock_null_vectors(pf_graph* g, int32_t op, int32_t* n_locked) {
     hipStream_t st = g->ctx->stream;
     PF_TRY(pf_reduce_ensure(g, 1));
     for (int32_t c = 0; c < nc; ++c) {
-        k_null_vector<<<nblk(g->n_pad), PF_BLOCK, 0, st>>>(pf_slot(g, c), g->label, g->rowptr, g->deg, g->n, g->n_pad,
+        k_null_vector<<<nblk(g->n_pad), PF_BLOCK, 0, st>>>(pf_slot(g, c), g->label, g->rowptr, g->deg, g->perm, g->n_pad,
                                                           g->roots[c], op == PF_OP_SYM);
         PF_HIP(hipGetLastError());
         PF_TRY(dots_device(g, c, c, 1, g->coef, nullptr, 0));
@@ -580,7 +619,7 @@ int pf_finalize_vectors(pf_graph* g, int32_t first, int32_t count, int32_t from_
     VecStats* part = reinterpret_cast<VecStats*>(g->partials);
     VecStats* fin = part + (size_t)count * g->n_chunks;
     dim3 grid((unsigned)g->n_chunks, (unsigned)count);
-    k_vec_stats_partial<<<grid, PF_BLOCK, 0, st>>>(g->ws, g->n_pad, g->n, first, g->sg, from_sym, g->n_chunks, part);
+    k_vec_stats_partial<<<grid, PF_BLOCK, 0, st>>>(g->ws, g->n_pad, g->n, first, g->sg, g->perm, from_sym, g->n_chunks, part);
     PF_HIP(hipGetLastError());
     k_vec_stats_finish<<<(unsigned)count, PF_WAVE, 0, st>>>(part, g->n_chunks, fin);
     PF_HIP(hipGetLastError());
@@ -605,7 +644,7 @@ int pf_finalize_vectors(pf_graph* g, int32_t first, int32_t count, int32_t from_
     hipError_t e = hipMalloc((void**)&d_out, sizeof(double) * (size_t)g->n * count);
     if (e == hipSuccess) e = hipMemcpyAsync(d_params, params.data(), sizeof(double) * params.size(), hipMemcpyHostToDevice, st);
     if (e == hipSuccess) {
-        k_vec_apply<<<nblk(g->n), PF_BLOCK, 0, st>>>(g->ws, g->n_pad, g->n, first, count, g->sg, from_sym, d_params, d_out);
+        k_vec_apply<<<nblk(g->n), PF_BLOCK, 0, st>>>(g->ws, g->n_pad, g->n, first, count, g->sg, g->iperm, from_sym, d_params, d_out);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, sizeof(double) * (size_t)g->n * count, hipMemcpyDeviceToHost, st);

@@ -1,0 +1,156 @@
+// Internal vertex renumbering for the eigensolver kernels.
+//
+// The reference's matrices keep the mesh's vertex order (and so does everything that crosses the
+// C-ABI: CSR(W), deg, eigenvectors).  Inside the solver the order is free, and it decides how
+// the SpMV behaves: x is gathered through 6-7 neighbour indices per row, and on a mesh whose
+// index order carries no spatial locality every gather touches its own cache line (measured:
+// 2.2 TB/s algorithmic).  So the operator is stored in a renumbered space:
+//   1. Morton (Z-order) code of each vertex position, 10 bits per axis -> radix sort: vertices
+//      that are close on the surface become close in index, a wave's 64 rows gather from a
+//      handful of lines;
+//   2. inside windows of PF_SIGMA consecutive rows, a stable sort by descending degree: the 64
+//      rows of a SELL slice then share one width and the padding disappears.
+// perm[new] = old (-1 on padding rows), iperm[old] = new.  The radix sorts are hipCUB's.
+#include <hipcub/hipcub.hpp>
+
+#include "pf_internal.h"
+
+namespace {
+
+constexpr int PF_SIGMA = 1024;
+
+inline unsigned nblk(int64_t n) { return (unsigned)((n + PF_BLOCK - 1) / PF_BLOCK); }
+
+__device__ __forceinline__ unsigned long long enc_f64(double d) {
+    const unsigned long long u = (unsigned long long)__double_as_longlong(d);
+    return (u >> 63) ? ~u : (u | (1ull << 63));
+}
+__device__ __forceinline__ double dec_f64(unsigned long long u) {
+    return __longlong_as_double((long long)((u >> 63) ? (u & ~(1ull << 63)) : ~u));
+}
+
+__global__ __launch_bounds__(PF_BLOCK) void k_bbox(const double* __restrict__ pts, int64_t n, unsigned long long* bbox) {
+    unsigned long long lo[3] = {~0ull, ~0ull, ~0ull}, hi[3] = {0ull, 0ull, 0ull};
+    for (int64_t i = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * PF_BLOCK) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const unsigned long long e = enc_f64(pts[3 * i + a]);
+            lo[a] = e < lo[a] ? e : lo[a];
+            hi[a] = e > hi[a] ? e : hi[a];
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        for (int off = PF_WAVE / 2; off > 0; off >>= 1) {
+            const unsigned long long l2 = __shfl_xor(lo[a], off, PF_WAVE), h2 = __shfl_xor(hi[a], off, PF_WAVE);
+            lo[a] = l2 < lo[a] ? l2 : lo[a];
+            hi[a] = h2 > hi[a] ? h2 : hi[a];
+        }
+        if ((threadIdx.x & (PF_WAVE - 1)) == 0) {
+            atomicMin(&bbox[a], lo[a]);
+            atomicMax(&bbox[3 + a], hi[a]);
+        }
+    }
+}
+
+__device__ __forceinline__ unsigned spread10(unsigned v) {  // 10 bits -> every third bit
+    v &= 0x3ffu;
+    v = (v | (v << 16)) & 0x030000ffu;
+    v = (v | (v << 8)) & 0x0300f00fu;
+    v = (v | (v << 4)) & 0x030c30c3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+
+__global__ __launch_bounds__(PF_BLOCK) void k_morton_keys(const double* __restrict__ pts, int64_t n,
+                                                          const unsigned long long* __restrict__ bbox,
+                                                          unsigned* __restrict__ keys, int32_t* __restrict__ vals) {
+    const int64_t i = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    unsigned code = 0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const double lo = dec_f64(bbox[a]), hi = dec_f64(bbox[3 + a]);
+        const double ext = hi - lo;
+        double t = ext > 0.0 ? (pts[3 * i + a] - lo) / ext : 0.0;
+        t = t < 0.0 ? 0.0 : (t > 1.0 ? 1.0 : t);
+        unsigned q = (unsigned)(t * 1023.0);
+        code |= spread10(q) << a;
+    }
+    keys[i] = code;
+    vals[i] = (int32_t)i;
+}
+
+// second key: window of PF_SIGMA Morton-consecutive rows, then descending degree
+__global__ __launch_bounds__(PF_BLOCK) void k_degree_keys(const int32_t* __restrict__ order, const int32_t* __restrict__ rowptr,
+                                                          int64_t n, unsigned* __restrict__ keys) {
+    const int64_t r = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
+    if (r >= n) return;
+    const int32_t old = order[r];
+    int32_t d = rowptr[old + 1] - rowptr[old];
+    d = d > 1023 ? 1023 : d;
+    keys[r] = ((unsigned)(r / PF_SIGMA) << 10) | (unsigned)(1023 - d);
+}
+
+__global__ __launch_bounds__(PF_BLOCK) void k_finish_perm(int32_t* __restrict__ perm, int32_t* __restrict__ iperm, int64_t n,
+                                                          int64_t n_pad) {
+    const int64_t r = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
+    if (r >= n_pad) return;
+    if (r < n) iperm[perm[r]] = (int32_t)r;
+    else perm[r] = -1;
+}
+
+}  // namespace
+
+// Fills g->perm [n_pad] and g->iperm [n] (both already allocated).
+int pf_compute_order(pf_graph* g, const double* d_pts) {
+    hipStream_t st = g->ctx->stream;
+    const int64_t n = g->n;
+    const int in = (int)n;
+    unsigned long long* bbox = nullptr;
+    unsigned *k0 = nullptr, *k1 = nullptr;
+    int32_t *v0 = nullptr, *v1 = nullptr;
+    void* tmp = nullptr;
+    size_t tmp_bytes = 0, need = 0;
+    int rc = PF_OK;
+    auto fail = [&](hipError_t e) {
+        if (e != hipSuccess && rc == PF_OK) {
+            pf_set_error("pf_compute_order: %s", hipGetErrorString(e));
+            rc = PF_E_HIP;
+        }
+        return e != hipSuccess;
+    };
+    do {
+        if (fail(hipMalloc((void**)&bbox, 6 * sizeof(unsigned long long)))) break;
+        if (fail(hipMalloc((void**)&k0, sizeof(unsigned) * n)) || fail(hipMalloc((void**)&k1, sizeof(unsigned) * n))) break;
+        if (fail(hipMalloc((void**)&v0, sizeof(int32_t) * n)) || fail(hipMalloc((void**)&v1, sizeof(int32_t) * n))) break;
+        if (fail(hipMemsetAsync(bbox, 0xff, 3 * sizeof(unsigned long long), st))) break;
+        if (fail(hipMemsetAsync(bbox + 3, 0x00, 3 * sizeof(unsigned long long), st))) break;
+        k_bbox<<<256, PF_BLOCK, 0, st>>>(d_pts, n, bbox);
+        k_morton_keys<<<nblk(n), PF_BLOCK, 0, st>>>(d_pts, n, bbox, k0, v0);
+        if (fail(hipGetLastError())) break;
+        if (fail(hipcub::DeviceRadixSort::SortPairs(nullptr, need, k0, k1, v0, v1, in, 0, 30, st))) break;
+        tmp_bytes = need;
+        int bits2 = 10;
+        for (int64_t w = (n + PF_SIGMA - 1) / PF_SIGMA; w > 0; w >>= 1) ++bits2;
+        if (fail(hipcub::DeviceRadixSort::SortPairs(nullptr, need, k0, k1, v0, v1, in, 0, bits2, st))) break;
+        tmp_bytes = need > tmp_bytes ? need : tmp_bytes;
+        if (fail(hipMalloc(&tmp, tmp_bytes))) break;
+        need = tmp_bytes;
+        if (fail(hipcub::DeviceRadixSort::SortPairs(tmp, need, k0, k1, v0, v1, in, 0, 30, st))) break;  // v1 = Morton order
+        k_degree_keys<<<nblk(n), PF_BLOCK, 0, st>>>(v1, g->rowptr, n, k0);
+        if (fail(hipGetLastError())) break;
+        need = tmp_bytes;
+        if (fail(hipcub::DeviceRadixSort::SortPairs(tmp, need, k0, k1, v1, g->perm, in, 0, bits2, st))) break;
+        k_finish_perm<<<nblk(g->n_pad), PF_BLOCK, 0, st>>>(g->perm, g->iperm, n, g->n_pad);
+        if (fail(hipGetLastError())) break;
+    } while (0);
+    hipStreamSynchronize(st);
+    hipFree(bbox);
+    hipFree(k0);
+    hipFree(k1);
+    hipFree(v0);
+    hipFree(v1);
+    hipFree(tmp);
+    return rc;
+}
