@@ -145,10 +145,13 @@ class Context(object):
         self._lib = lib
         self._h = h
         self.device = int(device)
+        self._children = weakref.WeakSet()  # graphs / meshes allocated from this context
         _live_contexts.add(self)
 
     def close(self):
         if getattr(self, "_h", None):
+            for child in list(self._children):  # device objects must go before their allocator
+                child.close()
             self._lib.pf_destroy(self._h)
             self._h = None
 
@@ -227,6 +230,7 @@ class DeviceMesh(object):
         self._h = h
         self.n, self.n_faces = pts.shape[0], f.shape[0]
         _live_graphs.add(self)
+        self.ctx._children.add(self)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -261,6 +265,7 @@ class DeviceLaplacian(object):
                                             f.shape[1] if f.shape[0] else 3, C.byref(h)))
         self._h = h
         _live_graphs.add(self)
+        self.ctx._children.add(self)
         info = GraphInfo()
         _check(self._lib.pf_graph_get_info(h, C.byref(info)))
         self.info = info

@@ -126,7 +126,7 @@ def _ordered_schur(H, symmetric, n_real, n_extra=0):
 
 
 def filtered_eigs(ops, n_wanted, symmetric, null_slots=0, cut=None, tol=1e-12, m_max=None,
-                  max_restarts=60, max_filter_resets=8, seed=0, strength=5.5, hi=2.0,
+                  max_restarts=60, max_filter_resets=8, seed=0, strength=3.5, hi=2.0,
                   nonsym_degree_cap=128, verbose=False):
     """Smallest `n_wanted` non-null eigenpairs of the Laplacian held by `ops`.
 
@@ -196,7 +196,7 @@ def filtered_eigs(ops, n_wanted, symmetric, null_slots=0, cut=None, tol=1e-12, m
                 exhausted = beta <= 1e-14 * max(abs(theta0), 1.0) or j >= n_active
                 if not exhausted:
                     ops.scale(A0 + j, 1.0 / beta)
-                if exhausted or (j >= q_target + 2 and ((j - q_target) % 4 == 0 or j == m_max)):
+                if exhausted or j >= q_target + 2:  # O(j^3) host work on a <= m_max x m_max matrix: negligible
                     theta, U, T, q, n_real, res, theta_min = ritz(j)
                     if verbose:
                         print("  j=%d q=%d theta_min=%.4g |theta|max=%.3g max res=%.3e" % (

@@ -3,9 +3,54 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
+#include <mutex>
+
 #include "pf_internal.h"
 
 static thread_local char g_err[1024] = "";
+static std::mutex g_ctx_mutex;
+static std::vector<pf_ctx*> g_ctxs;
+
+static pf_ctx* ctx_of_stream(hipStream_t st) {
+    std::lock_guard<std::mutex> lk(g_ctx_mutex);
+    for (pf_ctx* c : g_ctxs)
+        if (c->stream == st) return c;
+    return nullptr;
+}
+
+hipError_t pf_malloc(hipStream_t st, void** p, size_t bytes) {
+    *p = nullptr;
+    pf_ctx* c = ctx_of_stream(st);
+    if (!c) return hipErrorInvalidValue;
+    bytes = (std::max<size_t>(bytes, 1) + 255) & ~(size_t)255;
+    auto it = c->free_blocks.find(bytes);
+    if (it != c->free_blocks.end()) {
+        *p = it->second;
+        c->free_blocks.erase(it);
+    } else {
+        hipError_t e = hipMalloc(p, bytes);
+        if (e != hipSuccess) {  // give cached blocks back to the driver and retry once
+            (void)hipStreamSynchronize(st);
+            for (auto& kv : c->free_blocks) (void)hipFree(kv.second);
+            c->free_blocks.clear();
+            e = hipMalloc(p, bytes);
+            if (e != hipSuccess) return e;
+        }
+    }
+    c->live_blocks[*p] = bytes;
+    return hipSuccess;
+}
+
+void pf_free(hipStream_t st, void* p) {
+    if (!p) return;
+    pf_ctx* c = ctx_of_stream(st);
+    if (!c) return;
+    auto it = c->live_blocks.find(p);
+    if (it == c->live_blocks.end()) return;  // not ours (or already released)
+    c->free_blocks.emplace(it->second, p);
+    c->live_blocks.erase(it);
+}
 
 void pf_set_error(const char* fmt, ...) {
     va_list ap;
@@ -40,6 +85,10 @@ int pf_create(int device, pf_ctx** out) {
     pf_ctx* c = new pf_ctx();
     c->device = device;
     PF_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    {
+        std::lock_guard<std::mutex> lk(g_ctx_mutex);
+        g_ctxs.push_back(c);
+    }
     PF_HIP(hipEventCreate(&c->ev0));
     PF_HIP(hipEventCreate(&c->ev1));
     *out = c;
@@ -50,12 +99,21 @@ void pf_destroy(pf_ctx* c) {
     if (!c) return;
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
-    hipFree(c->knn_ref);
-    hipFree(c->knn_qry);
-    hipFree(c->knn_part_d2);
-    hipFree(c->knn_part_idx);
-    hipFree(c->knn_idx);
-    hipFree(c->knn_d2);
+    pf_free(c->stream, c->knn_ref);
+    pf_free(c->stream, c->knn_qry);
+    pf_free(c->stream, c->knn_part_d2);
+    pf_free(c->stream, c->knn_part_idx);
+    pf_free(c->stream, c->knn_idx);
+    pf_free(c->stream, c->knn_d2);
+    hipStreamSynchronize(c->stream);
+    for (auto& kv : c->free_blocks) hipFree(kv.second);
+    for (auto& kv : c->live_blocks) hipFree(kv.first);  // graphs the caller forgot to free
+    c->free_blocks.clear();
+    c->live_blocks.clear();
+    {
+        std::lock_guard<std::mutex> lk(g_ctx_mutex);
+        g_ctxs.erase(std::remove(g_ctxs.begin(), g_ctxs.end(), c), g_ctxs.end());
+    }
     hipEventDestroy(c->ev0);
     hipEventDestroy(c->ev1);
     hipStreamDestroy(c->stream);

@@ -265,9 +265,8 @@ __global__ __launch_bounds__(PF_BLOCK) void k_l_diag(const double* __restrict__ 
 inline unsigned nblk(int64_t n) { return (unsigned)((n + PF_BLOCK - 1) / PF_BLOCK); }
 
 template <typename T>
-int dev_alloc(T** p, int64_t count) {
-    *p = nullptr;
-    PF_HIP(hipMalloc((void**)p, sizeof(T) * (size_t)std::max<int64_t>(count, 1)));
+int dev_alloc(hipStream_t st, T** p, int64_t count) {
+    PF_HIP(pf_malloc(st, (void**)p, sizeof(T) * (size_t)std::max<int64_t>(count, 1)));
     return PF_OK;
 }
 
@@ -277,28 +276,30 @@ extern "C" {
 
 void pf_graph_free(pf_graph* g) {
     if (!g) return;
-    if (g->ctx) {
-        hipSetDevice(g->ctx->device);
-        hipStreamSynchronize(g->ctx->stream);
+    if (!g->ctx) {
+        delete g;
+        return;
     }
-    hipFree(g->rowptr);
-    hipFree(g->col);
-    hipFree(g->w);
-    hipFree(g->deg);
-    hipFree(g->g);
-    hipFree(g->sg);
-    hipFree(g->label);
-    hipFree(g->perm);
-    hipFree(g->iperm);
-    hipFree(g->stage);
-    hipFree(g->slice_ptr);
-    hipFree(g->scol);
-    hipFree(g->sval_rw);
-    hipFree(g->sval_sym);
-    hipFree(g->diag);
-    hipFree(g->ws);
-    hipFree(g->partials);
-    hipFree(g->coef);
+    hipSetDevice(g->ctx->device);
+    hipStream_t st = g->ctx->stream;
+    pf_free(st, g->rowptr);
+    pf_free(st, g->col);
+    pf_free(st, g->w);
+    pf_free(st, g->deg);
+    pf_free(st, g->g);
+    pf_free(st, g->sg);
+    pf_free(st, g->label);
+    pf_free(st, g->perm);
+    pf_free(st, g->iperm);
+    pf_free(st, g->stage);
+    pf_free(st, g->slice_ptr);
+    pf_free(st, g->scol);
+    pf_free(st, g->sval_rw);
+    pf_free(st, g->sval_sym);
+    pf_free(st, g->diag);
+    pf_free(st, g->ws);
+    pf_free(st, g->partials);
+    pf_free(st, g->coef);
     delete g;
 }
 
@@ -323,8 +324,9 @@ int pf_mesh_upload(pf_ctx* ctx, const double* pts, int64_t n, const int32_t* fac
     m->n = n;
     m->n_faces = n_faces;
     m->vpf = vpf;
-    int r = dev_alloc(&m->pts, 3 * n);
-    if (r == PF_OK) r = dev_alloc(&m->faces, n_faces * vpf);
+    hipStream_t st = ctx->stream;
+    int r = dev_alloc(st, &m->pts, 3 * n);
+    if (r == PF_OK) r = dev_alloc(st, &m->faces, n_faces * vpf);
     hipError_t e = hipSuccess;
     if (r == PF_OK) e = hipMemcpyAsync(m->pts, pts, sizeof(double) * 3 * n, hipMemcpyHostToDevice, ctx->stream);
     if (r == PF_OK && e == hipSuccess && n_faces)
@@ -341,8 +343,8 @@ int pf_mesh_upload(pf_ctx* ctx, const double* pts, int64_t n, const int32_t* fac
 
 void pf_mesh_free(pf_mesh* m) {
     if (!m) return;
-    hipFree(m->pts);
-    hipFree(m->faces);
+    pf_free(m->ctx->stream, m->pts);
+    pf_free(m->ctx->stream, m->faces);
     delete m;
 }
 
@@ -381,12 +383,12 @@ int pf_graph_build_device(pf_mesh* mesh, pf_graph** out) {
         std::vector<void*> tmp;
         bool ok = false;
         ~Guard() {
-            for (void* p : tmp) hipFree(p);
+            for (void* p : tmp) pf_free(g->ctx->stream, p);
             if (!ok) pf_graph_free(g);
         }
     } guard{g};
     auto scratch = [&](auto** p, int64_t count) -> int {
-        int r = dev_alloc(p, count);
+        int r = dev_alloc(st, p, count);
         if (r == PF_OK) guard.tmp.push_back((void*)*p);
         return r;
     };
@@ -406,15 +408,15 @@ int pf_graph_build_device(pf_mesh* mesh, pf_graph** out) {
     PF_TRY(scratch(&flags, 8));
     PF_TRY(scratch(&width64, g->n_slices + 1));
     PF_TRY(scratch(&d_roots, PF_MAX_ROOTS));
-    PF_TRY(dev_alloc(&g->rowptr, n + 1));
-    PF_TRY(dev_alloc(&g->deg, g->n_pad));
-    PF_TRY(dev_alloc(&g->g, g->n_pad));
-    PF_TRY(dev_alloc(&g->sg, g->n_pad));
-    PF_TRY(dev_alloc(&g->diag, g->n_pad));
-    PF_TRY(dev_alloc(&g->label, g->n_pad));
-    PF_TRY(dev_alloc(&g->perm, g->n_pad));
-    PF_TRY(dev_alloc(&g->iperm, g->n_pad));
-    PF_TRY(dev_alloc(&g->slice_ptr, g->n_slices + 1));
+    PF_TRY(dev_alloc(st, &g->rowptr, n + 1));
+    PF_TRY(dev_alloc(st, &g->deg, g->n_pad));
+    PF_TRY(dev_alloc(st, &g->g, g->n_pad));
+    PF_TRY(dev_alloc(st, &g->sg, g->n_pad));
+    PF_TRY(dev_alloc(st, &g->diag, g->n_pad));
+    PF_TRY(dev_alloc(st, &g->label, g->n_pad));
+    PF_TRY(dev_alloc(st, &g->perm, g->n_pad));
+    PF_TRY(dev_alloc(st, &g->iperm, g->n_pad));
+    PF_TRY(dev_alloc(st, &g->slice_ptr, g->n_slices + 1));
 
     PF_HIP(hipMemsetAsync(cnt, 0, sizeof(int32_t) * (n + 1), st));
     PF_HIP(hipMemsetAsync(cursor, 0, sizeof(int32_t) * (n + 1), st));
@@ -447,8 +449,8 @@ int pf_graph_build_device(pf_mesh* mesh, pf_graph** out) {
     PF_HIP(hipMemcpyAsync(&nnz32, g->rowptr + n, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     PF_HIP(hipStreamSynchronize(st));
     g->nnz_w = nnz32;
-    PF_TRY(dev_alloc(&g->col, g->nnz_w));
-    PF_TRY(dev_alloc(&g->w, g->nnz_w));
+    PF_TRY(dev_alloc(st, &g->col, g->nnz_w));
+    PF_TRY(dev_alloc(st, &g->w, g->nnz_w));
 
     int32_t* stats = flags + 2;  // [0] isolated, [1] max degree, [2] asym, [3] changed, [4] n_roots
     k_compact_rows<<<nblk(n), PF_BLOCK, 0, st>>>(start, g->rowptr, n, rcol, rw, g->col, g->w, g->deg, g->g, g->sg, stats);
@@ -497,9 +499,9 @@ int pf_graph_build_device(pf_mesh* mesh, pf_graph** out) {
         PF_HIP(hipStreamSynchronize(st));
         std::sort(g->roots.begin(), g->roots.end());
     }
-    PF_TRY(dev_alloc(&g->scol, g->sell_entries));
-    PF_TRY(dev_alloc(&g->sval_rw, g->sell_entries));
-    if (g->is_symmetric) PF_TRY(dev_alloc(&g->sval_sym, g->sell_entries));
+    PF_TRY(dev_alloc(st, &g->scol, g->sell_entries));
+    PF_TRY(dev_alloc(st, &g->sval_rw, g->sell_entries));
+    if (g->is_symmetric) PF_TRY(dev_alloc(st, &g->sval_sym, g->sell_entries));
     k_fill_sell<<<nblk(g->n_pad), PF_BLOCK, 0, st>>>(g->rowptr, g->col, g->w, g->deg, g->g, g->sg, g->perm, g->iperm, n, g->n_pad,
                                                      g->slice_ptr, g->scol, g->sval_rw, g->sval_sym, g->diag);
     PF_HIP(hipGetLastError());
@@ -540,33 +542,33 @@ int pf_graph_download(pf_graph* g, int32_t* rowptr, int32_t* colidx, double* w, 
     if (deg) PF_HIP(hipMemcpyAsync(deg, g->deg, sizeof(double) * g->n, hipMemcpyDeviceToHost, st));
     double* tmp_diag = nullptr;
     if (l_diag) {  // g->diag is stored in solver order: rebuild g_i deg_i in mesh order
-        PF_HIP(hipMalloc((void**)&tmp_diag, sizeof(double) * g->n));
+        PF_HIP(pf_malloc(st, (void**)&tmp_diag, sizeof(double) * g->n));
         k_l_diag<<<nblk(g->n), PF_BLOCK, 0, st>>>(g->deg, g->g, g->n, tmp_diag);
         hipError_t ed = hipGetLastError();
         if (ed == hipSuccess) ed = hipMemcpyAsync(l_diag, tmp_diag, sizeof(double) * g->n, hipMemcpyDeviceToHost, st);
         if (ed != hipSuccess) {
             hipStreamSynchronize(st);
-            hipFree(tmp_diag);
+            pf_free(st, tmp_diag);
             pf_set_error("pf_graph_download: %s", hipGetErrorString(ed));
             return PF_E_HIP;
         }
     }
     if (component_label) PF_HIP(hipMemcpyAsync(component_label, g->label, sizeof(int32_t) * g->n, hipMemcpyDeviceToHost, st));
     if (l_offdiag && g->nnz_w) {
-        PF_HIP(hipMalloc((void**)&tmp, sizeof(double) * g->nnz_w));
+        PF_HIP(pf_malloc(st, (void**)&tmp, sizeof(double) * g->nnz_w));
         k_l_offdiag<<<nblk(g->n), PF_BLOCK, 0, st>>>(g->rowptr, g->w, g->g, g->n, tmp);
         hipError_t e = hipGetLastError();
         if (e == hipSuccess) e = hipMemcpyAsync(l_offdiag, tmp, sizeof(double) * g->nnz_w, hipMemcpyDeviceToHost, st);
         if (e != hipSuccess) {
             hipStreamSynchronize(st);
-            hipFree(tmp);
+            pf_free(st, tmp);
             pf_set_error("pf_graph_download: %s", hipGetErrorString(e));
             return PF_E_HIP;
         }
     }
     hipError_t e = hipStreamSynchronize(st);
-    if (tmp) hipFree(tmp);
-    if (tmp_diag) hipFree(tmp_diag);
+    pf_free(st, tmp);
+    pf_free(st, tmp_diag);
     PF_HIP(e);
     return PF_OK;
 }

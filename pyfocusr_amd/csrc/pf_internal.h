@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <map>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/pyfocusr_hip.h"
@@ -56,6 +58,9 @@ struct pf_ctx {
     int64_t* knn_idx = nullptr;      // [n_qry]
     double* knn_d2 = nullptr;        // [n_qry]
     bool knn_ready = false, knn_done = false;
+    // allocator state
+    std::multimap<size_t, void*> free_blocks;   // size -> block
+    std::unordered_map<void*, size_t> live_blocks;
 };
 
 struct pf_graph {
@@ -96,6 +101,14 @@ struct pf_graph {
     int32_t coef_cap = 0;
     int64_t n_chunks = 0;
 };
+
+// Caching device allocator, one cache per ctx (pf_api.hip).  Every use of a block is enqueued on
+// the ctx's single stream, so a block released at enqueue time can be handed out again at once:
+// later work is ordered behind earlier work by the stream.  After the first build the assembler's
+// ~30 temporaries are recycled without a driver call (hipMalloc/hipFree cost 0.1-1 ms each and
+// hipFree synchronises the device).  Blocks go back to the driver in pf_destroy.
+hipError_t pf_malloc(hipStream_t st, void** p, size_t bytes);
+void pf_free(hipStream_t st, void* p);
 
 static inline double* pf_slot(pf_graph* g, int32_t s) { return g->ws + (int64_t)s * g->n_pad; }
 static inline double* pf_tmp(pf_graph* g, int which) { return g->ws + (int64_t)(g->n_slots + which) * g->n_pad; }

@@ -90,12 +90,12 @@ int launch_knn(pf_ctx* c, dim3 grid, int64_t refs_per_split) {
 }
 
 template <typename T>
-int grow(T** p, int64_t* cap, int64_t need) {
+int grow(hipStream_t st, T** p, int64_t* cap, int64_t need) {
     if (need <= *cap) return PF_OK;
-    hipFree(*p);
+    pf_free(st, *p);
     *p = nullptr;
     *cap = 0;
-    PF_HIP(hipMalloc((void**)p, sizeof(T) * (size_t)need));
+    PF_HIP(pf_malloc(st, (void**)p, sizeof(T) * (size_t)need));
     *cap = need;
     return PF_OK;
 }
@@ -110,8 +110,8 @@ int pf_knn_upload(pf_ctx* c, const double* ref, int64_t n_ref, const double* qry
              "pf_knn_upload: n_ref %lld, n_qry %lld, d %d out of range (1 <= d <= 8)", (long long)n_ref, (long long)n_qry, d);
     PF_HIP(hipSetDevice(c->device));
     c->knn_ready = c->knn_done = false;
-    PF_TRY(grow(&c->knn_ref, &c->knn_cap_ref, n_ref * 8));
-    PF_TRY(grow(&c->knn_qry, &c->knn_cap_qry, n_qry * 8));
+    PF_TRY(grow(c->stream, &c->knn_ref, &c->knn_cap_ref, n_ref * 8));
+    PF_TRY(grow(c->stream, &c->knn_qry, &c->knn_cap_qry, n_qry * 8));
     // enough (query-block x split) work items to cover 256 CUs several times
     const int64_t q_blocks = (n_qry + PF_BLOCK - 1) / PF_BLOCK;
     int64_t splits = (2048 + q_blocks - 1) / q_blocks;
@@ -119,19 +119,19 @@ int pf_knn_upload(pf_ctx* c, const double* ref, int64_t n_ref, const double* qry
     splits = std::min<int64_t>(splits, 65535);
     const int64_t need = splits * n_qry;
     if (need > c->knn_cap_part) {
-        hipFree(c->knn_part_d2);
-        hipFree(c->knn_part_idx);
-        hipFree(c->knn_idx);
-        hipFree(c->knn_d2);
+        pf_free(c->stream, c->knn_part_d2);
+        pf_free(c->stream, c->knn_part_idx);
+        pf_free(c->stream, c->knn_idx);
+        pf_free(c->stream, c->knn_d2);
         c->knn_part_d2 = nullptr;
         c->knn_part_idx = nullptr;
         c->knn_idx = nullptr;
         c->knn_d2 = nullptr;
         c->knn_cap_part = 0;
-        PF_HIP(hipMalloc((void**)&c->knn_part_d2, sizeof(double) * (size_t)need));
-        PF_HIP(hipMalloc((void**)&c->knn_part_idx, sizeof(int32_t) * (size_t)need));
-        PF_HIP(hipMalloc((void**)&c->knn_idx, sizeof(int64_t) * (size_t)need));
-        PF_HIP(hipMalloc((void**)&c->knn_d2, sizeof(double) * (size_t)need));
+        PF_HIP(pf_malloc(c->stream, (void**)&c->knn_part_d2, sizeof(double) * (size_t)need));
+        PF_HIP(pf_malloc(c->stream, (void**)&c->knn_part_idx, sizeof(int32_t) * (size_t)need));
+        PF_HIP(pf_malloc(c->stream, (void**)&c->knn_idx, sizeof(int64_t) * (size_t)need));
+        PF_HIP(pf_malloc(c->stream, (void**)&c->knn_d2, sizeof(double) * (size_t)need));
         c->knn_cap_part = (int32_t)std::min<int64_t>(need, INT32_MAX);
         PF_CHECK(need <= INT32_MAX, PF_E_ARG, "pf_knn_upload: problem too large");
     }

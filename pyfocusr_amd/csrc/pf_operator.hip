@@ -315,11 +315,10 @@ __global__ __launch_bounds__(PF_BLOCK) void k_mean_filter(const int32_t* __restr
 
 int stage_ensure(pf_graph* g, int64_t elems) {
     if (elems <= g->stage_cap) return PF_OK;
-    PF_HIP(hipStreamSynchronize(g->ctx->stream));
-    hipFree(g->stage);
+    pf_free(g->ctx->stream, g->stage);
     g->stage = nullptr;
     g->stage_cap = 0;
-    PF_HIP(hipMalloc((void**)&g->stage, sizeof(double) * (size_t)elems));
+    PF_HIP(pf_malloc(g->ctx->stream, (void**)&g->stage, sizeof(double) * (size_t)elems));
     g->stage_cap = elems;
     return PF_OK;
 }
@@ -382,20 +381,18 @@ int dots_device(pf_graph* g, int32_t w, int32_t first, int32_t count, double* d_
 
 int pf_reduce_ensure(pf_graph* g, int32_t count) {
     if (count > g->partial_cap) {
-        PF_HIP(hipStreamSynchronize(g->ctx->stream));
-        hipFree(g->partials);
+        pf_free(g->ctx->stream, g->partials);
         g->partials = nullptr;
         const int32_t cap = std::max(count, 64);
         // sized for VecStats partials (48 B) as well as plain doubles
-        PF_HIP(hipMalloc((void**)&g->partials, sizeof(VecStats) * (size_t)cap * (size_t)(g->n_chunks + 1)));
+        PF_HIP(pf_malloc(g->ctx->stream, (void**)&g->partials, sizeof(VecStats) * (size_t)cap * (size_t)(g->n_chunks + 1)));
         g->partial_cap = cap;
     }
     if (count > g->coef_cap) {
-        PF_HIP(hipStreamSynchronize(g->ctx->stream));
-        hipFree(g->coef);
+        pf_free(g->ctx->stream, g->coef);
         g->coef = nullptr;
         const int32_t cap = std::max(count, 64);
-        PF_HIP(hipMalloc((void**)&g->coef, sizeof(double) * 8 * (size_t)cap));
+        PF_HIP(pf_malloc(g->ctx->stream, (void**)&g->coef, sizeof(double) * 8 * (size_t)cap));
         g->coef_cap = cap;
     }
     return PF_OK;
@@ -410,12 +407,11 @@ int pf_ws_ensure(pf_graph* g, int32_t n_slots) {
     hipStream_t st = g->ctx->stream;
     double* nw = nullptr;
     const size_t bytes = sizeof(double) * (size_t)(n_slots + 2) * (size_t)g->n_pad;
-    PF_HIP(hipMalloc((void**)&nw, bytes));
+    PF_HIP(pf_malloc(st, (void**)&nw, bytes));
     PF_HIP(hipMemsetAsync(nw, 0, bytes, st));
     if (g->ws && g->n_slots > 0)
         PF_HIP(hipMemcpyAsync(nw, g->ws, sizeof(double) * (size_t)g->n_slots * g->n_pad, hipMemcpyDeviceToDevice, st));
-    PF_HIP(hipStreamSynchronize(st));
-    hipFree(g->ws);
+    pf_free(st, g->ws);
     g->ws = nw;
     g->n_slots = n_slots;
     return PF_OK;
@@ -579,15 +575,15 @@ int pf_combine(pf_graph* g, int32_t src_first, int32_t m, const double* Y, int32
     PF_CHECK(src_first + m <= dst_first || dst_first + k <= src_first, PF_E_ARG, "pf_combine: overlapping ranges");
     hipStream_t st = g->ctx->stream;
     double* dY = nullptr;
-    PF_HIP(hipMalloc((void**)&dY, sizeof(double) * (size_t)m * k));
+    PF_HIP(pf_malloc(st, (void**)&dY, sizeof(double) * (size_t)m * k));
     hipError_t e = hipMemcpyAsync(dY, Y, sizeof(double) * (size_t)m * k, hipMemcpyHostToDevice, st);
     for (int32_t c0 = 0; c0 < k && e == hipSuccess; c0 += COMBINE_COLS) {
         const int32_t nc = std::min(COMBINE_COLS, k - c0);
         k_combine<<<nblk(g->n_pad), PF_BLOCK, 0, st>>>(g->ws, g->n_pad, src_first, m, dY, k, c0, nc, dst_first);
         e = hipGetLastError();
     }
-    hipError_t e2 = hipStreamSynchronize(st);
-    hipFree(dY);
+    hipError_t e2 = hipStreamSynchronize(st);  // Y is the caller's host buffer
+    pf_free(st, dY);
     PF_HIP(e);
     PF_HIP(e2);
     return PF_OK;
@@ -640,8 +636,8 @@ int pf_finalize_vectors(pf_graph* g, int32_t first, int32_t count, int32_t from_
         params[4 * c + 3] = minmax ? 0.5 : 0.0;
     }
     double *d_params = nullptr, *d_out = nullptr;
-    PF_HIP(hipMalloc((void**)&d_params, sizeof(double) * params.size()));
-    hipError_t e = hipMalloc((void**)&d_out, sizeof(double) * (size_t)g->n * count);
+    PF_HIP(pf_malloc(st, (void**)&d_params, sizeof(double) * params.size()));
+    hipError_t e = pf_malloc(st, (void**)&d_out, sizeof(double) * (size_t)g->n * count);
     if (e == hipSuccess) e = hipMemcpyAsync(d_params, params.data(), sizeof(double) * params.size(), hipMemcpyHostToDevice, st);
     if (e == hipSuccess) {
         k_vec_apply<<<nblk(g->n), PF_BLOCK, 0, st>>>(g->ws, g->n_pad, g->n, first, count, g->sg, g->iperm, from_sym, d_params, d_out);
@@ -649,8 +645,8 @@ int pf_finalize_vectors(pf_graph* g, int32_t first, int32_t count, int32_t from_
     }
     if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, sizeof(double) * (size_t)g->n * count, hipMemcpyDeviceToHost, st);
     hipError_t e2 = hipStreamSynchronize(st);
-    hipFree(d_params);
-    hipFree(d_out);
+    pf_free(st, d_params);
+    pf_free(st, d_out);
     PF_HIP(e);
     PF_HIP(e2);
     return PF_OK;
@@ -672,8 +668,8 @@ int pf_mean_filter(pf_graph* g, const double* values, int32_t ncols, int32_t ite
     hipStream_t st = g->ctx->stream;
     const size_t bytes = sizeof(double) * (size_t)g->n * ncols;
     double *a = nullptr, *b = nullptr;
-    PF_HIP(hipMalloc((void**)&a, bytes));
-    hipError_t e = hipMalloc((void**)&b, bytes);
+    PF_HIP(pf_malloc(st, (void**)&a, bytes));
+    hipError_t e = pf_malloc(st, (void**)&b, bytes);
     if (e == hipSuccess) e = hipMemcpyAsync(a, values, bytes, hipMemcpyHostToDevice, st);
     for (int32_t it = 0; it < iterations && e == hipSuccess; ++it) {
         k_mean_filter<<<nblk(g->n), PF_BLOCK, 0, st>>>(g->rowptr, g->col, g->w, g->deg, g->n, ncols, a, b);
@@ -682,8 +678,8 @@ int pf_mean_filter(pf_graph* g, const double* values, int32_t ncols, int32_t ite
     }
     if (e == hipSuccess) e = hipMemcpyAsync(out, a, bytes, hipMemcpyDeviceToHost, st);
     hipError_t e2 = hipStreamSynchronize(st);
-    hipFree(a);
-    hipFree(b);
+    pf_free(st, a);
+    pf_free(st, b);
     PF_HIP(e);
     PF_HIP(e2);
     return PF_OK;

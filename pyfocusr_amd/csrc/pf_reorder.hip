@@ -121,9 +121,9 @@ int pf_compute_order(pf_graph* g, const double* d_pts) {
         return e != hipSuccess;
     };
     do {
-        if (fail(hipMalloc((void**)&bbox, 6 * sizeof(unsigned long long)))) break;
-        if (fail(hipMalloc((void**)&k0, sizeof(unsigned) * n)) || fail(hipMalloc((void**)&k1, sizeof(unsigned) * n))) break;
-        if (fail(hipMalloc((void**)&v0, sizeof(int32_t) * n)) || fail(hipMalloc((void**)&v1, sizeof(int32_t) * n))) break;
+        if (fail(pf_malloc(st, (void**)&bbox, 6 * sizeof(unsigned long long)))) break;
+        if (fail(pf_malloc(st, (void**)&k0, sizeof(unsigned) * n)) || fail(pf_malloc(st, (void**)&k1, sizeof(unsigned) * n))) break;
+        if (fail(pf_malloc(st, (void**)&v0, sizeof(int32_t) * n)) || fail(pf_malloc(st, (void**)&v1, sizeof(int32_t) * n))) break;
         if (fail(hipMemsetAsync(bbox, 0xff, 3 * sizeof(unsigned long long), st))) break;
         if (fail(hipMemsetAsync(bbox + 3, 0x00, 3 * sizeof(unsigned long long), st))) break;
         k_bbox<<<256, PF_BLOCK, 0, st>>>(d_pts, n, bbox);
@@ -135,7 +135,7 @@ int pf_compute_order(pf_graph* g, const double* d_pts) {
         for (int64_t w = (n + PF_SIGMA - 1) / PF_SIGMA; w > 0; w >>= 1) ++bits2;
         if (fail(hipcub::DeviceRadixSort::SortPairs(nullptr, need, k0, k1, v0, v1, in, 0, bits2, st))) break;
         tmp_bytes = need > tmp_bytes ? need : tmp_bytes;
-        if (fail(hipMalloc(&tmp, tmp_bytes))) break;
+        if (fail(pf_malloc(st, &tmp, tmp_bytes))) break;
         need = tmp_bytes;
         if (fail(hipcub::DeviceRadixSort::SortPairs(tmp, need, k0, k1, v0, v1, in, 0, 30, st))) break;  // v1 = Morton order
         k_degree_keys<<<nblk(n), PF_BLOCK, 0, st>>>(v1, g->rowptr, n, k0);
@@ -145,12 +145,11 @@ int pf_compute_order(pf_graph* g, const double* d_pts) {
         k_finish_perm<<<nblk(g->n_pad), PF_BLOCK, 0, st>>>(g->perm, g->iperm, n, g->n_pad);
         if (fail(hipGetLastError())) break;
     } while (0);
-    hipStreamSynchronize(st);
-    hipFree(bbox);
-    hipFree(k0);
-    hipFree(k1);
-    hipFree(v0);
-    hipFree(v1);
-    hipFree(tmp);
+    pf_free(st, bbox);
+    pf_free(st, k0);
+    pf_free(st, k1);
+    pf_free(st, v0);
+    pf_free(st, v1);
+    pf_free(st, tmp);
     return rc;
 }

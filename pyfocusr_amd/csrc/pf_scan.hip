@@ -86,7 +86,7 @@ int exclusive_scan(hipStream_t st, const T* in, T* out, int64_t n) {
         return PF_OK;
     }
     T* totals = nullptr;
-    PF_HIP(hipMalloc(&totals, sizeof(T) * blocks));
+    PF_HIP(pf_malloc(st, (void**)&totals, sizeof(T) * blocks));
     scan_block_totals<T><<<(unsigned)blocks, PF_BLOCK, 0, st>>>(in, totals, n);
     PF_HIP(hipGetLastError());
     int r = exclusive_scan<T>(st, totals, totals, blocks);
@@ -94,8 +94,7 @@ int exclusive_scan(hipStream_t st, const T* in, T* out, int64_t n) {
         scan_block_apply<T><<<(unsigned)blocks, PF_BLOCK, 0, st>>>(in, out, totals, n);
         if (hipGetLastError() != hipSuccess) r = PF_E_HIP;
     }
-    hipStreamSynchronize(st);
-    hipFree(totals);
+    pf_free(st, totals);
     return r;
 }
 

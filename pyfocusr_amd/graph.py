@@ -95,10 +95,10 @@ class Graph(object):
         # Mesh/points characteristics (graph.py:58-67)
         self.points, self._faces = mesh_arrays(vtk_mesh)
         self.n_points = int(self.points.shape[0])
-        self.pts_scale_range = np.ptp(self.points, axis=0)
-        self.max_pts_scale_range = np.max(self.pts_scale_range)
-        self.mean_pts_scale_range = np.mean(self.pts_scale_range)
-        self.normed_points = (self.points - np.min(self.points, axis=0)) / self.mean_pts_scale_range
+        # graph.py:63-67: bounding-box ranges and normed_points are only read by the optional
+        # point/feature coordinates of Focusr; they are computed on first access.
+        self._geometry = None
+        self._normed_points = None
 
         # Matrices (graph.py:70-76): filled from the device graph on demand.
         self._device = None
@@ -131,6 +131,34 @@ class Graph(object):
         if self._host is None:
             self._host = self.device.download()
         return self._host
+
+    def _geom(self):
+        if self._geometry is None:
+            rng = np.ptp(self.points, axis=0)
+            self._geometry = (rng, np.max(rng), np.mean(rng))
+        return self._geometry
+
+    @property
+    def pts_scale_range(self):
+        return self._geom()[0]
+
+    @property
+    def max_pts_scale_range(self):
+        return self._geom()[1]
+
+    @property
+    def mean_pts_scale_range(self):
+        return self._geom()[2]
+
+    @property
+    def normed_points(self):
+        if self._normed_points is None:
+            self._normed_points = (self.points - np.min(self.points, axis=0)) / self.mean_pts_scale_range
+        return self._normed_points
+
+    @normed_points.setter
+    def normed_points(self, value):
+        self._normed_points = value
 
     @property
     def adjacency_matrix(self):
@@ -225,7 +253,12 @@ class Graph(object):
             if force_randomization is True:
                 np.random.shuffle(list_points)
             return list_points
-        return np.random.choice(self.n_points, size=n_rand_samples, replace=replace)
+        if replace:
+            return np.random.choice(self.n_points, size=n_rand_samples, replace=True)
+        # same distribution as np.random.choice(replace=False) (graph.py:290) without permuting all
+        # n_points: a Generator seeded from the legacy global state (so np.random.seed still pins it).
+        rng = np.random.default_rng(np.random.randint(0, 2**31 - 1))
+        return rng.choice(self.n_points, size=n_rand_samples, replace=False)
 
     # ------------------------------------------------------------------ viewers (graph.py:296-314)
     def _no_viewer(self, *a, **k):

@@ -44,7 +44,7 @@ class NumpyOps(object):
     def upload(self, slot, x):
         self.ws[:, slot] = x
 
-    def download(self, first, count):
+    def download_slots(self, first, count):
         return np.array(self.ws[:, first : first + count])
 
     def copy(self, src, dst, count):

@@ -1,0 +1,315 @@
+"""CPU tests (`-m "not gpu"`): C-ABI surface, host logic (Krylov driver, Graph/eigsort
+shells, VTK reader, mesh generator) against the oracle and the golden fixtures.  No device
+compute happens here; the device is replaced by the numpy test double in tests/_numpy_ops.py."""
+import os
+import re
+import sys
+
+import numpy as np
+import pytest
+from scipy import sparse
+
+from oracle import reference_port as orc
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _numpy_ops import NumpyOps  # noqa: E402
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ------------------------------------------------------------------------------- C-ABI surface
+def header_functions():
+    text = open(os.path.join(REPO, "include", "pyfocusr_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(pf_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    import __graft_entry__ as entry
+    from pyfocusr_amd import _hip
+
+    entry.build()  # hipcc cross-compiles gfx950 without a GPU
+    assert os.path.exists(_hip.LIB_PATH)
+    lib = _hip.load_library()
+    declared = header_functions()
+    assert len(declared) >= 30
+    assert sorted(_hip.SIGNATURES) == declared  # the binding covers exactly the header
+    for name in declared:
+        assert getattr(lib, name) is not None
+    assert lib.pf_version() == 1
+
+
+def test_product_fails_loudly_without_gpu_or_library(monkeypatch):
+    from pyfocusr_amd import _hip
+
+    if _hip.load_library().pf_device_count() == 0:
+        with pytest.raises(_hip.HipUnavailable):
+            _hip.Context()
+        from pyfocusr_amd import Graph, PolyMesh
+        from pyfocusr_amd.meshgen import blob_mesh
+
+        g = Graph(blob_mesh(200, 0), n_spectral_features=2, verbose=False)
+        with pytest.raises(_hip.HipUnavailable):
+            g.get_graph_spectrum()  # no silent CPU fallback
+    monkeypatch.setattr(_hip, "_lib", None)
+    monkeypatch.setattr(_hip, "LIB_PATH", "/nonexistent/libpyfocusr_hip.so")
+    with pytest.raises(_hip.HipUnavailable):
+        _hip.load_library()
+
+
+def test_product_does_not_import_oracle():
+    for root, _, files in os.walk(os.path.join(REPO, "pyfocusr_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(root, f)).read()
+                assert "oracle" not in src.replace("oracle-", ""), f
+                assert "_numpy_ops" not in src, f
+
+
+# ------------------------------------------------------------------------------- mesh I/O
+def test_vtk_reader_and_mesh_protocol(tmp_path, golden):
+    from pyfocusr_amd import read_vtk_mesh
+    from pyfocusr_amd.vtk_functions import PolyMesh, mesh_arrays
+
+    g = golden("target_mesh")
+    pts, faces = g["points"][:50], np.array([[0, 1, 2], [2, 1, 3], [4, 3, 1]], dtype=np.int32)
+    path = tmp_path / "m.vtk"
+    with open(path, "w") as fh:
+        fh.write("# vtk DataFile Version 4.2\nvtk output\nASCII\nDATASET POLYDATA\nPOINTS %d double\n" % len(pts))
+        flat = pts.reshape(-1)
+        for i in range(0, len(flat), 9):
+            fh.write(" ".join(repr(float(v)) for v in flat[i:i + 9]) + "\n")
+        fh.write("POLYGONS %d %d\n" % (len(faces), 4 * len(faces)))
+        for f in faces:
+            fh.write("3 %d %d %d\n" % tuple(f))
+        fh.write("POINT_DATA %d\nSCALARS thickness_change_(mm) double\nLOOKUP_TABLE default\n" % len(pts))
+        fh.write(" ".join("0.5" for _ in range(len(pts))) + "\n")
+    m = read_vtk_mesh(str(path))
+    assert np.array_equal(m.points, pts) and np.array_equal(m.faces, faces)
+    assert m.GetPointData().GetNumberOfArrays() == 1
+    assert m.GetPointData().GetArray(0).GetName() == "thickness_change_(mm)"
+    # vtkPolyData protocol the reference walks (graph.py:58-62,155-164): edges (0,1),(1,2),(2,0)
+    assert m.GetNumberOfPoints() == 50 and m.GetNumberOfCells() == 3
+    cell = m.GetCell(1)
+    edges = [(cell.GetEdge(e).GetPointId(0), cell.GetEdge(e).GetPointId(1)) for e in range(cell.GetNumberOfEdges())]
+    assert edges == [(2, 1), (1, 3), (3, 2)]
+    assert m.GetPoint(3) == tuple(pts[3])
+
+    class Duck(object):  # no .points/.faces: generic walk
+        def __getattr__(self, name):
+            if name in ("points", "faces"):
+                raise AttributeError(name)
+            return getattr(m, name)
+
+    p2, f2 = mesh_arrays(Duck())
+    assert np.array_equal(p2, pts) and np.array_equal(f2, faces)
+    with pytest.raises(ValueError):
+        PolyMesh(pts, np.array([[0, 1, 50]]))
+
+
+def test_blob_mesh_is_closed_manifold():
+    from pyfocusr_amd.meshgen import blob_mesh
+
+    m = blob_mesh(2000, seed=5)
+    assert m.points.shape == (2000, 3) and m.faces.shape == (2 * 2000 - 4, 3)
+    W = orc.weighted_adjacency(m.points, m.faces)
+    assert abs(W - W.T).nnz == 0 and W.nnz == 3 * len(m.faces)  # every directed edge once, both directions
+    deg_count = np.diff(W.indptr)
+    assert deg_count.min() >= 3 and deg_count.max() <= 10
+    ncomp, _ = sparse.csgraph.connected_components(W, directed=False)
+    assert ncomp == 1
+    m2 = blob_mesh(2000, seed=5)
+    assert np.array_equal(m.points, m2.points) and np.array_equal(m.faces, m2.faces)
+
+
+# ------------------------------------------------------------------------------- Krylov driver
+def solve(points, faces, k, **kw):
+    from pyfocusr_amd._krylov import filtered_eigs
+
+    W = orc.weighted_adjacency(points, faces)
+    ops = NumpyOps(W)
+    c0 = ops.lock_null_vectors()
+    lam, first, st = filtered_eigs(ops, k, ops.symmetric, null_slots=c0, **kw)
+    X = ops.download_slots(first, len(lam))
+    if ops.symmetric:
+        X = X * ops.s[:, None]
+    X = X / np.linalg.norm(X, axis=0)
+    lam, X = orc.canonicalize(lam, X)
+    return lam, X, st, ops
+
+
+@pytest.mark.parametrize("name,k", [("target_mesh", 6), ("source_mesh", 3), ("target_mesh_15k", 5), ("source_mesh_15k", 9)])
+def test_filtered_krylov_schur_matches_reference(golden, name, k):
+    g = golden(name)
+    gk = {"target_mesh": 6, "source_mesh": 3, "target_mesh_15k": 5, "source_mesh_15k": 5}[name]
+    lam, X, st, ops = solve(g["points"], g["faces"], k)
+    gv = g["k%d_eig_vals" % gk]
+    m = min(len(gv), len(lam))
+    assert len(lam) == k
+    np.testing.assert_allclose(lam[:m], gv[:m], rtol=1e-8)
+    tol = 5e-7 if "15k" in name else 2e-9
+    assert np.max(np.abs(orc.minmax_normalize(X)[:, :m] - g["k%d_eig_vecs" % gk][:, :m])) < tol
+    assert st.residuals.max() < 1e-8 and st.filter_resets == 0
+    if not ops.symmetric:
+        assert st.degree <= 128  # complex outliers: degree capped
+
+
+def test_krylov_components_isolated_and_bad_cut():
+    from pyfocusr_amd.meshgen import blob_mesh
+
+    a, b = blob_mesh(400, seed=3), blob_mesh(500, seed=4)
+    pts = np.concatenate([a.points, b.points + 200.0, np.zeros((2, 3))])
+    faces = np.concatenate([a.faces, b.faces + 400])
+    ref = orc.graph_spectrum(pts, faces, 4)  # 2 + 2 nulls -> widened, 6 columns
+    lam, X, st, ops = solve(pts, faces, len(ref["eig_vals"]))
+    assert ops.n_isolated == 2 and st.n_null == 2
+    np.testing.assert_allclose(lam, ref["eig_vals"], rtol=1e-8)
+    assert np.all(X[-2:, :] == 0.0)  # isolated vertices stay out of every eigenvector
+    # a cut far too small must be detected and enlarged, not silently converge to wrong pairs
+    lam2, _, st2, _ = solve(pts, faces, len(ref["eig_vals"]), cut=1e-7)
+    assert st2.filter_resets >= 1
+    np.testing.assert_allclose(lam2, ref["eig_vals"], rtol=1e-8)
+    # thick restart path: tiny basis
+    lam3, _, st3, _ = solve(a.points, a.faces, 4, m_max=14)
+    assert st3.restarts >= 1
+    np.testing.assert_allclose(lam3, orc.graph_spectrum(a.points, a.faces, 4)["eig_vals"], rtol=1e-8)
+
+
+def test_widen_rule_matches_reference_trace(golden):
+    from pyfocusr_amd.graph import _widened_k
+
+    assert _widened_k(6, 5, 1, 1, 15000) == (6, 0)
+    assert _widened_k(6, 5, 1, 3, 15000) == (12, 1)  # source_mesh_15k: 9 columns returned
+    assert _widened_k(4, 3, 1, 9, 15000) == (12, 2)
+    g = golden("source_mesh_15k")
+    assert int(g["k5_n_retries"]) == 1 and g["k5_eig_vals"].shape == (9,)
+
+
+# ------------------------------------------------------------------------------- Graph / eigsort shells
+class FakeDevice(NumpyOps):
+    """NumpyOps + the download/finalize surface of DeviceLaplacian, for host-logic tests."""
+
+    def __init__(self, points, faces):
+        NumpyOps.__init__(self, orc.weighted_adjacency(points, faces))
+        self.n_components = len([c for c in np.unique(self.labels) if np.sum(self.labels == c) > 1])
+        self.nnz_w = self.W.nnz
+
+    def download(self, labels=False):
+        W = self.W
+        g = 1.0 / (self.deg + 1e-8)
+        rows = np.repeat(np.arange(self.n), np.diff(W.indptr))
+        return dict(rowptr=W.indptr.astype(np.int32), colidx=W.indices.astype(np.int32), w=W.data,
+                    l_offdiag=-(g[rows] * W.data), deg=self.deg, l_diag=g * self.deg)
+
+    def finalize_vectors(self, first, count, minmax):
+        X = self.download_slots(first, count)
+        if self.symmetric:
+            X = X * self.s[:, None]
+        X = X / np.linalg.norm(X, axis=0)
+        _, X = orc.canonicalize(np.arange(float(count)), X)
+        return orc.minmax_normalize(X) if minmax else X
+
+    def close(self):
+        pass
+
+
+class FakeCtx(object):
+    def knn1(self, ref, qry, return_d2=False):
+        return orc.knn1(ref, qry)
+
+
+def fake_graph(gold, k, **kw):
+    from pyfocusr_amd import Graph, PolyMesh
+
+    gr = Graph(PolyMesh(gold["points"], gold["faces"]), n_spectral_features=k, n_rand_samples=10**9,
+               ctx=FakeCtx(), verbose=False, **kw)
+    gr._device = FakeDevice(gold["points"], gold["faces"])
+    return gr
+
+
+@pytest.mark.parametrize("name", ["target_mesh", "source_mesh_15k"])
+def test_graph_shell_matrices_and_spectrum(golden, name):
+    g = golden(name)
+    k = 6 if name == "target_mesh" else 5
+    gr = fake_graph(g, k)
+    assert gr.adjacency_matrix.nnz == 0  # empty lil until computed (graph.py:70-72)
+    gr.get_weighted_adjacency_matrix()
+    gr.get_degree_matrix()
+    gr.get_G_matrix()
+    gr.get_laplacian_matrix()
+    L = gr.laplacian_matrix
+    assert np.array_equal(L.indptr, g["L_indptr"]) and np.array_equal(L.indices, g["L_indices"])
+    assert np.array_equal(L.data, g["L_data"])  # isolated rows carry no explicit zero diagonal
+    assert np.array_equal(gr.degree_matrix_inv.diagonal(), g["d_inv"])
+    assert np.array_equal(gr.normed_points, g["normed_points"])
+    assert np.array_equal(gr.pts_scale_range, g["pts_scale_range"])
+    gr.get_graph_spectrum()
+    assert gr.eig_vals.shape == g["k%d_eig_vals" % k].shape
+    np.testing.assert_allclose(gr.eig_vals, g["k%d_eig_vals" % k], rtol=1e-8)
+    assert gr.get_rand_eig_vecs().shape == gr.eig_vecs.shape
+    gr.get_eig_val_gap()
+    assert gr.eig_val_gap == np.mean(np.diff(gr.eig_vals))
+    with pytest.raises(NotImplementedError):
+        fake_graph(g, 3, list_features_to_calc=["curvature"])
+    np.random.seed(3)
+    a = gr.get_list_rand_idxs(100)
+    np.random.seed(3)
+    assert np.array_equal(a, gr.get_list_rand_idxs(100)) and len(np.unique(a)) == 100
+
+
+@pytest.mark.parametrize("pair,t,s,k,ns", [("pair_5k", "target_mesh", "source_mesh", 6, 3),
+                                           ("pair_15k", "target_mesh_15k", "source_mesh_15k", 5, 5)])
+def test_eigsort_and_focusr_host_logic(golden, pair, t, s, k, ns):
+    from pyfocusr_amd import Focusr, eigsort
+
+    p = golden(pair)
+    graphs = []
+    for name in (t, s):
+        gold = golden(name)
+        gr = fake_graph(gold, k)
+        gr.eig_vals = gold["k%d_eig_vals" % k].copy()
+        gr.eig_vecs = gold["k%d_eig_vecs" % k].copy()
+        graphs.append(gr)
+    gt, gs = graphs
+    sorter = eigsort(graph_target=gt, graph_source=gs, n_features=k, target_as_reference=True)
+    Q = sorter.sort_eigenmaps()
+    for name in ("c_lambda", "c_hist", "c_hist_f", "c_spatial", "c_spatial_f"):
+        np.testing.assert_allclose(getattr(sorter, name), p[name], rtol=1e-12, err_msg=name)
+    np.testing.assert_allclose(Q, p["Q"], rtol=1e-12)
+    assert np.array_equal(sorter.source_matches, p["source_matches"])
+    assert np.array_equal(gs.eig_vecs, p["eig_vecs_s_sorted"])
+    reg = object.__new__(Focusr)
+    reg._ctx = FakeCtx()
+    reg.graph_target, reg.graph_source, reg.Q, reg.n_spectral_features = gt, gs, Q, ns
+    reg.get_weighted_spectral_coords = True
+    reg.calc_spectral_coords()
+    reg.get_initial_correspondences()
+    np.testing.assert_allclose(reg.spectral_weights, p["spectral_weights"], rtol=1e-12)
+    assert np.array_equal(reg.corresponding_target_idx_for_each_source_pt, p["knn_idx_w"])
+    # source-as-reference branch (eigsort.py:77-78,111-122) against the oracle
+    gt2, gs2 = fake_graph(golden(t), k), fake_graph(golden(s), k)
+    for gr, name in ((gt2, t), (gs2, s)):
+        gr.eig_vals = golden(name)["k%d_eig_vals" % k].copy()
+        gr.eig_vecs = golden(name)["k%d_eig_vecs" % k].copy()
+    ref = orc.sort_eigenmaps(gt2.points, gs2.points, gt2.eig_vals, gs2.eig_vals, gt2.eig_vecs.copy(),
+                             gs2.eig_vecs.copy(), np.arange(gt2.n_points), np.arange(gs2.n_points), k,
+                             target_as_reference=False)
+    Q2 = eigsort(gt2, gs2, k, target_as_reference=False).sort_eigenmaps()
+    np.testing.assert_allclose(Q2, ref["Q"], rtol=1e-12)
+    assert np.array_equal(gt2.eig_vecs, ref["eig_vecs_t"]) and np.array_equal(gs2.eig_vecs, ref["eig_vecs_s"])
+
+
+def test_focusr_constructor_surface():
+    """Same positional order / defaults as focusr.py:23-69."""
+    import inspect
+
+    from pyfocusr_amd import Focusr
+
+    sig = inspect.signature(Focusr.__init__)
+    names = list(sig.parameters)
+    assert names[1:3] == ["vtk_mesh_target", "vtk_mesh_source"]
+    d = {k: v.default for k, v in sig.parameters.items()}
+    assert d["n_spectral_features"] == 3 and d["n_extra_spectral"] == 3 and d["icp_register_first"] is True
+    assert d["n_coords_spectral_ordering"] == 5000 and d["get_weighted_spectral_coords"] is True
+    assert d["graph_smoothing_iterations"] == 300 and d["projection_smooth_iterations"] == 40
+    assert d["list_features_to_calc"] == ["curvature"] and d["initial_correspondence_type"] == "kd"
