@@ -35,22 +35,24 @@ def spmv_algorithmic_bytes(n, nnz_l):
     return 12 * nnz_l + 20 * n + 4
 
 
-def hot_path_step(ctx, mesh_t, mesh_s, k, n_samples, timers):
+def hot_path_step(ctxs, mesh_t, mesh_s, k, n_samples, timers):
     """Same calls as Focusr.__init__ + align_maps (focusr.py:134-170, 514-545) without ICP/CPD."""
     from pyfocusr_amd import Graph, eigsort
+    from pyfocusr_amd.graph import compute_spectra
 
-    graphs = []
-    for mesh in (mesh_t, mesh_s):
-        t0 = time.perf_counter()
-        g = Graph(mesh, n_spectral_features=k, n_rand_samples=n_samples, ctx=ctx, verbose=False)
+    ctx = ctxs[0]
+    t0 = time.perf_counter()
+    graphs = [Graph(mesh, n_spectral_features=k, n_rand_samples=n_samples, ctx=c, verbose=False)
+              for mesh, c in zip((mesh_t, mesh_s), ctxs)]
+    for g in graphs:
         _ = g.device  # assembly from the resident mesh
-        ctx.sync()
-        t1 = time.perf_counter()
-        g.get_graph_spectrum()
-        t2 = time.perf_counter()
-        timers["assembly"] += t1 - t0
-        timers["eigensolve"] += t2 - t1
-        graphs.append(g)
+    for c in ctxs:
+        c.sync()
+    t1 = time.perf_counter()
+    compute_spectra(graphs)  # target and source concurrently, one HIP stream each
+    t2 = time.perf_counter()
+    timers["assembly"] += t1 - t0
+    timers["eigensolve"] += t2 - t1
     gt, gs = graphs
     t0 = time.perf_counter()
     Q = eigsort(gt, gs, k, target_as_reference=True).sort_eigenmaps()
@@ -143,6 +145,8 @@ def main():
     ap.add_argument("--samples", type=int, default=5000, help="n_coords_spectral_ordering (focusr.py:37)")
     ap.add_argument("--cpu-knn-sample", type=int, default=25000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--streams", type=int, default=2, choices=(1, 2),
+                    help="2: target and source eigensolves run concurrently on two HIP streams; 1: one after the other")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -164,13 +168,16 @@ def main():
     from pyfocusr_amd.meshgen import blob_mesh
 
     ctx = _hip.Context(local)
-    ctx.timing_enable(True)
+    ctxs = [ctx, _hip.Context(local) if args.streams == 2 else ctx]  # one stream per mesh of the pair
+    for c in set(ctxs):
+        c.timing_enable(True)
     mesh_t, mesh_s = blob_mesh(args.n, seed=2 * rank), blob_mesh(args.n, seed=2 * rank + 1)
-    for m in (mesh_t, mesh_s):
-        m._pf_device_mesh = _hip.DeviceMesh(m.points, m.faces, ctx=ctx)  # inputs resident in HBM
+    for m, c in zip((mesh_t, mesh_s), ctxs):
+        m._pf_device_mesh = _hip.DeviceMesh(m.points, m.faces, ctx=c)  # inputs resident in HBM
 
     def barrier():
-        ctx.sync()
+        for c in ctxs:
+            c.sync()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -178,21 +185,24 @@ def main():
     timers = dict(assembly=0.0, eigensolve=0.0, eigsort=0.0, knn=0.0, matvecs=0)
     np.random.seed(1234 + rank)
     for _ in range(args.warmup):
-        hot_path_step(ctx, mesh_t, mesh_s, args.k, args.samples, timers)
+        hot_path_step(ctxs, mesh_t, mesh_s, args.k, args.samples, timers)
     for key in timers:
         timers[key] = 0
-    ctx.timing(reset=True)
+    for c in set(ctxs):
+        c.timing(reset=True)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        idx, max_res, nnz, coords = hot_path_step(ctx, mesh_t, mesh_s, args.k, args.samples, timers)
+        idx, max_res, nnz, coords = hot_path_step(ctxs, mesh_t, mesh_s, args.k, args.samples, timers)
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    tm = ctx.timing()
+    tms = [c.timing() for c in set(ctxs)]
+    tm = dict(op_ms=sum(t["op_ms"] for t in tms), op_launches=sum(t["op_launches"] for t in tms),
+              knn_ms=tms[0]["knn_ms"])
 
     split = None
     if world == 2:

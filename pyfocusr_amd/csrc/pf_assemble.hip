@@ -374,7 +374,7 @@ int pf_graph_build_device(pf_mesh* mesh, pf_graph** out) {
     g->n = n;
     g->n_faces = n_faces;
     g->vpf = vpf;
-    g->n_pad = (n + PF_BLOCK - 1) / PF_BLOCK * PF_BLOCK;  // multiple of 256: no tails in vector kernels
+    g->n_pad = (n + 8 * PF_BLOCK - 1) / (8 * PF_BLOCK) * (8 * PF_BLOCK);  // whole blocks, a multiple of 8 of them (XCD remap)
     g->n_slices = g->n_pad / PF_WAVE;
     g->n_chunks = (g->n_pad + PF_DOT_CHUNK - 1) / PF_DOT_CHUNK;
 

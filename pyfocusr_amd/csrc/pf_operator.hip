@@ -31,7 +31,13 @@ __global__ __launch_bounds__(PF_BLOCK) void k_sell_op(const int64_t* __restrict_
                                                       const double* prev, double* out, double alpha, double shift,
                                                       double beta) {
 #pragma clang fp contract(fast)
-    const int64_t row = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
+    // Blocks are dealt round-robin over the 8 XCDs (private 4 MiB L2 each).  Give every XCD one
+    // contiguous eighth of the (Morton-ordered) rows: its slice of the matrix (~2.6 MB at 250k
+    // vertices) and of x then stays in its own L2 from one launch to the next.  gridDim.x is a
+    // multiple of 8 (n_pad is a multiple of 8 * PF_BLOCK); placement affects speed only.
+    const unsigned per_xcd = gridDim.x >> 3;
+    const unsigned blk = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    const int64_t row = (int64_t)blk * PF_BLOCK + threadIdx.x;
     const int64_t s = row >> 6;
     const int lane = threadIdx.x & (PF_WAVE - 1);
     const int64_t base = slice_ptr[s];
@@ -325,6 +331,7 @@ int stage_ensure(pf_graph* g, int64_t elems) {
 
 int check_slots(pf_graph* g, int32_t first, int32_t count, const char* who) {
     PF_CHECK(g != nullptr, PF_E_ARG, "%s: graph is NULL", who);
+    PF_HIP(hipSetDevice(g->ctx->device));  // the calling host thread may have another current device
     PF_CHECK(first >= 0 && count >= 0 && first + count <= g->n_slots, PF_E_ARG, "%s: slots [%d,%d) outside workspace of %d",
              who, first, first + count, g->n_slots);
     return PF_OK;
@@ -462,6 +469,7 @@ int pf_mask_isolated(pf_graph* g, int32_t slot) {
 
 int pf_lock_null_vectors(pf_graph* g, int32_t op, int32_t* n_locked) {
     PF_CHECK(g != nullptr && n_locked != nullptr, PF_E_ARG, "pf_lock_null_vectors: NULL argument");
+    PF_HIP(hipSetDevice(g->ctx->device));
     PF_CHECK(op == PF_OP_RW || (op == PF_OP_SYM && g->is_symmetric), PF_E_ARG,
              "pf_lock_null_vectors: operator %d not available (W symmetric: %d)", op, g->is_symmetric);
     const int32_t nc = g->n_components;
@@ -665,6 +673,7 @@ int pf_spmv_host(pf_graph* g, int32_t op, const double* x, double* y) {
 int pf_mean_filter(pf_graph* g, const double* values, int32_t ncols, int32_t iterations, double* out) {
     PF_CHECK(g != nullptr && values != nullptr && out != nullptr && ncols > 0 && iterations >= 0, PF_E_ARG,
              "pf_mean_filter: bad argument");
+    PF_HIP(hipSetDevice(g->ctx->device));
     hipStream_t st = g->ctx->stream;
     const size_t bytes = sizeof(double) * (size_t)g->n * ncols;
     double *a = nullptr, *b = nullptr;

@@ -23,7 +23,7 @@ import numpy as np
 
 from . import _hip
 from .eigsort import eigsort
-from .graph import Graph
+from .graph import Graph, compute_spectra
 from .main import print_header
 from .vtk_functions import PolyMesh, apply_transform, icp_transform, vtk_deep_copy
 
@@ -146,16 +146,17 @@ class Focusr(object):
             norm_node_features_std=norm_node_features_std,
             norm_node_features_cap_std=norm_node_features_cap_std,
             norm_node_features_0_1=norm_node_features_0_1,
-            ctx=self._ctx,
         )
+        # focusr.py:134-170 builds target then source; the two spectra are independent, so they run
+        # concurrently on two HIP streams of the same device.
+        self._ctx_source = _hip.Context(self._ctx.device)
         print("Starting to build first graph")
-        self.graph_target = Graph(vtk_mesh_target, **graph_kw)
+        self.graph_target = Graph(vtk_mesh_target, ctx=self._ctx, **graph_kw)
         print("Loaded Mesh 1")
-        self.graph_target.get_graph_spectrum()
-        print("Computed spectrum 1")
-        self.graph_source = Graph(vtk_mesh_source, **graph_kw)
+        self.graph_source = Graph(vtk_mesh_source, ctx=self._ctx_source, **graph_kw)
         print("Loaded Mesh 2")
-        self.graph_source.get_graph_spectrum()
+        compute_spectra([self.graph_target, self.graph_source])
+        print("Computed spectrum 1")
         print("Computed spectrum 2")
 
         self.Q = None

@@ -31,7 +31,7 @@ from . import _hip
 from ._krylov import MIN_EIG_VAL, filtered_eigs
 from .vtk_functions import mesh_arrays, vtk_deep_copy  # noqa: F401
 
-__all__ = ["Graph", "recursive_eig"]
+__all__ = ["Graph", "recursive_eig", "compute_spectra"]
 
 
 class _DeviceBackedCSR(sparse.csr_matrix):
@@ -270,6 +270,36 @@ class Graph(object):
     def mean_filter_graph(self, values, iterations=300):
         """out = ((D+I)^-1 (W+I))^iterations values, on the device."""
         return self.device.mean_filter(np.asarray(values, dtype=np.float64), iterations)
+
+
+def compute_spectra(graphs):
+    """`get_graph_spectrum()` of several graphs at once (Focusr.__init__ does target then
+    source, focusr.py:150,169; the two are independent).  Each graph runs from its own host
+    thread on its own HIP stream (`Graph(ctx=...)` should differ per graph): at 250k vertices
+    a Chebyshev step is a ~6 us launch-latency-bound kernel, so the two recurrences overlap on
+    the device almost perfectly.  ctypes releases the GIL during every library call."""
+    graphs = list(graphs)
+    if len(graphs) <= 1 or len({id(g._ctx) for g in graphs}) < len(graphs):
+        for g in graphs:
+            g.get_graph_spectrum()
+        return
+    import threading
+
+    errors = []
+
+    def run(g):
+        try:
+            g.get_graph_spectrum()
+        except BaseException as exc:  # noqa: BLE001 - re-raised in the caller's thread
+            errors.append(exc)
+
+    threads = [threading.Thread(target=run, args=(g,)) for g in graphs]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if errors:
+        raise errors[0]
 
 
 def _device_eigs(dev, k, n_k_needed, k_buffer=1, minmax=False, verbose=False, **solver_kw):
