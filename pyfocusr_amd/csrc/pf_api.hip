@@ -99,12 +99,6 @@ void pf_destroy(pf_ctx* c) {
     if (!c) return;
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
-    pf_free(c->stream, c->knn_ref);
-    pf_free(c->stream, c->knn_qry);
-    pf_free(c->stream, c->knn_part_d2);
-    pf_free(c->stream, c->knn_part_idx);
-    pf_free(c->stream, c->knn_idx);
-    pf_free(c->stream, c->knn_d2);
     hipStreamSynchronize(c->stream);
     for (auto& kv : c->free_blocks) hipFree(kv.second);
     for (auto& kv : c->live_blocks) hipFree(kv.first);  // graphs the caller forgot to free

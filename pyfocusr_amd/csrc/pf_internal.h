@@ -48,15 +48,25 @@ struct pf_ctx {
     double knn_ms = 0.0;
     double build_ms = 0.0;
     // nearest-neighbour state (pf_knn_upload / run / download)
-    double* knn_ref = nullptr;
-    double* knn_qry = nullptr;
-    int64_t knn_nref = 0, knn_nqry = 0, knn_cap_ref = 0, knn_cap_qry = 0;
+    double* knn_ref = nullptr;   // [n_ref][d] as uploaded
+    double* knn_qry = nullptr;   // [n_qry][d]
+    double* knn_ref_s = nullptr; // rows sorted along the search axis
+    double* knn_qry_s = nullptr;
+    unsigned* knn_ref_key = nullptr; // sorted grid-cell ids (references: row-major; queries: Morton)
+    unsigned* knn_qry_key = nullptr;
+    int32_t* knn_cell_start = nullptr; // [res*res + 1] first sorted reference of each cell
+    int64_t knn_cap_cell = 0;
+    int knn_res = 0;
+    void* knn_grid = nullptr; // KnnGrid (pf_knn.hip)
+    int32_t* knn_ref_orig = nullptr; // sorted position -> original index
+    int32_t* knn_qry_orig = nullptr;
+    unsigned long long* knn_ext = nullptr; // [16] per-axis min / max (encoded)
+    int64_t knn_nref = 0, knn_nqry = 0;
+    int64_t knn_cap_ref = 0, knn_cap_qry = 0, knn_cap_ref_s = 0, knn_cap_qry_s = 0, knn_cap_ref_key = 0,
+            knn_cap_qry_key = 0, knn_cap_ref_orig = 0, knn_cap_qry_orig = 0, knn_cap_idx = 0, knn_cap_d2 = 0;
     int32_t knn_d = 0;
-    int32_t knn_splits = 0, knn_cap_part = 0;
-    double* knn_part_d2 = nullptr;   // [splits][n_qry]
-    int32_t* knn_part_idx = nullptr; // [splits][n_qry]
-    int64_t* knn_idx = nullptr;      // [n_qry]
-    double* knn_d2 = nullptr;        // [n_qry]
+    int64_t* knn_idx = nullptr; // [n_qry]
+    double* knn_d2 = nullptr;   // [n_qry]
     bool knn_ready = false, knn_done = false;
     // allocator state
     std::multimap<size_t, void*> free_blocks;   // size -> block

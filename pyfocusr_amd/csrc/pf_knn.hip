@@ -1,90 +1,284 @@
-// Exhaustive 1-nearest-neighbour search in d <= 8 dimensions, float64.
+// Exact 1-nearest-neighbour search in d <= 8 dimensions, float64.
 //
 // Replaces `scipy.spatial.KDTree(target).query(source)` at
 // /root/reference/pyfocusr/focusr.py:351-353 (spectral coordinates, d = n_spectral_features)
 // and /root/reference/pyfocusr/eigsort.py:203-204 (normalised xyz, d = 3).
 //
-// FP64-VALU-bound, not a dense contraction: depth d <= 8, and the |x|^2+|y|^2-2xy expansion
-// that MFMA would need loses ~5 digits to cancellation at neighbour distances ~1e-3, which
-// breaks index parity.  So: direct sum of squared differences, accumulated left to right with
-// separate multiply and add (file compiled with -ffp-contract=off) — the same roundings as a
-// numpy brute force — strict '<' while scanning references in ascending index order, so the
-// lowest index wins ties.
+// Arithmetic (what makes indices AND distances bit-identical to a numpy brute force): squared
+// distance = sum over the d coordinates, left to right, of (q_c - r_c)^2 with separate multiply
+// and add (file compiled with -ffp-contract=off); the smallest value wins, the lowest reference
+// index on exact ties.  FP64-VALU-bound and not a dense contraction: depth d <= 8, and the
+// |x|^2+|y|^2-2xy form MFMA would need loses ~5 digits at neighbour distances ~1e-3.
 //
-// Layout: one query per lane held in registers; reference points streamed through LDS in
-// tiles (coalesced global reads, broadcast LDS reads: every lane reads the same reference).
-// The reference range is split over gridDim.y so small query sets still fill 256 CUs; a
-// second kernel merges the per-split minima in split order.
+// Search (exact, output identical to exhaustive search): the reference points are binned on a
+// uniform 2-D grid over the reference set's two widest axes and radix-sorted by cell (hipCUB),
+// row-major, so the cells of one grid row that fall in an x-interval are one contiguous run of
+// the sorted array.  Queries are sorted along a Morton curve of the same grid, so the 256
+// queries of a block are neighbours in that plane.  Phase 1: each lane scans the cells around
+// its own and gets an upper bound best0 on its nearest distance.  Every coordinate term of the
+// squared distance is <= the rounded sum (adding non-negative terms is monotone in floating
+// point), so only references within sqrt(best0) of the query on BOTH grid axes can win or tie:
+// the block takes the bounding rectangle of those squares in cell coordinates and, row by row,
+// streams the references inside it through LDS (coalesced loads, broadcast reads) for every lane
+// to scan exhaustively; ties go to the lowest original index.  Spectral embeddings of surfaces
+// are 2-manifolds, so the rectangle holds ~1 % of the references (~0.1 % once the clouds are
+// registered); for unrelated clouds it grows to the whole grid and the kernel degenerates into
+// the tiled brute force.
+#include <hipcub/hipcub.hpp>
+
 #include <algorithm>
 
 #include "pf_internal.h"
 
 namespace {
 
-constexpr int KNN_TILE = 512;  // reference points per LDS tile (d=8: 32 KiB)
+constexpr int KNN_TILE = 512;  // reference points per LDS tile (d=8: 32 KiB + 2 KiB of indices)
+
+inline unsigned nblk(int64_t n) { return (unsigned)((n + PF_BLOCK - 1) / PF_BLOCK); }
+
+struct KnnGrid {
+    int a0, a1;      // grid axes (a1 == a0 when d == 1)
+    int r0, r1;      // cells per axis
+    double lo0, lo1; // grid origin
+    double s0, s1;   // cells per unit length (0 when the extent is 0)
+};
+
+__device__ __forceinline__ unsigned long long enc_f64(double d) {
+    const unsigned long long u = (unsigned long long)__double_as_longlong(d);
+    return (u >> 63) ? ~u : (u | (1ull << 63));
+}
+__device__ __forceinline__ double dec_f64(unsigned long long u) {
+    return __longlong_as_double((long long)((u >> 63) ? (u & ~(1ull << 63)) : ~u));
+}
+
+// monotone non-decreasing in x (same expression for references, queries and interval ends)
+__device__ __forceinline__ int cell_of(double x, double lo, double scale, int r) {
+    const double t = (x - lo) * scale;
+    return t > 0.0 ? (t >= (double)r ? r - 1 : (int)t) : 0;
+}
 
 template <int D>
-__global__ __launch_bounds__(PF_BLOCK) void k_knn_partial(const double* __restrict__ ref, int64_t n_ref,
-                                                          const double* __restrict__ qry, int64_t n_qry,
-                                                          int64_t refs_per_split, double* __restrict__ part_d2,
-                                                          int32_t* __restrict__ part_idx) {
+__device__ __forceinline__ double pick(const double (&q)[D], int axis) {
+    double v = q[0];
+#pragma unroll
+    for (int c = 1; c < D; ++c) v = (c == axis) ? q[c] : v;
+    return v;
+}
+
+// per-axis [min, max] of the reference set (order-preserving integer encoding + 64-bit atomics)
+__global__ __launch_bounds__(PF_BLOCK) void k_extent(const double* __restrict__ pts, int64_t n, int d, unsigned long long* ext) {
+    for (int a = 0; a < d; ++a) {
+        unsigned long long lo = ~0ull, hi = 0ull;
+        for (int64_t i = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * PF_BLOCK) {
+            const unsigned long long e = enc_f64(pts[i * d + a]);
+            lo = e < lo ? e : lo;
+            hi = e > hi ? e : hi;
+        }
+        for (int off = PF_WAVE / 2; off > 0; off >>= 1) {
+            const unsigned long long l2 = __shfl_xor(lo, off, PF_WAVE), h2 = __shfl_xor(hi, off, PF_WAVE);
+            lo = l2 < lo ? l2 : lo;
+            hi = h2 > hi ? h2 : hi;
+        }
+        if ((threadIdx.x & (PF_WAVE - 1)) == 0) {
+            atomicMin(&ext[a], lo);
+            atomicMax(&ext[8 + a], hi);
+        }
+    }
+}
+
+__global__ void k_make_grid(const unsigned long long* __restrict__ ext, int d, int res, KnnGrid* g) {
+    if (threadIdx.x | blockIdx.x) return;
+    int b0 = 0, b1 = 0;
+    double w0 = -1.0, w1 = -1.0;
+    for (int a = 0; a < d; ++a) {
+        const double e = dec_f64(ext[8 + a]) - dec_f64(ext[a]);
+        if (e > w0) {
+            w1 = w0;
+            b1 = b0;
+            w0 = e;
+            b0 = a;
+        } else if (e > w1) {
+            w1 = e;
+            b1 = a;
+        }
+    }
+    if (d == 1) {
+        b1 = b0;
+        w1 = 0.0;
+    }
+    g->a0 = b0;
+    g->a1 = b1;
+    g->r0 = res;
+    g->r1 = d == 1 ? 1 : res;
+    g->lo0 = dec_f64(ext[b0]);
+    g->lo1 = dec_f64(ext[b1]);
+    g->s0 = (w0 > 0.0 && isfinite(w0)) ? (double)res / w0 : 0.0;
+    g->s1 = (d > 1 && w1 > 0.0 && isfinite(w1)) ? (double)res / w1 : 0.0;
+}
+
+__device__ __forceinline__ unsigned spread16(unsigned v) {
+    v &= 0xffffu;
+    v = (v | (v << 8)) & 0x00ff00ffu;
+    v = (v | (v << 4)) & 0x0f0f0f0fu;
+    v = (v | (v << 2)) & 0x33333333u;
+    v = (v | (v << 1)) & 0x55555555u;
+    return v;
+}
+
+// morton = 0: row-major cell id (references); 1: Morton code of the cell (queries)
+__global__ __launch_bounds__(PF_BLOCK) void k_cell_keys(const double* __restrict__ pts, int64_t n, int d,
+                                                        const KnnGrid* __restrict__ gp, int morton, unsigned* __restrict__ keys,
+                                                        int32_t* __restrict__ vals) {
+    const int64_t i = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const KnnGrid g = *gp;
+    const int cx = cell_of(pts[i * d + g.a0], g.lo0, g.s0, g.r0);
+    const int cy = cell_of(pts[i * d + g.a1], g.lo1, g.s1, g.r1);
+    keys[i] = morton ? (spread16((unsigned)cx) | (spread16((unsigned)cy) << 1)) : (unsigned)(cy * g.r0 + cx);
+    vals[i] = (int32_t)i;
+}
+
+__global__ __launch_bounds__(PF_BLOCK) void k_gather_rows(const double* __restrict__ pts, const int32_t* __restrict__ order,
+                                                          int64_t n, int d, double* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const int64_t src = order[i];
+    for (int c = 0; c < d; ++c) out[i * d + c] = pts[src * d + c];
+}
+
+// cell_start[c] = first sorted reference with cell id >= c   (c in [0, n_cells])
+__global__ __launch_bounds__(PF_BLOCK) void k_cell_start(const unsigned* __restrict__ keys, int64_t n, int64_t n_cells,
+                                                         int32_t* __restrict__ cell_start) {
+    const int64_t c = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
+    if (c > n_cells) return;
+    int64_t lo = 0, hi = n;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if ((int64_t)keys[mid] < c) lo = mid + 1; else hi = mid;
+    }
+    cell_start[c] = (int32_t)lo;
+}
+
+template <int D>
+__device__ __forceinline__ double dist2(const double (&q)[D], const double* __restrict__ r) {
+    double s = 0.0;
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+        const double df = q[c] - r[c];
+        const double sq = df * df;
+        s = (c == 0) ? sq : s + sq;
+    }
+    return s;
+}
+
+template <int D>
+__global__ __launch_bounds__(PF_BLOCK) void k_knn_grid(const double* __restrict__ ref_s /* rows sorted by cell */,
+                                                       const int32_t* __restrict__ ref_orig,
+                                                       const int32_t* __restrict__ cell_start, int64_t n_ref,
+                                                       const double* __restrict__ qry_s, const int32_t* __restrict__ qry_orig,
+                                                       int64_t n_qry, const KnnGrid* __restrict__ gp,
+                                                       int64_t* __restrict__ idx_out, double* __restrict__ d2_out) {
     __shared__ double tile[KNN_TILE * D];
-    const int64_t q = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
-    const int64_t r_begin = (int64_t)blockIdx.y * refs_per_split;
-    const int64_t r_end = r_begin + refs_per_split < n_ref ? r_begin + refs_per_split : n_ref;
-    double qc[D];
-    const int64_t qq = q < n_qry ? q : n_qry - 1;  // tail lanes replay the last query, result discarded
+    __shared__ int32_t tile_idx[KNN_TILE];
+    __shared__ int box[PF_BLOCK / PF_WAVE][4];
+    const KnnGrid g = *gp;
+    const int64_t qi = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
+    const int64_t qq = qi < n_qry ? qi : n_qry - 1;  // tail lanes replay the last query, result discarded
+    double q[D];
 #pragma unroll
-    for (int c = 0; c < D; ++c) qc[c] = qry[qq * D + c];
-    double best = INFINITY;
-    int32_t best_idx = (int32_t)r_begin;
-    for (int64_t t0 = r_begin; t0 < r_end; t0 += KNN_TILE) {
-        const int cnt = (int)((r_end - t0) < KNN_TILE ? (r_end - t0) : KNN_TILE);
-        __syncthreads();
-        for (int k = threadIdx.x; k < cnt * D; k += PF_BLOCK) tile[k] = ref[t0 * D + k];
-        __syncthreads();
-        for (int r = 0; r < cnt; ++r) {
-            double s = 0.0;
-#pragma unroll
-            for (int c = 0; c < D; ++c) {
-                const double df = qc[c] - tile[r * D + c];
-                const double sq = df * df;
-                s = (c == 0) ? sq : s + sq;
-            }
-            if (s < best) {
-                best = s;
-                best_idx = (int32_t)(t0 + r);
-            }
-        }
-    }
-    if (q < n_qry) {
-        part_d2[(int64_t)blockIdx.y * n_qry + q] = best;
-        part_idx[(int64_t)blockIdx.y * n_qry + q] = best_idx;
-    }
-}
+    for (int c = 0; c < D; ++c) q[c] = qry_s[qq * D + c];
+    const double qx = pick<D>(q, g.a0), qy = pick<D>(q, g.a1);
+    const int cx = cell_of(qx, g.lo0, g.s0, g.r0), cy = cell_of(qy, g.lo1, g.s1, g.r1);
 
-__global__ __launch_bounds__(PF_BLOCK) void k_knn_merge(const double* __restrict__ part_d2,
-                                                        const int32_t* __restrict__ part_idx, int64_t n_qry,
-                                                        int32_t splits, int64_t* __restrict__ idx, double* __restrict__ d2) {
-    const int64_t q = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
-    if (q >= n_qry) return;
-    double best = part_d2[q];
-    int32_t bi = part_idx[q];
-    for (int32_t s = 1; s < splits; ++s) {
-        const double v = part_d2[(int64_t)s * n_qry + q];
-        if (v < best) {  // strict: earlier split (lower indices) wins ties
-            best = v;
-            bi = part_idx[(int64_t)s * n_qry + q];
+    // ---- phase 1: upper bound from the cells around the query (grow the ring until something is found)
+    double best = INFINITY;
+    int32_t best_idx = 0x7fffffff;
+    for (int ring = 1; ring <= 4 && best == INFINITY; ++ring) {
+        const int y0 = cy - ring > 0 ? cy - ring : 0, y1 = cy + ring < g.r1 - 1 ? cy + ring : g.r1 - 1;
+        const int x0 = cx - ring > 0 ? cx - ring : 0, x1 = cx + ring < g.r0 - 1 ? cx + ring : g.r0 - 1;
+        for (int y = y0; y <= y1; ++y) {
+            const int32_t b = cell_start[y * g.r0 + x0], e = cell_start[y * g.r0 + x1 + 1];
+            for (int32_t r = b; r < e; ++r) {
+                const double s = dist2<D>(q, ref_s + (int64_t)r * D);
+                const int32_t o = ref_orig[r];
+                if (s < best || (s == best && o < best_idx)) {
+                    best = s;
+                    best_idx = o;
+                }
+            }
         }
     }
-    idx[q] = bi;
-    d2[q] = best;
+    // ---- block rectangle: every reference that can beat or tie a lane lies within rad of it on both axes
+    const double rad = sqrt(best) * (1.0 + 1e-9) + 1e-300;  // inflated against the rounding of sqrt / the subtractions
+    double xl = qx - rad, xh = qx + rad, yl = qy - rad, yh = qy + rad;
+    xl -= fabs(xl) * 1e-15;
+    xh += fabs(xh) * 1e-15;
+    yl -= fabs(yl) * 1e-15;
+    yh += fabs(yh) * 1e-15;
+    int bx0 = cell_of(xl, g.lo0, g.s0, g.r0), bx1 = cell_of(xh, g.lo0, g.s0, g.r0);
+    int by0 = cell_of(yl, g.lo1, g.s1, g.r1), by1 = cell_of(yh, g.lo1, g.s1, g.r1);
+    if (!(best < INFINITY)) {  // nothing nearby: the whole grid
+        bx0 = 0;
+        by0 = 0;
+        bx1 = g.r0 - 1;
+        by1 = g.r1 - 1;
+    }
+#pragma unroll
+    for (int off = PF_WAVE / 2; off > 0; off >>= 1) {
+        bx0 = min(bx0, __shfl_xor(bx0, off, PF_WAVE));
+        by0 = min(by0, __shfl_xor(by0, off, PF_WAVE));
+        bx1 = max(bx1, __shfl_xor(bx1, off, PF_WAVE));
+        by1 = max(by1, __shfl_xor(by1, off, PF_WAVE));
+    }
+    if ((threadIdx.x & (PF_WAVE - 1)) == 0) {
+        int* b = box[threadIdx.x / PF_WAVE];
+        b[0] = bx0;
+        b[1] = bx1;
+        b[2] = by0;
+        b[3] = by1;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < PF_BLOCK / PF_WAVE; ++w) {
+        bx0 = min(bx0, box[w][0]);
+        bx1 = max(bx1, box[w][1]);
+        by0 = min(by0, box[w][2]);
+        by1 = max(by1, box[w][3]);
+    }
+
+    // ---- phase 2: exhaustive scan of the rectangle, one contiguous run of references per grid row
+    for (int y = by0; y <= by1; ++y) {
+        const int32_t run_b = cell_start[y * g.r0 + bx0], run_e = cell_start[y * g.r0 + bx1 + 1];
+        for (int32_t t0 = run_b; t0 < run_e; t0 += KNN_TILE) {
+            const int cnt = (run_e - t0) < KNN_TILE ? (run_e - t0) : KNN_TILE;
+            __syncthreads();
+            for (int k = threadIdx.x; k < cnt * D; k += PF_BLOCK) tile[k] = ref_s[(int64_t)t0 * D + k];
+            for (int k = threadIdx.x; k < cnt; k += PF_BLOCK) tile_idx[k] = ref_orig[t0 + k];
+            __syncthreads();
+            for (int r = 0; r < cnt; ++r) {
+                const double s = dist2<D>(q, tile + r * D);
+                if (s <= best) {
+                    const int32_t o = tile_idx[r];
+                    if (s < best || o < best_idx) {
+                        best = s;
+                        best_idx = o;
+                    }
+                }
+            }
+        }
+    }
+    if (qi < n_qry) {
+        const int64_t dst = qry_orig[qi];
+        idx_out[dst] = best_idx;
+        d2_out[dst] = best;
+    }
 }
 
 template <int D>
-int launch_knn(pf_ctx* c, dim3 grid, int64_t refs_per_split) {
-    k_knn_partial<D><<<grid, PF_BLOCK, 0, c->stream>>>(c->knn_ref, c->knn_nref, c->knn_qry, c->knn_nqry, refs_per_split,
-                                                       c->knn_part_d2, c->knn_part_idx);
+int launch_knn(pf_ctx* c) {
+    k_knn_grid<D><<<nblk(c->knn_nqry), PF_BLOCK, 0, c->stream>>>(c->knn_ref_s, c->knn_ref_orig, c->knn_cell_start, c->knn_nref,
+                                                                 c->knn_qry_s, c->knn_qry_orig, c->knn_nqry,
+                                                                 (const KnnGrid*)c->knn_grid, c->knn_idx, c->knn_d2);
     PF_HIP(hipGetLastError());
     return PF_OK;
 }
@@ -100,48 +294,72 @@ int grow(hipStream_t st, T** p, int64_t* cap, int64_t need) {
     return PF_OK;
 }
 
+// sort one point set by grid cell: sorted keys, original indices, gathered rows
+int sort_points(pf_ctx* c, const double* pts, int64_t n, int d, int morton, int key_bits, unsigned* key_out, int32_t* orig_out,
+                double* rows_out) {
+    hipStream_t st = c->stream;
+    unsigned* k0 = nullptr;
+    int32_t* v0 = nullptr;
+    void* tmp = nullptr;
+    size_t bytes = 0;
+    int rc = PF_OK;
+    hipError_t e = pf_malloc(st, (void**)&k0, sizeof(unsigned) * n);
+    if (e == hipSuccess) e = pf_malloc(st, (void**)&v0, sizeof(int32_t) * n);
+    if (e == hipSuccess) {
+        k_cell_keys<<<nblk(n), PF_BLOCK, 0, st>>>(pts, n, d, (const KnnGrid*)c->knn_grid, morton, k0, v0);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, k0, key_out, v0, orig_out, (int)n, 0, key_bits, st);
+    if (e == hipSuccess) e = pf_malloc(st, &tmp, bytes);
+    if (e == hipSuccess) e = hipcub::DeviceRadixSort::SortPairs(tmp, bytes, k0, key_out, v0, orig_out, (int)n, 0, key_bits, st);
+    if (e == hipSuccess) {
+        k_gather_rows<<<nblk(n), PF_BLOCK, 0, st>>>(pts, orig_out, n, d, rows_out);
+        e = hipGetLastError();
+    }
+    if (e != hipSuccess) {
+        pf_set_error("pf_knn: %s", hipGetErrorString(e));
+        rc = PF_E_HIP;
+    }
+    pf_free(st, k0);
+    pf_free(st, v0);
+    pf_free(st, tmp);
+    return rc;
+}
+
 }  // namespace
 
 extern "C" {
 
 int pf_knn_upload(pf_ctx* c, const double* ref, int64_t n_ref, const double* qry, int64_t n_qry, int32_t d) {
     PF_CHECK(c && ref && qry, PF_E_ARG, "pf_knn_upload: NULL argument");
-    PF_CHECK(n_ref > 0 && n_ref < ((int64_t)1 << 31) && n_qry > 0 && d >= 1 && d <= 8, PF_E_ARG,
+    PF_CHECK(n_ref > 0 && n_ref < ((int64_t)1 << 31) && n_qry > 0 && n_qry < ((int64_t)1 << 31) && d >= 1 && d <= 8, PF_E_ARG,
              "pf_knn_upload: n_ref %lld, n_qry %lld, d %d out of range (1 <= d <= 8)", (long long)n_ref, (long long)n_qry, d);
     PF_HIP(hipSetDevice(c->device));
+    hipStream_t st = c->stream;
     c->knn_ready = c->knn_done = false;
-    PF_TRY(grow(c->stream, &c->knn_ref, &c->knn_cap_ref, n_ref * 8));
-    PF_TRY(grow(c->stream, &c->knn_qry, &c->knn_cap_qry, n_qry * 8));
-    // enough (query-block x split) work items to cover 256 CUs several times
-    const int64_t q_blocks = (n_qry + PF_BLOCK - 1) / PF_BLOCK;
-    int64_t splits = (2048 + q_blocks - 1) / q_blocks;
-    splits = std::max<int64_t>(1, std::min<int64_t>(splits, (n_ref + KNN_TILE - 1) / KNN_TILE));
-    splits = std::min<int64_t>(splits, 65535);
-    const int64_t need = splits * n_qry;
-    if (need > c->knn_cap_part) {
-        pf_free(c->stream, c->knn_part_d2);
-        pf_free(c->stream, c->knn_part_idx);
-        pf_free(c->stream, c->knn_idx);
-        pf_free(c->stream, c->knn_d2);
-        c->knn_part_d2 = nullptr;
-        c->knn_part_idx = nullptr;
-        c->knn_idx = nullptr;
-        c->knn_d2 = nullptr;
-        c->knn_cap_part = 0;
-        PF_HIP(pf_malloc(c->stream, (void**)&c->knn_part_d2, sizeof(double) * (size_t)need));
-        PF_HIP(pf_malloc(c->stream, (void**)&c->knn_part_idx, sizeof(int32_t) * (size_t)need));
-        PF_HIP(pf_malloc(c->stream, (void**)&c->knn_idx, sizeof(int64_t) * (size_t)need));
-        PF_HIP(pf_malloc(c->stream, (void**)&c->knn_d2, sizeof(double) * (size_t)need));
-        c->knn_cap_part = (int32_t)std::min<int64_t>(need, INT32_MAX);
-        PF_CHECK(need <= INT32_MAX, PF_E_ARG, "pf_knn_upload: problem too large");
-    }
-    c->knn_splits = (int32_t)splits;
+    PF_TRY(grow(st, &c->knn_ref, &c->knn_cap_ref, n_ref * 8));
+    PF_TRY(grow(st, &c->knn_ref_s, &c->knn_cap_ref_s, n_ref * 8));
+    PF_TRY(grow(st, &c->knn_ref_key, &c->knn_cap_ref_key, n_ref));
+    // grid resolution: ~4 references per cell if they were spread over the plane
+    int res = (int)sqrt((double)n_ref / 4.0);
+    res = res < 4 ? 4 : (res > 2048 ? 2048 : res);
+    c->knn_res = res;
+    PF_TRY(grow(st, &c->knn_cell_start, &c->knn_cap_cell, (int64_t)res * res + 2));
+    PF_TRY(grow(st, &c->knn_ref_orig, &c->knn_cap_ref_orig, n_ref));
+    PF_TRY(grow(st, &c->knn_qry, &c->knn_cap_qry, n_qry * 8));
+    PF_TRY(grow(st, &c->knn_qry_s, &c->knn_cap_qry_s, n_qry * 8));
+    PF_TRY(grow(st, &c->knn_qry_key, &c->knn_cap_qry_key, n_qry));
+    PF_TRY(grow(st, &c->knn_qry_orig, &c->knn_cap_qry_orig, n_qry));
+    PF_TRY(grow(st, &c->knn_idx, &c->knn_cap_idx, n_qry));
+    PF_TRY(grow(st, &c->knn_d2, &c->knn_cap_d2, n_qry));
+    if (!c->knn_ext) PF_HIP(pf_malloc(st, (void**)&c->knn_ext, 16 * sizeof(unsigned long long)));
+    if (!c->knn_grid) PF_HIP(pf_malloc(st, &c->knn_grid, sizeof(KnnGrid)));
     c->knn_nref = n_ref;
     c->knn_nqry = n_qry;
     c->knn_d = d;
-    PF_HIP(hipMemcpyAsync(c->knn_ref, ref, sizeof(double) * n_ref * d, hipMemcpyHostToDevice, c->stream));
-    PF_HIP(hipMemcpyAsync(c->knn_qry, qry, sizeof(double) * n_qry * d, hipMemcpyHostToDevice, c->stream));
-    PF_HIP(hipStreamSynchronize(c->stream));
+    PF_HIP(hipMemcpyAsync(c->knn_ref, ref, sizeof(double) * n_ref * d, hipMemcpyHostToDevice, st));
+    PF_HIP(hipMemcpyAsync(c->knn_qry, qry, sizeof(double) * n_qry * d, hipMemcpyHostToDevice, st));
+    PF_HIP(hipStreamSynchronize(st));
     c->knn_ready = true;
     return PF_OK;
 }
@@ -150,27 +368,36 @@ int pf_knn_run(pf_ctx* c) {
     PF_CHECK(c != nullptr, PF_E_ARG, "pf_knn_run: ctx is NULL");
     PF_CHECK(c->knn_ready, PF_E_STATE, "pf_knn_run: no uploaded problem");
     PF_HIP(hipSetDevice(c->device));
-    const int64_t q_blocks = (c->knn_nqry + PF_BLOCK - 1) / PF_BLOCK;
-    const int64_t per = (c->knn_nref + c->knn_splits - 1) / c->knn_splits;
-    dim3 grid((unsigned)q_blocks, (unsigned)c->knn_splits);
-    PF_HIP(hipEventRecord(c->ev0, c->stream));
+    hipStream_t st = c->stream;
+    const int d = c->knn_d;
+    PF_HIP(hipEventRecord(c->ev0, st));
+    PF_HIP(hipMemsetAsync(c->knn_ext, 0xff, 8 * sizeof(unsigned long long), st));
+    PF_HIP(hipMemsetAsync(c->knn_ext + 8, 0x00, 8 * sizeof(unsigned long long), st));
+    const int res = c->knn_res;
+    const int64_t n_cells = d == 1 ? res : (int64_t)res * res;
+    int cell_bits = 1;
+    while (((int64_t)1 << cell_bits) < n_cells) ++cell_bits;
+    k_extent<<<256, PF_BLOCK, 0, st>>>(c->knn_ref, c->knn_nref, d, c->knn_ext);
+    k_make_grid<<<1, 1, 0, st>>>(c->knn_ext, d, res, (KnnGrid*)c->knn_grid);
+    PF_HIP(hipGetLastError());
+    PF_TRY(sort_points(c, c->knn_ref, c->knn_nref, d, 0, cell_bits, c->knn_ref_key, c->knn_ref_orig, c->knn_ref_s));
+    k_cell_start<<<nblk(n_cells + 1), PF_BLOCK, 0, st>>>(c->knn_ref_key, c->knn_nref, n_cells, c->knn_cell_start);
+    PF_HIP(hipGetLastError());
+    PF_TRY(sort_points(c, c->knn_qry, c->knn_nqry, d, 1, 32, c->knn_qry_key, c->knn_qry_orig, c->knn_qry_s));
     int r = PF_E_ARG;
-    switch (c->knn_d) {
-        case 1: r = launch_knn<1>(c, grid, per); break;
-        case 2: r = launch_knn<2>(c, grid, per); break;
-        case 3: r = launch_knn<3>(c, grid, per); break;
-        case 4: r = launch_knn<4>(c, grid, per); break;
-        case 5: r = launch_knn<5>(c, grid, per); break;
-        case 6: r = launch_knn<6>(c, grid, per); break;
-        case 7: r = launch_knn<7>(c, grid, per); break;
-        case 8: r = launch_knn<8>(c, grid, per); break;
+    switch (d) {
+        case 1: r = launch_knn<1>(c); break;
+        case 2: r = launch_knn<2>(c); break;
+        case 3: r = launch_knn<3>(c); break;
+        case 4: r = launch_knn<4>(c); break;
+        case 5: r = launch_knn<5>(c); break;
+        case 6: r = launch_knn<6>(c); break;
+        case 7: r = launch_knn<7>(c); break;
+        case 8: r = launch_knn<8>(c); break;
         default: break;
     }
     PF_TRY(r);
-    k_knn_merge<<<(unsigned)q_blocks, PF_BLOCK, 0, c->stream>>>(c->knn_part_d2, c->knn_part_idx, c->knn_nqry, c->knn_splits,
-                                                               c->knn_idx, c->knn_d2);
-    PF_HIP(hipGetLastError());
-    PF_HIP(hipEventRecord(c->ev1, c->stream));
+    PF_HIP(hipEventRecord(c->ev1, st));
     PF_HIP(hipEventSynchronize(c->ev1));
     float ms = 0.f;
     PF_HIP(hipEventElapsedTime(&ms, c->ev0, c->ev1));
@@ -182,6 +409,7 @@ int pf_knn_run(pf_ctx* c) {
 int pf_knn_download(pf_ctx* c, int64_t* idx_out, double* d2_out) {
     PF_CHECK(c != nullptr && idx_out != nullptr, PF_E_ARG, "pf_knn_download: NULL argument");
     PF_CHECK(c->knn_done, PF_E_STATE, "pf_knn_download: pf_knn_run has not completed");
+    PF_HIP(hipSetDevice(c->device));
     PF_HIP(hipMemcpyAsync(idx_out, c->knn_idx, sizeof(int64_t) * c->knn_nqry, hipMemcpyDeviceToHost, c->stream));
     if (d2_out) PF_HIP(hipMemcpyAsync(d2_out, c->knn_d2, sizeof(double) * c->knn_nqry, hipMemcpyDeviceToHost, c->stream));
     PF_HIP(hipStreamSynchronize(c->stream));

@@ -316,6 +316,29 @@ def test_knn_ties_and_idempotence(ctx):
         ctx.knn1(np.zeros((4, 9)), np.zeros((4, 9)))
 
 
+def test_knn_window_edge_cases(ctx):
+    """The sorted-window search must stay exact where its pruning is stressed."""
+    rng = np.random.default_rng(11)
+
+    def check(ref, qry):
+        idx, d2 = ctx.knn1(ref, qry, return_d2=True)
+        bidx, bd2 = orc.knn1_bruteforce(ref, qry)
+        assert np.array_equal(idx, bidx) and np.array_equal(d2, bd2)
+
+    check(np.tile(rng.normal(size=(1, 4)), (700, 1)), rng.normal(size=(300, 4)))  # zero extent on every axis
+    ref = rng.normal(size=(3000, 3))
+    ref[:, 0] = np.where(rng.random(3000) < 0.5, 0.0, -0.0)  # widest axis elsewhere; signed zeros on one axis
+    check(ref, rng.normal(size=(1000, 3)))
+    ref = rng.normal(size=(2000, 2)) * np.array([100.0, 1e-3])
+    ref[:, 0] = np.round(ref[:, 0])  # many equal keys on the sort axis, winner decided by the other axis
+    check(ref, rng.normal(size=(900, 2)) * np.array([100.0, 1e-3]))
+    check(rng.uniform(0, 1, size=(5000, 5)), rng.uniform(10, 11, size=(777, 5)))  # disjoint clouds: window = everything
+    check(rng.normal(size=(5, 6)), rng.normal(size=(1000, 6)))  # fewer references than the probe width
+    grid = np.stack(np.meshgrid(np.arange(20.0), np.arange(20.0), np.arange(20.0), indexing="ij"), -1).reshape(-1, 3)
+    check(grid, grid + 0.5)  # every query has 8 exactly equidistant references: lowest index must win
+    check(grid[rng.permutation(len(grid))], grid + 0.5)
+
+
 @pytest.mark.parametrize("pair", ["pair_5k", "pair_15k"])
 def test_knn_golden_correspondence(golden, ctx, pair):
     """focusr.py:351-353 on the reference's own spectral coordinates: indices identical
