@@ -103,12 +103,12 @@ def cpu_baseline(mesh_t, k, coords, knn_sample):
                 pair_seconds=t_pair)
 
 
-def split_pair_step(ctx, dist, torch, rank, mesh, k, n_samples):
+def split_pair_step(ctx, dist, torch, tdev, rank, mesh, k, n_samples):
     """BASELINE config C4: rank 0 = target, rank 1 = source; all-gather of the normalised
     eigenvectors (n x k f64) over RCCL/xGMI; eigsort replicated (k x k work); KNN sharded by
     source rows; indices gathered on rank 0."""
     from pyfocusr_amd import Graph, eigsort
-    from pyfocusr_amd.parallel import gather_spectral, shard_rows
+    from pyfocusr_amd.parallel import all_gather_rows, gather_spectral, shard_rows
 
     g = Graph(mesh, n_spectral_features=k, n_rand_samples=n_samples, ctx=ctx, verbose=False)
     g.get_graph_spectrum()
@@ -128,11 +128,9 @@ def split_pair_step(ctx, dist, torch, rank, mesh, k, n_samples):
     src, tgt = gs.eig_vecs[:, :k] * w[None, :], gt.eig_vecs[:, :k] * w[None, :]
     lo, hi = shard_rows(len(src), 2, rank)
     part = ctx.knn1(tgt, src[lo:hi])
-    out = [torch.empty(shard_rows(len(src), 2, r)[1] - shard_rows(len(src), 2, r)[0], dtype=torch.int64, device="cuda")
-           for r in range(2)]
-    dist.all_gather(out, torch.from_numpy(part).cuda())
+    parts = all_gather_rows(dist, torch, part.astype(np.float64))  # ragged shards (float64 carries int32 exactly)
     g.device.close()
-    return torch.cat(out).cpu().numpy()
+    return np.concatenate([p[:, 0] for p in parts]).astype(np.int64)
 
 
 def main():
@@ -140,13 +138,17 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=250000, help="vertices per mesh")
+    ap.add_argument("--vertices", dest="n", type=int, default=250000, help="vertices per mesh")
     ap.add_argument("--k", type=int, default=5)
     ap.add_argument("--samples", type=int, default=5000, help="n_coords_spectral_ordering (focusr.py:37)")
     ap.add_argument("--cpu-knn-sample", type=int, default=25000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--streams", type=int, default=2, choices=(1, 2),
-                    help="2: target and source eigensolves run concurrently on two HIP streams; 1: one after the other")
+    ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
+                    help="torch.distributed backend; gloo + --share-gpu rehearses the N>1 path on a 1-GPU box")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses GPU 0")
+    ap.add_argument("--streams", type=int, default=1, choices=(1, 2),
+                    help="1: target and source Chebyshev recurrences in lockstep, two graphs per launch on one stream; "
+                         "2: two host threads, one HIP stream each")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -157,12 +159,18 @@ def main():
 
     import torch
 
+    if args.share_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dist = None
+    tdev = "cuda" if args.backend == "nccl" else "cpu"  # where the collectives' tensors live
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group("gloo")
 
     from pyfocusr_amd import _hip
     from pyfocusr_amd.meshgen import blob_mesh
@@ -197,22 +205,22 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=tdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     tms = [c.timing() for c in set(ctxs)]
     tm = dict(op_ms=sum(t["op_ms"] for t in tms), op_launches=sum(t["op_launches"] for t in tms),
-              knn_ms=tms[0]["knn_ms"])
+              op_bytes=sum(t["op_bytes"] for t in tms), knn_ms=tms[0]["knn_ms"])
 
     split = None
     if world == 2:
         for it in range(2):  # one warm-up, one timed
             barrier()
             s0 = time.perf_counter()
-            split_pair_step(ctx, dist, torch, rank, mesh_t if rank == 0 else mesh_s, args.k, args.samples)
+            split_pair_step(ctx, dist, torch, tdev, rank, mesh_t if rank == 0 else mesh_s, args.k, args.samples)
             barrier()
             split_s = time.perf_counter() - s0
-        t = torch.tensor([split_s], dtype=torch.float64, device="cuda")
+        t = torch.tensor([split_s], dtype=torch.float64, device=tdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         split = dict(workload="C4: one %d-vertex pair, target on GPU0 / source on GPU1, RCCL all-gather of spectral "
                               "coordinates, query-sharded KNN" % args.n, ms=1e3 * float(t.item()),
@@ -221,7 +229,10 @@ def main():
     if rank == 0:
         n = args.n
         kernel_us = 1e3 * tm["op_ms"] / max(tm["op_launches"], 1)
-        alg_bytes = spmv_algorithmic_bytes(n, nnz[0])
+        # bytes per launch: the library sums 12 nnz + 20 n + 4 over the graphs each launch advances
+        # (two per launch while the target and source recurrences run in lockstep)
+        alg_bytes = tm["op_bytes"] / max(tm["op_launches"], 1)
+        assert abs(spmv_algorithmic_bytes(n, nnz[0]) - (12 * nnz[0] + 20 * n + 4)) == 0
         achieved = alg_bytes / (kernel_us * 1e-6) / 1e9
         traffic = None
         pmc = os.path.join(REPO, "profiles", "pmc_summary.json")
@@ -252,6 +263,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_sell_op (fused SpMV + Chebyshev recurrence, SELL-64, f64)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
+                         "graphs_per_launch": alg_bytes / spmv_algorithmic_bytes(n, nnz[0]),
                          "avg_launch_us_hip_events": kernel_us, "launches": tm["op_launches"]},
         }
         if split is not None:

@@ -58,6 +58,7 @@ typedef struct pf_graph_info {
 typedef struct pf_timing {
     double op_ms;        /* accumulated device time of fused SpMV/Chebyshev launches (HIP events) */
     int64_t op_launches; /* number of those launches                                              */
+    double op_bytes;     /* algorithmic bytes they moved: sum of 12 nnz + 20 n + 4 per graph and step */
     double knn_ms;       /* device time of the last pf_knn_run                                    */
     double build_ms;     /* device time of the last pf_graph_build (kernels only)                 */
 } pf_timing;
@@ -99,6 +100,9 @@ int pf_ws_ensure(pf_graph* g, int32_t n_slots);
 int pf_ws_upload(pf_graph* g, int32_t slot, const double* x);            /* x[n]            */
 int pf_ws_download(pf_graph* g, int32_t first, int32_t count, double* out); /* out[count][n]  */
 int pf_ws_copy(pf_graph* g, int32_t src, int32_t dst, int32_t count);
+/* Krylov start vector into `slot`: a low-order polynomial of the vertex positions (rich in the low
+ * eigenmodes) plus counter-based noise from `seed`; zero on isolated vertices.  Deterministic. */
+int pf_start_vector(pf_graph* g, int32_t slot, uint64_t seed);
 int pf_mask_isolated(pf_graph* g, int32_t slot);                          /* x[i] = 0 where deg_i == 0 */
 /* unit-norm null vectors of `op`, one per component with >= 2 vertices, into slots
  * [0, n_components): 1_C for PF_OP_RW, sqrt(deg+1e-8) on C for PF_OP_SYM. */
@@ -109,6 +113,10 @@ int pf_spmv(pf_graph* g, int32_t op, int32_t src, int32_t dst);           /* dst
 /* dst = T_degree((c I - A)/e) src : `degree` launches of the fused SpMV + three-term
  * recurrence kernel.  src is preserved; dst != src. */
 int pf_cheb(pf_graph* g, int32_t op, int32_t src, int32_t dst, int32_t degree, double c, double e);
+/* Two independent recurrences (graphs a and b of one ctx) advanced in lockstep: step k of both in
+ * ONE launch while both have steps left, the longer one alone afterwards. */
+int pf_cheb2(pf_graph* ga, int32_t op_a, int32_t src_a, int32_t dst_a, int32_t degree_a, double c_a, double e_a,
+             pf_graph* gb, int32_t op_b, int32_t src_b, int32_t dst_b, int32_t degree_b, double c_b, double e_b);
 int pf_dots(pf_graph* g, int32_t w, int32_t first, int32_t count, double* out);  /* out[b] = <slot first+b, slot w> */
 /* classical Gram-Schmidt twice of slot w against slots [first, first+count): h[count] = summed
  * coefficients, *nrm = ||w|| afterwards (w is left un-normalised). */

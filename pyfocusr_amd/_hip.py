@@ -40,7 +40,8 @@ class GraphInfo(C.Structure):
 
 
 class Timing(C.Structure):
-    _fields_ = [("op_ms", C.c_double), ("op_launches", C.c_int64), ("knn_ms", C.c_double), ("build_ms", C.c_double)]
+    _fields_ = [("op_ms", C.c_double), ("op_launches", C.c_int64), ("op_bytes", C.c_double), ("knn_ms", C.c_double),
+                ("build_ms", C.c_double)]
 
 
 # name -> (restype, argtypes): every symbol include/pyfocusr_hip.h declares.
@@ -64,10 +65,13 @@ SIGNATURES = {
     "pf_ws_upload": (C.c_int, [C.c_void_p, C.c_int32, _f64p]),
     "pf_ws_download": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _f64p]),
     "pf_ws_copy": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
+    "pf_start_vector": (C.c_int, [C.c_void_p, C.c_int32, C.c_uint64]),
     "pf_mask_isolated": (C.c_int, [C.c_void_p, C.c_int32]),
     "pf_lock_null_vectors": (C.c_int, [C.c_void_p, C.c_int32, _i32p]),
     "pf_spmv": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
     "pf_cheb": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double]),
+    "pf_cheb2": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double,
+                           C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double]),
     "pf_dots": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, _f64p]),
     "pf_orth": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, _f64p, _f64p]),
     "pf_scale": (C.c_int, [C.c_void_p, C.c_int32, C.c_double]),
@@ -170,7 +174,8 @@ class Context(object):
     def timing(self, reset=False):
         t = Timing()
         _check(self._lib.pf_timing_get(self._h, C.byref(t), int(bool(reset))))
-        return dict(op_ms=t.op_ms, op_launches=int(t.op_launches), knn_ms=t.knn_ms, build_ms=t.build_ms)
+        return dict(op_ms=t.op_ms, op_launches=int(t.op_launches), op_bytes=t.op_bytes, knn_ms=t.knn_ms,
+                    build_ms=t.build_ms)
 
     # ---- nearest neighbour -------------------------------------------------------------
     def knn1(self, ref, qry, return_d2=False):
@@ -322,6 +327,9 @@ class DeviceLaplacian(object):
     def mask_isolated(self, slot):
         _check(self._lib.pf_mask_isolated(self._h, int(slot)))
 
+    def start_vector(self, slot, seed):
+        _check(self._lib.pf_start_vector(self._h, int(slot), int(seed)))
+
     def lock_null_vectors(self):
         k = C.c_int32()
         _check(self._lib.pf_lock_null_vectors(self._h, self.op, C.byref(k)))
@@ -332,6 +340,13 @@ class DeviceLaplacian(object):
 
     def cheb(self, src, dst, degree, c, e):
         _check(self._lib.pf_cheb(self._h, self.op, int(src), int(dst), int(degree), float(c), float(e)))
+
+    def cheb2(self, req_self, other, req_other):
+        """One lockstep filter application for two graphs of the same context:
+        req = (src, dst, degree, c, e)."""
+        a, b = req_self, req_other
+        _check(self._lib.pf_cheb2(self._h, self.op, int(a[0]), int(a[1]), int(a[2]), float(a[3]), float(a[4]),
+                                  other._h, other.op, int(b[0]), int(b[1]), int(b[2]), float(b[3]), float(b[4])))
 
     def dots(self, w, first, count):
         out = np.empty(int(count), dtype=np.float64)

@@ -125,10 +125,57 @@ def _ordered_schur(H, symmetric, n_real, n_extra=0):
     return theta, U, T, int(sdim), int(min(cnt[-1], n_real))
 
 
-def filtered_eigs(ops, n_wanted, symmetric, null_slots=0, cut=None, tol=1e-12, m_max=None,
-                  max_restarts=60, max_filter_resets=8, seed=0, strength=3.5, hi=2.0,
-                  nonsym_degree_cap=128, verbose=False):
-    """Smallest `n_wanted` non-null eigenpairs of the Laplacian held by `ops`.
+def drive(gen, ops):
+    """Run a solver generator to completion, executing each filter request on `ops`."""
+    try:
+        req = next(gen)
+        while True:
+            ops.cheb(*req)
+            req = gen.send(None)
+    except StopIteration as stop:
+        return stop.value
+
+
+def drive_pair(gen_a, ops_a, gen_b, ops_b):
+    """Run two solver generators in lockstep: while both have a filter application pending,
+    the two Chebyshev recurrences advance in shared kernel launches (`ops.cheb2`); once one
+    solver has finished the other continues alone.  Returns both results."""
+    gens, ops, reqs, results = [gen_a, gen_b], [ops_a, ops_b], [None, None], [None, None]
+
+    def advance(i, first=False):
+        try:
+            reqs[i] = next(gens[i]) if first else gens[i].send(None)
+        except StopIteration as stop:
+            reqs[i], results[i], gens[i] = None, stop.value, None
+
+    advance(0, True)
+    advance(1, True)
+    while gens[0] is not None or gens[1] is not None:
+        if gens[0] is not None and gens[1] is not None:
+            ops[0].cheb2(reqs[0], ops[1], reqs[1])
+            advance(0)
+            advance(1)
+        else:
+            i = 0 if gens[0] is not None else 1
+            ops[i].cheb(*reqs[i])
+            advance(i)
+    return results[0], results[1]
+
+
+def filtered_eigs(ops, n_wanted, symmetric, **kw):
+    """Smallest `n_wanted` non-null eigenpairs of the Laplacian held by `ops`
+    (see `filtered_eigs_gen` for arguments and return value)."""
+    return drive(filtered_eigs_gen(ops, n_wanted, symmetric, **kw), ops)
+
+
+def filtered_eigs_gen(ops, n_wanted, symmetric, null_slots=0, cut=None, tol=1e-12, m_max=None,
+                      max_restarts=60, max_filter_resets=8, seed=0, strength=3.5, hi=2.0,
+                      nonsym_degree_cap=128, verbose=False):
+    """Generator form of the solver: yields `(src, dst, degree, c, e)` whenever the Chebyshev
+    filter has to be applied (the only expensive device operation) and receives nothing back;
+    `drive` / `drive_pair` execute the requests.  Its return value is the solver result.
+
+    Smallest `n_wanted` non-null eigenpairs of the Laplacian held by `ops`.
 
     `ops` must already hold `null_slots` orthonormal null vectors of the operator
     in workspace slots [0, null_slots) (one per non-trivial connected component).
@@ -154,11 +201,11 @@ def filtered_eigs(ops, n_wanted, symmetric, null_slots=0, cut=None, tol=1e-12, m
     if cut is None:
         cut = 8.0 * (n_wanted + 1) / max(n_active, 1)
     degree_cap = 4000 if symmetric else int(nonsym_degree_cap)
-    rng = np.random.default_rng(seed)
+    n_starts = [int(seed)]
 
     def start_vector(slot, nbasis):
-        ops.upload(slot, rng.standard_normal(n))
-        ops.mask_isolated(slot)
+        ops.start_vector(slot, n_starts[0])  # generated on the device, zero on isolated vertices
+        n_starts[0] += 1
         _, nrm = ops.orth(slot, A0, nbasis)
         ops.scale(slot, 1.0 / nrm)
 
@@ -184,7 +231,7 @@ def filtered_eigs(ops, n_wanted, symmetric, null_slots=0, cut=None, tol=1e-12, m
         restarts = 0
         while outcome is None:
             while j < m_max and outcome is None:  # ---- expand
-                ops.cheb(A0 + j, A0 + j + 1, p, c, e)
+                yield (A0 + j, A0 + j + 1, p, c, e)
                 stats.matvecs += p
                 stats.outer_steps += 1
                 h, beta = ops.orth(A0 + j + 1, A0, j + 1)

@@ -130,11 +130,13 @@ int pf_timing_get(pf_ctx* c, pf_timing* out, int reset) {
     PF_CHECK(c != nullptr && out != nullptr, PF_E_ARG, "pf_timing_get: NULL argument");
     out->op_ms = c->op_ms;
     out->op_launches = c->op_launches;
+    out->op_bytes = c->op_bytes;
     out->knn_ms = c->knn_ms;
     out->build_ms = c->build_ms;
     if (reset) {
         c->op_ms = 0.0;
         c->op_launches = 0;
+        c->op_bytes = 0.0;
     }
     return PF_OK;
 }

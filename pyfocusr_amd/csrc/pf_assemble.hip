@@ -291,6 +291,7 @@ void pf_graph_free(pf_graph* g) {
     pf_free(st, g->label);
     pf_free(st, g->perm);
     pf_free(st, g->iperm);
+    pf_free(st, g->smooth);
     pf_free(st, g->stage);
     pf_free(st, g->slice_ptr);
     pf_free(st, g->scol);
@@ -416,6 +417,7 @@ int pf_graph_build_device(pf_mesh* mesh, pf_graph** out) {
     PF_TRY(dev_alloc(st, &g->label, g->n_pad));
     PF_TRY(dev_alloc(st, &g->perm, g->n_pad));
     PF_TRY(dev_alloc(st, &g->iperm, g->n_pad));
+    PF_TRY(dev_alloc(st, &g->smooth, g->n_pad));
     PF_TRY(dev_alloc(st, &g->slice_ptr, g->n_slices + 1));
 
     PF_HIP(hipMemsetAsync(cnt, 0, sizeof(int32_t) * (n + 1), st));

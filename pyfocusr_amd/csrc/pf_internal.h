@@ -45,6 +45,7 @@ struct pf_ctx {
     bool timing = false;
     double op_ms = 0.0;
     int64_t op_launches = 0;
+    double op_bytes = 0.0;
     double knn_ms = 0.0;
     double build_ms = 0.0;
     // nearest-neighbour state (pf_knn_upload / run / download)
@@ -90,6 +91,7 @@ struct pf_graph {
     // "new" order; everything that crosses the C-ABI is in the mesh's own ("old") order.
     int32_t* perm = nullptr;  // [n_pad] new -> old, -1 on padding rows
     int32_t* iperm = nullptr; // [n]     old -> new
+    double* smooth = nullptr; // [n_pad] solver order: low-order polynomial of the vertex position (Krylov start vector)
     double* stage = nullptr;  // [stage_cap] staging for permuted uploads/downloads
     int64_t stage_cap = 0;
     // SELL-64 operator storage (off-diagonals) + dense diagonal

@@ -23,29 +23,37 @@ inline unsigned nblk(int64_t n) { return (unsigned)((n + PF_BLOCK - 1) / PF_BLOC
 //   SpMV:            alpha = -1, shift = 0, beta = 0      -> out = A x
 //   Chebyshev k = 1: alpha = 1/e, shift = c, beta = 0
 //   Chebyshev k > 1: alpha = 2/e, shift = c, beta = 1     (out may alias prev)
+struct OpArgs {
+    const int64_t* slice_ptr;
+    const int32_t* scol;
+    const double* sval;
+    const double* diag;
+    const double* x;
+    const double* prev;
+    double* out;
+    double alpha, shift, beta;
+    unsigned n_blocks;  // multiple of 8
+};
+
 template <bool HAS_PREV>
-__global__ __launch_bounds__(PF_BLOCK) void k_sell_op(const int64_t* __restrict__ slice_ptr,
-                                                      const int32_t* __restrict__ scol,
-                                                      const double* __restrict__ sval,
-                                                      const double* __restrict__ diag, const double* __restrict__ x,
-                                                      const double* prev, double* out, double alpha, double shift,
-                                                      double beta) {
+__device__ __forceinline__ void sell_op_block(const OpArgs& a, unsigned bid) {
 #pragma clang fp contract(fast)
     // Blocks are dealt round-robin over the 8 XCDs (private 4 MiB L2 each).  Give every XCD one
     // contiguous eighth of the (Morton-ordered) rows: its slice of the matrix (~2.6 MB at 250k
-    // vertices) and of x then stays in its own L2 from one launch to the next.  gridDim.x is a
+    // vertices) and of x then stays in its own L2 from one launch to the next.  n_blocks is a
     // multiple of 8 (n_pad is a multiple of 8 * PF_BLOCK); placement affects speed only.
-    const unsigned per_xcd = gridDim.x >> 3;
-    const unsigned blk = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+    const unsigned per_xcd = a.n_blocks >> 3;
+    const unsigned blk = (bid & 7u) * per_xcd + (bid >> 3);
     const int64_t row = (int64_t)blk * PF_BLOCK + threadIdx.x;
     const int64_t s = row >> 6;
     const int lane = threadIdx.x & (PF_WAVE - 1);
-    const int64_t base = slice_ptr[s];
-    const int width = (int)((slice_ptr[s + 1] - base) >> 6);
+    const int64_t base = a.slice_ptr[s];
+    const int width = (int)((a.slice_ptr[s + 1] - base) >> 6);
+    const double* __restrict__ x = a.x;
     const double xi = x[row];
-    double acc = diag[row] * xi;
-    const int32_t* cp = scol + base + lane;
-    const double* vp = sval + base + lane;
+    double acc = a.diag[row] * xi;
+    const int32_t* __restrict__ cp = a.scol + base + lane;
+    const double* __restrict__ vp = a.sval + base + lane;
     int j = 0;
     for (; j + 4 <= width; j += 4) {
         const int32_t c0 = cp[(int64_t)(j + 0) * PF_WAVE], c1 = cp[(int64_t)(j + 1) * PF_WAVE];
@@ -59,9 +67,23 @@ __global__ __launch_bounds__(PF_BLOCK) void k_sell_op(const int64_t* __restrict_
         acc += v3 * x3;
     }
     for (; j < width; ++j) acc += vp[(int64_t)j * PF_WAVE] * x[cp[(int64_t)j * PF_WAVE]];
-    double r = alpha * (shift * xi - acc);
-    if (HAS_PREV) r -= beta * prev[row];
-    out[row] = r;
+    double r = a.alpha * (a.shift * xi - acc);
+    if (HAS_PREV) r -= a.beta * a.prev[row];
+    a.out[row] = r;
+}
+
+template <bool HAS_PREV>
+__global__ __launch_bounds__(PF_BLOCK) void k_sell_op(OpArgs a) {
+    sell_op_block<HAS_PREV>(a, blockIdx.x);
+}
+
+// the same step for two independent graphs in one launch (target and source mesh of a pair run
+// their Chebyshev recurrences in lockstep): a 250k-vertex step alone is ~5 us, of which ~3 us is
+// launch/ramp latency; two per launch amortise it.
+template <bool HAS_PREV>
+__global__ __launch_bounds__(PF_BLOCK) void k_sell_op2(OpArgs a, OpArgs b) {
+    if (blockIdx.x < a.n_blocks) sell_op_block<HAS_PREV>(a, blockIdx.x);
+    else sell_op_block<HAS_PREV>(b, blockIdx.x - a.n_blocks);
 }
 
 // partial[b][chunk] = sum over the chunk's rows of V_b[i] * w[i]   (fixed order -> deterministic)
@@ -128,6 +150,26 @@ __global__ __launch_bounds__(PF_BLOCK) void k_mask_isolated(double* __restrict__
     if (r >= n) return;
     const int32_t i = perm[r];
     if (rowptr[i + 1] == rowptr[i]) x[r] = 0.0;
+}
+
+// Krylov start vector, part 2: smooth part + counter-based noise (splitmix64 of (seed, vertex)), zero
+// on isolated vertices and padding.  Noise keeps every eigenmode present whatever the geometry.
+__global__ __launch_bounds__(PF_BLOCK) void k_start_vector(double* __restrict__ x, const double* __restrict__ smooth,
+                                                           const int32_t* __restrict__ perm, const int32_t* __restrict__ rowptr,
+                                                           int64_t n_pad, unsigned long long seed, double noise) {
+    const int64_t r = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
+    if (r >= n_pad) return;
+    const int32_t i = perm[r];
+    double v = 0.0;
+    if (i >= 0 && rowptr[i + 1] > rowptr[i]) {
+        unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(i + 1);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z ^= z >> 31;
+        const double u = (double)(z >> 11) * (1.0 / 9007199254740992.0) - 0.5;  // uniform in [-0.5, 0.5)
+        v = smooth[r] + noise * u;
+    }
+    x[r] = v;
 }
 
 // host order <-> solver order
@@ -343,22 +385,69 @@ const double* op_values(pf_graph* g, int32_t op) {
     return nullptr;
 }
 
+OpArgs op_args(pf_graph* g, const double* vals, const double* x, const double* prev, double* out, double alpha, double shift,
+               double beta) {
+    return OpArgs{g->slice_ptr, g->scol, vals, g->diag, x, prev, out, alpha, shift, beta, nblk(g->n_pad)};
+}
+
+int64_t op_bytes(const pf_graph* g) {  // 12 nnz + 20 n + 4, nnz counted with the diagonal
+    return 12 * (g->nnz_w + g->n - g->n_isolated) + 20 * g->n + 4;
+}
+
 int launch_op(pf_graph* g, const double* vals, const double* x, const double* prev, double* out, double alpha, double shift,
               double beta) {
     hipStream_t st = g->ctx->stream;
+    const OpArgs a = op_args(g, vals, x, prev, out, alpha, shift, beta);
     if (prev)
-        k_sell_op<true><<<nblk(g->n_pad), PF_BLOCK, 0, st>>>(g->slice_ptr, g->scol, vals, g->diag, x, prev, out, alpha, shift, beta);
+        k_sell_op<true><<<a.n_blocks, PF_BLOCK, 0, st>>>(a);
     else
-        k_sell_op<false><<<nblk(g->n_pad), PF_BLOCK, 0, st>>>(g->slice_ptr, g->scol, vals, g->diag, x, nullptr, out, alpha, shift, beta);
+        k_sell_op<false><<<a.n_blocks, PF_BLOCK, 0, st>>>(a);
     PF_HIP(hipGetLastError());
     return PF_OK;
 }
 
+int launch_op2(pf_graph* ga, const OpArgs& a, const OpArgs& b, bool has_prev) {
+    hipStream_t st = ga->ctx->stream;
+    if (has_prev)
+        k_sell_op2<true><<<a.n_blocks + b.n_blocks, PF_BLOCK, 0, st>>>(a, b);
+    else
+        k_sell_op2<false><<<a.n_blocks + b.n_blocks, PF_BLOCK, 0, st>>>(a, b);
+    PF_HIP(hipGetLastError());
+    return PF_OK;
+}
+
+// Rotating buffers of one Chebyshev recurrence: y0 = src; y1 = (c y0 - A y0)/e;
+// y_{k+1} = (2/e)(c y_k - A y_k) - y_{k-1}.  y_{k+1} overwrites y_{k-1} element-wise (thread i reads
+// prev[i] then writes out[i]); the caller's src is never overwritten; the last step lands in dst.
+struct ChebState {
+    pf_graph* g;
+    const double* vals;
+    const double* y_prev;
+    const double* y_cur;
+    double* bufs[2];
+    double* dst;
+    int32_t degree;
+    double c, e;
+    OpArgs step(int32_t k) {  // arguments of step k (1-based); advances the rotation
+        double* target;
+        if (k == degree) target = dst;
+        else if (k == 1) target = bufs[0];
+        else if (k == 2) target = bufs[1];
+        else target = const_cast<double*>(y_prev);
+        OpArgs a = k == 1 ? op_args(g, vals, y_prev, nullptr, target, 1.0 / e, c, 0.0)
+                          : op_args(g, vals, y_cur, y_prev, target, 2.0 / e, c, 1.0);
+        if (k > 1) y_prev = y_cur;
+        y_cur = target;
+        return a;
+    }
+};
+
 struct OpTimer {
     pf_ctx* c;
     int64_t launches;
+    double bytes;
     bool on;
-    OpTimer(pf_ctx* ctx, int64_t n) : c(ctx), launches(n), on(ctx->timing) {
+    OpTimer(pf_ctx* ctx, int64_t n, double b) : c(ctx), launches(n), bytes(b), on(ctx->timing) {
         if (on) hipEventRecord(c->ev0, c->stream);
     }
     int finish() {
@@ -369,6 +458,7 @@ struct OpTimer {
         PF_HIP(hipEventElapsedTime(&ms, c->ev0, c->ev1));
         c->op_ms += ms;
         c->op_launches += launches;
+        c->op_bytes += bytes;
         return PF_OK;
     }
 };
@@ -467,6 +557,14 @@ int pf_mask_isolated(pf_graph* g, int32_t slot) {
     return PF_OK;
 }
 
+int pf_start_vector(pf_graph* g, int32_t slot, uint64_t seed) {
+    PF_TRY(check_slots(g, slot, 1, "pf_start_vector"));
+    k_start_vector<<<nblk(g->n_pad), PF_BLOCK, 0, g->ctx->stream>>>(pf_slot(g, slot), g->smooth, g->perm, g->rowptr, g->n_pad,
+                                                                    (unsigned long long)seed, 0.5);
+    PF_HIP(hipGetLastError());
+    return PF_OK;
+}
+
 int pf_lock_null_vectors(pf_graph* g, int32_t op, int32_t* n_locked) {
     PF_CHECK(g != nullptr && n_locked != nullptr, PF_E_ARG, "pf_lock_null_vectors: NULL argument");
     PF_HIP(hipSetDevice(g->ctx->device));
@@ -497,7 +595,7 @@ int pf_spmv(pf_graph* g, int32_t op, int32_t src, int32_t dst) {
     PF_TRY(check_slots(g, dst, 1, "pf_spmv"));
     const double* vals = op_values(g, op);
     PF_CHECK(vals != nullptr && src != dst, PF_E_ARG, "pf_spmv: operator %d unavailable or src == dst", op);
-    OpTimer t(g->ctx, 1);
+    OpTimer t(g->ctx, 1, (double)op_bytes(g));
     PF_TRY(launch_op(g, vals, pf_slot(g, src), nullptr, pf_slot(g, dst), -1.0, 0.0, 0.0));
     return t.finish();
 }
@@ -508,23 +606,38 @@ int pf_cheb(pf_graph* g, int32_t op, int32_t src, int32_t dst, int32_t degree, d
     const double* vals = op_values(g, op);
     PF_CHECK(vals != nullptr && src != dst, PF_E_ARG, "pf_cheb: operator %d unavailable or src == dst", op);
     PF_CHECK(degree >= 1 && e > 0.0, PF_E_ARG, "pf_cheb: degree %d / half-width %g invalid", degree, e);
-    OpTimer t(g->ctx, degree);
-    // y0 = src; y1 = (c y0 - A y0)/e; y_{k+1} = (2/e)(c y_k - A y_k) - y_{k-1}.
-    // y_{k+1} overwrites y_{k-1} element-wise (thread i reads prev[i] then writes out[i]); the last step lands in dst.
-    const double* y_prev = pf_slot(g, src);
-    double* bufs[2] = {pf_tmp(g, 0), pf_tmp(g, 1)};
-    double* d = pf_slot(g, dst);
-    double* y1 = degree == 1 ? d : bufs[0];
-    PF_TRY(launch_op(g, vals, y_prev, nullptr, y1, 1.0 / e, c, 0.0));
-    const double* y_cur = y1;
-    for (int32_t k = 2; k <= degree; ++k) {
-        double* target;
-        if (k == degree) target = d;
-        else if (k == 2) target = bufs[1];          // y0 is the caller's src: never overwrite it
-        else target = const_cast<double*>(y_prev);  // recycle y_{k-2}'s buffer
-        PF_TRY(launch_op(g, vals, y_cur, y_prev, target, 2.0 / e, c, 1.0));
-        y_prev = y_cur;
-        y_cur = target;
+    OpTimer t(g->ctx, degree, (double)degree * op_bytes(g));
+    ChebState st{g, vals, pf_slot(g, src), pf_slot(g, src), {pf_tmp(g, 0), pf_tmp(g, 1)}, pf_slot(g, dst), degree, c, e};
+    for (int32_t k = 1; k <= degree; ++k) {
+        const OpArgs a = st.step(k);
+        PF_TRY(launch_op(g, a.sval, a.x, a.prev, a.out, a.alpha, a.shift, a.beta));
+    }
+    return t.finish();
+}
+
+int pf_cheb2(pf_graph* ga, int32_t op_a, int32_t src_a, int32_t dst_a, int32_t degree_a, double c_a, double e_a, pf_graph* gb,
+             int32_t op_b, int32_t src_b, int32_t dst_b, int32_t degree_b, double c_b, double e_b) {
+    PF_TRY(check_slots(ga, src_a, 1, "pf_cheb2"));
+    PF_TRY(check_slots(ga, dst_a, 1, "pf_cheb2"));
+    PF_TRY(check_slots(gb, src_b, 1, "pf_cheb2"));
+    PF_TRY(check_slots(gb, dst_b, 1, "pf_cheb2"));
+    PF_CHECK(ga != gb && ga->ctx == gb->ctx, PF_E_ARG, "pf_cheb2: the two graphs must differ and share one ctx (stream)");
+    const double* va = op_values(ga, op_a);
+    const double* vb = op_values(gb, op_b);
+    PF_CHECK(va && vb && src_a != dst_a && src_b != dst_b, PF_E_ARG, "pf_cheb2: operator unavailable or src == dst");
+    PF_CHECK(degree_a >= 1 && degree_b >= 1 && e_a > 0.0 && e_b > 0.0, PF_E_ARG, "pf_cheb2: bad degree / half-width");
+    const int32_t joint = std::min(degree_a, degree_b), longest = std::max(degree_a, degree_b);
+    OpTimer t(ga->ctx, longest, (double)degree_a * op_bytes(ga) + (double)degree_b * op_bytes(gb));
+    ChebState sa{ga, va, pf_slot(ga, src_a), pf_slot(ga, src_a), {pf_tmp(ga, 0), pf_tmp(ga, 1)}, pf_slot(ga, dst_a), degree_a, c_a, e_a};
+    ChebState sb{gb, vb, pf_slot(gb, src_b), pf_slot(gb, src_b), {pf_tmp(gb, 0), pf_tmp(gb, 1)}, pf_slot(gb, dst_b), degree_b, c_b, e_b};
+    for (int32_t k = 1; k <= joint; ++k) {
+        const OpArgs a = sa.step(k), b = sb.step(k);
+        PF_TRY(launch_op2(ga, a, b, k > 1));
+    }
+    for (int32_t k = joint + 1; k <= longest; ++k) {  // the longer recurrence finishes alone
+        ChebState& s1 = degree_a > degree_b ? sa : sb;
+        const OpArgs a = s1.step(k);
+        PF_TRY(launch_op(s1.g, a.sval, a.x, a.prev, a.out, a.alpha, a.shift, a.beta));
     }
     return t.finish();
 }

@@ -100,9 +100,33 @@ __global__ __launch_bounds__(PF_BLOCK) void k_finish_perm(int32_t* __restrict__ 
     else perm[r] = -1;
 }
 
+// Krylov start vector, part 1: a low-order polynomial of the vertex position (coordinates mapped to
+// [-1, 1] by the bounding box).  It is rich in the low eigenmodes the solver wants (a random vector
+// carries ~n^-1/2 of each), which saves about one outer step in twenty.  Stored in solver order.
+__global__ __launch_bounds__(PF_BLOCK) void k_smooth_start(const double* __restrict__ pts, const int32_t* __restrict__ perm,
+                                                           const unsigned long long* __restrict__ bbox, int64_t n_pad,
+                                                           double* __restrict__ out) {
+    const int64_t r = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
+    if (r >= n_pad) return;
+    const int32_t i = perm[r];
+    double v = 0.0;
+    if (i >= 0) {
+        double c[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const double lo = dec_f64(bbox[a]), hi = dec_f64(bbox[3 + a]);
+            const double h = 0.5 * (hi - lo);
+            c[a] = h > 0.0 ? (pts[3 * (int64_t)i + a] - 0.5 * (hi + lo)) / h : 0.0;
+        }
+        const double x = c[0], y = c[1], z = c[2];  // fixed, unequal coefficients: no accidental cancellation
+        v = 1.0 * x + 0.9 * y + 1.1 * z + 0.8 * x * y + 1.2 * y * z + 0.7 * x * z + 1.3 * (x * x - y * y) + 0.6 * z * z;
+    }
+    out[r] = v;
+}
+
 }  // namespace
 
-// Fills g->perm [n_pad] and g->iperm [n] (both already allocated).
+// Fills g->perm [n_pad], g->iperm [n] and g->smooth [n_pad] (all already allocated).
 int pf_compute_order(pf_graph* g, const double* d_pts) {
     hipStream_t st = g->ctx->stream;
     const int64_t n = g->n;
@@ -143,6 +167,7 @@ int pf_compute_order(pf_graph* g, const double* d_pts) {
         need = tmp_bytes;
         if (fail(hipcub::DeviceRadixSort::SortPairs(tmp, need, k0, k1, v1, g->perm, in, 0, bits2, st))) break;
         k_finish_perm<<<nblk(g->n_pad), PF_BLOCK, 0, st>>>(g->perm, g->iperm, n, g->n_pad);
+        k_smooth_start<<<nblk(g->n_pad), PF_BLOCK, 0, st>>>(d_pts, g->perm, bbox, g->n_pad, g->smooth);
         if (fail(hipGetLastError())) break;
     } while (0);
     pf_free(st, bbox);

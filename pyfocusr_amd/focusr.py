@@ -147,13 +147,12 @@ class Focusr(object):
             norm_node_features_cap_std=norm_node_features_cap_std,
             norm_node_features_0_1=norm_node_features_0_1,
         )
-        # focusr.py:134-170 builds target then source; the two spectra are independent, so they run
-        # concurrently on two HIP streams of the same device.
-        self._ctx_source = _hip.Context(self._ctx.device)
+        # focusr.py:134-170 builds target then source; the two spectra are independent, so their
+        # Chebyshev recurrences run in lockstep, two graphs per kernel launch.
         print("Starting to build first graph")
         self.graph_target = Graph(vtk_mesh_target, ctx=self._ctx, **graph_kw)
         print("Loaded Mesh 1")
-        self.graph_source = Graph(vtk_mesh_source, ctx=self._ctx_source, **graph_kw)
+        self.graph_source = Graph(vtk_mesh_source, ctx=self._ctx, **graph_kw)
         print("Loaded Mesh 2")
         compute_spectra([self.graph_target, self.graph_source])
         print("Computed spectrum 1")

@@ -28,7 +28,7 @@ import numpy as np
 from scipy import sparse
 
 from . import _hip
-from ._krylov import MIN_EIG_VAL, filtered_eigs
+from ._krylov import MIN_EIG_VAL, drive, drive_pair, filtered_eigs_gen
 from .vtk_functions import mesh_arrays, vtk_deep_copy  # noqa: F401
 
 __all__ = ["Graph", "recursive_eig", "compute_spectra"]
@@ -274,12 +274,14 @@ class Graph(object):
 
 def compute_spectra(graphs):
     """`get_graph_spectrum()` of several graphs at once (Focusr.__init__ does target then
-    source, focusr.py:150,169; the two are independent).  Each graph runs from its own host
-    thread on its own HIP stream (`Graph(ctx=...)` should differ per graph): at 250k vertices
-    a Chebyshev step is a ~6 us launch-latency-bound kernel, so the two recurrences overlap on
-    the device almost perfectly.  ctypes releases the GIL during every library call."""
+    source, focusr.py:150,169; the two are independent).  Two graphs of one context run in
+    lockstep on its stream (`_paired_spectra`); graphs of different contexts run from one host
+    thread each, every one on its own HIP stream (ctypes releases the GIL during library calls)."""
     graphs = list(graphs)
-    if len(graphs) <= 1 or len({id(g._ctx) for g in graphs}) < len(graphs):
+    if len(graphs) == 2 and graphs[0].device.ctx is graphs[1].device.ctx:
+        _paired_spectra(graphs[0], graphs[1])
+        return
+    if len(graphs) <= 1 or len({id(g.device.ctx) for g in graphs}) < len(graphs):
         for g in graphs:
             g.get_graph_spectrum()
         return
@@ -302,10 +304,30 @@ def compute_spectra(graphs):
         raise errors[0]
 
 
-def _device_eigs(dev, k, n_k_needed, k_buffer=1, minmax=False, verbose=False, **solver_kw):
-    """`recursive_eig` on a device graph.  Returns (eig_vals ascending, eig_vecs
-    (n, m), stats) with m = k_final - (#null eigenvalues) >= n_k_needed, exactly
-    the column count the reference's widen-and-retry loop ends with."""
+def _paired_spectra(ga, gb):
+    """Both spectra on ONE stream with the two Chebyshev recurrences advancing in shared kernel
+    launches (`pf_cheb2`): a 250k-vertex filter step alone is a ~5 us kernel of which ~3 us is
+    launch/ramp latency, so two graphs per launch cost ~1.5x one."""
+    gens = []
+    for g in (ga, gb):
+        if g.verbose:
+            print("Beginning Eigen Decomposition")
+        gens.append(_device_eigs_gen(g.device, k=g.n_spectral_features + 1, n_k_needed=g.n_spectral_features,
+                                     k_buffer=1, minmax=g.norm_eig_vecs is True, verbose=g.verbose))
+    ra, rb = drive_pair(gens[0], ga.device, gens[1], gb.device)
+    for g, (vals, vecs, stats) in ((ga, ra), (gb, rb)):
+        g.eig_vals, g.eig_vecs, g.eigs_stats = vals, vecs, stats
+        if g.verbose:
+            print("All final eigenvalues are: \n{}".format(g.eig_vals))
+            print("-" * 72)
+            print("Final eigenvalues of interest are: \n{}".format(g.eig_vals))
+
+
+def _device_eigs_gen(dev, k, n_k_needed, k_buffer=1, minmax=False, verbose=False, **solver_kw):
+    """`recursive_eig` on a device graph, as a generator of filter requests (see
+    `_krylov.filtered_eigs_gen`).  Result: (eig_vals ascending, eig_vecs (n, m), stats) with
+    m = k_final - (#null eigenvalues) >= n_k_needed, exactly the column count the reference's
+    widen-and-retry loop ends with."""
     n = dev.n
     n_null = dev.n_components + dev.n_isolated
     if verbose:
@@ -320,7 +342,7 @@ def _device_eigs(dev, k, n_k_needed, k_buffer=1, minmax=False, verbose=False, **
         if m_out == 0:
             return np.zeros(0), np.zeros((n, 0)), None
         c0 = dev.lock_null_vectors()
-        lam, first, stats = filtered_eigs(dev, m_out, dev.symmetric, null_slots=c0, **solver_kw)
+        lam, first, stats = yield from filtered_eigs_gen(dev, m_out, dev.symmetric, null_slots=c0, **solver_kw)
         extra_null = stats.n_null - c0
         if extra_null > 0 and len(lam) < m_out:  # a null vector the component count did not predict
             n_null += extra_null
@@ -328,6 +350,10 @@ def _device_eigs(dev, k, n_k_needed, k_buffer=1, minmax=False, verbose=False, **
         break
     vecs = dev.finalize_vectors(first, len(lam), minmax)
     return lam, vecs, stats
+
+
+def _device_eigs(dev, k, n_k_needed, k_buffer=1, minmax=False, verbose=False, **solver_kw):
+    return drive(_device_eigs_gen(dev, k, n_k_needed, k_buffer, minmax, verbose, **solver_kw), dev)
 
 
 def recursive_eig(matrix, k, n_k_needed, k_buffer=1, sigma=1e-10, which="LM"):

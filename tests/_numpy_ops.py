@@ -50,6 +50,11 @@ class NumpyOps(object):
     def copy(self, src, dst, count):
         self.ws[:, dst : dst + count] = self.ws[:, src : src + count].copy()
 
+    def start_vector(self, slot, seed):
+        x = np.random.default_rng(seed).standard_normal(self.n)
+        x[self.isolated] = 0.0
+        self.ws[:, slot] = x
+
     def mask_isolated(self, slot):
         self.ws[self.isolated, slot] = 0.0
 
@@ -77,6 +82,10 @@ class NumpyOps(object):
             y0, y1 = y1, (2.0 / e) * (c * y1 - A @ y1) - y0
         self.ws[:, dst] = y1
         self.launches += p
+
+    def cheb2(self, req_self, other, req_other):
+        self.cheb(*req_self)
+        other.cheb(*req_other)
 
     # -- vector kernels
     def dots(self, w, first, count):

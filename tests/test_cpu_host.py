@@ -175,6 +175,27 @@ def test_krylov_components_isolated_and_bad_cut():
     np.testing.assert_allclose(lam3, orc.graph_spectrum(a.points, a.faces, 4)["eig_vals"], rtol=1e-8)
 
 
+def test_lockstep_pair_driver_equals_single_solves(golden):
+    """`drive_pair` (two solvers sharing kernel launches) must return what two separate solves
+    return, also when the two need different degrees / step counts / a filter reset."""
+    from pyfocusr_amd._krylov import drive, drive_pair, filtered_eigs_gen
+    from pyfocusr_amd.meshgen import blob_mesh
+
+    a, b = golden("target_mesh"), blob_mesh(1500, seed=9)
+    single = []
+    for pts, faces, kw in ((a["points"], a["faces"], {}), (b.points, b.faces, dict(cut=1e-7))):
+        ops = NumpyOps(orc.weighted_adjacency(pts, faces))
+        c0 = ops.lock_null_vectors()
+        single.append(drive(filtered_eigs_gen(ops, 4, ops.symmetric, null_slots=c0, **kw), ops))
+    oa, ob = NumpyOps(orc.weighted_adjacency(a["points"], a["faces"])), NumpyOps(orc.weighted_adjacency(b.points, b.faces))
+    ga = filtered_eigs_gen(oa, 4, True, null_slots=oa.lock_null_vectors())
+    gb = filtered_eigs_gen(ob, 4, True, null_slots=ob.lock_null_vectors(), cut=1e-7)
+    ra, rb = drive_pair(ga, oa, gb, ob)
+    for (lam, first, st), (lam1, first1, st1) in ((ra, single[0]), (rb, single[1])):
+        assert np.array_equal(lam, lam1) and first == first1 and st.matvecs == st1.matvecs
+    assert rb[2].filter_resets >= 1 and ra[2].degree != rb[2].degree
+
+
 def test_widen_rule_matches_reference_trace(golden):
     from pyfocusr_amd.graph import _widened_k
 

@@ -266,6 +266,22 @@ def test_spectrum_vs_reference(golden, ctx, name, k):
     assert np.max(np.linalg.norm(R, axis=0)) < 1e-8
 
 
+def test_paired_spectra_equal_single(golden, ctx):
+    """Two graphs per kernel launch (pf_cheb2, different sizes and degrees) give bit-identical
+    results to one graph per launch."""
+    from pyfocusr_amd import Graph
+    from pyfocusr_amd.graph import compute_spectra
+
+    gs = [Graph(mesh_of(golden(n)), n_spectral_features=k, n_rand_samples=10**9, ctx=ctx, verbose=False)
+          for n, k in (("target_mesh", 6), ("target_mesh_15k", 5))]
+    compute_spectra(gs)
+    for g, (n, k) in zip(gs, (("target_mesh", 6), ("target_mesh_15k", 5))):
+        one = Graph(mesh_of(golden(n)), n_spectral_features=k, n_rand_samples=10**9, ctx=ctx, verbose=False)
+        one.get_graph_spectrum()
+        assert np.array_equal(g.eig_vals, one.eig_vals) and np.array_equal(g.eig_vecs, one.eig_vecs)
+        assert g.eigs_stats.matvecs == one.eigs_stats.matvecs
+
+
 def test_multi_component_and_recursive_eig(hip, ctx):
     """Two blobs + 3 unreferenced points: 2 null vectors + 3 isolated -> widen rule."""
     from pyfocusr_amd import Graph, PolyMesh, recursive_eig
