@@ -139,7 +139,8 @@ int pf_mean_filter(pf_graph* g, const double* values, int32_t ncols, int32_t ite
 
 /* ---- nearest neighbour (replaces scipy KDTree(ref).query(qry), k=1, p=2) ------------------ */
 /* focusr.py:351-353 (spectral coordinates, d = n_spectral_features) and eigsort.py:203-204
- * (d = 3).  Exhaustive search, squared distance accumulated left to right over the d
+ * (d = 3); d <= 16.  Exact search (uniform-grid pruning, result identical to exhaustive search): squared
+ * distance accumulated left to right over the d
  * coordinates without FMA contraction, lowest reference index wins ties.
  * ref: n_ref x d, qry: n_qry x d row-major float64; idx_out[n_qry] int64; d2_out nullable. */
 int pf_knn1(pf_ctx* ctx, const double* ref, int64_t n_ref, const double* qry, int64_t n_qry, int32_t d,

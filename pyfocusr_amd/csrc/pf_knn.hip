@@ -32,7 +32,7 @@
 
 namespace {
 
-constexpr int KNN_TILE = 512;  // reference points per LDS tile (d=8: 32 KiB + 2 KiB of indices)
+constexpr int KNN_LDS_DOUBLES = 4096;  // LDS tile budget: 32 KiB of coordinates -> 512 points at d = 8, 256 at d = 16
 
 inline unsigned nblk(int64_t n) { return (unsigned)((n + PF_BLOCK - 1) / PF_BLOCK); }
 
@@ -66,7 +66,7 @@ __device__ __forceinline__ double pick(const double (&q)[D], int axis) {
 }
 
 // per-axis [min, max] of the reference set (order-preserving integer encoding + 64-bit atomics)
-__global__ __launch_bounds__(PF_BLOCK) void k_extent(const double* __restrict__ pts, int64_t n, int d, unsigned long long* ext) {
+__global__ __launch_bounds__(PF_BLOCK) void k_extent(const double* __restrict__ pts, int64_t n, int d, unsigned long long* ext /* [2][16] */) {
     for (int a = 0; a < d; ++a) {
         unsigned long long lo = ~0ull, hi = 0ull;
         for (int64_t i = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * PF_BLOCK) {
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(PF_BLOCK) void k_extent(const double* __restrict__ 
         }
         if ((threadIdx.x & (PF_WAVE - 1)) == 0) {
             atomicMin(&ext[a], lo);
-            atomicMax(&ext[8 + a], hi);
+            atomicMax(&ext[16 + a], hi);
         }
     }
 }
@@ -91,7 +91,7 @@ __global__ void k_make_grid(const unsigned long long* __restrict__ ext, int d, i
     int b0 = 0, b1 = 0;
     double w0 = -1.0, w1 = -1.0;
     for (int a = 0; a < d; ++a) {
-        const double e = dec_f64(ext[8 + a]) - dec_f64(ext[a]);
+        const double e = dec_f64(ext[16 + a]) - dec_f64(ext[a]);
         if (e > w0) {
             w1 = w0;
             b1 = b0;
@@ -178,6 +178,7 @@ __global__ __launch_bounds__(PF_BLOCK) void k_knn_grid(const double* __restrict_
                                                        const double* __restrict__ qry_s, const int32_t* __restrict__ qry_orig,
                                                        int64_t n_qry, const KnnGrid* __restrict__ gp,
                                                        int64_t* __restrict__ idx_out, double* __restrict__ d2_out) {
+    constexpr int KNN_TILE = KNN_LDS_DOUBLES / (D <= 8 ? 8 : 16);
     __shared__ double tile[KNN_TILE * D];
     __shared__ int32_t tile_idx[KNN_TILE];
     __shared__ int box[PF_BLOCK / PF_WAVE][4];
@@ -332,13 +333,13 @@ extern "C" {
 
 int pf_knn_upload(pf_ctx* c, const double* ref, int64_t n_ref, const double* qry, int64_t n_qry, int32_t d) {
     PF_CHECK(c && ref && qry, PF_E_ARG, "pf_knn_upload: NULL argument");
-    PF_CHECK(n_ref > 0 && n_ref < ((int64_t)1 << 31) && n_qry > 0 && n_qry < ((int64_t)1 << 31) && d >= 1 && d <= 8, PF_E_ARG,
-             "pf_knn_upload: n_ref %lld, n_qry %lld, d %d out of range (1 <= d <= 8)", (long long)n_ref, (long long)n_qry, d);
+    PF_CHECK(n_ref > 0 && n_ref < ((int64_t)1 << 31) && n_qry > 0 && n_qry < ((int64_t)1 << 31) && d >= 1 && d <= 16, PF_E_ARG,
+             "pf_knn_upload: n_ref %lld, n_qry %lld, d %d out of range (1 <= d <= 16)", (long long)n_ref, (long long)n_qry, d);
     PF_HIP(hipSetDevice(c->device));
     hipStream_t st = c->stream;
     c->knn_ready = c->knn_done = false;
-    PF_TRY(grow(st, &c->knn_ref, &c->knn_cap_ref, n_ref * 8));
-    PF_TRY(grow(st, &c->knn_ref_s, &c->knn_cap_ref_s, n_ref * 8));
+    PF_TRY(grow(st, &c->knn_ref, &c->knn_cap_ref, n_ref * 16));
+    PF_TRY(grow(st, &c->knn_ref_s, &c->knn_cap_ref_s, n_ref * 16));
     PF_TRY(grow(st, &c->knn_ref_key, &c->knn_cap_ref_key, n_ref));
     // grid resolution: ~4 references per cell if they were spread over the plane
     int res = (int)sqrt((double)n_ref / 4.0);
@@ -346,13 +347,13 @@ int pf_knn_upload(pf_ctx* c, const double* ref, int64_t n_ref, const double* qry
     c->knn_res = res;
     PF_TRY(grow(st, &c->knn_cell_start, &c->knn_cap_cell, (int64_t)res * res + 2));
     PF_TRY(grow(st, &c->knn_ref_orig, &c->knn_cap_ref_orig, n_ref));
-    PF_TRY(grow(st, &c->knn_qry, &c->knn_cap_qry, n_qry * 8));
-    PF_TRY(grow(st, &c->knn_qry_s, &c->knn_cap_qry_s, n_qry * 8));
+    PF_TRY(grow(st, &c->knn_qry, &c->knn_cap_qry, n_qry * 16));
+    PF_TRY(grow(st, &c->knn_qry_s, &c->knn_cap_qry_s, n_qry * 16));
     PF_TRY(grow(st, &c->knn_qry_key, &c->knn_cap_qry_key, n_qry));
     PF_TRY(grow(st, &c->knn_qry_orig, &c->knn_cap_qry_orig, n_qry));
     PF_TRY(grow(st, &c->knn_idx, &c->knn_cap_idx, n_qry));
     PF_TRY(grow(st, &c->knn_d2, &c->knn_cap_d2, n_qry));
-    if (!c->knn_ext) PF_HIP(pf_malloc(st, (void**)&c->knn_ext, 16 * sizeof(unsigned long long)));
+    if (!c->knn_ext) PF_HIP(pf_malloc(st, (void**)&c->knn_ext, 32 * sizeof(unsigned long long)));
     if (!c->knn_grid) PF_HIP(pf_malloc(st, &c->knn_grid, sizeof(KnnGrid)));
     c->knn_nref = n_ref;
     c->knn_nqry = n_qry;
@@ -371,8 +372,8 @@ int pf_knn_run(pf_ctx* c) {
     hipStream_t st = c->stream;
     const int d = c->knn_d;
     PF_HIP(hipEventRecord(c->ev0, st));
-    PF_HIP(hipMemsetAsync(c->knn_ext, 0xff, 8 * sizeof(unsigned long long), st));
-    PF_HIP(hipMemsetAsync(c->knn_ext + 8, 0x00, 8 * sizeof(unsigned long long), st));
+    PF_HIP(hipMemsetAsync(c->knn_ext, 0xff, 16 * sizeof(unsigned long long), st));
+    PF_HIP(hipMemsetAsync(c->knn_ext + 16, 0x00, 16 * sizeof(unsigned long long), st));
     const int res = c->knn_res;
     const int64_t n_cells = d == 1 ? res : (int64_t)res * res;
     int cell_bits = 1;
@@ -394,6 +395,14 @@ int pf_knn_run(pf_ctx* c) {
         case 6: r = launch_knn<6>(c); break;
         case 7: r = launch_knn<7>(c); break;
         case 8: r = launch_knn<8>(c); break;
+        case 9: r = launch_knn<9>(c); break;
+        case 10: r = launch_knn<10>(c); break;
+        case 11: r = launch_knn<11>(c); break;
+        case 12: r = launch_knn<12>(c); break;
+        case 13: r = launch_knn<13>(c); break;
+        case 14: r = launch_knn<14>(c); break;
+        case 15: r = launch_knn<15>(c); break;
+        case 16: r = launch_knn<16>(c); break;
         default: break;
     }
     PF_TRY(r);

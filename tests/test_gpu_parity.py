@@ -305,7 +305,7 @@ def test_multi_component_and_recursive_eig(hip, ctx):
 
 
 # ------------------------------------------------------------------------------- KNN
-@pytest.mark.parametrize("d", [1, 2, 3, 5, 8])
+@pytest.mark.parametrize("d", [1, 2, 3, 5, 8, 10, 16])
 @pytest.mark.parametrize("n_ref,n_qry", [(1, 1), (300, 77), (5000, 5000), (1000, 70000)])
 def test_knn_bit_exact(ctx, d, n_ref, n_qry):
     rng = np.random.default_rng(100 * d + n_ref)
@@ -329,7 +329,7 @@ def test_knn_ties_and_idempotence(ctx):
     expect[3999] = 17
     assert np.array_equal(idx, expect) and np.all(d2 == 0.0)
     with pytest.raises(Exception):
-        ctx.knn1(np.zeros((4, 9)), np.zeros((4, 9)))
+        ctx.knn1(np.zeros((4, 17)), np.zeros((4, 17)))
 
 
 def test_knn_window_edge_cases(ctx):

@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""Size sweep of the hot path: per mesh size, GPU assembly / eigensolve / KNN times,
+SpMV launch time and roofline fraction, and the oracle's scipy `eigs` time on the host for
+comparison.  python tools/sweep.py [--cpu-max 250000] n1 n2 ...   -> markdown table on stdout."""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import reference_port as orc  # noqa: E402  (comparison column only)
+from pyfocusr_amd import Graph, _hip, eigsort  # noqa: E402
+from pyfocusr_amd.graph import compute_spectra  # noqa: E402
+from pyfocusr_amd.meshgen import blob_mesh  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("sizes", type=int, nargs="*", default=[10000, 30000, 100000, 250000, 500000, 1000000])
+ap.add_argument("--cpu-max", type=int, default=250000)
+ap.add_argument("--k", type=int, default=5)
+args = ap.parse_args()
+
+ctx = _hip.default_context()
+ctx.timing_enable(True)
+print("| n | k | assembly ms (pair) | eigensolve ms (pair) | matvecs/mesh | us/launch (2 graphs) | GB/s alg. | % of 8 TB/s | eigsort ms | KNN ms | "
+      "eigenpairs/s (pair, all stages) | scipy eigs s/mesh | max residual |")
+print("|---|---|---|---|---|---|---|---|---|---|---|---|---|")
+for n in args.sizes:
+    k = args.k if n < 1000000 else 10  # BASELINE config C5: k = 10 at 1M
+    meshes = [blob_mesh(n, seed=s) for s in (0, 1)]
+    for m in meshes:
+        m._pf_device_mesh = _hip.DeviceMesh(m.points, m.faces, ctx=ctx)
+    best = None
+    for rep in range(3):
+        ctx.timing(reset=True)
+        t0 = time.perf_counter()
+        gs = [Graph(m, n_spectral_features=k, n_rand_samples=5000, ctx=ctx, verbose=False) for m in meshes]
+        for g in gs:
+            _ = g.device
+        ctx.sync()
+        t1 = time.perf_counter()
+        compute_spectra(gs)
+        t2 = time.perf_counter()
+        Q = eigsort(gs[0], gs[1], k, target_as_reference=True).sort_eigenmaps()  # focusr.py:515-522
+        w = Q[:k] * np.max((gs[1].eig_vals[:k], gs[0].eig_vals[:k]), axis=0)
+        w = np.exp(-(w**2) / (2 * np.mean(w) ** 2))
+        t2b = time.perf_counter()
+        idx = ctx.knn1(gs[0].eig_vecs[:, :k] * w[None, :], gs[1].eig_vecs[:, :k] * w[None, :])
+        t3 = time.perf_counter()
+        tm = ctx.timing()
+        row = dict(asm=t1 - t0, eig=t2 - t1, sort=t2b - t2, knn=t3 - t2b, us=1e3 * tm["op_ms"] / tm["op_launches"],
+                   gbs=tm["op_bytes"] / tm["op_ms"] / 1e6, mv=sum(g.eigs_stats.matvecs for g in gs) / 2,
+                   res=max(g.eigs_stats.residuals.max() for g in gs))
+        for g in gs:
+            g.device.close()
+        if best is None or row["eig"] < best["eig"]:
+            best = row
+    cpu = ""
+    if n <= args.cpu_max:
+        W, deg, d_inv, L = orc.graph_matrices(meshes[0].points, meshes[0].faces)
+        t0 = time.perf_counter()
+        orc.recursive_eig(L, k + 1, k)
+        cpu = "%.2f" % (time.perf_counter() - t0)
+    total = best["asm"] + best["eig"] + best["sort"] + best["knn"]
+    print("| %d | %d | %.2f | %.2f | %d | %.2f | %.0f | %.1f | %.2f | %.2f | %.1f | %s | %.1e |" % (
+        n, k, 1e3 * best["asm"], 1e3 * best["eig"], best["mv"], best["us"], best["gbs"], best["gbs"] / 80.0,
+        1e3 * best["sort"], 1e3 * best["knn"], 2 * k / total, cpu, best["res"]), flush=True)
+    for m in meshes:
+        m._pf_device_mesh.close()
