@@ -145,6 +145,10 @@ int pf_mean_filter(pf_graph* g, const double* values, int32_t ncols, int32_t ite
  * ref: n_ref x d, qry: n_qry x d row-major float64; idx_out[n_qry] int64; d2_out nullable. */
 int pf_knn1(pf_ctx* ctx, const double* ref, int64_t n_ref, const double* qry, int64_t n_qry, int32_t d,
             int64_t* idx_out, double* d2_out);
+/* k nearest neighbours (1 <= k <= 4, d <= 4), ascending by (distance, index): the 3-NN of
+ * Focusr.get_weighted_final_node_locations (focusr.py:409-412).  idx_out / d2_out: n_qry x k row-major. */
+int pf_knn(pf_ctx* ctx, const double* ref, int64_t n_ref, const double* qry, int64_t n_qry, int32_t d, int32_t k,
+           int64_t* idx_out, double* d2_out);
 /* split form (inputs resident in HBM across the timed region) */
 int pf_knn_upload(pf_ctx* ctx, const double* ref, int64_t n_ref, const double* qry, int64_t n_qry, int32_t d);
 int pf_knn_run(pf_ctx* ctx);

@@ -309,3 +309,27 @@ def spectral_coords(vecs_s, vecs_t, ns, weights=None):
     if weights is None:
         return vecs_s[:, :ns], vecs_t[:, :ns]
     return vecs_s[:, :ns] * weights[None, :], vecs_t[:, :ns] * weights[None, :]
+
+
+# --------------------------------------------------------------------------------------
+# focusr.py:368-431 smoothed correspondences and final node locations ("next" rows f1/f2)
+# --------------------------------------------------------------------------------------
+def smoothed_correspondences(W_t, W_s, points_t, idx_initial, graph_iters=300, proj_iters=40):
+    """focusr.py:368-396 with final_correspondence_type == "kd"."""
+    smoothed_target = mean_filter_graph(W_t, points_t, iterations=graph_iters)
+    projected = mean_filter_graph(W_s, smoothed_target[idx_initial, :], iterations=proj_iters)
+    return smoothed_target, projected, knn1(smoothed_target, projected)
+
+
+def weighted_final_node_locations(smoothed_target, projected, points_t, n_closest_pts=3):
+    """focusr.py:401-426, the reference's per-point loop."""
+    out = np.zeros((len(projected), 3))
+    tree = KDTree(smoothed_target)
+    for i in range(len(projected)):
+        d, idx = tree.query(projected[i, :], k=n_closest_pts)
+        if 0 in d:
+            out[i, :] = points_t[idx[np.where(d == 0)[0][0]]]
+        else:
+            w = 1 / d[:, None]
+            out[i, :] = np.sum(points_t[idx, :] * w, axis=0) / (sum(w))
+    return out

@@ -81,6 +81,7 @@ SIGNATURES = {
     "pf_spmv_host": (C.c_int, [C.c_void_p, C.c_int32, _f64p, _f64p]),
     "pf_mean_filter": (C.c_int, [C.c_void_p, _f64p, C.c_int32, C.c_int32, _f64p]),
     "pf_knn1": (C.c_int, [C.c_void_p, _f64p, C.c_int64, _f64p, C.c_int64, C.c_int32, _i64p, _f64p]),
+    "pf_knn": (C.c_int, [C.c_void_p, _f64p, C.c_int64, _f64p, C.c_int64, C.c_int32, C.c_int32, _i64p, _f64p]),
     "pf_knn_upload": (C.c_int, [C.c_void_p, _f64p, C.c_int64, _f64p, C.c_int64, C.c_int32]),
     "pf_knn_run": (C.c_int, [C.c_void_p]),
     "pf_knn_download": (C.c_int, [C.c_void_p, _i64p, _f64p]),
@@ -188,6 +189,17 @@ class Context(object):
         _check(self._lib.pf_knn1(self._h, _f64(ref), ref.shape[0], _f64(qry), qry.shape[0], ref.shape[1],
                                  idx.ctypes.data_as(_i64p), _f64(d2) if return_d2 else None))
         return (idx, d2) if return_d2 else idx
+
+    def knn(self, ref, qry, k):
+        """(idx (n_qry, k) int64, squared distances (n_qry, k)), ascending by (distance, index); k <= 4, d <= 4."""
+        ref, qry = _c_f64(ref), _c_f64(qry)
+        if ref.ndim != 2 or qry.ndim != 2 or ref.shape[1] != qry.shape[1]:
+            raise ValueError("ref and qry must be (n, d) arrays with equal d")
+        idx = np.empty((qry.shape[0], int(k)), dtype=np.int64)
+        d2 = np.empty((qry.shape[0], int(k)), dtype=np.float64)
+        _check(self._lib.pf_knn(self._h, _f64(ref), ref.shape[0], _f64(qry), qry.shape[0], ref.shape[1], int(k),
+                                idx.ctypes.data_as(_i64p), _f64(d2)))
+        return idx, d2
 
     def knn_upload(self, ref, qry):
         ref, qry = _c_f64(ref), _c_f64(qry)

@@ -66,6 +66,7 @@ struct pf_ctx {
     int64_t knn_cap_ref = 0, knn_cap_qry = 0, knn_cap_ref_s = 0, knn_cap_qry_s = 0, knn_cap_ref_key = 0,
             knn_cap_qry_key = 0, knn_cap_ref_orig = 0, knn_cap_qry_orig = 0, knn_cap_idx = 0, knn_cap_d2 = 0;
     int32_t knn_d = 0;
+    int32_t knn_k = 1, knn_k_next = 1; // neighbours per query (pf_knn sets knn_k_next before the upload)
     int64_t* knn_idx = nullptr; // [n_qry]
     double* knn_d2 = nullptr;   // [n_qry]
     bool knn_ready = false, knn_done = false;

@@ -171,7 +171,25 @@ __device__ __forceinline__ double dist2(const double (&q)[D], const double* __re
     return s;
 }
 
-template <int D>
+// sorted insertion of candidate (s, o) into the lane's K best, ordered by (distance, original index)
+template <int K>
+__device__ __forceinline__ void topk_insert(double (&best)[K], int32_t (&bidx)[K], double s, int32_t o) {
+    if (!(s < best[K - 1] || (s == best[K - 1] && o < bidx[K - 1]))) return;
+    best[K - 1] = s;
+    bidx[K - 1] = o;
+#pragma unroll
+    for (int j = K - 1; j > 0; --j) {
+        const bool sw = best[j] < best[j - 1] || (best[j] == best[j - 1] && bidx[j] < bidx[j - 1]);
+        const double ts = best[j - 1];
+        const int32_t to = bidx[j - 1];
+        best[j - 1] = sw ? best[j] : ts;
+        bidx[j - 1] = sw ? bidx[j] : to;
+        best[j] = sw ? ts : best[j];
+        bidx[j] = sw ? to : bidx[j];
+    }
+}
+
+template <int D, int K>
 __global__ __launch_bounds__(PF_BLOCK) void k_knn_grid(const double* __restrict__ ref_s /* rows sorted by cell */,
                                                        const int32_t* __restrict__ ref_orig,
                                                        const int32_t* __restrict__ cell_start, int64_t n_ref,
@@ -191,24 +209,30 @@ __global__ __launch_bounds__(PF_BLOCK) void k_knn_grid(const double* __restrict_
     const double qx = pick<D>(q, g.a0), qy = pick<D>(q, g.a1);
     const int cx = cell_of(qx, g.lo0, g.s0, g.r0), cy = cell_of(qy, g.lo1, g.s1, g.r1);
 
-    // ---- phase 1: upper bound from the cells around the query (grow the ring until something is found)
-    double best = INFINITY;
-    int32_t best_idx = 0x7fffffff;
-    for (int ring = 1; ring <= 4 && best == INFINITY; ++ring) {
+    // ---- phase 1: upper bound from the cells around the query (grow the ring until K candidates are found)
+    double bestk[K];
+    int32_t bidx[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        bestk[j] = INFINITY;
+        bidx[j] = 0x7fffffff;
+    }
+    for (int ring = 1; ring <= 4 && bestk[K - 1] == INFINITY; ++ring) {
+#pragma unroll
+        for (int j = 0; j < K; ++j) {  // the larger ring re-visits the smaller one: start over
+            bestk[j] = INFINITY;
+            bidx[j] = 0x7fffffff;
+        }
         const int y0 = cy - ring > 0 ? cy - ring : 0, y1 = cy + ring < g.r1 - 1 ? cy + ring : g.r1 - 1;
         const int x0 = cx - ring > 0 ? cx - ring : 0, x1 = cx + ring < g.r0 - 1 ? cx + ring : g.r0 - 1;
         for (int y = y0; y <= y1; ++y) {
             const int32_t b = cell_start[y * g.r0 + x0], e = cell_start[y * g.r0 + x1 + 1];
             for (int32_t r = b; r < e; ++r) {
-                const double s = dist2<D>(q, ref_s + (int64_t)r * D);
-                const int32_t o = ref_orig[r];
-                if (s < best || (s == best && o < best_idx)) {
-                    best = s;
-                    best_idx = o;
-                }
+                topk_insert<K>(bestk, bidx, dist2<D>(q, ref_s + (int64_t)r * D), ref_orig[r]);
             }
         }
     }
+    const double best = bestk[K - 1];  // every reference that can enter the K best lies within sqrt(best)
     // ---- block rectangle: every reference that can beat or tie a lane lies within rad of it on both axes
     const double rad = sqrt(best) * (1.0 + 1e-9) + 1e-300;  // inflated against the rounding of sqrt / the subtractions
     double xl = qx - rad, xh = qx + rad, yl = qy - rad, yh = qy + rad;
@@ -258,30 +282,45 @@ __global__ __launch_bounds__(PF_BLOCK) void k_knn_grid(const double* __restrict_
             __syncthreads();
             for (int r = 0; r < cnt; ++r) {
                 const double s = dist2<D>(q, tile + r * D);
-                if (s <= best) {
+                if (s <= bestk[K - 1]) {
                     const int32_t o = tile_idx[r];
-                    if (s < best || o < best_idx) {
-                        best = s;
-                        best_idx = o;
-                    }
+                    bool seen = false;  // phase 1 already holds some of the window's points
+#pragma unroll
+                    for (int j = 0; j < K; ++j) seen |= (bidx[j] == o);
+                    if (!seen) topk_insert<K>(bestk, bidx, s, o);
                 }
             }
         }
     }
     if (qi < n_qry) {
         const int64_t dst = qry_orig[qi];
-        idx_out[dst] = best_idx;
-        d2_out[dst] = best;
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            idx_out[dst * K + j] = bidx[j];
+            d2_out[dst * K + j] = bestk[j];
+        }
     }
 }
 
-template <int D>
-int launch_knn(pf_ctx* c) {
-    k_knn_grid<D><<<nblk(c->knn_nqry), PF_BLOCK, 0, c->stream>>>(c->knn_ref_s, c->knn_ref_orig, c->knn_cell_start, c->knn_nref,
+template <int D, int K>
+int launch_knn_k(pf_ctx* c) {
+    k_knn_grid<D, K><<<nblk(c->knn_nqry), PF_BLOCK, 0, c->stream>>>(c->knn_ref_s, c->knn_ref_orig, c->knn_cell_start, c->knn_nref,
                                                                  c->knn_qry_s, c->knn_qry_orig, c->knn_nqry,
                                                                  (const KnnGrid*)c->knn_grid, c->knn_idx, c->knn_d2);
     PF_HIP(hipGetLastError());
     return PF_OK;
+}
+
+template <int D>
+int launch_knn(pf_ctx* c) {
+    if (c->knn_k == 1) return launch_knn_k<D, 1>(c);
+    if constexpr (D <= 4) {  // k > 1: the 3-NN of focusr.py:409-412 lives in 3-D
+        if (c->knn_k == 2) return launch_knn_k<D, 2>(c);
+        if (c->knn_k == 3) return launch_knn_k<D, 3>(c);
+        if (c->knn_k == 4) return launch_knn_k<D, 4>(c);
+    }
+    pf_set_error("pf_knn: k = %d with d = %d is not supported (k <= 4 needs d <= 4)", c->knn_k, D);
+    return PF_E_ARG;
 }
 
 template <typename T>
@@ -332,7 +371,11 @@ int sort_points(pf_ctx* c, const double* pts, int64_t n, int d, int morton, int 
 extern "C" {
 
 int pf_knn_upload(pf_ctx* c, const double* ref, int64_t n_ref, const double* qry, int64_t n_qry, int32_t d) {
+    PF_CHECK(c != nullptr, PF_E_ARG, "pf_knn_upload: ctx is NULL");
+    const int32_t k = c->knn_k_next;
+    c->knn_k_next = 1;
     PF_CHECK(c && ref && qry, PF_E_ARG, "pf_knn_upload: NULL argument");
+    PF_CHECK(k >= 1 && k <= 4 && k <= n_ref, PF_E_ARG, "pf_knn: k = %d out of range (1..4, <= n_ref)", k);
     PF_CHECK(n_ref > 0 && n_ref < ((int64_t)1 << 31) && n_qry > 0 && n_qry < ((int64_t)1 << 31) && d >= 1 && d <= 16, PF_E_ARG,
              "pf_knn_upload: n_ref %lld, n_qry %lld, d %d out of range (1 <= d <= 16)", (long long)n_ref, (long long)n_qry, d);
     PF_HIP(hipSetDevice(c->device));
@@ -351,8 +394,9 @@ int pf_knn_upload(pf_ctx* c, const double* ref, int64_t n_ref, const double* qry
     PF_TRY(grow(st, &c->knn_qry_s, &c->knn_cap_qry_s, n_qry * 16));
     PF_TRY(grow(st, &c->knn_qry_key, &c->knn_cap_qry_key, n_qry));
     PF_TRY(grow(st, &c->knn_qry_orig, &c->knn_cap_qry_orig, n_qry));
-    PF_TRY(grow(st, &c->knn_idx, &c->knn_cap_idx, n_qry));
-    PF_TRY(grow(st, &c->knn_d2, &c->knn_cap_d2, n_qry));
+    PF_TRY(grow(st, &c->knn_idx, &c->knn_cap_idx, n_qry * k));
+    PF_TRY(grow(st, &c->knn_d2, &c->knn_cap_d2, n_qry * k));
+    c->knn_k = k;
     if (!c->knn_ext) PF_HIP(pf_malloc(st, (void**)&c->knn_ext, 32 * sizeof(unsigned long long)));
     if (!c->knn_grid) PF_HIP(pf_malloc(st, &c->knn_grid, sizeof(KnnGrid)));
     c->knn_nref = n_ref;
@@ -419,10 +463,20 @@ int pf_knn_download(pf_ctx* c, int64_t* idx_out, double* d2_out) {
     PF_CHECK(c != nullptr && idx_out != nullptr, PF_E_ARG, "pf_knn_download: NULL argument");
     PF_CHECK(c->knn_done, PF_E_STATE, "pf_knn_download: pf_knn_run has not completed");
     PF_HIP(hipSetDevice(c->device));
-    PF_HIP(hipMemcpyAsync(idx_out, c->knn_idx, sizeof(int64_t) * c->knn_nqry, hipMemcpyDeviceToHost, c->stream));
-    if (d2_out) PF_HIP(hipMemcpyAsync(d2_out, c->knn_d2, sizeof(double) * c->knn_nqry, hipMemcpyDeviceToHost, c->stream));
+    const size_t count = (size_t)c->knn_nqry * c->knn_k;
+    PF_HIP(hipMemcpyAsync(idx_out, c->knn_idx, sizeof(int64_t) * count, hipMemcpyDeviceToHost, c->stream));
+    if (d2_out) PF_HIP(hipMemcpyAsync(d2_out, c->knn_d2, sizeof(double) * count, hipMemcpyDeviceToHost, c->stream));
     PF_HIP(hipStreamSynchronize(c->stream));
     return PF_OK;
+}
+
+int pf_knn(pf_ctx* c, const double* ref, int64_t n_ref, const double* qry, int64_t n_qry, int32_t d, int32_t k,
+           int64_t* idx_out, double* d2_out) {
+    PF_CHECK(c != nullptr, PF_E_ARG, "pf_knn: ctx is NULL");
+    c->knn_k_next = k;
+    PF_TRY(pf_knn_upload(c, ref, n_ref, qry, n_qry, d));
+    PF_TRY(pf_knn_run(c));
+    return pf_knn_download(c, idx_out, d2_out);
 }
 
 int pf_knn1(pf_ctx* c, const double* ref, int64_t n_ref, const double* qry, int64_t n_qry, int32_t d, int64_t* idx_out,

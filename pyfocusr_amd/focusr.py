@@ -7,8 +7,9 @@ the same defaults, builds both graphs and their spectra eagerly (:134-170), and
 [CPD registration] -> nearest-neighbour correspondence -> [smoothing].
 
 On the device: Laplacian assembly + eigensolve (`Graph`), the 3-D NN of `eigsort`,
-`get_kd_correspondence` (focusr.py:351-353 -> `pf_knn1`) and the graph mean
-filter behind `get_smoothed_correspondences` (focusr.py:368-396).
+`get_kd_correspondence` (focusr.py:351-353 -> `pf_knn1`), the graph mean filter
+behind `get_smoothed_correspondences` (focusr.py:368-396) and the 3-NN query of
+`get_weighted_final_node_locations` (focusr.py:401-426 -> `pf_knn`, k = 3).
 
 Outside the hot path, kept as thin shells:
 * ICP pre-alignment (:110-131) and VTK mesh outputs need the `vtk` package;
@@ -16,8 +17,7 @@ Outside the hot path, kept as thin shells:
   importable, otherwise `registration` may be injected as a callable
   `(source_coords, target_coords, kind) -> new_target_coords`, and when neither
   is available the step is skipped with a notice;
-* Hungarian point correspondence (:340-349, O(N^3)) and the 3-NN weighted final
-  locations (:401-426) are not implemented.
+* Hungarian point correspondence (:340-349, O(N^3)) is not implemented.
 """
 import numpy as np
 
@@ -119,9 +119,6 @@ class Focusr(object):
                                           "and outside the MI355X hot path; use 'kd'")
             if kind != "kd":
                 raise ValueError("correspondence type must be 'kd'")
-        if return_average_final_points:
-            raise NotImplementedError("3-NN weighted final locations (focusr.py:401-426) are not implemented yet; "
-                                      "pass return_average_final_points=False")
 
         print("Starting ICP")
         self._icp_transform = None
@@ -234,22 +231,58 @@ class Focusr(object):
             iterations=self.projection_smooth_iterations)
         self.get_kd_correspondence(self.smoothed_target_coords, self.source_projected_on_target)
 
+    def get_weighted_final_node_locations(self, n_closest_pts=3):
+        """focusr.py:401-426: every source point goes to the inverse-distance-weighted average of the
+        `n_closest_pts` target vertices nearest to its projection (a coincident vertex wins outright).
+        The reference loops over points with one `tree.query(k=3)` each; here one device call."""
+        idx, d2 = self._ctx.knn(self.smoothed_target_coords, self.source_projected_on_target, n_closest_pts)
+        dist = np.sqrt(d2)
+        pts = self.graph_target.points
+        with np.errstate(divide="ignore", invalid="ignore"):
+            w = 1.0 / dist
+            num = pts[idx[:, 0], :] * w[:, 0:1]
+            den = w[:, 0:1].copy()
+            for j in range(1, idx.shape[1]):
+                num = num + pts[idx[:, j], :] * w[:, j:j + 1]
+                den = den + w[:, j:j + 1]
+            out = num / den
+        coincident = dist == 0.0
+        rows = np.nonzero(coincident.any(axis=1))[0]
+        if len(rows):  # focusr.py:415-419: first zero-distance neighbour
+            first = np.argmax(coincident[rows], axis=1)
+            out[rows, :] = pts[idx[rows, first], :]
+        self.weighted_avg_transformed_points = out
+
     def get_nearest_neighbour_final_node_locations(self):
         """focusr.py:428-431."""
         self.nearest_neighbor_transformed_points = self.graph_target.points[
             self.corresponding_target_idx_for_each_source_pt, :]
 
-    def get_source_mesh_transformed_nearest_neighbour(self):
-        """focusr.py:615-625 for `PolyMesh` inputs (VTK inputs go through `vtk_deep_copy`)."""
+    def _source_mesh_with_points(self, new_points):
         mesh = self.graph_source.vtk_mesh
         if isinstance(mesh, PolyMesh):
-            self.nearest_neighbour_transformed_mesh = PolyMesh(
-                self.nearest_neighbor_transformed_points, mesh.faces.copy(), list(mesh.point_data))
-            return
-        self.nearest_neighbour_transformed_mesh = vtk_deep_copy(mesh)
-        points = self.nearest_neighbour_transformed_mesh.GetPoints()
+            return PolyMesh(new_points, mesh.faces.copy(), list(mesh.point_data))
+        out = vtk_deep_copy(mesh)
+        points = out.GetPoints()
         for i in range(self.graph_source.n_points):
-            points.SetPoint(i, self.nearest_neighbor_transformed_points[i])
+            points.SetPoint(i, new_points[i])
+        return out
+
+    def get_source_mesh_transformed_nearest_neighbour(self):
+        """focusr.py:615-625."""
+        self.nearest_neighbour_transformed_mesh = self._source_mesh_with_points(self.nearest_neighbor_transformed_points)
+
+    def get_source_mesh_transformed_weighted_avg(self):
+        """focusr.py:603-613."""
+        self.weighted_avg_transformed_mesh = self._source_mesh_with_points(self.weighted_avg_transformed_points)
+
+    def get_average_shape(self, align_type="weighted"):
+        """focusr.py:433-453: mean of each source vertex and its image on the target."""
+        if align_type == "nearest":
+            moved = self.graph_target.points[self.corresponding_target_idx_for_each_source_pt, :]
+        else:
+            moved = self.weighted_avg_transformed_points
+        self.average_mesh = self._source_mesh_with_points((moved + self.graph_source.points) / 2)
 
     # ------------------------------------------------------------------ spectral weighting (focusr.py:459-508)
     def calc_c_weighting_spectral(self):
@@ -306,9 +339,16 @@ class Focusr(object):
             self.get_smoothed_correspondences()
             print("Number of unique correspondences after smoothing: {}".format(
                 len(np.unique(self.corresponding_target_idx_for_each_source_pt))))
+        if self.return_average_final_points is True:
+            if self.smoothed_target_coords is None:  # focusr.py:409 needs the smoothed coordinates
+                raise RuntimeError("return_average_final_points needs smooth_correspondences=True")
+            self.get_weighted_final_node_locations()
         if self.return_nearest_final_points is True:
             self.get_nearest_neighbour_final_node_locations()
-            if self.return_transformed_mesh is True:
+        if self.return_transformed_mesh is True:
+            if self.return_average_final_points is True:
+                self.get_source_mesh_transformed_weighted_avg()
+            if self.return_nearest_final_points is True:
                 self.get_source_mesh_transformed_nearest_neighbour()
 
     @property
