@@ -195,12 +195,14 @@ def filtered_eigs_gen(ops, n_wanted, symmetric, null_slots=0, cut=None, tol=1e-1
     if m_max is None:
         m_max = max(3 * q_target + 24, 48)
     m_max = int(min(m_max, n_active))
-    reg = m_max + 1  # region A: Krylov basis + residual vector; region B: restart / Ritz products
+    reg = max(m_max + 1, 2 * q_target + 2)  # region A: Krylov basis + residual vector; region B: restart / Ritz products
     ops.ws_ensure(2 * reg)
     A0, B0 = 0, reg
     if cut is None:
         cut = 8.0 * (n_wanted + 1) / max(n_active, 1)
     degree_cap = 4000 if symmetric else int(nonsym_degree_cap)
+    plain = False  # no filter: B = (hi - A)/hi.  For tiny / dense-ish graphs whose wanted eigenvalues are not
+    #                a small corner of [0, hi]; the Krylov space is then exhausted or restarted as usual.
     n_starts = [int(seed)]
 
     def start_vector(slot, nbasis):
@@ -218,9 +220,15 @@ def filtered_eigs_gen(ops, n_wanted, symmetric, null_slots=0, cut=None, tol=1e-1
         return theta, U, T, q, n_real, res, theta_min
 
     while True:
-        c, e, p = choose_filter(cut, hi=hi, strength=strength, max_degree=degree_cap)
+        if cut >= 0.5 * hi:
+            plain = True
+        if plain:
+            c, e, p = hi, hi, 1
+        else:
+            c, e, p = choose_filter(cut, hi=hi, strength=strength, max_degree=degree_cap)
         stats.degree, stats.cut = p, cut
         theta0 = _cheb_value(0.0, c, e, p)
+        band = -1.0 if plain else 1.5  # wanted Ritz values must clear the damped band [-1, 1] (none in plain mode)
         # Krylov-Schur state  B V_j = V_j H + v_j b^T ;  null vectors are locked exact Ritz pairs.
         j = c0
         H = np.zeros((m_max, m_max))
@@ -248,11 +256,11 @@ def filtered_eigs_gen(ops, n_wanted, symmetric, null_slots=0, cut=None, tol=1e-1
                     if verbose:
                         print("  j=%d q=%d theta_min=%.4g |theta|max=%.3g max res=%.3e" % (
                             j, q, theta_min, np.max(np.abs(theta)), np.max(res)))
-                    if n_real >= q_target and np.all(res <= tol * max(theta_min, 1.0)) and theta_min > 1.5:
+                    if n_real >= q_target and np.all(res <= tol * max(theta_min, 1.0)) and theta_min > band:
                         outcome = "converged"
                     elif not symmetric and np.max(np.abs(theta)) > 1e7 * max(theta_min, 1.0) and p > 16:
                         outcome = "range"  # complex outliers eat the dynamic range: lower the degree
-                    elif (j >= q + 12 or exhausted) and theta_min < 1.5:
+                    elif (j >= q + 12 or exhausted) and theta_min < band:
                         outcome = "cut"  # wanted eigenvalues sit inside the damped band
                     elif exhausted:
                         outcome = "converged"
@@ -290,6 +298,7 @@ def filtered_eigs_gen(ops, n_wanted, symmetric, null_slots=0, cut=None, tol=1e-1
                 cut = max(4.0 * cut, 2.5 * lam_est[-1] * (n_wanted + 1) / len(lam_est))
             else:
                 cut = 8.0 * cut
+            cut = min(cut, hi)
         if verbose:
             print("  filter reset (%s): cut %.3e degree cap %d" % (outcome, cut, degree_cap))
 

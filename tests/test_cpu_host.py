@@ -175,6 +175,34 @@ def test_krylov_components_isolated_and_bad_cut():
     np.testing.assert_allclose(lam3, orc.graph_spectrum(a.points, a.faces, 4)["eig_vals"], rtol=1e-8)
 
 
+TET = (np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1.3]], float), np.array([[0, 2, 1], [0, 1, 3], [1, 2, 3], [0, 3, 2]]))
+OCT = (np.array([[1, 0, 0], [-1, 0, 0], [0, 1.1, 0], [0, -1.2, 0], [0, 0, 1.3], [0, 0, -0.9]], float),
+       np.array([[0, 2, 4], [2, 1, 4], [1, 3, 4], [3, 0, 4], [2, 0, 5], [1, 2, 5], [3, 1, 5], [0, 3, 5]]))
+
+
+def dense_nonnull(points, faces):
+    W, deg, d_inv, L = orc.graph_matrices(points, faces)
+    ev = np.sort(np.linalg.eigvals(L.toarray()).real)
+    return ev[ev > 1e-10]
+
+
+@pytest.mark.parametrize("mesh,k", [(TET, 1), (TET, 3), (OCT, 3), (OCT, 5)])
+def test_krylov_tiny_meshes_plain_mode(mesh, k):
+    """Meshes so small that the wanted eigenvalues are not a corner of the spectrum: the solver drops the
+    filter (degree 1) and exhausts the Krylov space.  (scipy's eigs refuses k >= n-1 here.)"""
+    lam, X, st, ops = solve(mesh[0], mesh[1], k)
+    np.testing.assert_allclose(lam, dense_nonnull(*mesh)[:k], rtol=1e-10)
+    assert st.degree == 1
+
+
+def test_krylov_many_pairs_of_a_small_mesh():
+    from pyfocusr_amd.meshgen import blob_mesh
+
+    m = blob_mesh(40, seed=1)
+    lam, X, st, ops = solve(m.points, m.faces, 30)
+    np.testing.assert_allclose(lam, dense_nonnull(m.points, m.faces)[:30], rtol=1e-9)
+
+
 def test_lockstep_pair_driver_equals_single_solves(golden):
     """`drive_pair` (two solvers sharing kernel launches) must return what two separate solves
     return, also when the two need different degrees / step counts / a filter reset."""

@@ -106,6 +106,39 @@ def test_assembly_quads_and_duplicates(hip, ctx):
     assert np.array_equal(h["w"], W.data) and np.array_equal(h["deg"], deg)
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_assembly_random_triangle_soups(hip, ctx, seed):
+    """Non-manifold inputs: random faces over random points (one-way edges, directed edges shared by
+    many faces, unreferenced vertices, hub vertices): W, deg and the scipy view of L stay bit-identical
+    to the reference's set-semantics construction."""
+    from pyfocusr_amd import Graph, PolyMesh
+
+    rng = np.random.default_rng(seed)
+    n = int(rng.integers(5, 400))
+    n_faces = int(rng.integers(1, 4 * n))
+    pts = rng.normal(size=(n, 3)) * rng.uniform(0.1, 50)
+    faces = np.array([rng.choice(n, 3, replace=False) for _ in range(n_faces)], dtype=np.int32)
+    if seed % 2:  # a hub: one vertex in many faces
+        faces[: n_faces // 2, 0] = 0
+        faces = faces[(faces[:, 1] != 0) & (faces[:, 2] != 0)]
+    W, deg, d_inv, L = orc.graph_matrices(pts, faces)
+    gr = Graph(PolyMesh(pts, faces), n_spectral_features=2, n_rand_samples=10**9, ctx=ctx, verbose=False)
+    gr.get_weighted_adjacency_matrix()
+    gr.get_degree_matrix()
+    gr.get_laplacian_matrix()
+    A, Lg = gr.adjacency_matrix, gr.laplacian_matrix
+    assert np.array_equal(A.indptr, W.indptr) and np.array_equal(A.indices, W.indices) and np.array_equal(A.data, W.data)
+    assert np.array_equal(gr.degree_matrix.diagonal(), deg)
+    assert np.array_equal(Lg.indptr, L.indptr) and np.array_equal(Lg.indices, L.indices) and np.array_equal(Lg.data, L.data)
+    dev = gr.device
+    assert dev.symmetric == (abs(W - W.T).nnz == 0) and dev.n_isolated == int(np.sum(deg == 0))
+    assert dev.max_degree == int(np.diff(W.indptr).max())
+    x = rng.standard_normal(n)
+    y = dev.spmv_host(x, op=hip.PF_OP_RW)  # SELL storage after renumbering == the CSR it came from
+    Lfull = sparse.csr_matrix(L)
+    np.testing.assert_allclose(y, Lfull @ x, rtol=0, atol=1e-13 * max(1.0, np.abs(x).max()) * max(1, dev.max_degree))
+
+
 # ------------------------------------------------------------------------------- operator kernels
 def host_operator(g, dev):
     n = len(g["points"])
@@ -264,6 +297,27 @@ def test_spectrum_vs_reference(golden, ctx, name, k):
     L = sparse.csr_matrix((g["L_data"], g["L_indices"], g["L_indptr"]), shape=(n, n))
     R = L @ gr2.eig_vecs - gr2.eig_vecs * gr2.eig_vals[None, :]
     assert np.max(np.linalg.norm(R, axis=0)) < 1e-8
+
+
+def test_tiny_meshes(ctx):
+    """n = 4 and n = 6: far below one wavefront; the solver runs unfiltered (scipy eigs refuses k >= n-1)."""
+    from pyfocusr_amd import Graph, PolyMesh
+
+    tet = (np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1.3]], float), np.array([[0, 2, 1], [0, 1, 3], [1, 2, 3], [0, 3, 2]]))
+    octa = (np.array([[1, 0, 0], [-1, 0, 0], [0, 1.1, 0], [0, -1.2, 0], [0, 0, 1.3], [0, 0, -0.9]], float),
+            np.array([[0, 2, 4], [2, 1, 4], [1, 3, 4], [3, 0, 4], [2, 0, 5], [1, 2, 5], [3, 1, 5], [0, 3, 5]]))
+    for (pts, faces), k in ((tet, 2), (tet, 3), (octa, 4)):
+        gr = Graph(PolyMesh(pts, faces), n_spectral_features=k, n_rand_samples=100, ctx=ctx, verbose=False)
+        gr.get_graph_spectrum()
+        W, deg, d_inv, L = orc.graph_matrices(pts, faces)
+        ev = np.sort(np.linalg.eigvals(L.toarray()).real)
+        ev = ev[ev > 1e-10]
+        np.testing.assert_allclose(gr.eig_vals, ev[:len(gr.eig_vals)], rtol=1e-10)
+        assert gr.eig_vecs.shape == (len(pts), min(k, len(pts) - 1))
+        R = L @ gr.eig_vecs  # eigenvectors are min-max normalised: check directions through the raw solve
+        gr2 = Graph(PolyMesh(pts, faces), n_spectral_features=k, norm_eig_vecs=False, n_rand_samples=100, ctx=ctx, verbose=False)
+        gr2.get_graph_spectrum()
+        assert np.max(np.abs(L @ gr2.eig_vecs - gr2.eig_vecs * gr2.eig_vals[None, :])) < 1e-10
 
 
 def test_paired_spectra_equal_single(golden, ctx):
