@@ -88,6 +88,12 @@ int pf_mesh_upload(pf_ctx* ctx, const double* pts, int64_t n, const int32_t* fac
                    int32_t verts_per_face, pf_mesh** out);
 void pf_mesh_free(pf_mesh* mesh);
 int pf_graph_build_device(pf_mesh* mesh, pf_graph** out);
+/* A device graph from a general sparse matrix A in CSR (sorted, unique columns; explicit diagonal optional)
+ * instead of a mesh: what `recursive_eig(matrix, ...)` (graph.py:357-389) needs when it is handed a scipy
+ * matrix.  PF_OP_RW applies A itself; is_symmetric reports A == A^T numerically (PF_OP_SYM is then the same
+ * operator); deg/l_diag hold the diagonal; rows without off-diagonal entries count as isolated. */
+int pf_graph_from_matrix(pf_ctx* ctx, int64_t n, const int32_t* rowptr, const int32_t* colidx, const double* values,
+                         pf_graph** out);
 void pf_graph_free(pf_graph* g);
 int pf_graph_get_info(pf_graph* g, pf_graph_info* out);
 /* CSR(W): rowptr[n+1], colidx[nnz_w], w[nnz_w]; l_offdiag[nnz_w] = -w/(deg_i+1e-8);

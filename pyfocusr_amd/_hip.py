@@ -58,6 +58,7 @@ SIGNATURES = {
     "pf_mesh_upload": (C.c_int, [C.c_void_p, _f64p, C.c_int64, _i32p, C.c_int64, C.c_int32, C.POINTER(C.c_void_p)]),
     "pf_mesh_free": (None, [C.c_void_p]),
     "pf_graph_build_device": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "pf_graph_from_matrix": (C.c_int, [C.c_void_p, C.c_int64, _i32p, _i32p, _f64p, C.POINTER(C.c_void_p)]),
     "pf_graph_free": (None, [C.c_void_p]),
     "pf_graph_get_info": (C.c_int, [C.c_void_p, C.POINTER(GraphInfo)]),
     "pf_graph_download": (C.c_int, [C.c_void_p, _i32p, _i32p, _f64p, _f64p, _f64p, _f64p, _i32p]),
@@ -265,9 +266,17 @@ class DeviceLaplacian(object):
     """Device-resident graph of one mesh: CSR(W), deg, SELL-64 operators, workspace.
     Also the `ops` object the Krylov driver (`_krylov.filtered_eigs`) drives."""
 
-    def __init__(self, points=None, faces=None, ctx=None, device_mesh=None):
+    def __init__(self, points=None, faces=None, ctx=None, device_mesh=None, matrix=None):
         h = C.c_void_p()
-        if device_mesh is not None:
+        if matrix is not None:  # (rowptr, colidx, values) of a general CSR matrix, canonical format
+            self.ctx = ctx if ctx is not None else default_context()
+            self._lib = self.ctx._lib
+            rp = np.ascontiguousarray(matrix[0], dtype=np.int32)
+            ci = np.ascontiguousarray(matrix[1], dtype=np.int32)
+            va = _c_f64(matrix[2])
+            _check(self._lib.pf_graph_from_matrix(self.ctx._h, len(rp) - 1, rp.ctypes.data_as(_i32p),
+                                                  ci.ctypes.data_as(_i32p), _f64(va), C.byref(h)))
+        elif device_mesh is not None:
             self.ctx = device_mesh.ctx
             self._lib = self.ctx._lib
             _check(self._lib.pf_graph_build_device(device_mesh._h, C.byref(h)))

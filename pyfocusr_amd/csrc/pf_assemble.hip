@@ -97,8 +97,7 @@ __global__ __launch_bounds__(PF_BLOCK) void k_compact_rows(const int32_t* __rest
                                                            const int32_t* __restrict__ rcol,
                                                            const double* __restrict__ rw, int32_t* __restrict__ col,
                                                            double* __restrict__ w, double* __restrict__ deg,
-                                                           double* __restrict__ g, double* __restrict__ sg,
-                                                           int32_t* __restrict__ stats /* [0]=n_isolated [1]=max_degree */) {
+                                                           double* __restrict__ g, double* __restrict__ sg) {
     const int64_t i = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
     if (i >= n) return;
     const int32_t src = start[i];
@@ -114,12 +113,22 @@ __global__ __launch_bounds__(PF_BLOCK) void k_compact_rows(const int32_t* __rest
     const double gi = 1.0 / (d + 1e-8);  // graph.py:219
     g[i] = gi;
     sg[i] = sqrt(gi);
-    if (cntu == 0) atomicAdd(&stats[0], 1);
-    atomicMax(&stats[1], cntu);
 }
 
+__global__ __launch_bounds__(PF_BLOCK) void k_row_stats(const int32_t* __restrict__ rowptr, int64_t n,
+                                                        int32_t* __restrict__ stats /* [0]=n_isolated [1]=max_degree */) {
+    const int64_t i = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const int32_t c = rowptr[i + 1] - rowptr[i];
+    if (c == 0) atomicAdd(&stats[0], 1);
+    atomicMax(&stats[1], c);
+}
+
+// values == nullptr: structural symmetry (mesh graphs: W_ij and W_ji are then equal bit for bit);
+// otherwise the values must agree as well (general Laplacians handed in as CSR).
 __global__ __launch_bounds__(PF_BLOCK) void k_symmetry_probe(const int32_t* __restrict__ rowptr,
-                                                             const int32_t* __restrict__ col, int64_t n,
+                                                             const int32_t* __restrict__ col,
+                                                             const double* __restrict__ values, int64_t n,
                                                              int32_t* __restrict__ asym) {
     const int64_t i = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
     if (i >= n) return;
@@ -131,7 +140,7 @@ __global__ __launch_bounds__(PF_BLOCK) void k_symmetry_probe(const int32_t* __re
             const int32_t mid = (lo + hi) >> 1;
             const int32_t c = col[mid];
             if (c == (int32_t)i) {
-                found = true;
+                found = values == nullptr || values[mid] == values[a];
                 break;
             }
             if (c < (int32_t)i) lo = mid + 1; else hi = mid - 1;
@@ -272,6 +281,125 @@ int dev_alloc(hipStream_t st, T** p, int64_t count) {
 
 }  // namespace
 
+namespace {
+
+// split a general CSR matrix into its diagonal and off-diagonals: w = -A_ij, deg = A_ii, g = sg = 1, so that the
+// operator storage (-g_i w) reproduces A_ij and the dense diagonal g_i deg_i reproduces A_ii.
+__global__ __launch_bounds__(PF_BLOCK) void k_csr_count_offdiag(const int32_t* __restrict__ rp, const int32_t* __restrict__ ci,
+                                                                int64_t n, int32_t* __restrict__ cnt, int32_t* __restrict__ flags) {
+    const int64_t i = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    int32_t c = 0, prev = -1;
+    for (int32_t a = rp[i]; a < rp[i + 1]; ++a) {
+        const int32_t j = ci[a];
+        if (j < 0 || j >= n || j <= prev) atomicOr(flags, 1);  // out of range, unsorted or duplicated column
+        prev = j;
+        c += (j != (int32_t)i);
+    }
+    cnt[i] = c;
+}
+
+__global__ __launch_bounds__(PF_BLOCK) void k_csr_split(const int32_t* __restrict__ rp, const int32_t* __restrict__ ci,
+                                                        const double* __restrict__ va, const int32_t* __restrict__ rowptr,
+                                                        int64_t n, int32_t* __restrict__ col, double* __restrict__ w,
+                                                        double* __restrict__ deg, double* __restrict__ g, double* __restrict__ sg) {
+    const int64_t i = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    int32_t o = rowptr[i];
+    double d = 0.0;
+    for (int32_t a = rp[i]; a < rp[i + 1]; ++a) {
+        const int32_t j = ci[a];
+        if (j == (int32_t)i) d = va[a];
+        else {
+            col[o] = j;
+            w[o] = -va[a];
+            ++o;
+        }
+    }
+    deg[i] = d;
+    g[i] = 1.0;
+    sg[i] = 1.0;
+}
+
+// Common tail of the builders: CSR(W) (or the off-diagonals of a general Laplacian), deg, g, sg are in
+// place; derive symmetry, statistics, components, the solver renumbering and the SELL-64 storage.
+int finish_graph(pf_graph* g, const double* d_pts, bool numeric_symmetry) {
+    hipStream_t st = g->ctx->stream;
+    const int64_t n = g->n;
+    int32_t *flags = nullptr, *d_roots = nullptr;
+    int64_t* width64 = nullptr;
+    struct Tmp {
+        hipStream_t st;
+        std::vector<void*> p;
+        ~Tmp() {
+            for (void* q : p) pf_free(st, q);
+        }
+    } tmp{st, {}};
+    PF_TRY(dev_alloc(st, &flags, 8));
+    tmp.p.push_back(flags);
+    PF_TRY(dev_alloc(st, &width64, g->n_slices + 1));
+    tmp.p.push_back(width64);
+    PF_TRY(dev_alloc(st, &d_roots, PF_MAX_ROOTS));
+    tmp.p.push_back(d_roots);
+    PF_HIP(hipMemsetAsync(flags, 0, sizeof(int32_t) * 8, st));
+    int32_t* stats = flags + 2;  // [0] isolated, [1] max degree, [2] asym, [3] changed, [4] n_roots
+    k_row_stats<<<nblk(n), PF_BLOCK, 0, st>>>(g->rowptr, n, stats);
+    PF_HIP(hipGetLastError());
+    k_symmetry_probe<<<nblk(n), PF_BLOCK, 0, st>>>(g->rowptr, g->col, numeric_symmetry ? g->w : nullptr, n, stats + 2);
+    PF_HIP(hipGetLastError());
+
+    // components
+    k_label_init<<<nblk(g->n_pad), PF_BLOCK, 0, st>>>(g->label, g->n_pad);
+    PF_HIP(hipGetLastError());
+    for (int round = 0; round < 64; ++round) {
+        PF_HIP(hipMemsetAsync(stats + 3, 0, sizeof(int32_t), st));
+        k_label_hook<<<nblk(n), PF_BLOCK, 0, st>>>(g->rowptr, g->col, n, g->label, stats + 3);
+        PF_HIP(hipGetLastError());
+        k_label_compress<<<nblk(n), PF_BLOCK, 0, st>>>(g->label, n);
+        PF_HIP(hipGetLastError());
+        int32_t changed = 0;
+        PF_HIP(hipMemcpyAsync(&changed, stats + 3, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        PF_HIP(hipStreamSynchronize(st));
+        if (!changed) break;
+        PF_CHECK(round < 63, PF_E_HIP, "pf_graph_build: component labelling did not converge");
+    }
+    k_collect_roots<<<nblk(n), PF_BLOCK, 0, st>>>(g->label, g->rowptr, n, d_roots, stats + 4);
+    PF_HIP(hipGetLastError());
+
+    // solver-internal renumbering (Morton order, degree-sorted windows), then SELL-64 in that order
+    PF_TRY(pf_compute_order(g, d_pts));
+    k_slice_widths<<<nblk(g->n_pad), PF_BLOCK, 0, st>>>(g->rowptr, g->perm, n, g->n_slices, width64);
+    PF_HIP(hipGetLastError());
+    PF_HIP(hipMemsetAsync(width64 + g->n_slices, 0, sizeof(int64_t), st));
+    PF_TRY(pf_exclusive_scan_i64(st, width64, g->slice_ptr, g->n_slices + 1));
+    int32_t h_stats[6];
+    PF_HIP(hipMemcpyAsync(h_stats, stats, sizeof(int32_t) * 5, hipMemcpyDeviceToHost, st));
+    PF_HIP(hipMemcpyAsync(&g->sell_entries, g->slice_ptr + g->n_slices, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    PF_HIP(hipStreamSynchronize(st));
+    g->n_isolated = h_stats[0];
+    g->max_degree = h_stats[1];
+    g->is_symmetric = h_stats[2] ? 0 : 1;
+    const int32_t n_roots = h_stats[4];
+    PF_CHECK(n_roots <= PF_MAX_ROOTS, PF_E_ARG, "pf_graph_build: %d connected components exceed the supported %d",
+             n_roots, PF_MAX_ROOTS);
+    g->n_components = n_roots;
+    g->roots.resize(n_roots);
+    if (n_roots) {
+        PF_HIP(hipMemcpyAsync(g->roots.data(), d_roots, sizeof(int32_t) * n_roots, hipMemcpyDeviceToHost, st));
+        PF_HIP(hipStreamSynchronize(st));
+        std::sort(g->roots.begin(), g->roots.end());
+    }
+    PF_TRY(dev_alloc(st, &g->scol, g->sell_entries));
+    PF_TRY(dev_alloc(st, &g->sval_rw, g->sell_entries));
+    if (g->is_symmetric) PF_TRY(dev_alloc(st, &g->sval_sym, g->sell_entries));
+    k_fill_sell<<<nblk(g->n_pad), PF_BLOCK, 0, st>>>(g->rowptr, g->col, g->w, g->deg, g->g, g->sg, g->perm, g->iperm, n, g->n_pad,
+                                                     g->slice_ptr, g->scol, g->sval_rw, g->sval_sym, g->diag);
+    PF_HIP(hipGetLastError());
+    return PF_OK;
+}
+
+}  // namespace
+
 extern "C" {
 
 void pf_graph_free(pf_graph* g) {
@@ -398,8 +526,6 @@ int pf_graph_build_device(pf_mesh* mesh, pf_graph** out) {
     const int32_t* d_faces = mesh->faces;
     int32_t *cnt = nullptr, *start = nullptr, *cursor = nullptr, *rcol = nullptr, *ucnt = nullptr, *flags = nullptr;
     double* rw = nullptr;
-    int64_t* width64 = nullptr;
-    int32_t* d_roots = nullptr;
     PF_TRY(scratch(&cnt, n + 1));
     PF_TRY(scratch(&start, n + 1));
     PF_TRY(scratch(&cursor, n + 1));
@@ -407,8 +533,6 @@ int pf_graph_build_device(pf_mesh* mesh, pf_graph** out) {
     PF_TRY(scratch(&rcol, n_edges));
     PF_TRY(scratch(&rw, n_edges));
     PF_TRY(scratch(&flags, 8));
-    PF_TRY(scratch(&width64, g->n_slices + 1));
-    PF_TRY(scratch(&d_roots, PF_MAX_ROOTS));
     PF_TRY(dev_alloc(st, &g->rowptr, n + 1));
     PF_TRY(dev_alloc(st, &g->deg, g->n_pad));
     PF_TRY(dev_alloc(st, &g->g, g->n_pad));
@@ -454,59 +578,91 @@ int pf_graph_build_device(pf_mesh* mesh, pf_graph** out) {
     PF_TRY(dev_alloc(st, &g->col, g->nnz_w));
     PF_TRY(dev_alloc(st, &g->w, g->nnz_w));
 
-    int32_t* stats = flags + 2;  // [0] isolated, [1] max degree, [2] asym, [3] changed, [4] n_roots
-    k_compact_rows<<<nblk(n), PF_BLOCK, 0, st>>>(start, g->rowptr, n, rcol, rw, g->col, g->w, g->deg, g->g, g->sg, stats);
+    k_compact_rows<<<nblk(n), PF_BLOCK, 0, st>>>(start, g->rowptr, n, rcol, rw, g->col, g->w, g->deg, g->g, g->sg);
     PF_HIP(hipGetLastError());
-    k_symmetry_probe<<<nblk(n), PF_BLOCK, 0, st>>>(g->rowptr, g->col, n, stats + 2);
-    PF_HIP(hipGetLastError());
-
-    // components
-    k_label_init<<<nblk(g->n_pad), PF_BLOCK, 0, st>>>(g->label, g->n_pad);
-    PF_HIP(hipGetLastError());
-    for (int round = 0; round < 64; ++round) {
-        PF_HIP(hipMemsetAsync(stats + 3, 0, sizeof(int32_t), st));
-        k_label_hook<<<nblk(n), PF_BLOCK, 0, st>>>(g->rowptr, g->col, n, g->label, stats + 3);
-        PF_HIP(hipGetLastError());
-        k_label_compress<<<nblk(n), PF_BLOCK, 0, st>>>(g->label, n);
-        PF_HIP(hipGetLastError());
-        int32_t changed = 0;
-        PF_HIP(hipMemcpyAsync(&changed, stats + 3, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-        PF_HIP(hipStreamSynchronize(st));
-        if (!changed) break;
-        PF_CHECK(round < 63, PF_E_HIP, "pf_graph_build: component labelling did not converge");
-    }
-    k_collect_roots<<<nblk(n), PF_BLOCK, 0, st>>>(g->label, g->rowptr, n, d_roots, stats + 4);
-    PF_HIP(hipGetLastError());
-
-    // solver-internal renumbering (Morton order, degree-sorted windows), then SELL-64 in that order
-    PF_TRY(pf_compute_order(g, d_pts));
-    k_slice_widths<<<nblk(g->n_pad), PF_BLOCK, 0, st>>>(g->rowptr, g->perm, n, g->n_slices, width64);
-    PF_HIP(hipGetLastError());
-    PF_HIP(hipMemsetAsync(width64 + g->n_slices, 0, sizeof(int64_t), st));
-    PF_TRY(pf_exclusive_scan_i64(st, width64, g->slice_ptr, g->n_slices + 1));
-    int32_t h_stats[6];
-    PF_HIP(hipMemcpyAsync(h_stats, stats, sizeof(int32_t) * 5, hipMemcpyDeviceToHost, st));
-    PF_HIP(hipMemcpyAsync(&g->sell_entries, g->slice_ptr + g->n_slices, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    PF_TRY(finish_graph(g, d_pts, false));
+    PF_HIP(hipEventRecord(ctx->ev1, st));
     PF_HIP(hipStreamSynchronize(st));
-    g->n_isolated = h_stats[0];
-    g->max_degree = h_stats[1];
-    g->is_symmetric = h_stats[2] ? 0 : 1;
-    const int32_t n_roots = h_stats[4];
-    PF_CHECK(n_roots <= PF_MAX_ROOTS, PF_E_ARG, "pf_graph_build: %d connected components exceed the supported %d",
-             n_roots, PF_MAX_ROOTS);
-    g->n_components = n_roots;
-    g->roots.resize(n_roots);
-    if (n_roots) {
-        PF_HIP(hipMemcpyAsync(g->roots.data(), d_roots, sizeof(int32_t) * n_roots, hipMemcpyDeviceToHost, st));
-        PF_HIP(hipStreamSynchronize(st));
-        std::sort(g->roots.begin(), g->roots.end());
+    float ms = 0.f;
+    PF_HIP(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    ctx->build_ms = ms;
+    guard.ok = true;
+    *out = g;
+    return PF_OK;
+}
+
+int pf_graph_from_matrix(pf_ctx* ctx, int64_t n, const int32_t* rowptr, const int32_t* colidx, const double* values,
+                         pf_graph** out) {
+    PF_CHECK(ctx && rowptr && out, PF_E_ARG, "pf_graph_from_matrix: NULL argument");
+    PF_CHECK(n > 0 && n < (int64_t)1 << 31, PF_E_ARG, "pf_graph_from_matrix: n = %lld out of range", (long long)n);
+    const int64_t nnz = rowptr[n];
+    PF_CHECK(nnz >= 0 && nnz < (int64_t)1 << 31 && (nnz == 0 || (colidx && values)), PF_E_ARG,
+             "pf_graph_from_matrix: bad nnz %lld", (long long)nnz);
+    *out = nullptr;
+    PF_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    pf_graph* g = new pf_graph();
+    g->ctx = ctx;
+    g->n = n;
+    g->n_pad = (n + 8 * PF_BLOCK - 1) / (8 * PF_BLOCK) * (8 * PF_BLOCK);
+    g->n_slices = g->n_pad / PF_WAVE;
+    g->n_chunks = (g->n_pad + PF_DOT_CHUNK - 1) / PF_DOT_CHUNK;
+    struct Guard {
+        pf_graph* g;
+        std::vector<void*> tmp;
+        bool ok = false;
+        ~Guard() {
+            for (void* p : tmp) pf_free(g->ctx->stream, p);
+            if (!ok) pf_graph_free(g);
+        }
+    } guard{g};
+    int32_t *rp = nullptr, *ci = nullptr, *cnt = nullptr, *flags = nullptr;
+    double* va = nullptr;
+    auto scratch = [&](auto** p, int64_t count) -> int {
+        int r = dev_alloc(st, p, count);
+        if (r == PF_OK) guard.tmp.push_back((void*)*p);
+        return r;
+    };
+    PF_TRY(scratch(&rp, n + 1));
+    PF_TRY(scratch(&ci, nnz));
+    PF_TRY(scratch(&va, nnz));
+    PF_TRY(scratch(&cnt, n + 1));
+    PF_TRY(scratch(&flags, 8));
+    PF_TRY(dev_alloc(st, &g->rowptr, n + 1));
+    PF_TRY(dev_alloc(st, &g->deg, g->n_pad));
+    PF_TRY(dev_alloc(st, &g->g, g->n_pad));
+    PF_TRY(dev_alloc(st, &g->sg, g->n_pad));
+    PF_TRY(dev_alloc(st, &g->diag, g->n_pad));
+    PF_TRY(dev_alloc(st, &g->label, g->n_pad));
+    PF_TRY(dev_alloc(st, &g->perm, g->n_pad));
+    PF_TRY(dev_alloc(st, &g->iperm, g->n_pad));
+    PF_TRY(dev_alloc(st, &g->smooth, g->n_pad));
+    PF_TRY(dev_alloc(st, &g->slice_ptr, g->n_slices + 1));
+    PF_HIP(hipMemcpyAsync(rp, rowptr, sizeof(int32_t) * (n + 1), hipMemcpyHostToDevice, st));
+    if (nnz) {
+        PF_HIP(hipMemcpyAsync(ci, colidx, sizeof(int32_t) * nnz, hipMemcpyHostToDevice, st));
+        PF_HIP(hipMemcpyAsync(va, values, sizeof(double) * nnz, hipMemcpyHostToDevice, st));
     }
-    PF_TRY(dev_alloc(st, &g->scol, g->sell_entries));
-    PF_TRY(dev_alloc(st, &g->sval_rw, g->sell_entries));
-    if (g->is_symmetric) PF_TRY(dev_alloc(st, &g->sval_sym, g->sell_entries));
-    k_fill_sell<<<nblk(g->n_pad), PF_BLOCK, 0, st>>>(g->rowptr, g->col, g->w, g->deg, g->g, g->sg, g->perm, g->iperm, n, g->n_pad,
-                                                     g->slice_ptr, g->scol, g->sval_rw, g->sval_sym, g->diag);
+    PF_HIP(hipMemsetAsync(cnt, 0, sizeof(int32_t) * (n + 1), st));
+    PF_HIP(hipMemsetAsync(flags, 0, sizeof(int32_t) * 8, st));
+    PF_HIP(hipMemsetAsync(g->deg, 0, sizeof(double) * g->n_pad, st));
+    PF_HIP(hipMemsetAsync(g->g, 0, sizeof(double) * g->n_pad, st));
+    PF_HIP(hipMemsetAsync(g->sg, 0, sizeof(double) * g->n_pad, st));
+    PF_HIP(hipEventRecord(ctx->ev0, st));
+    k_csr_count_offdiag<<<nblk(n), PF_BLOCK, 0, st>>>(rp, ci, n, cnt, flags);
     PF_HIP(hipGetLastError());
+    PF_TRY(pf_exclusive_scan_i32(st, cnt, g->rowptr, n + 1));
+    int32_t h_flag = 0, nnz32 = 0;
+    PF_HIP(hipMemcpyAsync(&h_flag, flags, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    PF_HIP(hipMemcpyAsync(&nnz32, g->rowptr + n, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    PF_HIP(hipStreamSynchronize(st));
+    PF_CHECK(!h_flag, PF_E_ARG, "pf_graph_from_matrix: column indices must be in range, sorted and unique within each row");
+    g->nnz_w = nnz32;
+    PF_TRY(dev_alloc(st, &g->col, g->nnz_w));
+    PF_TRY(dev_alloc(st, &g->w, g->nnz_w));
+    k_csr_split<<<nblk(n), PF_BLOCK, 0, st>>>(rp, ci, va, g->rowptr, n, g->col, g->w, g->deg, g->g, g->sg);
+    PF_HIP(hipGetLastError());
+    PF_TRY(finish_graph(g, nullptr, true));
     PF_HIP(hipEventRecord(ctx->ev1, st));
     PF_HIP(hipStreamSynchronize(st));
     float ms = 0.f;

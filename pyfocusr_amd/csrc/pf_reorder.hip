@@ -92,6 +92,11 @@ __global__ __launch_bounds__(PF_BLOCK) void k_degree_keys(const int32_t* __restr
     keys[r] = ((unsigned)(r / PF_SIGMA) << 10) | (unsigned)(1023 - d);
 }
 
+__global__ __launch_bounds__(PF_BLOCK) void k_iota(int32_t* __restrict__ v, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
+    if (i < n) v[i] = (int32_t)i;
+}
+
 __global__ __launch_bounds__(PF_BLOCK) void k_finish_perm(int32_t* __restrict__ perm, int32_t* __restrict__ iperm, int64_t n,
                                                           int64_t n_pad) {
     const int64_t r = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
@@ -150,8 +155,13 @@ int pf_compute_order(pf_graph* g, const double* d_pts) {
         if (fail(pf_malloc(st, (void**)&v0, sizeof(int32_t) * n)) || fail(pf_malloc(st, (void**)&v1, sizeof(int32_t) * n))) break;
         if (fail(hipMemsetAsync(bbox, 0xff, 3 * sizeof(unsigned long long), st))) break;
         if (fail(hipMemsetAsync(bbox + 3, 0x00, 3 * sizeof(unsigned long long), st))) break;
-        k_bbox<<<256, PF_BLOCK, 0, st>>>(d_pts, n, bbox);
-        k_morton_keys<<<nblk(n), PF_BLOCK, 0, st>>>(d_pts, n, bbox, k0, v0);
+        if (d_pts) {
+            k_bbox<<<256, PF_BLOCK, 0, st>>>(d_pts, n, bbox);
+            k_morton_keys<<<nblk(n), PF_BLOCK, 0, st>>>(d_pts, n, bbox, k0, v0);
+        } else {  // no geometry (graph handed in as a matrix): keep the caller's order, only sort degrees in windows
+            if (fail(hipMemsetAsync(k0, 0, sizeof(unsigned) * n, st))) break;
+            k_iota<<<nblk(n), PF_BLOCK, 0, st>>>(v0, n);
+        }
         if (fail(hipGetLastError())) break;
         if (fail(hipcub::DeviceRadixSort::SortPairs(nullptr, need, k0, k1, v0, v1, in, 0, 30, st))) break;
         tmp_bytes = need;
@@ -167,7 +177,8 @@ int pf_compute_order(pf_graph* g, const double* d_pts) {
         need = tmp_bytes;
         if (fail(hipcub::DeviceRadixSort::SortPairs(tmp, need, k0, k1, v1, g->perm, in, 0, bits2, st))) break;
         k_finish_perm<<<nblk(g->n_pad), PF_BLOCK, 0, st>>>(g->perm, g->iperm, n, g->n_pad);
-        k_smooth_start<<<nblk(g->n_pad), PF_BLOCK, 0, st>>>(d_pts, g->perm, bbox, g->n_pad, g->smooth);
+        if (d_pts) k_smooth_start<<<nblk(g->n_pad), PF_BLOCK, 0, st>>>(d_pts, g->perm, bbox, g->n_pad, g->smooth);
+        else if (fail(hipMemsetAsync(g->smooth, 0, sizeof(double) * g->n_pad, st))) break;  // start vector = noise only
         if (fail(hipGetLastError())) break;
     } while (0);
     pf_free(st, bbox);

@@ -329,10 +329,13 @@ def _device_eigs_gen(dev, k, n_k_needed, k_buffer=1, minmax=False, verbose=False
     m = k_final - (#null eigenvalues) >= n_k_needed, exactly the column count the reference's
     widen-and-retry loop ends with."""
     n = dev.n
-    n_null = dev.n_components + dev.n_isolated
+    lock = getattr(dev, "lock_nulls", True)  # False: general matrix whose rows do not sum to zero
+    n_locked_null = dev.n_components + dev.n_isolated if lock else 0
+    extra = 0  # null eigenvalues the solver itself found (they occupy Ritz slots: not locked)
     if verbose:
         print("Starting!")
     while True:
+        n_null = n_locked_null + extra
         k_final, retries = _widened_k(k, n_k_needed, k_buffer, n_null, n)
         if verbose:
             for _ in range(retries):
@@ -341,11 +344,11 @@ def _device_eigs_gen(dev, k, n_k_needed, k_buffer=1, minmax=False, verbose=False
         m_out = max(min(k_final - n_null, n - n_null), 0)
         if m_out == 0:
             return np.zeros(0), np.zeros((n, 0)), None
-        c0 = dev.lock_null_vectors()
-        lam, first, stats = yield from filtered_eigs_gen(dev, m_out, dev.symmetric, null_slots=c0, **solver_kw)
-        extra_null = stats.n_null - c0
-        if extra_null > 0 and len(lam) < m_out:  # a null vector the component count did not predict
-            n_null += extra_null
+        c0 = dev.lock_null_vectors() if lock else 0
+        lam, first, stats = yield from filtered_eigs_gen(dev, m_out + extra, dev.symmetric, null_slots=c0, **solver_kw)
+        found = stats.n_null - c0
+        if found > extra and len(lam) < m_out:  # null vectors the component count did not predict
+            extra = found
             continue
         break
     vecs = dev.finalize_vectors(first, len(lam), minmax)
@@ -356,18 +359,47 @@ def _device_eigs(dev, k, n_k_needed, k_buffer=1, minmax=False, verbose=False, **
     return drive(_device_eigs_gen(dev, k, n_k_needed, k_buffer, minmax, verbose, **solver_kw), dev)
 
 
-def recursive_eig(matrix, k, n_k_needed, k_buffer=1, sigma=1e-10, which="LM"):
-    """graph.py:357-389 for a Laplacian produced by `Graph.get_laplacian_matrix()`.
+def _device_from_matrix(matrix, ctx=None):
+    """Upload a general sparse matrix (the argument of the reference's `recursive_eig`) and work out
+    what the filtered solver needs to know about it: an upper bound of the spectrum (Gershgorin) and
+    whether the indicator vectors of its connected components are null vectors (rows summing to 0)."""
+    A = sparse.csr_matrix(matrix, dtype=np.float64, copy=True)
+    if A.shape[0] != A.shape[1]:
+        raise ValueError("expected a square matrix")
+    A.sum_duplicates()
+    A.sort_indices()
+    n = A.shape[0]
+    dev = _hip.DeviceLaplacian(matrix=(A.indptr, A.indices, A.data), ctx=ctx)
+    absA = abs(A)
+    hi = float(np.asarray(absA.sum(axis=1)).max()) if A.nnz else 1.0
+    scale = float(absA.max()) if A.nnz else 1.0
+    row_sums = np.abs(np.asarray(A @ np.ones(n)))
+    dev.lock_nulls = bool(row_sums.max() <= 1e-12 * max(scale, 1e-300))
+    offdiag = np.diff(A.indptr) - (A.diagonal() != 0)
+    if np.any((offdiag == 0) & (A.diagonal() != 0)):
+        raise NotImplementedError("rows whose only entry is a non-zero diagonal are not supported")
+    return dev, dict(hi=max(hi, 1e-300), cut=8.0 * (1 + 1) / max(n, 1) * max(hi, 1e-300) / 2.0)
 
-    The reference hands a scipy matrix to ARPACK; here the matrix must carry its
-    device graph (`Graph.laplacian_matrix` does).  `sigma`/`which` select ARPACK's
-    shift-invert mode in the reference and have no counterpart here: the
-    eigenvalues nearest zero are always the ones computed.  Returns raw
-    (un-normalised, unit-2-norm) eigenvectors, sorted ascending."""
+
+def recursive_eig(matrix, k, n_k_needed, k_buffer=1, sigma=1e-10, which="LM"):
+    """graph.py:357-389: the `n_k_needed` (or more, after widening) eigenpairs of `matrix` nearest zero
+    with eigenvalue > 1e-10.
+
+    A Laplacian produced by `Graph.get_laplacian_matrix()` carries its device graph and is solved in
+    place; any other scipy sparse matrix (the reference's signature) is uploaded with
+    `pf_graph_from_matrix`.  `sigma`/`which` select ARPACK's shift-invert mode in the reference and have no
+    counterpart here: the eigenvalues nearest zero of a positive semi-definite operator are always the
+    ones computed.  Returns raw (un-normalised, unit-2-norm) eigenvectors, sorted ascending."""
     dev = getattr(matrix, "_pf_device", None)
-    if dev is None:
-        raise NotImplementedError(
-            "recursive_eig needs a Laplacian built by pyfocusr_amd.Graph (device-resident); "
-            "arbitrary scipy matrices are not uploaded")
-    vals, vecs, _ = _device_eigs(dev, k, n_k_needed, k_buffer, minmax=False, verbose=True)
+    solver_kw = {}
+    owned = False
+    if dev is None or getattr(dev, "_h", None) is None:
+        dev, solver_kw = _device_from_matrix(matrix)
+        solver_kw["cut"] = solver_kw["cut"] * (n_k_needed + 1) / 2.0
+        owned = True
+    try:
+        vals, vecs, _ = _device_eigs(dev, k, n_k_needed, k_buffer, minmax=False, verbose=True, **solver_kw)
+    finally:
+        if owned:
+            dev.close()
     return vals, vecs

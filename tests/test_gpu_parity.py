@@ -320,6 +320,31 @@ def test_tiny_meshes(ctx):
         assert np.max(np.abs(L @ gr2.eig_vecs - gr2.eig_vecs * gr2.eig_vals[None, :])) < 1e-10
 
 
+def test_recursive_eig_on_plain_scipy_matrices(golden):
+    """graph.py:357-389 with matrices that do not come from `Graph`: the random-walk Laplacian of the
+    fixtures (non-symmetric values), its symmetrised form, and a shifted copy without null vectors."""
+    from pyfocusr_amd import recursive_eig
+
+    g = golden("target_mesh")
+    n = len(g["points"])
+    L = sparse.csr_matrix((g["L_data"], g["L_indices"], g["L_indptr"]), shape=(n, n))
+    vals, vecs = recursive_eig(L, k=7, n_k_needed=6)
+    np.testing.assert_allclose(vals, g["k6_eig_vals"], rtol=1e-8)
+    _, canon = orc.canonicalize(vals, vecs)
+    assert np.max(np.abs(canon - g["k6_eig_vecs_raw"])) < 2e-9
+    s = np.sqrt(1.0 / (g["deg"] + 1e-8))
+    W = sparse.csr_matrix((g["W_data"], g["W_indices"], g["W_indptr"]), shape=(n, n))
+    S = sparse.diags(s) @ (sparse.diags(g["deg"]) - W) @ sparse.diags(s)
+    vals_s, vecs_s = recursive_eig(S, k=4, n_k_needed=3)  # symmetric: null vector is not constant -> found, then filtered
+    np.testing.assert_allclose(vals_s, g["k3_eig_vals"], rtol=1e-8)
+    R = S @ vecs_s - vecs_s * vals_s[None, :]
+    assert np.max(np.abs(R)) < 1e-10
+    vals_sh, _ = recursive_eig(L + 0.01 * sparse.eye(n), k=4, n_k_needed=3)
+    np.testing.assert_allclose(vals_sh[:3], np.concatenate([[0.01], g["k3_eig_vals"][:2] + 0.01]), rtol=1e-8)
+    with pytest.raises(ValueError):
+        recursive_eig(sparse.csr_matrix(np.ones((3, 4))), k=2, n_k_needed=1)
+
+
 def test_paired_spectra_equal_single(golden, ctx):
     """Two graphs per kernel launch (pf_cheb2, different sizes and degrees) give bit-identical
     results to one graph per launch."""
@@ -354,8 +379,10 @@ def test_multi_component_and_recursive_eig(hip, ctx):
     vals, vecs = recursive_eig(gr.laplacian_matrix, k=5, n_k_needed=4)
     np.testing.assert_allclose(vals, ref["eig_vals"], rtol=1e-8)
     assert vecs.shape == ref["eig_vecs_raw"].shape
-    with pytest.raises(NotImplementedError):
-        recursive_eig(sparse.csr_matrix(gr.laplacian_matrix), k=5, n_k_needed=4)
+    # the reference's signature: any scipy sparse matrix (uploaded with pf_graph_from_matrix)
+    vals2, vecs2 = recursive_eig(sparse.csr_matrix(gr.laplacian_matrix), k=5, n_k_needed=4)
+    np.testing.assert_allclose(vals2, ref["eig_vals"], rtol=1e-8)
+    assert vecs2.shape == vecs.shape
 
 
 # ------------------------------------------------------------------------------- KNN
