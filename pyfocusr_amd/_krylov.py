@@ -251,7 +251,7 @@ def filtered_eigs_gen(ops, n_wanted, symmetric, null_slots=0, cut=None, tol=1e-1
                 exhausted = beta <= 1e-14 * max(abs(theta0), 1.0) or j >= n_active
                 if not exhausted:
                     ops.scale(A0 + j, 1.0 / beta)
-                if exhausted or j >= q_target + 2:  # O(j^3) host work on a <= m_max x m_max matrix: negligible
+                if exhausted or j == m_max or j >= q_target + 8:  # Ritz check: ~0.2 ms of host work per call
                     theta, U, T, q, n_real, res, theta_min = ritz(j)
                     if verbose:
                         print("  j=%d q=%d theta_min=%.4g |theta|max=%.3g max res=%.3e" % (
