@@ -127,6 +127,11 @@ int pf_dots(pf_graph* g, int32_t w, int32_t first, int32_t count, double* out); 
 /* classical Gram-Schmidt twice of slot w against slots [first, first+count): h[count] = summed
  * coefficients, *nrm = ||w|| afterwards (w is left un-normalised). */
 int pf_orth(pf_graph* g, int32_t w, int32_t first, int32_t count, double* h, double* nrm);
+/* The same in two phases, so that the host can queue the next filter application before it reads the
+ * coefficients: begin enqueues the kernels (and, if `normalize`, w <- w/||w|| with the norm taken on the
+ * device) plus an asynchronous copy of the results; end waits for them.  One orth in flight per graph. */
+int pf_orth_begin(pf_graph* g, int32_t w, int32_t first, int32_t count, int32_t normalize);
+int pf_orth_end(pf_graph* g, double* h, double* nrm);
 int pf_scale(pf_graph* g, int32_t slot, double alpha);
 /* slots [dst_first, dst_first+k) = slots [src_first, src_first+m) * Y, Y row-major m x k; ranges must not overlap */
 int pf_combine(pf_graph* g, int32_t src_first, int32_t m, const double* Y, int32_t k, int32_t dst_first);

@@ -75,6 +75,8 @@ SIGNATURES = {
                            C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double]),
     "pf_dots": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, _f64p]),
     "pf_orth": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, _f64p, _f64p]),
+    "pf_orth_begin": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "pf_orth_end": (C.c_int, [C.c_void_p, _f64p, _f64p]),
     "pf_scale": (C.c_int, [C.c_void_p, C.c_int32, C.c_double]),
     "pf_combine": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _f64p, C.c_int32, C.c_int32]),
     "pf_resnorm": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_double, _f64p]),
@@ -379,6 +381,16 @@ class DeviceLaplacian(object):
         nrm = C.c_double()
         _check(self._lib.pf_orth(self._h, int(w), int(first), int(count), _f64(h), C.byref(nrm)))
         return h[: int(count)], float(nrm.value)
+
+    def orth_begin(self, w, first, count, normalize=True):
+        _check(self._lib.pf_orth_begin(self._h, int(w), int(first), int(count), int(bool(normalize))))
+        self._orth_count = int(count)
+
+    def orth_end(self):
+        h = np.empty(max(self._orth_count, 1), dtype=np.float64)
+        nrm = C.c_double()
+        _check(self._lib.pf_orth_end(self._h, _f64(h), C.byref(nrm)))
+        return h[: self._orth_count], float(nrm.value)
 
     def scale(self, slot, alpha):
         _check(self._lib.pf_scale(self._h, int(slot), float(alpha)))

@@ -238,24 +238,32 @@ def filtered_eigs_gen(ops, n_wanted, symmetric, null_slots=0, cut=None, tol=1e-1
         outcome = None  # "converged" | "cut" | "range"
         restarts = 0
         while outcome is None:
+            spec = False  # the filter application of the current step was already queued speculatively
+            near = False  # the last Ritz check was within ~3 digits of the tolerance: the next step probably converges
             while j < m_max and outcome is None:  # ---- expand
-                yield (A0 + j, A0 + j + 1, p, c, e)
-                stats.matvecs += p
+                if not spec:
+                    yield (A0 + j, A0 + j + 1, p, c, e)
+                    stats.matvecs += p
                 stats.outer_steps += 1
-                h, beta = ops.orth(A0 + j + 1, A0, j + 1)
+                # CGS2 + normalisation entirely on the device; the coefficients come back asynchronously
+                ops.orth_begin(A0 + j + 1, A0, j + 1, normalize=True)
+                spec = j + 1 < m_max and not near  # (a speculative application after the last step would be wasted)
+                if spec:  # keep the device busy: queue the next filter application before reading this step's result
+                    yield (A0 + j + 1, A0 + j + 2, p, c, e)
+                    stats.matvecs += p
+                h, beta = ops.orth_end()
                 H[:j + 1, j] = h
                 H[j, :j] = b[:j]
                 j += 1
                 b[:] = 0.0
                 b[j - 1] = beta
                 exhausted = beta <= 1e-14 * max(abs(theta0), 1.0) or j >= n_active
-                if not exhausted:
-                    ops.scale(A0 + j, 1.0 / beta)
                 if exhausted or j == m_max or j >= q_target + 8:  # Ritz check: ~0.2 ms of host work per call
                     theta, U, T, q, n_real, res, theta_min = ritz(j)
                     if verbose:
                         print("  j=%d q=%d theta_min=%.4g |theta|max=%.3g max res=%.3e" % (
                             j, q, theta_min, np.max(np.abs(theta)), np.max(res)))
+                    near = n_real >= q_target and theta_min > band and np.all(res <= 1e3 * tol * max(theta_min, 1.0))
                     if n_real >= q_target and np.all(res <= tol * max(theta_min, 1.0)) and theta_min > band:
                         outcome = "converged"
                     elif not symmetric and np.max(np.abs(theta)) > 1e7 * max(theta_min, 1.0) and p > 16:

@@ -59,6 +59,22 @@ void pf_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+int pf_timing_collect(pf_ctx* c) {
+    if (c->spans_pending.empty()) return PF_OK;
+    PF_HIP(hipSetDevice(c->device));
+    PF_HIP(hipStreamSynchronize(c->stream));
+    for (auto& sp : c->spans_pending) {
+        float ms = 0.f;
+        PF_HIP(hipEventElapsedTime(&ms, sp.e0, sp.e1));
+        c->op_ms += ms;
+        c->op_launches += sp.launches;
+        c->op_bytes += sp.bytes;
+        c->spans_free.emplace_back(sp.e0, sp.e1);
+    }
+    c->spans_pending.clear();
+    return PF_OK;
+}
+
 extern "C" {
 
 int pf_version(void) { return PF_VERSION; }
@@ -108,6 +124,14 @@ void pf_destroy(pf_ctx* c) {
         std::lock_guard<std::mutex> lk(g_ctx_mutex);
         g_ctxs.erase(std::remove(g_ctxs.begin(), g_ctxs.end(), c), g_ctxs.end());
     }
+    for (auto& sp : c->spans_pending) {
+        hipEventDestroy(sp.e0);
+        hipEventDestroy(sp.e1);
+    }
+    for (auto& pr : c->spans_free) {
+        hipEventDestroy(pr.first);
+        hipEventDestroy(pr.second);
+    }
     hipEventDestroy(c->ev0);
     hipEventDestroy(c->ev1);
     hipStreamDestroy(c->stream);
@@ -128,6 +152,7 @@ int pf_timing_enable(pf_ctx* c, int on) {
 
 int pf_timing_get(pf_ctx* c, pf_timing* out, int reset) {
     PF_CHECK(c != nullptr && out != nullptr, PF_E_ARG, "pf_timing_get: NULL argument");
+    PF_TRY(pf_timing_collect(c));
     out->op_ms = c->op_ms;
     out->op_launches = c->op_launches;
     out->op_bytes = c->op_bytes;

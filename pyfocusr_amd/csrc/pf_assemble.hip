@@ -429,6 +429,11 @@ void pf_graph_free(pf_graph* g) {
     pf_free(st, g->ws);
     pf_free(st, g->partials);
     pf_free(st, g->coef);
+    if (g->orth_host) {
+        hipStreamSynchronize(st);
+        hipHostFree(g->orth_host);
+    }
+    if (g->orth_ev) hipEventDestroy(g->orth_ev);
     delete g;
 }
 

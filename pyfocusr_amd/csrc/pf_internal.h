@@ -70,6 +70,15 @@ struct pf_ctx {
     int64_t* knn_idx = nullptr; // [n_qry]
     double* knn_d2 = nullptr;   // [n_qry]
     bool knn_ready = false, knn_done = false;
+    // operator timing: event pairs recorded around filter applications, resolved lazily in pf_timing_get so
+    // that timing never blocks the host (the solver queues the next application while this one runs)
+    struct TimedSpan {
+        hipEvent_t e0, e1;
+        int64_t launches;
+        double bytes;
+    };
+    std::vector<TimedSpan> spans_pending;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> spans_free;
     // allocator state
     std::multimap<size_t, void*> free_blocks;   // size -> block
     std::unordered_map<void*, size_t> live_blocks;
@@ -113,6 +122,11 @@ struct pf_graph {
     double* coef = nullptr;     // device coefficients: [3][coef_cap]
     int32_t coef_cap = 0;
     int64_t n_chunks = 0;
+    // split-phase orthogonalisation (pf_orth_begin / pf_orth_end): results land in pinned host memory
+    double* orth_host = nullptr; // [orth_host_cap + 1] pinned
+    int32_t orth_host_cap = 0;
+    int32_t orth_pending = -1;   // count of the orth in flight, -1 if none
+    hipEvent_t orth_ev = nullptr;
 };
 
 // Caching device allocator, one cache per ctx (pf_api.hip).  Every use of a block is enqueued on
@@ -120,6 +134,7 @@ struct pf_graph {
 // later work is ordered behind earlier work by the stream.  After the first build the assembler's
 // ~30 temporaries are recycled without a driver call (hipMalloc/hipFree cost 0.1-1 ms each and
 // hipFree synchronises the device).  Blocks go back to the driver in pf_destroy.
+int pf_timing_collect(pf_ctx* c);  // pf_api.hip: fold finished spans into op_ms / op_launches / op_bytes
 hipError_t pf_malloc(hipStream_t st, void** p, size_t bytes);
 void pf_free(hipStream_t st, void* p);
 

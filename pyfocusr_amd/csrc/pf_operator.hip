@@ -144,6 +144,14 @@ __global__ __launch_bounds__(PF_BLOCK) void k_scale(double* __restrict__ x, int6
     if (i < n_pad) x[i] *= alpha;
 }
 
+// x *= 1/sqrt(*nrm2) with the norm still on the device (no host round trip between a Lanczos step and the next
+// filter application); left alone when the norm is ~0 (invariant subspace: the host stops the iteration)
+__global__ __launch_bounds__(PF_BLOCK) void k_scale_rsqrt(double* __restrict__ x, int64_t n_pad, const double* __restrict__ nrm2) {
+    const int64_t i = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
+    const double v = *nrm2;
+    if (i < n_pad && v > 1e-280) x[i] *= 1.0 / sqrt(v);
+}
+
 __global__ __launch_bounds__(PF_BLOCK) void k_mask_isolated(double* __restrict__ x, const int32_t* __restrict__ rowptr,
                                                             const int32_t* __restrict__ perm, int64_t n) {
     const int64_t r = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
@@ -447,18 +455,24 @@ struct OpTimer {
     int64_t launches;
     double bytes;
     bool on;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
     OpTimer(pf_ctx* ctx, int64_t n, double b) : c(ctx), launches(n), bytes(b), on(ctx->timing) {
-        if (on) hipEventRecord(c->ev0, c->stream);
+        if (!on) return;
+        if (c->spans_pending.size() >= 4096) (void)pf_timing_collect(c);  // bound the number of live events
+        if (!c->spans_free.empty()) {
+            e0 = c->spans_free.back().first;
+            e1 = c->spans_free.back().second;
+            c->spans_free.pop_back();
+        } else if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
+            on = false;
+            return;
+        }
+        hipEventRecord(e0, c->stream);
     }
-    int finish() {
+    int finish() {  // never blocks: the span is resolved in pf_timing_get
         if (!on) return PF_OK;
-        PF_HIP(hipEventRecord(c->ev1, c->stream));
-        PF_HIP(hipEventSynchronize(c->ev1));
-        float ms = 0.f;
-        PF_HIP(hipEventElapsedTime(&ms, c->ev0, c->ev1));
-        c->op_ms += ms;
-        c->op_launches += launches;
-        c->op_bytes += bytes;
+        PF_HIP(hipEventRecord(e1, c->stream));
+        c->spans_pending.push_back({e0, e1, launches, bytes});
         return PF_OK;
     }
 };
@@ -654,17 +668,28 @@ int pf_dots(pf_graph* g, int32_t w, int32_t first, int32_t count, double* out) {
     return PF_OK;
 }
 
-int pf_orth(pf_graph* g, int32_t w, int32_t first, int32_t count, double* h, double* nrm) {
-    PF_TRY(check_slots(g, w, 1, "pf_orth"));
-    PF_TRY(check_slots(g, first, count, "pf_orth"));
-    PF_CHECK(nrm != nullptr && (h != nullptr || count == 0), PF_E_ARG, "pf_orth: NULL output");
-    PF_CHECK(w < first || w >= first + count, PF_E_ARG, "pf_orth: w inside the basis range");
+int pf_orth_begin(pf_graph* g, int32_t w, int32_t first, int32_t count, int32_t normalize) {
+    PF_TRY(check_slots(g, w, 1, "pf_orth_begin"));
+    PF_TRY(check_slots(g, first, count, "pf_orth_begin"));
+    PF_CHECK(w < first || w >= first + count, PF_E_ARG, "pf_orth_begin: w inside the basis range");
+    PF_CHECK(g->orth_pending < 0, PF_E_STATE, "pf_orth_begin: a previous pf_orth_begin has not been collected");
     hipStream_t st = g->ctx->stream;
     PF_TRY(pf_reduce_ensure(g, std::max(count, 1)));
+    if (count > g->orth_host_cap || !g->orth_host) {
+        if (g->orth_host) {
+            PF_HIP(hipStreamSynchronize(st));
+            PF_HIP(hipHostFree(g->orth_host));
+            g->orth_host = nullptr;
+        }
+        const int32_t cap = std::max(count, 64);
+        PF_HIP(hipHostMalloc((void**)&g->orth_host, sizeof(double) * (size_t)(cap + 1), hipHostMallocDefault));
+        g->orth_host_cap = cap;
+    }
+    if (!g->orth_ev) PF_HIP(hipEventCreateWithFlags(&g->orth_ev, hipEventDisableTiming));
     const int32_t cap = g->coef_cap;
-    double* hpass = g->coef;            // coefficients of the current pass
-    double* hsum = g->coef + cap;       // h1 + h2
-    double* nrm2 = g->coef + 2 * cap;   // ||w||^2
+    double* hpass = g->coef;           // coefficients of the current pass
+    double* hsum = g->coef + cap;      // h1 + h2
+    double* nrm2 = g->coef + 2 * cap;  // ||w||^2
     if (count > 0) {
         for (int pass = 0; pass < 2; ++pass) {
             PF_TRY(dots_device(g, w, first, count, hpass, hsum, pass));
@@ -673,13 +698,35 @@ int pf_orth(pf_graph* g, int32_t w, int32_t first, int32_t count, double* h, dou
         }
     }
     PF_TRY(dots_device(g, w, w, 1, nrm2, nullptr, 0));
-    std::vector<double> host((size_t)count + 1);
-    if (count > 0) PF_HIP(hipMemcpyAsync(host.data(), hsum, sizeof(double) * count, hipMemcpyDeviceToHost, st));
-    PF_HIP(hipMemcpyAsync(host.data() + count, nrm2, sizeof(double), hipMemcpyDeviceToHost, st));
-    PF_HIP(hipStreamSynchronize(st));
-    for (int32_t b = 0; b < count; ++b) h[b] = host[b];
-    *nrm = sqrt(host[count] > 0.0 ? host[count] : 0.0);
+    if (normalize) {
+        k_scale_rsqrt<<<nblk(g->n_pad), PF_BLOCK, 0, st>>>(pf_slot(g, w), g->n_pad, nrm2);
+        PF_HIP(hipGetLastError());
+    }
+    if (count > 0) PF_HIP(hipMemcpyAsync(g->orth_host, hsum, sizeof(double) * count, hipMemcpyDeviceToHost, st));
+    PF_HIP(hipMemcpyAsync(g->orth_host + count, nrm2, sizeof(double), hipMemcpyDeviceToHost, st));
+    PF_HIP(hipEventRecord(g->orth_ev, st));
+    g->orth_pending = count;
     return PF_OK;
+}
+
+int pf_orth_end(pf_graph* g, double* h, double* nrm) {
+    PF_CHECK(g != nullptr && nrm != nullptr, PF_E_ARG, "pf_orth_end: NULL argument");
+    PF_CHECK(g->orth_pending >= 0, PF_E_STATE, "pf_orth_end: no pf_orth_begin in flight");
+    const int32_t count = g->orth_pending;
+    PF_CHECK(h != nullptr || count == 0, PF_E_ARG, "pf_orth_end: h is NULL");
+    PF_HIP(hipSetDevice(g->ctx->device));
+    PF_HIP(hipEventSynchronize(g->orth_ev));
+    g->orth_pending = -1;
+    for (int32_t b = 0; b < count; ++b) h[b] = g->orth_host[b];
+    const double v = g->orth_host[count];
+    *nrm = sqrt(v > 0.0 ? v : 0.0);
+    return PF_OK;
+}
+
+int pf_orth(pf_graph* g, int32_t w, int32_t first, int32_t count, double* h, double* nrm) {
+    PF_CHECK(nrm != nullptr && (h != nullptr || count == 0), PF_E_ARG, "pf_orth: NULL output");
+    PF_TRY(pf_orth_begin(g, w, first, count, 0));
+    return pf_orth_end(g, h, nrm);
 }
 
 int pf_scale(pf_graph* g, int32_t slot, double alpha) {

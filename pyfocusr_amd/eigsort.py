@@ -70,15 +70,20 @@ class eigsort(object):
             for p2 in zip(target_matches, source_matches)
             if p2 == p1
         ]
-        for mode_0, mode_1 in flipped_pairs:
-            if self.target_as_reference is True:
-                self.graph_source.eig_vecs[:, mode_1] = self.graph_source.eig_vecs[:, mode_1] * -1
-            elif self.target_as_reference is False:
-                self.graph_target.eig_vecs[:, mode_0] = self.graph_target.eig_vecs[:, mode_0] * -1
+        # eigsort.py:108-122: negate the flipped columns of the non-reference graph, then move its columns into
+        # the reference's order.  Same result as the reference's two statements, without copying the whole
+        # (n, k) array when the assignment is the identity (the usual case) — at 250k vertices that copy
+        # costs more than the rest of eigsort together.
         if self.target_as_reference is True:
-            self.graph_source.eig_vecs[:, target_matches] = self.graph_source.eig_vecs[:, source_matches]
-        elif self.target_as_reference is False:
-            self.graph_target.eig_vecs[:, source_matches] = self.graph_target.eig_vecs[:, target_matches]
+            vecs, flip_cols = self.graph_source.eig_vecs, [m1 for _, m1 in flipped_pairs]
+            dst, src = np.asarray(target_matches), np.asarray(source_matches)
+        else:
+            vecs, flip_cols = self.graph_target.eig_vecs, [m0 for m0, _ in flipped_pairs]
+            dst, src = np.asarray(source_matches), np.asarray(target_matches)
+        for col in flip_cols:
+            vecs[:, col] = vecs[:, col] * -1
+        if not np.array_equal(dst, src):
+            vecs[:, dst] = vecs[:, src]
         self.target_matches, self.source_matches = np.asarray(target_matches), np.asarray(source_matches)
         self.flipped_pairs = flipped_pairs
 

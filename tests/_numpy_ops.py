@@ -101,6 +101,15 @@ class NumpyOps(object):
         self.ws[:, w] = x
         return h1 + h2, float(np.linalg.norm(x))
 
+    def orth_begin(self, w, first, count, normalize=True):
+        h, nrm = self.orth(w, first, count)
+        if normalize and nrm > 1e-140:
+            self.ws[:, w] /= nrm
+        self._orth_result = (h, nrm)
+
+    def orth_end(self):
+        return self._orth_result
+
     def scale(self, slot, alpha):
         self.ws[:, slot] *= alpha
 
