@@ -60,7 +60,7 @@ def _cheb_inverse(theta, c, e, p):
     return c - e * math.cosh(math.acosh(max(theta, 1.0)) / p)
 
 
-def choose_filter(cut, hi=2.0, strength=5.5, min_degree=8, max_degree=4000):
+def choose_filter(cut, hi=2.0, strength=2.0, min_degree=8, max_degree=4000):
     """Damped interval [cut, hi]; degree such that eigenvalues <= cut/2 are
     amplified by >= cosh(strength) relative to the damped part."""
     cut = min(max(cut, 1e-12), 0.5 * hi)
@@ -169,7 +169,7 @@ def filtered_eigs(ops, n_wanted, symmetric, **kw):
 
 
 def filtered_eigs_gen(ops, n_wanted, symmetric, null_slots=0, cut=None, tol=1e-12, m_max=None,
-                      max_restarts=60, max_filter_resets=8, seed=0, strength=3.5, hi=2.0,
+                      max_restarts=60, max_filter_resets=8, seed=0, strength=2.0, hi=2.0,
                       nonsym_degree_cap=128, verbose=False):
     """Generator form of the solver: yields `(src, dst, degree, c, e)` whenever the Chebyshev
     filter has to be applied (the only expensive device operation) and receives nothing back;
@@ -199,7 +199,7 @@ def filtered_eigs_gen(ops, n_wanted, symmetric, null_slots=0, cut=None, tol=1e-1
     ops.ws_ensure(2 * reg)
     A0, B0 = 0, reg
     if cut is None:
-        cut = 8.0 * (n_wanted + 1) / max(n_active, 1)
+        cut = 12.0 * (n_wanted + 1) / max(n_active, 1)
     degree_cap = 4000 if symmetric else int(nonsym_degree_cap)
     plain = False  # no filter: B = (hi - A)/hi.  For tiny / dense-ish graphs whose wanted eigenvalues are not
     #                a small corner of [0, hi]; the Krylov space is then exhausted or restarted as usual.
