@@ -136,8 +136,8 @@ def split_pair_step(ctx, dist, torch, tdev, rank, mesh, k, n_samples):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--vertices", dest="n", type=int, default=250000, help="vertices per mesh")
     ap.add_argument("--k", type=int, default=5)
     ap.add_argument("--samples", type=int, default=5000, help="n_coords_spectral_ordering (focusr.py:37)")
