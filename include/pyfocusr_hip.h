@@ -53,6 +53,8 @@ typedef struct pf_graph_info {
     int32_t max_degree;    /* longest row of W                                      */
     int64_t sell_entries;  /* stored off-diagonal slots incl. padding (SELL-64)     */
     int64_t n_pad;         /* workspace slot stride in elements                     */
+    int64_t n_oneway;      /* entries (i,j) of W without a matching (j,i): 0 iff symmetric;
+                              every boundary edge of an open mesh is one (graph.py:178)      */
 } pf_graph_info;
 
 typedef struct pf_timing {
@@ -116,13 +118,14 @@ int pf_lock_null_vectors(pf_graph* g, int32_t op, int32_t* n_locked);
 
 /* ---- eigensolver kernels (replace scipy eigs/ARPACK+SuperLU at graph.py:372) ------------- */
 int pf_spmv(pf_graph* g, int32_t op, int32_t src, int32_t dst);           /* dst = A src     */
-/* dst = T_degree((c I - A)/e) src : `degree` launches of the fused SpMV + three-term
- * recurrence kernel.  src is preserved; dst != src. */
-int pf_cheb(pf_graph* g, int32_t op, int32_t src, int32_t dst, int32_t degree, double c, double e);
+/* dst = T_degree((c I - A)/e) src / rho^degree : `degree` launches of the fused SpMV + three-term
+ * recurrence kernel (scaled by rho >= 1 per step so that high degrees cannot overflow; rho = 1 is the
+ * plain Chebyshev polynomial).  src is preserved; dst != src. */
+int pf_cheb(pf_graph* g, int32_t op, int32_t src, int32_t dst, int32_t degree, double c, double e, double rho);
 /* Two independent recurrences (graphs a and b of one ctx) advanced in lockstep: step k of both in
  * ONE launch while both have steps left, the longer one alone afterwards. */
-int pf_cheb2(pf_graph* ga, int32_t op_a, int32_t src_a, int32_t dst_a, int32_t degree_a, double c_a, double e_a,
-             pf_graph* gb, int32_t op_b, int32_t src_b, int32_t dst_b, int32_t degree_b, double c_b, double e_b);
+int pf_cheb2(pf_graph* ga, int32_t op_a, int32_t src_a, int32_t dst_a, int32_t degree_a, double c_a, double e_a, double rho_a,
+             pf_graph* gb, int32_t op_b, int32_t src_b, int32_t dst_b, int32_t degree_b, double c_b, double e_b, double rho_b);
 int pf_dots(pf_graph* g, int32_t w, int32_t first, int32_t count, double* out);  /* out[b] = <slot first+b, slot w> */
 /* classical Gram-Schmidt twice of slot w against slots [first, first+count): h[count] = summed
  * coefficients, *nrm = ||w|| afterwards (w is left un-normalised). */

@@ -36,7 +36,7 @@ class PfError(RuntimeError):
 class GraphInfo(C.Structure):
     _fields_ = [("n", C.c_int64), ("n_faces", C.c_int64), ("nnz_w", C.c_int64), ("nnz_l", C.c_int64),
                 ("is_symmetric", C.c_int32), ("n_isolated", C.c_int32), ("n_components", C.c_int32),
-                ("max_degree", C.c_int32), ("sell_entries", C.c_int64), ("n_pad", C.c_int64)]
+                ("max_degree", C.c_int32), ("sell_entries", C.c_int64), ("n_pad", C.c_int64), ("n_oneway", C.c_int64)]
 
 
 class Timing(C.Structure):
@@ -70,9 +70,9 @@ SIGNATURES = {
     "pf_mask_isolated": (C.c_int, [C.c_void_p, C.c_int32]),
     "pf_lock_null_vectors": (C.c_int, [C.c_void_p, C.c_int32, _i32p]),
     "pf_spmv": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
-    "pf_cheb": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double]),
-    "pf_cheb2": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double,
-                           C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double]),
+    "pf_cheb": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double]),
+    "pf_cheb2": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double,
+                           C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double]),
     "pf_dots": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, _f64p]),
     "pf_orth": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, _f64p, _f64p]),
     "pf_orth_begin": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
@@ -304,6 +304,7 @@ class DeviceLaplacian(object):
         self.n_isolated = int(info.n_isolated)
         self.n_components = int(info.n_components)
         self.max_degree = int(info.max_degree)
+        self.n_oneway = int(info.n_oneway)
         self.op = PF_OP_SYM if self.symmetric else PF_OP_RW
 
     def close(self):
@@ -361,15 +362,15 @@ class DeviceLaplacian(object):
     def spmv(self, src, dst):
         _check(self._lib.pf_spmv(self._h, self.op, int(src), int(dst)))
 
-    def cheb(self, src, dst, degree, c, e):
-        _check(self._lib.pf_cheb(self._h, self.op, int(src), int(dst), int(degree), float(c), float(e)))
+    def cheb(self, src, dst, degree, c, e, rho=1.0):
+        _check(self._lib.pf_cheb(self._h, self.op, int(src), int(dst), int(degree), float(c), float(e), float(rho)))
 
     def cheb2(self, req_self, other, req_other):
         """One lockstep filter application for two graphs of the same context:
-        req = (src, dst, degree, c, e)."""
+        req = (src, dst, degree, c, e, rho)."""
         a, b = req_self, req_other
-        _check(self._lib.pf_cheb2(self._h, self.op, int(a[0]), int(a[1]), int(a[2]), float(a[3]), float(a[4]),
-                                  other._h, other.op, int(b[0]), int(b[1]), int(b[2]), float(b[3]), float(b[4])))
+        _check(self._lib.pf_cheb2(self._h, self.op, int(a[0]), int(a[1]), int(a[2]), float(a[3]), float(a[4]), float(a[5]),
+                                  other._h, other.op, int(b[0]), int(b[1]), int(b[2]), float(b[3]), float(b[4]), float(b[5])))
 
     def dots(self, w, first, count):
         out = np.empty(int(count), dtype=np.float64)

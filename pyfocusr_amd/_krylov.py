@@ -55,6 +55,18 @@ def _cheb_value(lam, c, e, p):
     return s * math.cosh(p * math.acosh(abs(t)))
 
 
+def _cheb_value_scaled(lam, c, e, p, rho):
+    """T_p((c - lam)/e) / rho^p without overflow."""
+    if rho == 1.0:
+        return _cheb_value(lam, c, e, p)
+    t = (c - lam) / e
+    if abs(t) <= 1.0:
+        return math.cos(p * math.acos(t)) * math.exp(-p * math.log(rho))
+    u = math.acosh(abs(t))
+    s = 1.0 if t > 0 or p % 2 == 0 else -1.0
+    return s * 0.5 * math.exp(p * (u - math.log(rho))) * (1.0 + math.exp(-2.0 * p * u))
+
+
 def _cheb_inverse(theta, c, e, p):
     """lam < a with T_p((c-lam)/e) = theta > 1."""
     return c - e * math.cosh(math.acosh(max(theta, 1.0)) / p)
@@ -72,7 +84,27 @@ def choose_filter(cut, hi=2.0, strength=2.0, min_degree=8, max_degree=4000):
     return c, e, p
 
 
-def _ordered_schur(H, symmetric, n_real, n_extra=0):
+def choose_filter_ellipse(cut, half_height, hi=2.0, strength=2.0, min_degree=8, max_degree=4000):
+    """Filter for a non-normal operator whose spectrum fills a strip around [0, hi] (open meshes: every
+    boundary edge is one-way, graph.py:178, and L gets complex eigenvalues everywhere): the damped set is the
+    ellipse with vertices cut and hi on the real axis and semi-minor axis `half_height`.  Same recurrence
+    T_p((c - A)/e) with the foci c +- e pulled inwards; inside the ellipse |T_p| <= bulk, outside it grows.
+    The recurrence is scaled by rho = (a + b)/e per step, so inside the ellipse |T_p / rho^p| <= ~0.5 whatever the
+    degree.  Returns (c, e, p, rho)."""
+    cut = min(max(cut, 1e-12), 0.5 * hi)
+    c = 0.5 * (hi + cut)
+    a = 0.5 * (hi - cut)
+    b = min(half_height, 0.9 * a)
+    e = math.sqrt(a * a - b * b)
+    rho = (a + b) / e  # modulus of t + sqrt(t^2 - 1) on the ellipse
+    t = (c - 0.5 * cut) / e
+    growth_rate = math.log(t + math.sqrt(t * t - 1.0)) - math.log(rho)  # wanted (at cut/2) vs bulk, per degree
+    p = int(math.ceil(strength / max(growth_rate, 1e-12)))
+    p = max(min_degree, min(max_degree, p))
+    return c, e, p, rho
+
+
+def _ordered_schur(H, symmetric, n_real, n_extra=0, count_all=False):
     """Orthogonal U, (quasi-)triangular T with H = U T U^T, ordered so that the
     leading q columns span the dominant (largest-modulus) invariant subspace of
     the filtered operator that contains `n_real` real positive Ritz values — the
@@ -93,7 +125,10 @@ def _ordered_schur(H, symmetric, n_real, n_extra=0):
     ev = np.linalg.eigvals(H)
     order = np.argsort(-np.abs(ev), kind="stable")
     ev = ev[order]
-    is_real = (np.abs(ev.imag) <= 1e-9 * np.abs(ev)) & (ev.real > 0)
+    if count_all:  # ellipse mode: every dominant Ritz value is an image of a low eigenvalue, real or complex
+        is_real = np.ones(len(ev), dtype=bool)
+    else:
+        is_real = (np.abs(ev.imag) <= 1e-9 * np.abs(ev)) & (ev.real > 0)
     cnt = np.cumsum(is_real)
     hit = np.nonzero(cnt >= n_real)[0]
     q = int(hit[0]) + 1 if len(hit) else m
@@ -168,12 +203,37 @@ def filtered_eigs(ops, n_wanted, symmetric, **kw):
     return drive(filtered_eigs_gen(ops, n_wanted, symmetric, **kw), ops)
 
 
-def filtered_eigs_gen(ops, n_wanted, symmetric, null_slots=0, cut=None, tol=1e-12, m_max=None,
-                      max_restarts=60, max_filter_resets=8, seed=0, strength=2.0, hi=2.0,
-                      nonsym_degree_cap=128, verbose=False):
+class _NeedEllipse(Exception):
+    """The interval filter cannot handle this non-normal operator (complex wanted eigenvalues, or too many
+    complex outliers to carry): switch to the ellipse filter."""
+
+
+def filtered_eigs_gen(ops, n_wanted, symmetric, ellipse=None, **kw):
+    """Solver generator (see `_solve_gen`).  For a non-symmetric operator the cheap strategy — interval filter,
+    complex outliers carried as dominant Ritz values — is tried first unless `ellipse` is True (the caller knows
+    the graph has many one-way edges); if it fails the ellipse filter takes over."""
+    if symmetric or ellipse is False:
+        return (yield from _solve_gen(ops, n_wanted, symmetric, **kw))
+    if ellipse is None:
+        try:
+            return (yield from _solve_gen(ops, n_wanted, symmetric, **kw))
+        except _NeedEllipse:
+            pass
+    half_height = 0.125 * kw.get("hi", 2.0)
+    for _ in range(4):
+        try:
+            return (yield from _solve_gen(ops, n_wanted, symmetric, half_height=half_height, **kw))
+        except _NeedEllipse:
+            half_height *= 1.6  # outliers above the assumed strip: make the ellipse taller
+    raise RuntimeError("filtered Krylov-Schur: could not enclose the complex spectrum in an ellipse")
+
+
+def _solve_gen(ops, n_wanted, symmetric, null_slots=0, cut=None, tol=1e-12, m_max=None,
+               max_restarts=60, max_filter_resets=8, seed=0, strength=2.0, hi=2.0,
+               nonsym_degree_cap=128, half_height=None, verbose=False):
     """Generator form of the solver: yields `(src, dst, degree, c, e)` whenever the Chebyshev
     filter has to be applied (the only expensive device operation) and receives nothing back;
-    `drive` / `drive_pair` execute the requests.  Its return value is the solver result.
+    `drive` / `drive_pair` execute the requests (`(src, dst, degree, c, e, rho)`).  Its return value is the solver result.
 
     Smallest `n_wanted` non-null eigenpairs of the Laplacian held by `ops`.
 
@@ -188,6 +248,8 @@ def filtered_eigs_gen(ops, n_wanted, symmetric, null_slots=0, cut=None, tol=1e-1
     n_active = n - ops.n_isolated
     stats = EigsStats()
     c0 = int(null_slots)
+    if c0 > 0 and ops.lock_null_vectors() != c0:  # (re)write slots [0, c0): a previous attempt's extraction reuses them
+        raise RuntimeError("null_slots does not match the graph's component count")
     n_wanted = int(min(n_wanted, max(n_active - c0, 0)))
     if n_wanted <= 0:
         return np.zeros(0), 0, stats
@@ -200,7 +262,8 @@ def filtered_eigs_gen(ops, n_wanted, symmetric, null_slots=0, cut=None, tol=1e-1
     A0, B0 = 0, reg
     if cut is None:
         cut = 12.0 * (n_wanted + 1) / max(n_active, 1)
-    degree_cap = 4000 if symmetric else int(nonsym_degree_cap)
+    ellipse = half_height is not None and not symmetric
+    degree_cap = 4000 if (symmetric or ellipse) else int(nonsym_degree_cap)
     plain = False  # no filter: B = (hi - A)/hi.  For tiny / dense-ish graphs whose wanted eigenvalues are not
     #                a small corner of [0, hi]; the Krylov space is then exhausted or restarted as usual.
     n_starts = [int(seed)]
@@ -212,23 +275,32 @@ def filtered_eigs_gen(ops, n_wanted, symmetric, null_slots=0, cut=None, tol=1e-1
         ops.scale(slot, 1.0 / nrm)
 
     def ritz(j, n_extra=0):
-        theta, U, T, q, n_real = _ordered_schur(H[:j, :j], symmetric, q_target, n_extra)
+        theta, U, T, q, n_real = _ordered_schur(H[:j, :j], symmetric, q_target, n_extra, count_all=ellipse)
         res = np.abs(b[:j] @ U[:, :q])
         lead = theta[:q]
-        real_lead = lead[(np.abs(lead.imag) <= 1e-9 * np.abs(lead)) & (lead.real > 0)].real
-        theta_min = float(np.min(real_lead)) if len(real_lead) else 0.0
+        if ellipse:
+            theta_min = float(np.min(np.abs(lead))) if len(lead) else 0.0
+        else:
+            real_lead = lead[(np.abs(lead.imag) <= 1e-9 * np.abs(lead)) & (lead.real > 0)].real
+            theta_min = float(np.min(real_lead)) if len(real_lead) else 0.0
+            if not symmetric and q > q_target + 16:
+                raise _NeedEllipse()  # too many complex outliers to carry along
         return theta, U, T, q, n_real, res, theta_min
 
     while True:
         if cut >= 0.5 * hi:
             plain = True
+        rho = 1.0
         if plain:
             c, e, p = hi, hi, 1
+        elif ellipse:
+            c, e, p, rho = choose_filter_ellipse(cut, half_height, hi=hi, strength=strength, max_degree=degree_cap)
         else:
             c, e, p = choose_filter(cut, hi=hi, strength=strength, max_degree=degree_cap)
         stats.degree, stats.cut = p, cut
-        theta0 = _cheb_value(0.0, c, e, p)
-        band = -1.0 if plain else 1.5  # wanted Ritz values must clear the damped band [-1, 1] (none in plain mode)
+        theta0 = _cheb_value_scaled(0.0, c, e, p, rho)
+        bulk = 0.5 * (1.0 + rho ** (-2.0 * p))  # bound of the scaled polynomial on the damped set (1 for the interval)
+        band = -1.0 if plain else 1.5 * bulk  # wanted Ritz values must clear the damped set (none in plain mode)
         # Krylov-Schur state  B V_j = V_j H + v_j b^T ;  null vectors are locked exact Ritz pairs.
         j = c0
         H = np.zeros((m_max, m_max))
@@ -242,14 +314,14 @@ def filtered_eigs_gen(ops, n_wanted, symmetric, null_slots=0, cut=None, tol=1e-1
             near = False  # the last Ritz check was within ~3 digits of the tolerance: the next step probably converges
             while j < m_max and outcome is None:  # ---- expand
                 if not spec:
-                    yield (A0 + j, A0 + j + 1, p, c, e)
+                    yield (A0 + j, A0 + j + 1, p, c, e, rho)
                     stats.matvecs += p
                 stats.outer_steps += 1
                 # CGS2 + normalisation entirely on the device; the coefficients come back asynchronously
                 ops.orth_begin(A0 + j + 1, A0, j + 1, normalize=True)
                 spec = j + 1 < m_max and not near  # (a speculative application after the last step would be wasted)
                 if spec:  # keep the device busy: queue the next filter application before reading this step's result
-                    yield (A0 + j + 1, A0 + j + 2, p, c, e)
+                    yield (A0 + j + 1, A0 + j + 2, p, c, e, rho)
                     stats.matvecs += p
                 h, beta = ops.orth_end()
                 H[:j + 1, j] = h
@@ -266,7 +338,7 @@ def filtered_eigs_gen(ops, n_wanted, symmetric, null_slots=0, cut=None, tol=1e-1
                     near = n_real >= q_target and theta_min > band and np.all(res <= 1e3 * tol * max(theta_min, 1.0))
                     if n_real >= q_target and np.all(res <= tol * max(theta_min, 1.0)) and theta_min > band:
                         outcome = "converged"
-                    elif not symmetric and np.max(np.abs(theta)) > 1e7 * max(theta_min, 1.0) and p > 16:
+                    elif not symmetric and not ellipse and np.max(np.abs(theta)) > 1e7 * max(theta_min, 1.0) and p > 16:
                         outcome = "range"  # complex outliers eat the dynamic range: lower the degree
                     elif (j >= q + 12 or exhausted) and theta_min < band:
                         outcome = "cut"  # wanted eigenvalues sit inside the damped band
@@ -275,6 +347,8 @@ def filtered_eigs_gen(ops, n_wanted, symmetric, null_slots=0, cut=None, tol=1e-1
             if outcome is not None:
                 break
             if restarts >= max_restarts:
+                if not symmetric and not ellipse:
+                    raise _NeedEllipse()
                 raise RuntimeError("filtered Krylov-Schur did not converge (max residual %.3e)" % np.max(res))
             # ---- thick restart: keep the dominant Schur vectors + a buffer
             theta, U, T, n_keep, _, _, _ = ritz(j, n_extra=max(4, q_target // 2))
@@ -295,13 +369,15 @@ def filtered_eigs_gen(ops, n_wanted, symmetric, null_slots=0, cut=None, tol=1e-1
             break
         stats.filter_resets += 1
         if stats.filter_resets > max_filter_resets:
+            if not symmetric and not ellipse:
+                raise _NeedEllipse()
             raise RuntimeError("could not place the Chebyshev filter (cut %g, degree %d)" % (cut, p))
         if outcome == "range":
             degree_cap = max(16, p // 2)
         else:
             lead = theta[:q]
-            lam_est = sorted(_cheb_inverse(t.real, c, e, p) for t in lead
-                             if abs(t.imag) <= 1e-9 * abs(t) and t.real > 1.5)[c0:]
+            lam_est = [] if ellipse else sorted(_cheb_inverse(t.real, c, e, p) for t in lead
+                                                if abs(t.imag) <= 1e-9 * abs(t) and t.real > 1.5)[c0:]
             if len(lam_est) >= 2:
                 cut = max(4.0 * cut, 2.5 * lam_est[-1] * (n_wanted + 1) / len(lam_est))
             else:
@@ -324,11 +400,28 @@ def filtered_eigs_gen(ops, n_wanted, symmetric, null_slots=0, cut=None, tol=1e-1
         lam, R = np.linalg.eigh(0.5 * (HA + HA.T))
     else:
         lam_c, R_c = np.linalg.eig(HA)
-        order = np.argsort(lam_c.real, kind="stable")[:q_target]  # complex outliers have Re ~ 1
-        if np.max(np.abs(lam_c.imag[order])) > 1e-9:
-            raise RuntimeError("wanted eigenvalues of the asymmetric Laplacian are not real")
-        lam = lam_c.real[order]
-        R = np.real(R_c[:, order])
+        order = np.argsort(lam_c.real, kind="stable")  # complex outliers carried by the interval filter have Re ~ 1
+        take = q_target
+        if take < q and abs(lam_c[order[take - 1]].imag) > 1e-9 and np.isclose(
+                lam_c[order[take - 1]].real, lam_c[order[take]].real, rtol=1e-9, atol=0):
+            take += 1  # never split a conjugate pair
+        order = order[:take]
+        sel = lam_c[order]
+        is_cplx = np.abs(sel.imag) > 1e-9 * np.maximum(np.abs(sel), 1e-300)
+        if np.any(is_cplx) and not ellipse:
+            raise _NeedEllipse()  # open mesh: the low eigenvalues themselves are complex
+        if ellipse and np.any(sel.real > cut):
+            raise _NeedEllipse()  # junk from above the assumed strip crept into the dominant subspace
+        lam = sel.real  # the reference keeps np.real(eig_vals): a conjugate pair shows up as a repeated value
+        R = np.empty((q, take))
+        for col, i in enumerate(order):
+            y = R_c[:, i]
+            if is_cplx[col]:
+                # reference: np.real(eig_vecs) of BOTH conjugate vectors, i.e. the same real part twice, with
+                # ARPACK's run-dependent phase.  Fix the phase (largest component real positive) instead.
+                piv = np.argmax(np.abs(y))
+                y = y * (np.conj(y[piv]) / abs(y[piv]))
+            R[:, col] = np.real(y)
         R /= np.linalg.norm(R, axis=0, keepdims=True)
     keep = np.where(lam > MIN_EIG_VAL)[0]
     stats.n_null = int(min(q_target, len(lam)) - len(keep)) if not symmetric else int(np.sum(lam <= MIN_EIG_VAL))
@@ -340,5 +433,6 @@ def filtered_eigs_gen(ops, n_wanted, symmetric, null_slots=0, cut=None, tol=1e-1
         raise RuntimeError("workspace too small for Ritz extraction")
     ops.combine(B0, q, R, X0)  # X = Z R
     ops.combine(A0, q, R, AX0)  # A X = (A Z) R
+    # (for a complex pair the real part alone is not an eigenvector: its "residual" is |Im lambda| * |Im x|)
     stats.residuals = np.array([ops.resnorm(AX0 + i, X0 + i, lam[i]) for i in range(nk)])
     return lam, X0, stats

@@ -145,10 +145,7 @@ __global__ __launch_bounds__(PF_BLOCK) void k_symmetry_probe(const int32_t* __re
             }
             if (c < (int32_t)i) lo = mid + 1; else hi = mid - 1;
         }
-        if (!found) {
-            atomicOr(asym, 1);
-            return;
-        }
+        if (!found) atomicAdd(asym, 1);  // one-way (or numerically unequal) entry
     }
 }
 
@@ -379,6 +376,7 @@ int finish_graph(pf_graph* g, const double* d_pts, bool numeric_symmetry) {
     g->n_isolated = h_stats[0];
     g->max_degree = h_stats[1];
     g->is_symmetric = h_stats[2] ? 0 : 1;
+    g->n_oneway = h_stats[2];
     const int32_t n_roots = h_stats[4];
     PF_CHECK(n_roots <= PF_MAX_ROOTS, PF_E_ARG, "pf_graph_build: %d connected components exceed the supported %d",
              n_roots, PF_MAX_ROOTS);
@@ -690,6 +688,7 @@ int pf_graph_get_info(pf_graph* g, pf_graph_info* o) {
     o->max_degree = g->max_degree;
     o->sell_entries = g->sell_entries;
     o->n_pad = g->n_pad;
+    o->n_oneway = g->n_oneway;
     return PF_OK;
 }
 

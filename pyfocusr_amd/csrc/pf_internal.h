@@ -111,7 +111,7 @@ struct pf_graph {
     double* sval_rw = nullptr;    // -g_i W_ij
     double* sval_sym = nullptr;   // -W_ij sqrt(g_i g_j)   (only when symmetric)
     double* diag = nullptr;       // deg_i g_i  (both operators)
-    int32_t is_symmetric = 0, n_isolated = 0, n_components = 0, max_degree = 0;
+    int32_t is_symmetric = 0, n_isolated = 0, n_components = 0, max_degree = 0, n_oneway = 0;
     std::vector<int32_t> roots; // roots of components with >= 2 vertices, ascending
     // workspace: n_slots vectors + 2 Chebyshev temporaries, stride n_pad
     double* ws = nullptr;

@@ -435,15 +435,15 @@ struct ChebState {
     double* bufs[2];
     double* dst;
     int32_t degree;
-    double c, e;
+    double c, e, rho;  // rho > 1: recurrence scaled by rho^-k, so the result is T_p(.) / rho^p (no overflow at high degree)
     OpArgs step(int32_t k) {  // arguments of step k (1-based); advances the rotation
         double* target;
         if (k == degree) target = dst;
         else if (k == 1) target = bufs[0];
         else if (k == 2) target = bufs[1];
         else target = const_cast<double*>(y_prev);
-        OpArgs a = k == 1 ? op_args(g, vals, y_prev, nullptr, target, 1.0 / e, c, 0.0)
-                          : op_args(g, vals, y_cur, y_prev, target, 2.0 / e, c, 1.0);
+        OpArgs a = k == 1 ? op_args(g, vals, y_prev, nullptr, target, 1.0 / (e * rho), c, 0.0)
+                          : op_args(g, vals, y_cur, y_prev, target, 2.0 / (e * rho), c, 1.0 / (rho * rho));
         if (k > 1) y_prev = y_cur;
         y_cur = target;
         return a;
@@ -614,14 +614,14 @@ int pf_spmv(pf_graph* g, int32_t op, int32_t src, int32_t dst) {
     return t.finish();
 }
 
-int pf_cheb(pf_graph* g, int32_t op, int32_t src, int32_t dst, int32_t degree, double c, double e) {
+int pf_cheb(pf_graph* g, int32_t op, int32_t src, int32_t dst, int32_t degree, double c, double e, double rho) {
     PF_TRY(check_slots(g, src, 1, "pf_cheb"));
     PF_TRY(check_slots(g, dst, 1, "pf_cheb"));
     const double* vals = op_values(g, op);
     PF_CHECK(vals != nullptr && src != dst, PF_E_ARG, "pf_cheb: operator %d unavailable or src == dst", op);
-    PF_CHECK(degree >= 1 && e > 0.0, PF_E_ARG, "pf_cheb: degree %d / half-width %g invalid", degree, e);
+    PF_CHECK(degree >= 1 && e > 0.0 && rho >= 1.0, PF_E_ARG, "pf_cheb: degree %d / half-width %g / rho %g invalid", degree, e, rho);
     OpTimer t(g->ctx, degree, (double)degree * op_bytes(g));
-    ChebState st{g, vals, pf_slot(g, src), pf_slot(g, src), {pf_tmp(g, 0), pf_tmp(g, 1)}, pf_slot(g, dst), degree, c, e};
+    ChebState st{g, vals, pf_slot(g, src), pf_slot(g, src), {pf_tmp(g, 0), pf_tmp(g, 1)}, pf_slot(g, dst), degree, c, e, rho};
     for (int32_t k = 1; k <= degree; ++k) {
         const OpArgs a = st.step(k);
         PF_TRY(launch_op(g, a.sval, a.x, a.prev, a.out, a.alpha, a.shift, a.beta));
@@ -629,8 +629,8 @@ int pf_cheb(pf_graph* g, int32_t op, int32_t src, int32_t dst, int32_t degree, d
     return t.finish();
 }
 
-int pf_cheb2(pf_graph* ga, int32_t op_a, int32_t src_a, int32_t dst_a, int32_t degree_a, double c_a, double e_a, pf_graph* gb,
-             int32_t op_b, int32_t src_b, int32_t dst_b, int32_t degree_b, double c_b, double e_b) {
+int pf_cheb2(pf_graph* ga, int32_t op_a, int32_t src_a, int32_t dst_a, int32_t degree_a, double c_a, double e_a, double rho_a,
+             pf_graph* gb, int32_t op_b, int32_t src_b, int32_t dst_b, int32_t degree_b, double c_b, double e_b, double rho_b) {
     PF_TRY(check_slots(ga, src_a, 1, "pf_cheb2"));
     PF_TRY(check_slots(ga, dst_a, 1, "pf_cheb2"));
     PF_TRY(check_slots(gb, src_b, 1, "pf_cheb2"));
@@ -639,11 +639,12 @@ int pf_cheb2(pf_graph* ga, int32_t op_a, int32_t src_a, int32_t dst_a, int32_t d
     const double* va = op_values(ga, op_a);
     const double* vb = op_values(gb, op_b);
     PF_CHECK(va && vb && src_a != dst_a && src_b != dst_b, PF_E_ARG, "pf_cheb2: operator unavailable or src == dst");
-    PF_CHECK(degree_a >= 1 && degree_b >= 1 && e_a > 0.0 && e_b > 0.0, PF_E_ARG, "pf_cheb2: bad degree / half-width");
+    PF_CHECK(degree_a >= 1 && degree_b >= 1 && e_a > 0.0 && e_b > 0.0 && rho_a >= 1.0 && rho_b >= 1.0, PF_E_ARG,
+             "pf_cheb2: bad degree / half-width / rho");
     const int32_t joint = std::min(degree_a, degree_b), longest = std::max(degree_a, degree_b);
     OpTimer t(ga->ctx, longest, (double)degree_a * op_bytes(ga) + (double)degree_b * op_bytes(gb));
-    ChebState sa{ga, va, pf_slot(ga, src_a), pf_slot(ga, src_a), {pf_tmp(ga, 0), pf_tmp(ga, 1)}, pf_slot(ga, dst_a), degree_a, c_a, e_a};
-    ChebState sb{gb, vb, pf_slot(gb, src_b), pf_slot(gb, src_b), {pf_tmp(gb, 0), pf_tmp(gb, 1)}, pf_slot(gb, dst_b), degree_b, c_b, e_b};
+    ChebState sa{ga, va, pf_slot(ga, src_a), pf_slot(ga, src_a), {pf_tmp(ga, 0), pf_tmp(ga, 1)}, pf_slot(ga, dst_a), degree_a, c_a, e_a, rho_a};
+    ChebState sb{gb, vb, pf_slot(gb, src_b), pf_slot(gb, src_b), {pf_tmp(gb, 0), pf_tmp(gb, 1)}, pf_slot(gb, dst_b), degree_b, c_b, e_b, rho_b};
     for (int32_t k = 1; k <= joint; ++k) {
         const OpArgs a = sa.step(k), b = sb.step(k);
         PF_TRY(launch_op2(ga, a, b, k > 1));

@@ -345,7 +345,12 @@ def _device_eigs_gen(dev, k, n_k_needed, k_buffer=1, minmax=False, verbose=False
         if m_out == 0:
             return np.zeros(0), np.zeros((n, 0)), None
         c0 = dev.lock_null_vectors() if lock else 0
-        lam, first, stats = yield from filtered_eigs_gen(dev, m_out + extra, dev.symmetric, null_slots=c0, **solver_kw)
+        # many one-way edges (an open mesh: every boundary edge) make L strongly non-normal: go straight to the
+        # ellipse filter; a handful (the bundled 15k meshes) are cheaper to carry as outliers of the interval filter
+        kw = dict(solver_kw)
+        if not dev.symmetric and "ellipse" not in kw:
+            kw["ellipse"] = True if getattr(dev, "n_oneway", 0) > 32 else None
+        lam, first, stats = yield from filtered_eigs_gen(dev, m_out + extra, dev.symmetric, null_slots=c0, **kw)
         found = stats.n_null - c0
         if found > extra and len(lam) < m_out:  # null vectors the component count did not predict
             extra = found

@@ -74,12 +74,12 @@ class NumpyOps(object):
         self.ws[:, dst] = self.A @ self.ws[:, src]
         self.launches += 1
 
-    def cheb(self, src, dst, p, c, e):
+    def cheb(self, src, dst, p, c, e, rho=1.0):
         A = self.A
         y0 = self.ws[:, src]
-        y1 = (c * y0 - A @ y0) / e
+        y1 = (c * y0 - A @ y0) / (e * rho)
         for _ in range(p - 1):
-            y0, y1 = y1, (2.0 / e) * (c * y1 - A @ y1) - y0
+            y0, y1 = y1, (2.0 / (e * rho)) * (c * y1 - A @ y1) - y0 / (rho * rho)
         self.ws[:, dst] = y1
         self.launches += p
 

@@ -203,6 +203,34 @@ def test_krylov_many_pairs_of_a_small_mesh():
     np.testing.assert_allclose(lam, dense_nonnull(m.points, m.faces)[:30], rtol=1e-9)
 
 
+def grid_mesh(nx, ny, seed=0):
+    """Open surface: every boundary edge belongs to one face only, hence is one-way in W (graph.py:178)."""
+    r = np.random.default_rng(seed)
+    x, y = np.meshgrid(np.arange(nx, dtype=float), np.arange(ny, dtype=float), indexing="ij")
+    z = 0.3 * np.sin(x / 5) + 0.2 * np.cos(y / 7)
+    pts = np.stack([x, y, z], -1).reshape(-1, 3) + 0.05 * r.normal(size=(nx * ny, 3))
+    idx = np.arange(nx * ny).reshape(nx, ny)
+    a, b, c, d = idx[:-1, :-1].ravel(), idx[1:, :-1].ravel(), idx[1:, 1:].ravel(), idx[:-1, 1:].ravel()
+    return pts, np.concatenate([np.stack([a, b, c], 1), np.stack([a, c, d], 1)])
+
+
+@pytest.mark.parametrize("nx,ny", [(40, 40), (100, 80)])
+def test_krylov_open_mesh_complex_spectrum(nx, ny):
+    """Open meshes make L non-normal with complex LOW eigenvalues; the reference keeps the real parts
+    (graph.py:386), so conjugate pairs show up as repeated eigenvalues.  The interval filter cannot work
+    here; the solver must switch to the ellipse filter and return the same real parts."""
+    pts, faces = grid_mesh(nx, ny)
+    ref = orc.graph_spectrum(pts, faces, 5)
+    lam, X, st, ops = solve(pts, faces, 5)
+    assert not ops.symmetric and st.filter_resets == 0
+    m = min(len(lam), len(ref["eig_vals"]))
+    assert m >= 5
+    np.testing.assert_allclose(lam[:m], ref["eig_vals"][:m], rtol=1e-7)
+    assert np.isclose(lam[0], lam[1], rtol=1e-9)  # a conjugate pair
+    lam2, _, st2, _ = solve(pts, faces, 5, ellipse=True)  # what Graph asks for when it sees many one-way edges
+    np.testing.assert_allclose(lam2[:m], ref["eig_vals"][:m], rtol=1e-7)
+
+
 def test_lockstep_pair_driver_equals_single_solves(golden):
     """`drive_pair` (two solvers sharing kernel launches) must return what two separate solves
     return, also when the two need different degrees / step counts / a filter reset."""

@@ -178,6 +178,9 @@ def test_spmv_and_cheb(golden, devices, hip, name):
             y0, y1 = y1, (2.0 / e) * (c * y1 - A @ y1) - y0
         assert np.max(np.abs(got - y1)) <= 1e-12 * np.max(np.abs(y1)), p
         assert np.array_equal(dev.download_slots(0, 1)[:, 0], x)  # src preserved
+        rho = 1.3  # scaled recurrence: T_p / rho^p
+        dev.cheb(0, 2, p, c, e, rho)
+        np.testing.assert_allclose(dev.download_slots(2, 1)[:, 0], y1 / rho**p, rtol=1e-11, atol=1e-13 * np.max(np.abs(y1)) / rho**p)
 
 
 def test_vector_kernels(golden, devices):
@@ -343,6 +346,29 @@ def test_recursive_eig_on_plain_scipy_matrices(golden):
     np.testing.assert_allclose(vals_sh[:3], np.concatenate([[0.01], g["k3_eig_vals"][:2] + 0.01]), rtol=1e-8)
     with pytest.raises(ValueError):
         recursive_eig(sparse.csr_matrix(np.ones((3, 4))), k=2, n_k_needed=1)
+
+
+def test_open_mesh_complex_spectrum(ctx):
+    """An open surface (712 one-way boundary edges): complex low eigenvalues, reported like the reference
+    reports them (real parts, conjugate pairs as repeated values); the ellipse filter path on the device."""
+    from pyfocusr_amd import Graph, PolyMesh
+
+    nx, ny = 100, 80
+    r = np.random.default_rng(0)
+    x, y = np.meshgrid(np.arange(nx, dtype=float), np.arange(ny, dtype=float), indexing="ij")
+    pts = np.stack([x, y, 0.3 * np.sin(x / 5) + 0.2 * np.cos(y / 7)], -1).reshape(-1, 3) + 0.05 * r.normal(size=(nx * ny, 3))
+    idx = np.arange(nx * ny).reshape(nx, ny)
+    a, b, c, d = idx[:-1, :-1].ravel(), idx[1:, :-1].ravel(), idx[1:, 1:].ravel(), idx[:-1, 1:].ravel()
+    faces = np.concatenate([np.stack([a, b, c], 1), np.stack([a, c, d], 1)])
+    ref = orc.graph_spectrum(pts, faces, 5)
+    gr = Graph(PolyMesh(pts, faces), n_spectral_features=5, n_rand_samples=10**9, ctx=ctx, verbose=False)
+    gr.get_graph_spectrum()
+    assert 2 * gr.device.n_oneway == abs(ref["W"] - ref["W"].T).nnz == 712 and not gr.device.symmetric
+    m = min(len(gr.eig_vals), len(ref["eig_vals"]))
+    assert m >= 5
+    np.testing.assert_allclose(gr.eig_vals[:m], ref["eig_vals"][:m], rtol=1e-7)
+    assert np.isclose(gr.eig_vals[0], gr.eig_vals[1], rtol=1e-9)
+    assert np.all(np.isfinite(gr.eig_vecs)) and gr.eig_vecs.min() == -0.5 and gr.eig_vecs.max() == 0.5
 
 
 def test_paired_spectra_equal_single(golden, ctx):
