@@ -44,7 +44,7 @@ __global__ __launch_bounds__(PF_BLOCK) void k_scatter_edges(const int32_t* __res
                                                             const double* __restrict__ pts, int64_t n_edges,
                                                             int32_t vpf, const int32_t* __restrict__ start,
                                                             int32_t* __restrict__ cursor, int32_t* __restrict__ rcol,
-                                                            double* __restrict__ rw) {
+                                                            double* __restrict__ rw, int32_t* __restrict__ flags) {
     const int64_t e = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
     if (e >= n_edges) return;
     const int64_t f = e / vpf;
@@ -56,6 +56,7 @@ __global__ __launch_bounds__(PF_BLOCK) void k_scatter_edges(const int32_t* __res
     const double dz = pts[3 * (int64_t)src + 2] - pts[3 * (int64_t)dst + 2];
     const double d2 = (dx * dx + dy * dy) + dz * dz;  // np.sum(np.square(.)): left to right
     const double wv = 1.0 / sqrt(d2);                 // graph.py:177-178
+    if (!isfinite(wv)) atomicOr(flags, 4);            // coincident or non-finite vertices: the reference stores inf / nan
     const int32_t slot = start[src] + atomicAdd(&cursor[src], 1);
     rcol[slot] = dst;
     rw[slot] = wv;
@@ -568,8 +569,13 @@ int pf_graph_build_device(pf_mesh* mesh, pf_graph** out) {
 
     PF_TRY(pf_exclusive_scan_i32(st, cnt, start, n + 1));
     if (n_edges) {
-        k_scatter_edges<<<nblk(n_edges), PF_BLOCK, 0, st>>>(d_faces, d_pts, n_edges, vpf, start, cursor, rcol, rw);
+        k_scatter_edges<<<nblk(n_edges), PF_BLOCK, 0, st>>>(d_faces, d_pts, n_edges, vpf, start, cursor, rcol, rw, flags);
         PF_HIP(hipGetLastError());
+        PF_HIP(hipMemcpyAsync(h_flags, flags, sizeof(h_flags), hipMemcpyDeviceToHost, st));
+        PF_HIP(hipStreamSynchronize(st));
+        PF_CHECK(!(h_flags[0] & 4), PF_E_DEGENERATE,
+                 "pf_graph_build: an edge has zero length or non-finite coordinates (the reference would store an "
+                 "infinite weight, graph.py:177-178)");
     }
     k_sort_unique_rows<<<nblk(n), PF_BLOCK, 0, st>>>(start, n, rcol, rw, ucnt);
     PF_HIP(hipGetLastError());

@@ -91,6 +91,16 @@ def test_assembly_errors(hip, ctx):
     with pytest.raises(hip.PfError) as e:
         hip.DeviceLaplacian(pts, np.array([[0, 1, 10]], dtype=np.int32), ctx=ctx)
     assert e.value.code == -1
+    dup = pts.copy()
+    dup[3] = dup[2]  # coincident vertices joined by an edge: 1/0
+    with pytest.raises(hip.PfError) as e:
+        hip.DeviceLaplacian(dup, np.array([[1, 2, 3], [4, 5, 6]], dtype=np.int32), ctx=ctx)
+    assert e.value.code == -3
+    bad = pts.copy()
+    bad[5, 1] = np.nan
+    with pytest.raises(hip.PfError):
+        hip.DeviceLaplacian(bad, np.array([[4, 5, 6]], dtype=np.int32), ctx=ctx)
+    hip.DeviceLaplacian(dup, np.array([[0, 1, 2], [4, 5, 6]], dtype=np.int32), ctx=ctx).close()  # duplicates not joined: fine
 
 
 def test_assembly_quads_and_duplicates(hip, ctx):
