@@ -232,7 +232,6 @@ def main():
         # bytes per launch: the library sums 12 nnz + 20 n + 4 over the graphs each launch advances
         # (two per launch while the target and source recurrences run in lockstep)
         alg_bytes = tm["op_bytes"] / max(tm["op_launches"], 1)
-        assert abs(spmv_algorithmic_bytes(n, nnz[0]) - (12 * nnz[0] + 20 * n + 4)) == 0
         achieved = alg_bytes / (kernel_us * 1e-6) / 1e9
         traffic = None
         pmc = os.path.join(REPO, "profiles", "pmc_summary.json")

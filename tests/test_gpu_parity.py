@@ -472,6 +472,33 @@ def test_knn_window_edge_cases(ctx):
     check(grid[rng.permutation(len(grid))], grid + 0.5)
 
 
+def test_knn_property_random_shapes(ctx):
+    """Property test (hypothesis): any point sets, any d <= 16 — device result == brute force, bit for bit."""
+    from hypothesis import given, settings
+    from hypothesis import strategies as st
+
+    @settings(max_examples=40, deadline=None)
+    @given(st.integers(1, 16), st.integers(1, 700), st.integers(1, 900), st.integers(0, 2**31 - 1),
+           st.sampled_from(["uniform", "clustered", "lattice", "line"]))
+    def run(d, n_ref, n_qry, seed, kind):
+        rng = np.random.default_rng(seed)
+        if kind == "uniform":
+            ref, qry = rng.uniform(-1, 1, (n_ref, d)), rng.uniform(-1, 1, (n_qry, d))
+        elif kind == "clustered":
+            centres = rng.normal(size=(3, d))
+            ref = centres[rng.integers(0, 3, n_ref)] + 1e-3 * rng.normal(size=(n_ref, d))
+            qry = centres[rng.integers(0, 3, n_qry)] + 1e-3 * rng.normal(size=(n_qry, d))
+        elif kind == "lattice":  # many exact ties
+            ref, qry = rng.integers(0, 4, (n_ref, d)).astype(float), rng.integers(0, 4, (n_qry, d)) + 0.5
+        else:  # all points on one line: the second grid axis is degenerate
+            ref, qry = np.outer(rng.uniform(-1, 1, n_ref), np.ones(d)), np.outer(rng.uniform(-1, 1, n_qry), np.ones(d))
+        idx, d2 = ctx.knn1(ref, qry, return_d2=True)
+        bidx, bd2 = orc.knn1_bruteforce(ref, qry)
+        assert np.array_equal(idx, bidx) and np.array_equal(d2, bd2)
+
+    run()
+
+
 @pytest.mark.parametrize("pair", ["pair_5k", "pair_15k"])
 def test_knn_golden_correspondence(golden, ctx, pair):
     """focusr.py:351-353 on the reference's own spectral coordinates: indices identical

@@ -93,3 +93,33 @@ def test_eigsort_and_correspondence(golden, pair, t, s, k, ns):
         assert np.array_equal(idx, p["knn_idx_" + tag])
         bidx, _ = orc.knn1_bruteforce(ct, cs)
         assert np.array_equal(bidx, p["knn_idx_" + tag])
+
+
+def test_set_semantics_properties():
+    """Property test (hypothesis) of the oracle's vectorised adjacency against the reference's literal
+    per-edge loop (graph.py:156-178) on random polygon soups: directed set semantics, row sums of L."""
+    from hypothesis import given, settings
+    from hypothesis import strategies as st
+
+    @settings(max_examples=60, deadline=None)
+    @given(st.integers(3, 40), st.integers(1, 80), st.integers(3, 5), st.integers(0, 2**31 - 1))
+    def run(n, n_faces, vpf, seed):
+        rng = np.random.default_rng(seed)
+        pts = rng.normal(size=(n, 3))
+        if n < vpf:
+            return
+        faces = np.array([rng.choice(n, vpf, replace=False) for _ in range(n_faces)])
+        lil = sparse.lil_matrix((n, n))
+        for f in faces:  # the reference's loop: edge e of a cell joins vertices e and e+1 (mod v)
+            for e in range(vpf):
+                p1, p2 = int(f[e]), int(f[(e + 1) % vpf])
+                lil[p1, p2] = 1.0 / np.sqrt(np.sum(np.square(pts[p1] - pts[p2])))
+        W, deg, d_inv, L = orc.graph_matrices(pts, faces)
+        ref = lil.tocsr()
+        ref.sort_indices()
+        assert np.array_equal(W.indptr, ref.indptr) and np.array_equal(W.indices, ref.indices)
+        assert np.array_equal(W.data, ref.data)
+        assert np.array_equal(deg, np.asarray(lil.sum(axis=1))[:, 0])
+        assert np.max(np.abs(np.asarray(L.sum(axis=1)))) < 1e-14  # random-walk Laplacian: rows sum to ~0
+
+    run()
