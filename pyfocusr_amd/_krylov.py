@@ -123,6 +123,25 @@ def _ordered_schur(H, symmetric, n_real, n_extra=0, count_all=False):
         q = min(n_real + n_extra, m)
         return w[order].astype(np.complex128), U[:, order], np.diag(w[order]), q, min(n_real, m)
     ev = np.linalg.eigvals(H)
+    q, thr, n_found, _ = _select_dominant(ev, n_real, n_extra, count_all)
+    T, U, sdim = sla.schur(H, output="real", sort=lambda r, i: math.hypot(r, i) > thr)
+    theta = np.diag(T).astype(np.complex128)
+    i = 0
+    while i < m - 1:  # 2x2 blocks -> complex pair
+        if T[i + 1, i] != 0.0:
+            ev2 = np.linalg.eigvals(T[i:i + 2, i:i + 2])
+            theta[i], theta[i + 1] = ev2[0], ev2[1]
+            i += 2
+        else:
+            i += 1
+    return theta, U, T, int(sdim), n_found
+
+
+def _select_dominant(ev, n_real, n_extra, count_all):
+    """How many of the largest-modulus Ritz values `ev` make up the wanted dominant set: enough to contain
+    `n_real` images of low eigenvalues (+ `n_extra`), never splitting a conjugate pair.  Returns
+    (q, modulus threshold between kept and dropped, number of wanted images found, order by modulus)."""
+    m = len(ev)
     order = np.argsort(-np.abs(ev), kind="stable")
     ev = ev[order]
     if count_all:  # ellipse mode: every dominant Ritz value is an image of a low eigenvalue, real or complex
@@ -147,17 +166,7 @@ def _ordered_schur(H, symmetric, n_real, n_extra=0, count_all=False):
             thr = 0.5 * (abs(ev[q - 1]) + abs(ev[q])) if q < m else -1.0
     else:
         thr = -1.0
-    T, U, sdim = sla.schur(H, output="real", sort=lambda r, i: math.hypot(r, i) > thr)
-    theta = np.diag(T).astype(np.complex128)
-    i = 0
-    while i < m - 1:  # 2x2 blocks -> complex pair
-        if T[i + 1, i] != 0.0:
-            ev2 = np.linalg.eigvals(T[i:i + 2, i:i + 2])
-            theta[i], theta[i + 1] = ev2[0], ev2[1]
-            i += 2
-        else:
-            i += 1
-    return theta, U, T, int(sdim), int(min(cnt[-1], n_real))
+    return q, thr, int(min(cnt[-1], n_real)) if m else 0, order
 
 
 def drive(gen, ops):
@@ -274,9 +283,17 @@ def _solve_gen(ops, n_wanted, symmetric, null_slots=0, cut=None, tol=1e-12, m_ma
         _, nrm = ops.orth(slot, A0, nbasis)
         ops.scale(slot, 1.0 / nrm)
 
-    def ritz(j, n_extra=0):
-        theta, U, T, q, n_real = _ordered_schur(H[:j, :j], symmetric, q_target, n_extra, count_all=ellipse)
-        res = np.abs(b[:j] @ U[:, :q])
+    def ritz(j, n_extra=0, full=True):
+        if symmetric or full:
+            theta, U, T, q, n_real = _ordered_schur(H[:j, :j], symmetric, q_target, n_extra, count_all=ellipse)
+            res = np.abs(b[:j] @ U[:, :q])
+        else:
+            # convergence check only: eigenvector residuals |b^T s_i| from LAPACK's eig; the ordered real Schur
+            # form (a Python callback per eigenvalue in scipy) is computed once, when it is needed
+            ev, S = np.linalg.eig(H[:j, :j])
+            q, _, n_real, order = _select_dominant(ev, q_target, n_extra, ellipse)
+            theta, U, T = ev[order], None, None
+            res = np.abs(b[:j] @ S[:, order[:q]])
         lead = theta[:q]
         if ellipse:
             theta_min = float(np.min(np.abs(lead))) if len(lead) else 0.0
@@ -331,7 +348,7 @@ def _solve_gen(ops, n_wanted, symmetric, null_slots=0, cut=None, tol=1e-12, m_ma
                 b[j - 1] = beta
                 exhausted = beta <= 1e-14 * max(abs(theta0), 1.0) or j >= n_active
                 if exhausted or j == m_max or j >= q_target + 8:  # Ritz check: ~0.2 ms of host work per call
-                    theta, U, T, q, n_real, res, theta_min = ritz(j)
+                    theta, U, T, q, n_real, res, theta_min = ritz(j, full=False)
                     if verbose:
                         print("  j=%d q=%d theta_min=%.4g |theta|max=%.3g max res=%.3e" % (
                             j, q, theta_min, np.max(np.abs(theta)), np.max(res)))
@@ -344,6 +361,8 @@ def _solve_gen(ops, n_wanted, symmetric, null_slots=0, cut=None, tol=1e-12, m_ma
                         outcome = "cut"  # wanted eigenvalues sit inside the damped band
                     elif exhausted:
                         outcome = "converged"
+                    if outcome == "converged" and U is None:
+                        theta, U, T, q, n_real, res, theta_min = ritz(j)  # the Schur vectors the extraction needs
             if outcome is not None:
                 break
             if restarts >= max_restarts:
