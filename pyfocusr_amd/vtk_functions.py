@@ -186,6 +186,19 @@ def mesh_arrays(mesh):
             np.ascontiguousarray(mesh.points, dtype=np.float64).reshape(-1, 3),
             np.ascontiguousarray(mesh.faces, dtype=np.int32),
         )
+    if _vtk is not None and hasattr(mesh, "GetPolys") and hasattr(mesh, "GetPoints"):
+        try:  # a real vtkPolyData: read the arrays in bulk instead of walking cells in Python
+            from vtk.util.numpy_support import vtk_to_numpy
+
+            pts = np.ascontiguousarray(vtk_to_numpy(mesh.GetPoints().GetData()), dtype=np.float64).reshape(-1, 3)
+            polys = mesh.GetPolys()
+            conn = vtk_to_numpy(polys.GetConnectivityArray())
+            offs = vtk_to_numpy(polys.GetOffsetsArray())
+            widths = np.diff(offs)
+            if (len(widths) and np.all(widths == widths[0]) and polys.GetNumberOfCells() == mesh.GetNumberOfCells()):
+                return pts, np.ascontiguousarray(conn.reshape(-1, int(widths[0])), dtype=np.int32)
+        except Exception:  # noqa: BLE001 - older VTK without offsets/connectivity arrays: generic walk below
+            pass
     n = mesh.GetNumberOfPoints()
     pts = np.zeros((n, 3))
     for i in range(n):
