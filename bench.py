@@ -173,6 +173,8 @@ def main():
     ap.add_argument("--samples", type=int, default=5000, help="n_coords_spectral_ordering (focusr.py:37)")
     ap.add_argument("--cpu-knn-sample", type=int, default=25000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pair", choices=("auto", "on", "off"), default="auto",
+                    help="two graphs per kernel launch (pf_cheb2): auto = by L2 footprint (off at 250k vertices)")
     ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
                     help="torch.distributed backend; gloo + --share-gpu rehearses the N>1 path on a 1-GPU box")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses GPU 0")
@@ -203,7 +205,10 @@ def main():
             dist.init_process_group("gloo")
 
     from pyfocusr_amd import _hip
+    from pyfocusr_amd import graph as _graph
     from pyfocusr_amd.meshgen import blob_mesh
+
+    _graph.PAIRED_LAUNCHES = {"auto": None, "on": True, "off": False}[args.pair]
 
     ctx = _hip.Context(local)
     ctxs = [ctx, _hip.Context(local) if args.streams == 2 else ctx]  # one stream per mesh of the pair

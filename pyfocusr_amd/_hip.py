@@ -13,7 +13,7 @@ import weakref
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libpyfocusr_hip.so")
+LIB_PATH = os.environ.get("PYFOCUSR_HIP_LIB", os.path.join(_HERE, "csrc", "libpyfocusr_hip.so"))  # env: tuning builds
 
 PF_OP_RW = 0
 PF_OP_SYM = 1

@@ -240,7 +240,7 @@ __global__ __launch_bounds__(PF_BLOCK) void k_fill_sell(const int32_t* __restric
         diag[row] = 0.0;
     }
     for (int32_t j = 0; j < width; ++j) {
-        const int64_t idx = base + (int64_t)j * PF_WAVE + lane;
+        const int64_t idx = pf_sell_index(base, width, j, lane);
         if (j < cnt) {
             const int32_t c = col[b + j];
             const double wv = w[b + j];
@@ -507,7 +507,7 @@ int pf_graph_build_device(pf_mesh* mesh, pf_graph** out) {
     g->n = n;
     g->n_faces = n_faces;
     g->vpf = vpf;
-    g->n_pad = (n + 8 * PF_BLOCK - 1) / (8 * PF_BLOCK) * (8 * PF_BLOCK);  // whole blocks, a multiple of 8 of them (XCD remap)
+    g->n_pad = (n + 4095) / 4096 * 4096;  // whole blocks of up to 512 rows, a multiple of 8 of them (XCD remap)
     g->n_slices = g->n_pad / PF_WAVE;
     g->n_chunks = (g->n_pad + PF_DOT_CHUNK - 1) / PF_DOT_CHUNK;
 
@@ -613,7 +613,7 @@ int pf_graph_from_matrix(pf_ctx* ctx, int64_t n, const int32_t* rowptr, const in
     pf_graph* g = new pf_graph();
     g->ctx = ctx;
     g->n = n;
-    g->n_pad = (n + 8 * PF_BLOCK - 1) / (8 * PF_BLOCK) * (8 * PF_BLOCK);
+    g->n_pad = (n + 4095) / 4096 * 4096;
     g->n_slices = g->n_pad / PF_WAVE;
     g->n_chunks = (g->n_pad + PF_DOT_CHUNK - 1) / PF_DOT_CHUNK;
     struct Guard {

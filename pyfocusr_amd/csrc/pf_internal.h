@@ -138,6 +138,16 @@ int pf_timing_collect(pf_ctx* c);  // pf_api.hip: fold finished spans into op_ms
 hipError_t pf_malloc(hipStream_t st, void** p, size_t bytes);
 void pf_free(hipStream_t st, void* p);
 
+// SELL-64 entry layout inside a slice of `width` entries per row: entries come in PAIRS per lane, so that one
+// lane reads two values with one 16-byte load and two column indices with one 8-byte load (the widest
+// coalesced access: 1 KiB of values per wave instruction); a slice of odd width keeps its last entry in a
+// plain 64-lane row behind the pairs.  No padding is added by the pairing.
+__host__ __device__ static inline int64_t pf_sell_index(int64_t base, int32_t width, int32_t j, int lane) {
+    const int32_t pairs = width >> 1;
+    return j < 2 * pairs ? base + (int64_t)(j >> 1) * (2 * PF_WAVE) + 2 * lane + (j & 1)
+                         : base + (int64_t)pairs * (2 * PF_WAVE) + lane;
+}
+
 static inline double* pf_slot(pf_graph* g, int32_t s) { return g->ws + (int64_t)s * g->n_pad; }
 static inline double* pf_tmp(pf_graph* g, int which) { return g->ws + (int64_t)(g->n_slots + which) * g->n_pad; }
 

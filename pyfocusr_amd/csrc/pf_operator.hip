@@ -19,6 +19,19 @@ namespace {
 
 inline unsigned nblk(int64_t n) { return (unsigned)((n + PF_BLOCK - 1) / PF_BLOCK); }
 
+// tuning knobs of the operator kernel (tools/tune_spmv.sh builds variants with -D...)
+#ifndef PF_OP_BLOCK
+#define PF_OP_BLOCK 256
+#endif
+#ifndef PF_OP_NT
+#define PF_OP_NT 0
+#endif
+#if PF_OP_NT
+#define PF_STREAM_LOAD(p) __builtin_nontemporal_load(p)
+#else
+#define PF_STREAM_LOAD(p) (*(p))
+#endif
+
 // out = alpha * (shift * x - A x) - beta * prev          (A = diag + SELL off-diagonals)
 //   SpMV:            alpha = -1, shift = 0, beta = 0      -> out = A x
 //   Chebyshev k = 1: alpha = 1/e, shift = c, beta = 0
@@ -44,7 +57,7 @@ __device__ __forceinline__ void sell_op_block(const OpArgs& a, unsigned bid) {
     // multiple of 8 (n_pad is a multiple of 8 * PF_BLOCK); placement affects speed only.
     const unsigned per_xcd = a.n_blocks >> 3;
     const unsigned blk = (bid & 7u) * per_xcd + (bid >> 3);
-    const int64_t row = (int64_t)blk * PF_BLOCK + threadIdx.x;
+    const int64_t row = (int64_t)blk * PF_OP_BLOCK + threadIdx.x;
     const int64_t s = row >> 6;
     const int lane = threadIdx.x & (PF_WAVE - 1);
     const int64_t base = a.slice_ptr[s];
@@ -52,28 +65,37 @@ __device__ __forceinline__ void sell_op_block(const OpArgs& a, unsigned bid) {
     const double* __restrict__ x = a.x;
     const double xi = x[row];
     double acc = a.diag[row] * xi;
-    const int32_t* __restrict__ cp = a.scol + base + lane;
-    const double* __restrict__ vp = a.sval + base + lane;
+    // pairs of entries per lane (pf_sell_index): one 16-byte load of two values + one 8-byte load of two columns
+    const int pairs = width >> 1;
+    const double2* __restrict__ vp2 = reinterpret_cast<const double2*>(a.sval + base) + lane;
+    const int2* __restrict__ cp2 = reinterpret_cast<const int2*>(a.scol + base) + lane;
     int j = 0;
-    for (; j + 4 <= width; j += 4) {
-        const int32_t c0 = cp[(int64_t)(j + 0) * PF_WAVE], c1 = cp[(int64_t)(j + 1) * PF_WAVE];
-        const int32_t c2 = cp[(int64_t)(j + 2) * PF_WAVE], c3 = cp[(int64_t)(j + 3) * PF_WAVE];
-        const double v0 = vp[(int64_t)(j + 0) * PF_WAVE], v1 = vp[(int64_t)(j + 1) * PF_WAVE];
-        const double v2 = vp[(int64_t)(j + 2) * PF_WAVE], v3 = vp[(int64_t)(j + 3) * PF_WAVE];
-        const double x0 = x[c0], x1 = x[c1], x2 = x[c2], x3 = x[c3];
-        acc += v0 * x0;
-        acc += v1 * x1;
-        acc += v2 * x2;
-        acc += v3 * x3;
+    for (; j + 2 <= pairs; j += 2) {
+        const int2 c0 = PF_STREAM_LOAD(cp2 + (int64_t)(j + 0) * PF_WAVE), c1 = PF_STREAM_LOAD(cp2 + (int64_t)(j + 1) * PF_WAVE);
+        const double2 v0 = PF_STREAM_LOAD(vp2 + (int64_t)(j + 0) * PF_WAVE), v1 = PF_STREAM_LOAD(vp2 + (int64_t)(j + 1) * PF_WAVE);
+        const double x0 = x[c0.x], x1 = x[c0.y], x2 = x[c1.x], x3 = x[c1.y];
+        acc += v0.x * x0;
+        acc += v0.y * x1;
+        acc += v1.x * x2;
+        acc += v1.y * x3;
     }
-    for (; j < width; ++j) acc += vp[(int64_t)j * PF_WAVE] * x[cp[(int64_t)j * PF_WAVE]];
+    for (; j < pairs; ++j) {
+        const int2 c0 = PF_STREAM_LOAD(cp2 + (int64_t)j * PF_WAVE);
+        const double2 v0 = PF_STREAM_LOAD(vp2 + (int64_t)j * PF_WAVE);
+        acc += v0.x * x[c0.x];
+        acc += v0.y * x[c0.y];
+    }
+    if (width & 1) {
+        const int64_t t = base + (int64_t)pairs * (2 * PF_WAVE) + lane;
+        acc += PF_STREAM_LOAD(a.sval + t) * x[PF_STREAM_LOAD(a.scol + t)];
+    }
     double r = a.alpha * (a.shift * xi - acc);
     if (HAS_PREV) r -= a.beta * a.prev[row];
     a.out[row] = r;
 }
 
 template <bool HAS_PREV>
-__global__ __launch_bounds__(PF_BLOCK) void k_sell_op(OpArgs a) {
+__global__ __launch_bounds__(PF_OP_BLOCK) void k_sell_op(OpArgs a) {
     sell_op_block<HAS_PREV>(a, blockIdx.x);
 }
 
@@ -81,7 +103,7 @@ __global__ __launch_bounds__(PF_BLOCK) void k_sell_op(OpArgs a) {
 // their Chebyshev recurrences in lockstep): a 250k-vertex step alone is ~5 us, of which ~3 us is
 // launch/ramp latency; two per launch amortise it.
 template <bool HAS_PREV>
-__global__ __launch_bounds__(PF_BLOCK) void k_sell_op2(OpArgs a, OpArgs b) {
+__global__ __launch_bounds__(PF_OP_BLOCK) void k_sell_op2(OpArgs a, OpArgs b) {
     if (blockIdx.x < a.n_blocks) sell_op_block<HAS_PREV>(a, blockIdx.x);
     else sell_op_block<HAS_PREV>(b, blockIdx.x - a.n_blocks);
 }
@@ -395,7 +417,7 @@ const double* op_values(pf_graph* g, int32_t op) {
 
 OpArgs op_args(pf_graph* g, const double* vals, const double* x, const double* prev, double* out, double alpha, double shift,
                double beta) {
-    return OpArgs{g->slice_ptr, g->scol, vals, g->diag, x, prev, out, alpha, shift, beta, nblk(g->n_pad)};
+    return OpArgs{g->slice_ptr, g->scol, vals, g->diag, x, prev, out, alpha, shift, beta, (unsigned)(g->n_pad / PF_OP_BLOCK)};
 }
 
 int64_t op_bytes(const pf_graph* g) {  // 12 nnz + 20 n + 4, nnz counted with the diagonal
@@ -407,9 +429,9 @@ int launch_op(pf_graph* g, const double* vals, const double* x, const double* pr
     hipStream_t st = g->ctx->stream;
     const OpArgs a = op_args(g, vals, x, prev, out, alpha, shift, beta);
     if (prev)
-        k_sell_op<true><<<a.n_blocks, PF_BLOCK, 0, st>>>(a);
+        k_sell_op<true><<<a.n_blocks, PF_OP_BLOCK, 0, st>>>(a);
     else
-        k_sell_op<false><<<a.n_blocks, PF_BLOCK, 0, st>>>(a);
+        k_sell_op<false><<<a.n_blocks, PF_OP_BLOCK, 0, st>>>(a);
     PF_HIP(hipGetLastError());
     return PF_OK;
 }
@@ -417,9 +439,9 @@ int launch_op(pf_graph* g, const double* vals, const double* x, const double* pr
 int launch_op2(pf_graph* ga, const OpArgs& a, const OpArgs& b, bool has_prev) {
     hipStream_t st = ga->ctx->stream;
     if (has_prev)
-        k_sell_op2<true><<<a.n_blocks + b.n_blocks, PF_BLOCK, 0, st>>>(a, b);
+        k_sell_op2<true><<<a.n_blocks + b.n_blocks, PF_OP_BLOCK, 0, st>>>(a, b);
     else
-        k_sell_op2<false><<<a.n_blocks + b.n_blocks, PF_BLOCK, 0, st>>>(a, b);
+        k_sell_op2<false><<<a.n_blocks + b.n_blocks, PF_OP_BLOCK, 0, st>>>(a, b);
     PF_HIP(hipGetLastError());
     return PF_OK;
 }

@@ -272,13 +272,28 @@ class Graph(object):
         return self.device.mean_filter(np.asarray(values, dtype=np.float64), iterations)
 
 
+PAIRED_LAUNCHES = None  # True / False force the choice of `_pair_pays`; None: decide per pair of graphs
+_L2_BUDGET = 8 * 3.5e6  # bytes of operator storage the eight 4 MiB XCD L2s keep resident next to the vectors
+
+
+def _pair_pays(ga, gb):
+    """Should two graphs share kernel launches (`pf_cheb2`)?  Sharing amortises the ~3 us launch latency of a
+    Chebyshev step, but if ONE operator fits the XCD L2s and the two together do not, sharing turns L2 hits
+    into Infinity-Cache reads and loses (measured on MI355X: 2 x 50k vertices 4.2 us shared vs 6.2 us apart;
+    2 x 250k 9.6 vs 9.0; 2 x 1M 29.7 vs 32.9)."""
+    if PAIRED_LAUNCHES is not None:
+        return bool(PAIRED_LAUNCHES)
+    sizes = [12.0 * g.device.nnz_l + 16.0 * g.device.n for g in (ga, gb)]
+    return not (max(sizes) <= _L2_BUDGET < sum(sizes))
+
+
 def compute_spectra(graphs):
     """`get_graph_spectrum()` of several graphs at once (Focusr.__init__ does target then
     source, focusr.py:150,169; the two are independent).  Two graphs of one context run in
     lockstep on its stream (`_paired_spectra`); graphs of different contexts run from one host
     thread each, every one on its own HIP stream (ctypes releases the GIL during library calls)."""
     graphs = list(graphs)
-    if len(graphs) == 2 and graphs[0].device.ctx is graphs[1].device.ctx:
+    if len(graphs) == 2 and graphs[0].device.ctx is graphs[1].device.ctx and _pair_pays(graphs[0], graphs[1]):
         _paired_spectra(graphs[0], graphs[1])
         return
     if len(graphs) <= 1 or len({id(g.device.ctx) for g in graphs}) < len(graphs):

@@ -385,8 +385,10 @@ def test_paired_spectra_equal_single(golden, ctx):
     """Two graphs per kernel launch (pf_cheb2, different sizes and degrees) give bit-identical
     results to one graph per launch."""
     from pyfocusr_amd import Graph
+    from pyfocusr_amd import graph as graph_mod
     from pyfocusr_amd.graph import compute_spectra
 
+    assert graph_mod._pair_pays(*[Graph(mesh_of(golden(n)), ctx=ctx, verbose=False) for n in ("target_mesh", "source_mesh")])
     gs = [Graph(mesh_of(golden(n)), n_spectral_features=k, n_rand_samples=10**9, ctx=ctx, verbose=False)
           for n, k in (("target_mesh", 6), ("target_mesh_15k", 5))]
     compute_spectra(gs)
