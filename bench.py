@@ -173,8 +173,12 @@ def main():
     ap.add_argument("--samples", type=int, default=5000, help="n_coords_spectral_ordering (focusr.py:37)")
     ap.add_argument("--cpu-knn-sample", type=int, default=25000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--pair", choices=("auto", "on", "off"), default="auto",
-                    help="two graphs per kernel launch (pf_cheb2): auto = by L2 footprint (off at 250k vertices)")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="only the headline workload (no bundled-15k-pair measurement): keeps rocprofv3 kernel statistics "
+                         "to the 250k launches")
+    ap.add_argument("--pair", choices=("on", "off"), default="on",
+                    help="on: the target and source recurrences share kernel launches (pf_cheb2, the library default); "
+                         "off: one graph per launch, the two solves one after the other")
     ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
                     help="torch.distributed backend; gloo + --share-gpu rehearses the N>1 path on a 1-GPU box")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses GPU 0")
@@ -208,7 +212,7 @@ def main():
     from pyfocusr_amd import graph as _graph
     from pyfocusr_amd.meshgen import blob_mesh
 
-    _graph.PAIRED_LAUNCHES = {"auto": None, "on": True, "off": False}[args.pair]
+    _graph.PAIRED_LAUNCHES = args.pair == "on"
 
     ctx = _hip.Context(local)
     ctxs = [ctx, _hip.Context(local) if args.streams == 2 else ctx]  # one stream per mesh of the pair
@@ -304,7 +308,7 @@ def main():
         }
         if split is not None:
             out["split_pair"] = split
-        if world == 1:
+        if world == 1 and not args.no_extras:
             c2 = bundled_15k_pair(ctx, 5)
             if c2 is not None:
                 out["bundled_15k_pair"] = c2

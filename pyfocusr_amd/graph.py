@@ -272,19 +272,16 @@ class Graph(object):
         return self.device.mean_filter(np.asarray(values, dtype=np.float64), iterations)
 
 
-PAIRED_LAUNCHES = None  # True / False force the choice of `_pair_pays`; None: decide per pair of graphs
-_L2_BUDGET = 8 * 3.5e6  # bytes of operator storage the eight 4 MiB XCD L2s keep resident next to the vectors
+PAIRED_LAUNCHES = True  # two graphs of one context advance their Chebyshev recurrences in shared launches
 
 
 def _pair_pays(ga, gb):
     """Should two graphs share kernel launches (`pf_cheb2`)?  Sharing amortises the ~3 us launch latency of a
-    Chebyshev step, but if ONE operator fits the XCD L2s and the two together do not, sharing turns L2 hits
-    into Infinity-Cache reads and loses (measured on MI355X: 2 x 50k vertices 4.2 us shared vs 6.2 us apart;
-    2 x 250k 9.6 vs 9.0; 2 x 1M 29.7 vs 32.9)."""
-    if PAIRED_LAUNCHES is not None:
-        return bool(PAIRED_LAUNCHES)
-    sizes = [12.0 * g.device.nnz_l + 16.0 * g.device.n for g in (ga, gb)]
-    return not (max(sizes) <= _L2_BUDGET < sum(sizes))
+    Chebyshev step: 2 x 50k vertices take 4.2 us shared vs 6.2 us apart, 2 x 1M 29.7 vs 32.9.  Around 250k
+    vertices it is a wash (9.6 us shared vs 2 x 4.5 apart): ONE operator then just fits the eight 4 MiB XCD
+    L2s and stays resident from launch to launch, two do not.  The shared form is kept everywhere: the gain of
+    the split form at that size is ~2 % and disappears under a profiler, which flushes L2 between dispatches."""
+    return bool(PAIRED_LAUNCHES)
 
 
 def compute_spectra(graphs):
