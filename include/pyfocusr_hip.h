@@ -168,6 +168,22 @@ int pf_knn_upload(pf_ctx* ctx, const double* ref, int64_t n_ref, const double* q
 int pf_knn_run(pf_ctx* ctx);
 int pf_knn_download(pf_ctx* ctx, int64_t* idx_out, double* d2_out);
 
+/* ---- closest point on a triangulated surface (ICP pre-alignment, "next" row f3) --------------------------
+ * Replaces the vtkCellLocator::FindClosestPoint loop inside vtkIterativeClosestPointTransform, which the
+ * reference runs through vtk_functions.py:12-29 (called from focusr.py:110-131).  Polygons with more than three
+ * vertices are fan-triangulated (0,j+1,j+2).  Exact: the minimum over all triangles of the exact point-triangle
+ * distance; lowest face index on exact ties.
+ *   pf_surface_create   points [n][3] f64, faces [n_faces][verts_per_face] i32 (host) -> device search structure
+ *   pf_surface_closest  qry [n_qry][3] f64 (host) -> out_pts [n_qry][3] closest surface points, out_face [n_qry]
+ *                       face index (-1 and NaN point for a NaN query), out_d2 [n_qry] squared distances; each
+ *                       output may be NULL. */
+typedef struct pf_surface pf_surface;
+int pf_surface_create(pf_ctx* ctx, const double* points, int64_t n, const int32_t* faces, int64_t n_faces,
+                      int32_t verts_per_face, pf_surface** out);
+void pf_surface_free(pf_surface* s);
+int pf_surface_closest(pf_surface* s, const double* qry, int64_t n_qry, double* out_pts, int32_t* out_face,
+                       double* out_d2);
+
 #ifdef __cplusplus
 }
 #endif

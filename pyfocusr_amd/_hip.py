@@ -88,6 +88,9 @@ SIGNATURES = {
     "pf_knn_upload": (C.c_int, [C.c_void_p, _f64p, C.c_int64, _f64p, C.c_int64, C.c_int32]),
     "pf_knn_run": (C.c_int, [C.c_void_p]),
     "pf_knn_download": (C.c_int, [C.c_void_p, _i64p, _f64p]),
+    "pf_surface_create": (C.c_int, [C.c_void_p, _f64p, C.c_int64, _i32p, C.c_int64, C.c_int32, C.POINTER(C.c_void_p)]),
+    "pf_surface_free": (None, [C.c_void_p]),
+    "pf_surface_closest": (C.c_int, [C.c_void_p, _f64p, C.c_int64, _f64p, _i32p, _f64p]),
 }
 
 _lib = None
@@ -255,6 +258,46 @@ class DeviceMesh(object):
     def close(self):
         if getattr(self, "_h", None):
             self._lib.pf_mesh_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+
+class DeviceSurface(object):
+    """Triangle soup of one mesh in HBM (Morton-sorted, chunk boxes) for exact closest-point queries
+    (`pf_surface_*`): the search inside the ICP pre-alignment."""
+
+    def __init__(self, points, faces, ctx=None):
+        self.ctx = ctx if ctx is not None else default_context()
+        self._lib = self.ctx._lib
+        pts = _c_f64(points).reshape(-1, 3)
+        f = np.ascontiguousarray(faces, dtype=np.int32)
+        if f.ndim != 2 or f.shape[0] == 0:
+            raise ValueError("faces must be a non-empty (F, verts_per_face) array")
+        h = C.c_void_p()
+        _check(self._lib.pf_surface_create(self.ctx._h, _f64(pts), pts.shape[0], f.ctypes.data_as(_i32p), f.shape[0],
+                                           f.shape[1], C.byref(h)))
+        self._h = h
+        self.n, self.n_faces = pts.shape[0], f.shape[0]
+        _live_graphs.add(self)
+        self.ctx._children.add(self)
+
+    def closest(self, queries):
+        """(points (q,3) f64, face (q,) i32, squared distance (q,) f64) of the closest surface point of each query."""
+        q = _c_f64(queries).reshape(-1, 3)
+        pts = np.empty_like(q)
+        face = np.empty(len(q), dtype=np.int32)
+        d2 = np.empty(len(q), dtype=np.float64)
+        _check(self._lib.pf_surface_closest(self._h, _f64(q), len(q), _f64(pts), face.ctypes.data_as(_i32p), _f64(d2)))
+        return pts, face, d2
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.pf_surface_free(self._h)
             self._h = None
 
     def __del__(self):

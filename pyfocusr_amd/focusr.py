@@ -122,12 +122,14 @@ class Focusr(object):
 
         print("Starting ICP")
         self._icp_transform = None
-        if icp_register_first is True:  # focusr.py:110-131 (VTK C++)
+        if icp_register_first is True:  # focusr.py:110-131
             if icp_reg_target_to_source is True:
-                icp = icp_transform(target=vtk_mesh_source, source=vtk_mesh_target, transform_mode=icp_registration_mode)
+                icp = icp_transform(target=vtk_mesh_source, source=vtk_mesh_target, transform_mode=icp_registration_mode,
+                                    ctx=self._ctx)
                 vtk_mesh_target = apply_transform(source=vtk_mesh_target, transform=icp)
             else:
-                icp = icp_transform(target=vtk_mesh_target, source=vtk_mesh_source, transform_mode=icp_registration_mode)
+                icp = icp_transform(target=vtk_mesh_target, source=vtk_mesh_source, transform_mode=icp_registration_mode,
+                                    ctx=self._ctx)
                 vtk_mesh_source = apply_transform(source=vtk_mesh_source, transform=icp)
             self._icp_transform = icp
 

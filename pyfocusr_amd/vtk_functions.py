@@ -12,9 +12,11 @@ a light object that
   GetCell(c).GetNumberOfEdges()/GetEdge(e).GetPointId(0|1)` with VTK's polygon
   edge order (0,1),(1,2),...,(v-1,0).
 
-ICP / curvature / deep copy (`vtk_functions.py:12-81`) are VTK C++ object
-plumbing outside the hot path: they are delegated to a real
-`vtk` install when one is importable and raise `NotImplementedError` otherwise.
+ICP (`vtk_functions.py:12-37`): real `vtkPolyData` inputs go to
+VTK's own `vtkIterativeClosestPointTransform` when the `vtk` wheel is importable;
+everything else (always the case in the build image) runs the same iteration with
+the closest-point search on the MI355X (`pyfocusr_amd/icp.py`).  Curvature
+(`vtk_functions.py:40-74`) stays VTK-only.
 """
 import numpy as np
 
@@ -223,9 +225,21 @@ def _need_vtk(what):
         )
 
 
-def icp_transform(target, source, numberOfIterations=100, number_landmarks=1000, transform_mode="rigid"):
-    """`vtk_functions.py:12-29`; delegated to VTK when present."""
-    _need_vtk("icp_transform")
+def _is_vtk_polydata(mesh):
+    return _vtk is not None and isinstance(mesh, _vtk.vtkPolyData)
+
+
+def icp_transform(target, source, numberOfIterations=100, number_landmarks=1000, transform_mode="rigid", ctx=None):
+    """`vtk_functions.py:12-29`.  Same arguments; returns an object with `GetMatrix()`."""
+    if transform_mode not in ("rigid", "similarity"):
+        raise ValueError("Error invalid transform mode")
+    if not (_is_vtk_polydata(target) and _is_vtk_polydata(source)):
+        from . import icp as _icp
+
+        t_pts, t_faces = mesh_arrays(target)
+        s_pts, _ = mesh_arrays(source)
+        return _icp.icp_transform(t_pts, t_faces, s_pts, numberOfIterations=numberOfIterations,
+                                  number_landmarks=number_landmarks, transform_mode=transform_mode, ctx=ctx)
     icp = _vtk.vtkIterativeClosestPointTransform()
     if transform_mode == "rigid":
         icp.GetLandmarkTransform().SetModeToRigidBody()
@@ -244,7 +258,15 @@ def icp_transform(target, source, numberOfIterations=100, number_landmarks=1000,
 
 
 def apply_transform(source, transform):
-    """`vtk_functions.py:32-37`; delegated to VTK when present."""
+    """`vtk_functions.py:32-37`: a new mesh with the transform applied to the points."""
+    if hasattr(transform, "transform_points"):  # pyfocusr_amd.icp.IcpTransform
+        if _is_vtk_polydata(source):
+            t = _vtk.vtkTransform()
+            t.SetMatrix([transform.GetMatrix().GetElement(i, j) for i in range(4) for j in range(4)])
+            transform = t
+        else:
+            pts, faces = mesh_arrays(source)
+            return PolyMesh(transform.transform_points(pts), faces, list(getattr(source, "point_data", [])))
     _need_vtk("apply_transform")
     f = _vtk.vtkTransformPolyDataFilter()
     f.SetInputData(source)
