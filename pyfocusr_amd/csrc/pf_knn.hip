@@ -171,6 +171,30 @@ __device__ __forceinline__ double dist2(const double (&q)[D], const double* __re
     return s;
 }
 
+// the same sum split at coordinate P: s = dist2_head, then dist2_tail continues the very same accumulation, so the
+// result is bit-identical to dist2.  Adding non-negative terms is monotone in floating point: head <= full sum,
+// which lets a wave drop a candidate after P coordinates when the head already exceeds every lane's bound.
+template <int D, int P>
+__device__ __forceinline__ double dist2_head(const double (&q)[D], const double* __restrict__ r) {
+    double s = 0.0;
+#pragma unroll
+    for (int c = 0; c < P; ++c) {
+        const double df = q[c] - r[c];
+        const double sq = df * df;
+        s = (c == 0) ? sq : s + sq;
+    }
+    return s;
+}
+template <int D, int P>
+__device__ __forceinline__ double dist2_tail(const double (&q)[D], const double* __restrict__ r, double s) {
+#pragma unroll
+    for (int c = P; c < D; ++c) {
+        const double df = q[c] - r[c];
+        s = s + df * df;
+    }
+    return s;
+}
+
 // sorted insertion of candidate (s, o) into the lane's K best, ordered by (distance, original index)
 template <int K>
 __device__ __forceinline__ void topk_insert(double (&best)[K], int32_t (&bidx)[K], double s, int32_t o) {
@@ -232,47 +256,60 @@ __global__ __launch_bounds__(PF_BLOCK) void k_knn_grid(const double* __restrict_
             }
         }
     }
-    const double best = bestk[K - 1];  // every reference that can enter the K best lies within sqrt(best)
-    // ---- block rectangle: every reference that can beat or tie a lane lies within rad of it on both axes
-    const double rad = sqrt(best) * (1.0 + 1e-9) + 1e-300;  // inflated against the rounding of sqrt / the subtractions
-    double xl = qx - rad, xh = qx + rad, yl = qy - rad, yh = qy + rad;
-    xl -= fabs(xl) * 1e-15;
-    xh += fabs(xh) * 1e-15;
-    yl -= fabs(yl) * 1e-15;
-    yh += fabs(yh) * 1e-15;
-    int bx0 = cell_of(xl, g.lo0, g.s0, g.r0), bx1 = cell_of(xh, g.lo0, g.s0, g.r0);
-    int by0 = cell_of(yl, g.lo1, g.s1, g.r1), by1 = cell_of(yh, g.lo1, g.s1, g.r1);
-    if (!(best < INFINITY)) {  // nothing nearby: the whole grid
-        bx0 = 0;
-        by0 = 0;
-        bx1 = g.r0 - 1;
-        by1 = g.r1 - 1;
-    }
+    // ---- block rectangle: every reference that can beat or tie a lane lies within rad = sqrt(its K-th best) of it on
+    // both grid axes.  The rectangle is the union over the block's lanes; it is re-derived while the scan proceeds
+    // (bounds only shrink), which matters when the two clouds are poorly aligned and the first bound is loose.
+    auto block_rectangle = [&](int& bx0, int& bx1, int& by0, int& by1) {
+        const double best = bestk[K - 1];
+        const double rad = sqrt(best) * (1.0 + 1e-9) + 1e-300;  // inflated against the rounding of sqrt / the subtractions
+        double xl = qx - rad, xh = qx + rad, yl = qy - rad, yh = qy + rad;
+        xl -= fabs(xl) * 1e-15;
+        xh += fabs(xh) * 1e-15;
+        yl -= fabs(yl) * 1e-15;
+        yh += fabs(yh) * 1e-15;
+        bx0 = cell_of(xl, g.lo0, g.s0, g.r0), bx1 = cell_of(xh, g.lo0, g.s0, g.r0);
+        by0 = cell_of(yl, g.lo1, g.s1, g.r1), by1 = cell_of(yh, g.lo1, g.s1, g.r1);
+        if (!(best < INFINITY)) {  // nothing nearby: the whole grid
+            bx0 = 0;
+            by0 = 0;
+            bx1 = g.r0 - 1;
+            by1 = g.r1 - 1;
+        }
 #pragma unroll
-    for (int off = PF_WAVE / 2; off > 0; off >>= 1) {
-        bx0 = min(bx0, __shfl_xor(bx0, off, PF_WAVE));
-        by0 = min(by0, __shfl_xor(by0, off, PF_WAVE));
-        bx1 = max(bx1, __shfl_xor(bx1, off, PF_WAVE));
-        by1 = max(by1, __shfl_xor(by1, off, PF_WAVE));
-    }
-    if ((threadIdx.x & (PF_WAVE - 1)) == 0) {
-        int* b = box[threadIdx.x / PF_WAVE];
-        b[0] = bx0;
-        b[1] = bx1;
-        b[2] = by0;
-        b[3] = by1;
-    }
-    __syncthreads();
+        for (int off = PF_WAVE / 2; off > 0; off >>= 1) {
+            bx0 = min(bx0, __shfl_xor(bx0, off, PF_WAVE));
+            by0 = min(by0, __shfl_xor(by0, off, PF_WAVE));
+            bx1 = max(bx1, __shfl_xor(bx1, off, PF_WAVE));
+            by1 = max(by1, __shfl_xor(by1, off, PF_WAVE));
+        }
+        __syncthreads();  // the previous round's readers are done with box[]
+        if ((threadIdx.x & (PF_WAVE - 1)) == 0) {
+            int* b = box[threadIdx.x / PF_WAVE];
+            b[0] = bx0;
+            b[1] = bx1;
+            b[2] = by0;
+            b[3] = by1;
+        }
+        __syncthreads();
 #pragma unroll
-    for (int w = 0; w < PF_BLOCK / PF_WAVE; ++w) {
-        bx0 = min(bx0, box[w][0]);
-        bx1 = max(bx1, box[w][1]);
-        by0 = min(by0, box[w][2]);
-        by1 = max(by1, box[w][3]);
-    }
+        for (int w = 0; w < PF_BLOCK / PF_WAVE; ++w) {
+            bx0 = min(bx0, box[w][0]);
+            bx1 = max(bx1, box[w][1]);
+            by0 = min(by0, box[w][2]);
+            by1 = max(by1, box[w][3]);
+        }
+    };
+    int bx0, bx1, by0, by1;
+    block_rectangle(bx0, bx1, by0, by1);
 
-    // ---- phase 2: exhaustive scan of the rectangle, one contiguous run of references per grid row
-    for (int y = by0; y <= by1; ++y) {
+    // ---- phase 2: exhaustive scan of the rectangle, one contiguous run of references per grid row; rows are taken
+    // from the middle outwards so that the bounds tighten early and the outer rows drop out
+    const int mid = (by0 + by1) / 2;
+    const int half = max(mid - by0, by1 - mid);
+    int since_refresh = 0;
+    for (int t = 0; t <= 2 * half; ++t) {
+        const int y = (t & 1) ? mid + (t + 1) / 2 : mid - t / 2;
+        if (y < by0 || y > by1) continue;  // block-uniform
         const int32_t run_b = cell_start[y * g.r0 + bx0], run_e = cell_start[y * g.r0 + bx1 + 1];
         for (int32_t t0 = run_b; t0 < run_e; t0 += KNN_TILE) {
             const int cnt = (run_e - t0) < KNN_TILE ? (run_e - t0) : KNN_TILE;
@@ -281,7 +318,15 @@ __global__ __launch_bounds__(PF_BLOCK) void k_knn_grid(const double* __restrict_
             for (int k = threadIdx.x; k < cnt; k += PF_BLOCK) tile_idx[k] = ref_orig[t0 + k];
             __syncthreads();
             for (int r = 0; r < cnt; ++r) {
-                const double s = dist2<D>(q, tile + r * D);
+                double s;
+                if constexpr (D >= 6) {  // deep embeddings: most of the rectangle is far away in the other coordinates
+                    constexpr int P = D / 2;
+                    s = dist2_head<D, P>(q, tile + r * D);
+                    if (!__any(s <= bestk[K - 1])) continue;  // wave-uniform: no lane can take this candidate
+                    s = dist2_tail<D, P>(q, tile + r * D, s);
+                } else {
+                    s = dist2<D>(q, tile + r * D);
+                }
                 if (s <= bestk[K - 1]) {
                     const int32_t o = tile_idx[r];
                     bool seen = false;  // phase 1 already holds some of the window's points
@@ -290,6 +335,16 @@ __global__ __launch_bounds__(PF_BLOCK) void k_knn_grid(const double* __restrict_
                     if (!seen) topk_insert<K>(bestk, bidx, s, o);
                 }
             }
+        }
+        since_refresh += run_e - run_b;
+        if (since_refresh >= 4 * KNN_TILE && by1 - by0 >= 8) {  // worth a re-derivation (two barriers, ~30 shuffles)
+            since_refresh = 0;
+            int nx0, nx1, ny0, ny1;
+            block_rectangle(nx0, nx1, ny0, ny1);
+            bx0 = max(bx0, nx0);
+            bx1 = min(bx1, nx1);
+            by0 = max(by0, ny0);
+            by1 = min(by1, ny1);
         }
     }
     if (qi < n_qry) {
