@@ -91,6 +91,10 @@ SIGNATURES = {
     "pf_surface_create": (C.c_int, [C.c_void_p, _f64p, C.c_int64, _i32p, C.c_int64, C.c_int32, C.POINTER(C.c_void_p)]),
     "pf_surface_free": (None, [C.c_void_p]),
     "pf_surface_closest": (C.c_int, [C.c_void_p, _f64p, C.c_int64, _f64p, _i32p, _f64p]),
+    "pf_cpd_create": (C.c_int, [C.c_void_p, _f64p, C.c_int64, _f64p, C.c_int64, C.c_int32, C.POINTER(C.c_void_p)]),
+    "pf_cpd_free": (None, [C.c_void_p]),
+    "pf_cpd_estep": (C.c_int, [C.c_void_p, _f64p, C.c_double, C.c_double, _f64p, _f64p, _f64p]),
+    "pf_cpd_gram": (C.c_int, [C.c_void_p, _f64p, C.c_int64, _f64p, C.c_int64, C.c_int32, C.c_double, _f64p, C.c_int32, _f64p]),
 }
 
 _lib = None
@@ -305,6 +309,56 @@ class DeviceSurface(object):
             self.close()
         except Exception:  # noqa: BLE001
             pass
+
+
+class DeviceCpd(object):
+    """Fixed set X (N,d) and moving set Y (M,d) resident in HBM for the E-steps of a CPD registration."""
+
+    def __init__(self, X, Y, ctx=None):
+        self.ctx = ctx if ctx is not None else default_context()
+        self._lib = self.ctx._lib
+        X, Y = _c_f64(X), _c_f64(Y)
+        if X.ndim != 2 or Y.ndim != 2 or X.shape[1] != Y.shape[1]:
+            raise ValueError("X (N,d) and Y (M,d) must share d")
+        self.N, self.M, self.D = X.shape[0], Y.shape[0], X.shape[1]
+        h = C.c_void_p()
+        _check(self._lib.pf_cpd_create(self.ctx._h, _f64(X), self.N, _f64(Y), self.M, self.D, C.byref(h)))
+        self._h = h
+        self._P1, self._Pt1, self._PX = np.empty(self.M), np.empty(self.N), np.empty((self.M, self.D))
+        _live_graphs.add(self)
+        self.ctx._children.add(self)
+
+    def estep(self, TY, sigma2, w=0.0):
+        """(P1 (M,), Pt1 (N,), PX (M,d)) for the moving set at TY; the arrays are reused by the next call."""
+        TY = _c_f64(TY)
+        if TY.shape != (self.M, self.D):
+            raise ValueError("TY must be (%d, %d)" % (self.M, self.D))
+        _check(self._lib.pf_cpd_estep(self._h, _f64(TY), float(sigma2), float(w), _f64(self._P1), _f64(self._Pt1),
+                                      _f64(self._PX)))
+        return self._P1, self._Pt1, self._PX
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.pf_cpd_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+
+def gaussian_gram_product(A, B, beta, V, ctx=None):
+    """G(A,B) @ V with G_ij = exp(-|a_i - b_j|^2 / (2 beta^2)), evaluated on the device without forming G."""
+    ctx = ctx if ctx is not None else default_context()
+    A, B, V = _c_f64(A), _c_f64(B), _c_f64(V)
+    if A.ndim != 2 or B.ndim != 2 or A.shape[1] != B.shape[1] or V.ndim != 2 or V.shape[0] != B.shape[0]:
+        raise ValueError("shapes: A (a,d), B (b,d), V (b,c)")
+    out = np.empty((A.shape[0], V.shape[1]))
+    _check(ctx._lib.pf_cpd_gram(ctx._h, _f64(A), A.shape[0], _f64(B), B.shape[0], A.shape[1], float(beta), _f64(V),
+                                V.shape[1], _f64(out)))
+    return out
 
 
 class DeviceLaplacian(object):

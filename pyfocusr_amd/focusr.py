@@ -11,12 +11,13 @@ On the device: Laplacian assembly + eigensolve (`Graph`), the 3-D NN of `eigsort
 behind `get_smoothed_correspondences` (focusr.py:368-396) and the 3-NN query of
 `get_weighted_final_node_locations` (focusr.py:401-426 -> `pf_knn`, k = 3).
 
-Outside the hot path, kept as thin shells:
-* ICP pre-alignment (:110-131) and VTK mesh outputs need the `vtk` package;
-* CPD registration (:297-334) is the third-party `cycpd` package: used when
-  importable, otherwise `registration` may be injected as a callable
-  `(source_coords, target_coords, kind) -> new_target_coords`, and when neither
-  is available the step is skipped with a notice;
+"Next" rows of SURVEY.md §8f:
+* ICP pre-alignment (:110-131): `pyfocusr_amd/icp.py` (closest-point search on the
+  device) unless both meshes are real vtkPolyData and `vtk` is importable;
+* CPD registration (:297-334): an injected callable `registration(source_coords,
+  target_coords, kind) -> new_target_coords` if given, else the third-party
+  `cycpd` when importable (what the reference calls), else `pyfocusr_amd/cpd.py`
+  (same algorithm, E-step and affinity products on the device);
 * Hungarian point correspondence (:340-349, O(N^3)) is not implemented.
 """
 import numpy as np
@@ -26,6 +27,8 @@ from .eigsort import eigsort
 from .graph import Graph, compute_spectra
 from .main import print_header
 from .vtk_functions import PolyMesh, apply_transform, icp_transform, vtk_deep_copy
+
+from . import cpd as _native_cpd
 
 try:  # pragma: no cover - not installed in the build image
     import cycpd
@@ -133,6 +136,12 @@ class Focusr(object):
                 vtk_mesh_source = apply_transform(source=vtk_mesh_source, transform=icp)
             self._icp_transform = icp
 
+        if (len(list_features_to_calc) and not (use_features_as_coords or use_features_in_graph
+                                                or include_features_in_adj_matrix)):
+            # The reference computes them (default: VTK curvature, graph.py:84-119) and, with these switches off,
+            # never reads them again (graph.py:191,167; focusr.py:524).  VTK-only: skipped when nothing consumes them.
+            print("Node features %s are not consumed by any enabled option: not computed" % list(list_features_to_calc))
+            list_features_to_calc = []
         graph_kw = dict(
             n_spectral_features=self.n_total_spectral_features,
             n_rand_samples=n_coords_spectral_ordering,
@@ -200,18 +209,17 @@ class Focusr(object):
             self.target_spectral_coords = np.asarray(
                 self.registration(self.source_spectral_coords, self.target_spectral_coords, reg_type))
             return
-        if cycpd is None:
-            print("cycpd is not installed: skipping the %s CPD registration of spectral coordinates" % reg_type)
-            return
+        backend, extra = (cycpd, {}) if cycpd is not None else (_native_cpd, {"ctx": self._ctx})
         if reg_type == "deformable":
-            reg = cycpd.deformable_registration(
+            reg = backend.deformable_registration(
                 **{"X": X, "Y": Y, "num_eig": self.non_rigid_n_eigens, "max_iterations": self.non_rigid_max_iterations,
                    "tolerance": self.non_rigid_tolerance, "alpha": self.non_rigid_alpha, "beta": self.non_rigid_beta,
-                   "verbose": self.verbose})
+                   "verbose": self.verbose}, **extra)
             _, self.non_rigid_params = reg.register()
         elif reg_type == "affine":
-            reg = cycpd.affine_registration(
-                **{"X": X, "Y": Y, "max_iterations": self.rigid_reg_max_iterations, "tolerance": self.rigid_tolerance})
+            reg = backend.affine_registration(
+                **{"X": X, "Y": Y, "max_iterations": self.rigid_reg_max_iterations, "tolerance": self.rigid_tolerance},
+                **extra)
             _, self.rigid_params = reg.register()
         self.target_spectral_coords = reg.transform_point_cloud(self.target_spectral_coords)
 

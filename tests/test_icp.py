@@ -164,7 +164,7 @@ def test_icp_recovers_known_motion_and_focusr_defaults(golden, ctx):
 
     gs = golden("source_mesh")
     reg = Focusr(PolyMesh(pts, faces), PolyMesh(gs["points"], gs["faces"]), n_spectral_features=3, n_extra_spectral=3,
-                 list_features_to_calc=[], ctx=ctx, registration=lambda src, tgt, kind: tgt)
+                 ctx=ctx, registration=lambda src, tgt, kind: tgt)   # list_features_to_calc left at its default
     assert reg.icp_transform is not None and reg.icp_transform.n_iterations == 100
     np.testing.assert_allclose(reg.graph_target.eig_vals, gt["k6_eig_vals"], rtol=1e-8)
     np.testing.assert_allclose(reg.graph_source.eig_vals, gs["k6_eig_vals"], rtol=1e-7)  # points moved by a rigid map
