@@ -193,11 +193,15 @@ int pf_surface_closest(pf_surface* s, const double* qry, int64_t n_qry, double* 
  *                  P1 [M] = P 1, Pt1 [N] = P^T 1, PX [M][d] = P X with
  *                  P_mn = exp(-|x_n - ty_m|^2 / 2 sigma2) / (sum_m' exp(..) + (2 pi sigma2)^(d/2) w/(1-w) M/N)
  *                  (a zero column sum is replaced by DBL_EPSILON first).  Outputs may be NULL.
+ *   pf_cpd_set_basis / pf_cpd_weighted_gram   Q [M][K] (host) stays on the device; H [K][K] = Q^T diag(P1) Q with
+ *                  the P1 of the last pf_cpd_estep: the K x K matrix of the low-rank (Woodbury) deformable M-step.
  *   pf_cpd_gram    out [n_a][n_cols] = G(A,B) V,  G_ij = exp(-|a_i - b_j|^2 / 2 beta^2), V [n_b][n_cols] (all host). */
 typedef struct pf_cpd pf_cpd;
 int pf_cpd_create(pf_ctx* ctx, const double* X, int64_t N, const double* Y, int64_t M, int32_t d, pf_cpd** out);
 void pf_cpd_free(pf_cpd* h);
 int pf_cpd_estep(pf_cpd* h, const double* TY, double sigma2, double w, double* P1, double* Pt1, double* PX);
+int pf_cpd_set_basis(pf_cpd* h, const double* Q, int32_t K);
+int pf_cpd_weighted_gram(pf_cpd* h, double* H);
 int pf_cpd_gram(pf_ctx* ctx, const double* A, int64_t n_a, const double* B, int64_t n_b, int32_t d, double beta,
                 const double* V, int32_t n_cols, double* out);
 

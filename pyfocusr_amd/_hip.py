@@ -94,6 +94,8 @@ SIGNATURES = {
     "pf_cpd_create": (C.c_int, [C.c_void_p, _f64p, C.c_int64, _f64p, C.c_int64, C.c_int32, C.POINTER(C.c_void_p)]),
     "pf_cpd_free": (None, [C.c_void_p]),
     "pf_cpd_estep": (C.c_int, [C.c_void_p, _f64p, C.c_double, C.c_double, _f64p, _f64p, _f64p]),
+    "pf_cpd_set_basis": (C.c_int, [C.c_void_p, _f64p, C.c_int32]),
+    "pf_cpd_weighted_gram": (C.c_int, [C.c_void_p, _f64p]),
     "pf_cpd_gram": (C.c_int, [C.c_void_p, _f64p, C.c_int64, _f64p, C.c_int64, C.c_int32, C.c_double, _f64p, C.c_int32, _f64p]),
 }
 
@@ -336,6 +338,19 @@ class DeviceCpd(object):
         _check(self._lib.pf_cpd_estep(self._h, _f64(TY), float(sigma2), float(w), _f64(self._P1), _f64(self._Pt1),
                                       _f64(self._PX)))
         return self._P1, self._Pt1, self._PX
+
+    def set_basis(self, Q):
+        """Keep the low-rank basis Q (M,K) on the device for `weighted_gram`."""
+        Q = _c_f64(Q)
+        if Q.ndim != 2 or Q.shape[0] != self.M:
+            raise ValueError("Q must be (%d, K)" % self.M)
+        _check(self._lib.pf_cpd_set_basis(self._h, _f64(Q), Q.shape[1]))
+        self._H = np.empty((Q.shape[1], Q.shape[1]))
+
+    def weighted_gram(self):
+        """Q^T diag(P1) Q with the P1 of the last E-step."""
+        _check(self._lib.pf_cpd_weighted_gram(self._h, _f64(self._H)))
+        return self._H
 
     def close(self):
         if getattr(self, "_h", None):

@@ -20,6 +20,7 @@ host.  Parity with cycpd itself is unpinned (absent from the build image); `test
 checks this module against a dense CPU restatement of the same algorithm.
 """
 import numpy as np
+from scipy.fft import idct
 
 from . import _hip
 
@@ -58,8 +59,9 @@ class _ExpectationMaximisation(object):
         self.Np = 0.0
 
     def register(self, callback=lambda **kwargs: None):
-        dev = _hip.DeviceCpd(self.X, self.Y, ctx=self._ctx)
+        dev = self._dev = _hip.DeviceCpd(self.X, self.Y, ctx=self._ctx)
         try:
+            self._on_device(dev)
             self.transform_point_cloud()
             while self.iteration < self.max_iterations and self.diff > self.tolerance:
                 self.P1, self.Pt1, self.PX = dev.estep(self.TY, self.sigma2, self.w)
@@ -73,8 +75,12 @@ class _ExpectationMaximisation(object):
                 if self.verbose:
                     print("CPD iteration %d: sigma2 %.3e, change %.3e" % (self.iteration, self.sigma2, self.diff))
         finally:
+            self._dev = None
             dev.close()
         return self.TY, self.get_registration_parameters()
+
+    def _on_device(self, dev):
+        pass
 
 
 class affine_registration(_ExpectationMaximisation):
@@ -116,36 +122,68 @@ class affine_registration(_ExpectationMaximisation):
         return self.B, self.t
 
 
-def low_rank_affinity(Y, beta, num_eig, ctx=None, oversample=28, max_iterations=60, rtol=1e-13, seed=0):
-    """(Q (M,K), S (K,)) with G(Y,Y) ~ Q diag(S) Q^T, K = min(num_eig, M): the leading eigenpairs of the Gaussian
-    affinity by subspace iteration with Rayleigh-Ritz on a random (K + oversample)-dimensional start, iterated
-    until the K Ritz values move by less than rtol * the largest.  The spectrum of a Gaussian kernel matrix
-    decays geometrically (2-3 applications of G suffice for wide kernels such as the reference's beta = 3 on
-    unit-sized coordinates); directions whose eigenvalue is below ~1e-15 of the largest are numerically in G's
-    null space and carry no displacement."""
+EIG_FLOOR = 1e-14  # eigenvalues of G below EIG_FLOOR * largest are rounding noise (G is positive semi-definite)
+
+
+def low_rank_affinity(Y, beta, num_eig, ctx=None, oversample=28, max_iterations=30, rtol=1e-13, seed=0):
+    """(Q (M,K'), S (K',)) with G(Y,Y) ~ Q diag(S) Q^T: the leading eigenpairs of the Gaussian affinity, at most
+    `num_eig` of them and only those above EIG_FLOOR * the largest.  Every product G @ V runs on the device.
+
+    A Rayleigh-Ritz step on a random (num_eig + oversample)-dimensional block first reveals the numerical rank.
+    * Wide kernel (the reference's default beta = 3 on unit-sized coordinates): the spectrum decays
+      geometrically and only ~15 eigenvalues exceed 1e-14 of the largest; the rest of the requested 100 are
+      numerically G's null space — they carry no displacement (their 1/S term in the Woodbury system pins
+      their coefficients to zero), so they are dropped, and subspace iteration in the span of the leading Ritz
+      vectors converges in two or three more products.
+    * Narrow kernel (rank >= num_eig): implicitly restarted Lanczos (ARPACK `eigsh`, machine-precision
+      tolerance) with the device product as its operator."""
     M = Y.shape[0]
     K = int(min(num_eig, M))
     p = int(min(M, K + oversample))
-    V = np.linalg.qr(np.random.default_rng(seed).standard_normal((M, p)))[0]
+    rng = np.random.default_rng(seed)
+    # random orthonormal block without a QR: p columns of the orthonormal DCT matrix with random row signs
+    E = np.zeros((M, p))
+    E[rng.choice(M, p, replace=False), np.arange(p)] = 1.0
+    V = idct(E, axis=0, norm="ortho") * rng.choice([-1.0, 1.0], size=M)[:, None]
     prev = None
-    for _ in range(max_iterations):
+    for it in range(max_iterations):
         GV = _hip.gaussian_gram_product(Y, Y, beta, V, ctx=ctx)
         H = V.T @ GV
         s, U = np.linalg.eigh((H + H.T) / 2)
-        idx = np.argsort(np.abs(s))[::-1][:K]
-        top = s[idx]
-        if p == M or (prev is not None and np.max(np.abs(top - prev)) <= rtol * abs(top[0])):
-            break
+        idx = np.argsort(np.abs(s))[::-1]
+        rank = int(max(1, np.count_nonzero(s[idx] > EIG_FLOOR * abs(s[idx[0]]))))
+        if V.shape[1] == M:
+            keep = min(K, rank)
+            return V @ U[:, idx[:keep]], s[idx[:keep]]
+        if it == 0 and rank >= K and rank >= V.shape[1] - 2:
+            break  # not rank-deficient within the block: Lanczos below
+        keep = min(K, rank)
+        top = s[idx[:keep]]
+        m = keep if prev is None else min(keep, len(prev))  # a value sitting on the floor may come and go
+        if prev is not None and np.max(np.abs(top[:m] - prev[:m])) <= rtol * abs(top[0]):
+            return V @ U[:, idx[:keep]], top
         prev = top
+        p_next = int(min(V.shape[1], rank + 12))
+        if p_next < V.shape[1]:  # continue in the span of the leading Ritz vectors
+            GV = GV @ U[:, idx[:p_next]]
         V = np.linalg.qr(GV)[0]
-    return V @ U[:, idx], top
+    from scipy.sparse.linalg import LinearOperator, eigsh
+
+    def product(v):
+        v = np.asarray(v, dtype=np.float64)
+        return _hip.gaussian_gram_product(Y, Y, beta, v.reshape(M, -1), ctx=ctx).reshape(v.shape)
+
+    op = LinearOperator((M, M), matvec=product, matmat=product, dtype=np.float64)
+    s, Q = eigsh(op, k=min(K, M - 1), which="LA", v0=rng.standard_normal(M), ncv=min(M, max(2 * K + 1, K + 40)))
+    order = np.argsort(s)[::-1]
+    s, Q = s[order], Q[:, order]
+    keep = int(max(1, np.count_nonzero(s > EIG_FLOOR * s[0])))
+    return Q[:, :keep], s[:keep]
 
 
 class deformable_registration(_ExpectationMaximisation):
     """TY = Y + G W with G the Gaussian affinity of Y (width beta) in the low-rank form G ~ Q S Q^T
     (`num_eig` eigenpairs; Section 6 of the CPD paper), regularisation weight alpha."""
-
-    EIG_FLOOR = 1e-15  # eigenvalues of G below EIG_FLOOR * largest are rounding noise (G is positive semi-definite)
 
     def __init__(self, alpha=None, beta=None, num_eig=100, low_rank=True, *args, **kwargs):
         super(deformable_registration, self).__init__(*args, **kwargs)
@@ -158,15 +196,18 @@ class deformable_registration(_ExpectationMaximisation):
         self.num_eig = int(num_eig)
         self.W = np.zeros((self.M, self.D))
         self.Q, self.S = low_rank_affinity(self.Y, self.beta, self.num_eig, ctx=self._ctx)
-        self.S = np.maximum(self.S, self.EIG_FLOOR * np.max(self.S))
         self.inv_S = 1.0 / self.S
+
+    def _on_device(self, dev):
+        dev.set_basis(self.Q)
 
     def update_transform(self):
         # Woodbury form of (diag(P1) G + alpha sigma2 I) W = PX - diag(P1) Y with G = Q S Q^T
         F = self.PX - self.P1[:, None] * self.Y
         dPQ = self.P1[:, None] * self.Q
         lam = self.alpha * self.sigma2
-        Z = np.linalg.solve(lam * np.diag(self.inv_S) + self.Q.T @ dPQ, self.Q.T @ F)
+        QtPQ = self._dev.weighted_gram() if getattr(self, "_dev", None) is not None else self.Q.T @ dPQ
+        Z = np.linalg.solve(lam * np.diag(self.inv_S) + QtPQ, self.Q.T @ F)
         self.W = (F - dPQ @ Z) / lam
 
     def transform_point_cloud(self, Y=None):

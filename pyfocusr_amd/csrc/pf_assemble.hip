@@ -425,6 +425,8 @@ void pf_graph_free(pf_graph* g) {
     pf_free(st, g->sval_rw);
     pf_free(st, g->sval_sym);
     pf_free(st, g->diag);
+    pf_free(st, g->mf_col);
+    pf_free(st, g->mf_val);
     pf_free(st, g->ws);
     pf_free(st, g->partials);
     pf_free(st, g->coef);

@@ -30,12 +30,18 @@ struct pf_cpd {
     double* part = nullptr; // scratch: max(chunks_m * N, chunks_n * M * (D + 1))
     double* out = nullptr;  // [N] Pt1 | [M] P1 | [M][D] PX
     int32_t chunks_m = 0, chunks_n = 0;
+    // low-rank basis of the deformable model (pf_cpd_set_basis): H = Q^T diag(P1) Q per iteration
+    double* Q = nullptr;      // [M][K]
+    double* hpart = nullptr;  // [chunks_h][K][K]
+    double* H = nullptr;      // [K][K]
+    int32_t K = 0, chunks_h = 0;
 };
 
 namespace {
 
-constexpr int CPD_TILE = 256;    // points of the walked set per LDS tile
-constexpr int CPD_CHUNK = 1024;  // points of the walked set per block (blockIdx.y)
+constexpr int CPD_TILE = 128;   // points of the walked set per LDS tile
+constexpr int CPD_CHUNK = 128;  // points of the walked set per block (blockIdx.y): 5000 x 5000 -> 20 x 40 blocks = 3200
+                                // waves; with 1024-point chunks the 400 waves left most SIMDs idle behind exp()'s latency
 constexpr int GRAM_COLS = 8;     // columns of V per thread
 
 inline unsigned nblk(int64_t n) { return (unsigned)((n + PF_BLOCK - 1) / PF_BLOCK); }
@@ -172,6 +178,37 @@ __global__ __launch_bounds__(PF_BLOCK) void k_gram(const double* __restrict__ A,
     }
 }
 
+// hpart[chunk][i][j] = sum over the chunk's m of w_m Q[m][i] Q[m][j]; 16 x 16 outputs per block
+constexpr int GRAM_TILE = 16;
+constexpr int GRAM_CHUNK = 512;
+__global__ __launch_bounds__(GRAM_TILE* GRAM_TILE) void k_weighted_gram(const double* __restrict__ Q, const double* __restrict__ w,
+                                                                         int64_t M, int32_t K, double* __restrict__ part) {
+    __shared__ double qi[GRAM_TILE][GRAM_TILE + 1], qj[GRAM_TILE][GRAM_TILE + 1];  // [m within step][column]
+    const int tx = threadIdx.x % GRAM_TILE, ty = threadIdx.x / GRAM_TILE;
+    const int i0 = blockIdx.y * GRAM_TILE, j0 = blockIdx.x * GRAM_TILE;
+    const int64_t m0 = (int64_t)blockIdx.z * GRAM_CHUNK, m1 = m0 + GRAM_CHUNK < M ? m0 + GRAM_CHUNK : M;
+    double acc = 0.0;
+    for (int64_t mb = m0; mb < m1; mb += GRAM_TILE) {
+        const int64_t m = mb + ty;  // thread (ty, tx) stages row m, columns i0 + tx and j0 + tx
+        const bool ok = m < m1;
+        __syncthreads();
+        qi[ty][tx] = (ok && i0 + tx < K) ? Q[m * K + i0 + tx] * w[m] : 0.0;
+        qj[ty][tx] = (ok && j0 + tx < K) ? Q[m * K + j0 + tx] : 0.0;
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < GRAM_TILE; ++r) acc += qi[r][ty] * qj[r][tx];
+    }
+    if (i0 + ty < K && j0 + tx < K) part[((int64_t)blockIdx.z * K + i0 + ty) * K + j0 + tx] = acc;
+}
+
+__global__ __launch_bounds__(PF_BLOCK) void k_sum_chunks(const double* __restrict__ part, int chunks, int64_t n, double* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    double s = 0.0;
+    for (int k = 0; k < chunks; ++k) s += part[(int64_t)k * n + i];
+    out[i] = s;
+}
+
 template <int D>
 int run_estep(pf_cpd* h, double inv2s, double c) {
     hipStream_t st = h->ctx->stream;
@@ -241,6 +278,9 @@ void pf_cpd_free(pf_cpd* h) {
     pf_free(st, h->den);
     pf_free(st, h->part);
     pf_free(st, h->out);
+    pf_free(st, h->Q);
+    pf_free(st, h->hpart);
+    pf_free(st, h->H);
     delete h;
 }
 
@@ -273,6 +313,40 @@ int pf_cpd_create(pf_ctx* ctx, const double* X, int64_t N, const double* Y, int6
         return PF_E_HIP;
     }
     *out = h;
+    return PF_OK;
+}
+
+int pf_cpd_set_basis(pf_cpd* h, const double* Q, int32_t K) {
+    PF_CHECK(h && Q, PF_E_ARG, "pf_cpd_set_basis: NULL argument");
+    PF_CHECK(K >= 1 && K <= 4096, PF_E_ARG, "pf_cpd_set_basis: K = %d out of range (1..4096)", K);
+    PF_HIP(hipSetDevice(h->ctx->device));
+    hipStream_t st = h->ctx->stream;
+    pf_free(st, h->Q);
+    pf_free(st, h->hpart);
+    pf_free(st, h->H);
+    h->Q = h->hpart = h->H = nullptr;
+    h->K = 0;
+    h->chunks_h = (int32_t)((h->M + GRAM_CHUNK - 1) / GRAM_CHUNK);
+    PF_HIP(pf_malloc(st, (void**)&h->Q, sizeof(double) * h->M * K));
+    PF_HIP(pf_malloc(st, (void**)&h->hpart, sizeof(double) * (size_t)h->chunks_h * K * K));
+    PF_HIP(pf_malloc(st, (void**)&h->H, sizeof(double) * (size_t)K * K));
+    PF_HIP(hipMemcpyAsync(h->Q, Q, sizeof(double) * h->M * K, hipMemcpyHostToDevice, st));
+    PF_HIP(hipStreamSynchronize(st));
+    h->K = K;
+    return PF_OK;
+}
+
+int pf_cpd_weighted_gram(pf_cpd* h, double* H) {
+    PF_CHECK(h && H, PF_E_ARG, "pf_cpd_weighted_gram: NULL argument");
+    PF_CHECK(h->K > 0, PF_E_STATE, "pf_cpd_weighted_gram: no basis (pf_cpd_set_basis) on this handle");
+    PF_HIP(hipSetDevice(h->ctx->device));
+    hipStream_t st = h->ctx->stream;
+    const unsigned tiles = (unsigned)((h->K + GRAM_TILE - 1) / GRAM_TILE);
+    k_weighted_gram<<<dim3(tiles, tiles, (unsigned)h->chunks_h), GRAM_TILE * GRAM_TILE, 0, st>>>(h->Q, h->out + h->N, h->M, h->K, h->hpart);
+    k_sum_chunks<<<nblk((int64_t)h->K * h->K), PF_BLOCK, 0, st>>>(h->hpart, h->chunks_h, (int64_t)h->K * h->K, h->H);
+    PF_HIP(hipGetLastError());
+    PF_HIP(hipMemcpyAsync(H, h->H, sizeof(double) * (size_t)h->K * h->K, hipMemcpyDeviceToHost, st));
+    PF_HIP(hipStreamSynchronize(st));
     return PF_OK;
 }
 

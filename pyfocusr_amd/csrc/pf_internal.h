@@ -111,6 +111,10 @@ struct pf_graph {
     double* sval_rw = nullptr;    // -g_i W_ij
     double* sval_sym = nullptr;   // -W_ij sqrt(g_i g_j)   (only when symmetric)
     double* diag = nullptr;       // deg_i g_i  (both operators)
+    // mean-filter operator (pf_mean_filter, built on first use): rows of (D+I)^-1 (W+I) in solver order, SELL-64
+    // with slice s at slice_ptr[s] + 64 s and width + 1 entries per row, in DESCENDING mesh column order
+    int32_t* mf_col = nullptr;    // [sell_entries + n_pad]
+    double* mf_val = nullptr;
     int32_t is_symmetric = 0, n_isolated = 0, n_components = 0, max_degree = 0, n_oneway = 0;
     std::vector<int32_t> roots; // roots of components with >= 2 vertices, ascending
     // workspace: n_slots vectors + 2 Chebyshev temporaries, stride n_pad

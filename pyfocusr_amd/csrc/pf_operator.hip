@@ -365,30 +365,107 @@ __global__ __launch_bounds__(PF_BLOCK) void k_vec_apply(const double* __restrict
     }
 }
 
-// out = (W x + x) * dinv1   per column; values row-major n x ncols   (graph.py:349-353)
-__global__ __launch_bounds__(PF_BLOCK) void k_mean_filter(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
-                                                          const double* __restrict__ w, const double* __restrict__ deg,
-                                                          int64_t n, int32_t ncols, const double* __restrict__ in,
-                                                          double* __restrict__ out) {
-    const int64_t i = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
-    if (i >= n) return;
-    const double dinv = 1.0 / (1.0 + deg[i]);
-    for (int c = 0; c < ncols; ++c) {
-        // scipy: average_mat = D_inv @ (W + I) is a sparse-sparse product whose rows come out in
-        // DESCENDING column order (SMMP linked list); average_mat @ v then sums in that order.
-        double acc = 0.0;
+// Mean filter (graph.py:349-353): out = ((D+I)^-1 (W+I)) in, applied `iterations` times to an n x ncols array.
+// scipy forms average_mat = D_inv @ (W + I) as a sparse-sparse product whose rows come out in DESCENDING column
+// order (SMMP linked list), and average_mat @ v then sums in that order with the products (dinv*w)*v.  The same
+// terms in the same order are kept here, but rows and gathers live in the solver's Morton/degree order (SELL-64,
+// coalesced entry loads, neighbours close in memory) instead of the mesh's own vertex order.
+__global__ __launch_bounds__(PF_BLOCK) void k_fill_mean_filter(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                               const double* __restrict__ w, const double* __restrict__ deg,
+                                                               const int32_t* __restrict__ perm, const int32_t* __restrict__ iperm,
+                                                               int64_t n_pad, const int64_t* __restrict__ slice_ptr,
+                                                               int32_t* __restrict__ mf_col, double* __restrict__ mf_val) {
+    const int64_t row = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
+    if (row >= n_pad) return;
+    const int64_t s = row / PF_WAVE;
+    const int lane = (int)(row & (PF_WAVE - 1));
+    const int32_t width = (int32_t)((slice_ptr[s + 1] - slice_ptr[s]) / PF_WAVE) + 1;
+    const int64_t base = slice_ptr[s] + (int64_t)PF_WAVE * s;
+    const int32_t i = perm[row];
+    int32_t e = 0;
+    if (i >= 0) {
+        const double dinv = 1.0 / (1.0 + deg[i]);
         bool diag_done = false;
         for (int32_t a = rowptr[i + 1] - 1; a >= rowptr[i]; --a) {
             const int32_t j = col[a];
-            if (!diag_done && j < (int32_t)i) {
-                acc += dinv * in[i * ncols + c];
+            if (!diag_done && j < i) {
+                mf_col[base + (int64_t)PF_WAVE * e + lane] = (int32_t)row;
+                mf_val[base + (int64_t)PF_WAVE * e + lane] = dinv;
+                ++e;
                 diag_done = true;
             }
-            acc += (dinv * w[a]) * in[(int64_t)j * ncols + c];
+            mf_col[base + (int64_t)PF_WAVE * e + lane] = iperm[j];
+            mf_val[base + (int64_t)PF_WAVE * e + lane] = dinv * w[a];
+            ++e;
         }
-        if (!diag_done) acc += dinv * in[i * ncols + c];
-        out[i * ncols + c] = acc;
+        if (!diag_done) {
+            mf_col[base + (int64_t)PF_WAVE * e + lane] = (int32_t)row;
+            mf_val[base + (int64_t)PF_WAVE * e + lane] = dinv;
+            ++e;
+        }
     }
+    for (; e < width; ++e) {  // padding: 0 * own value
+        mf_col[base + (int64_t)PF_WAVE * e + lane] = (int32_t)row;
+        mf_val[base + (int64_t)PF_WAVE * e + lane] = 0.0;
+    }
+}
+
+// NC > 0: compile-time column count; NC == 0: run-time ncols (one pass over the entries per column)
+template <int NC>
+__global__ __launch_bounds__(PF_BLOCK) void k_mean_filter(const int64_t* __restrict__ slice_ptr, const int32_t* __restrict__ mf_col,
+                                                          const double* __restrict__ mf_val, const int32_t* __restrict__ perm,
+                                                          int64_t n_pad, int32_t ncols, const double* __restrict__ in,
+                                                          double* __restrict__ out) {
+    const int64_t row = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
+    if (row >= n_pad) return;
+    const int64_t s = row / PF_WAVE;
+    const int lane = (int)(row & (PF_WAVE - 1));
+    const int32_t width = (int32_t)((slice_ptr[s + 1] - slice_ptr[s]) / PF_WAVE) + 1;
+    const int64_t base = slice_ptr[s] + (int64_t)PF_WAVE * s + lane;
+    const bool real = perm[row] >= 0;
+    if constexpr (NC > 0) {
+        double acc[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) acc[c] = 0.0;
+        for (int32_t e = 0; e < width; ++e) {
+            const int64_t j = mf_col[base + (int64_t)PF_WAVE * e];
+            const double v = mf_val[base + (int64_t)PF_WAVE * e];
+            // padding entries (0 * own value) must not touch the sum: 0 * inf or -0.0 would change bits
+            if (v != 0.0 || j != row) {
+#pragma unroll
+                for (int c = 0; c < NC; ++c) acc[c] += v * in[j * NC + c];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < NC; ++c) out[row * NC + c] = real ? acc[c] : 0.0;
+    } else {
+        for (int32_t c = 0; c < ncols; ++c) {
+            double acc = 0.0;
+            for (int32_t e = 0; e < width; ++e) {
+                const double v = mf_val[base + (int64_t)PF_WAVE * e];
+                const int64_t j = mf_col[base + (int64_t)PF_WAVE * e];
+                if (v != 0.0 || j != row) acc += v * in[j * ncols + c];
+            }
+            out[row * ncols + c] = real ? acc : 0.0;
+        }
+    }
+}
+
+// rows between mesh order [n][ncols] and solver order [n_pad][ncols]
+__global__ __launch_bounds__(PF_BLOCK) void k_rows_in(const double* __restrict__ src, const int32_t* __restrict__ perm, int64_t n_pad,
+                                                      int32_t ncols, double* __restrict__ dst) {
+    const int64_t t = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
+    if (t >= n_pad * ncols) return;
+    const int64_t row = t / ncols;
+    const int32_t old = perm[row];
+    dst[t] = old >= 0 ? src[(int64_t)old * ncols + (t - row * ncols)] : 0.0;
+}
+__global__ __launch_bounds__(PF_BLOCK) void k_rows_out(const double* __restrict__ src, const int32_t* __restrict__ iperm, int64_t n,
+                                                       int32_t ncols, double* __restrict__ dst) {
+    const int64_t t = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
+    if (t >= n * ncols) return;
+    const int64_t old = t / ncols;
+    dst[t] = src[(int64_t)iperm[old] * ncols + (t - old * ncols)];
 }
 
 int stage_ensure(pf_graph* g, int64_t elems) {
@@ -858,18 +935,34 @@ int pf_mean_filter(pf_graph* g, const double* values, int32_t ncols, int32_t ite
              "pf_mean_filter: bad argument");
     PF_HIP(hipSetDevice(g->ctx->device));
     hipStream_t st = g->ctx->stream;
-    const size_t bytes = sizeof(double) * (size_t)g->n * ncols;
-    double *a = nullptr, *b = nullptr;
-    PF_HIP(pf_malloc(st, (void**)&a, bytes));
-    hipError_t e = pf_malloc(st, (void**)&b, bytes);
-    if (e == hipSuccess) e = hipMemcpyAsync(a, values, bytes, hipMemcpyHostToDevice, st);
-    for (int32_t it = 0; it < iterations && e == hipSuccess; ++it) {
-        k_mean_filter<<<nblk(g->n), PF_BLOCK, 0, st>>>(g->rowptr, g->col, g->w, g->deg, g->n, ncols, a, b);
-        e = hipGetLastError();
-        std::swap(a, b);
+    if (!g->mf_col) {  // first use: the filter's rows in solver order
+        const size_t entries = (size_t)(g->sell_entries + g->n_pad);
+        PF_HIP(pf_malloc(st, (void**)&g->mf_col, sizeof(int32_t) * entries));
+        PF_HIP(pf_malloc(st, (void**)&g->mf_val, sizeof(double) * entries));
+        k_fill_mean_filter<<<nblk(g->n_pad), PF_BLOCK, 0, st>>>(g->rowptr, g->col, g->w, g->deg, g->perm, g->iperm, g->n_pad,
+                                                                g->slice_ptr, g->mf_col, g->mf_val);
+        PF_HIP(hipGetLastError());
     }
-    if (e == hipSuccess) e = hipMemcpyAsync(out, a, bytes, hipMemcpyDeviceToHost, st);
+    const size_t bytes_mesh = sizeof(double) * (size_t)g->n * ncols, bytes_pad = sizeof(double) * (size_t)g->n_pad * ncols;
+    double *m = nullptr, *a = nullptr, *b = nullptr;
+    PF_HIP(pf_malloc(st, (void**)&m, bytes_mesh));
+    hipError_t e = pf_malloc(st, (void**)&a, bytes_pad);
+    if (e == hipSuccess) e = pf_malloc(st, (void**)&b, bytes_pad);
+    if (e == hipSuccess) e = hipMemcpyAsync(m, values, bytes_mesh, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) {
+        k_rows_in<<<nblk(g->n_pad * ncols), PF_BLOCK, 0, st>>>(m, g->perm, g->n_pad, ncols, a);
+        for (int32_t it = 0; it < iterations; ++it) {
+            if (ncols == 3) k_mean_filter<3><<<nblk(g->n_pad), PF_BLOCK, 0, st>>>(g->slice_ptr, g->mf_col, g->mf_val, g->perm, g->n_pad, ncols, a, b);
+            else if (ncols == 1) k_mean_filter<1><<<nblk(g->n_pad), PF_BLOCK, 0, st>>>(g->slice_ptr, g->mf_col, g->mf_val, g->perm, g->n_pad, ncols, a, b);
+            else k_mean_filter<0><<<nblk(g->n_pad), PF_BLOCK, 0, st>>>(g->slice_ptr, g->mf_col, g->mf_val, g->perm, g->n_pad, ncols, a, b);
+            std::swap(a, b);
+        }
+        k_rows_out<<<nblk(g->n * ncols), PF_BLOCK, 0, st>>>(a, g->iperm, g->n, ncols, m);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out, m, bytes_mesh, hipMemcpyDeviceToHost, st);
     hipError_t e2 = hipStreamSynchronize(st);
+    pf_free(st, m);
     pf_free(st, a);
     pf_free(st, b);
     PF_HIP(e);

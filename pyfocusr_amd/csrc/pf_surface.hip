@@ -6,13 +6,18 @@
 // point-triangle distance (ties: lowest triangle index), the same as a brute-force scan.  Pruning
 // only removes triangles that provably cannot win:
 //   build   triangles (polygons fan-triangulated) are sorted along a Morton curve of their centroids
-//           (hipCUB radix sort) and cut into chunks of 256 consecutive ones, each with its bounding box;
+//           (hipCUB radix sort) and cut into chunks of 64 consecutive ones, each with its bounding box;
 //           coordinates are stored SoA so that a wave reads 64 consecutive triangles coalesced.
-//   query   ONE WAVE PER QUERY POINT.  (1) every lane measures the point-box distance of its share of
-//           the chunks; the nearest chunk is scanned first and yields an upper bound.  (2) the chunks
-//           whose box is not farther than the bound (64 box tests per ballot) are scanned, 4 triangles
-//           per lane, the bound shrinking after each.  A landmark near the surface touches ~5-10 of the
-//           ~2000 chunks of a 500k-triangle mesh.
+//           64 consecutive chunks form a super-chunk with its own box (two levels are enough: 500k
+//           triangles = 7813 chunks = 123 super-chunks, two per lane).
+//   query   ONE BLOCK (4 waves) PER QUERY POINT.  (1) the nearest super-chunk, then the nearest chunk inside it, by
+//           point-box distance (one box per lane); that chunk is scanned first and yields an upper bound.
+//           (2) one ballot over the super-chunk boxes, then per surviving super-chunk one ballot over its
+//           64 chunk boxes; the surviving chunks are dealt round-robin to the 4 waves, which scan them one
+//           triangle per lane, 4 chunks per step (loads issued together), re-deriving the bound after
+//           every step.  Measured on a 250k pair: 41 chunk scans per landmark on average but 420 for the
+//           farthest one, and the kernel lasts as long as its slowest query — hence 4 waves x 4 chunks
+//           per step on that chain of dependent loads.
 // The arithmetic of closest_on_triangle is Ericson's region walk, operation for operation the one in
 // oracle/icp_port.py (compiled with -ffp-contract=off), so points and distances are bit-identical to it.
 #include <hipcub/hipcub.hpp>
@@ -29,11 +34,13 @@ struct pf_surface {
     double* tri = nullptr;       // SoA [9][n_tri]: ax ay az bx by bz cx cy cz, Morton order
     int32_t* tri_orig = nullptr; // [n_tri] sorted position -> triangle index (face * (vpf-2) + fan position)
     double* box = nullptr;       // [n_chunks][6] lo xyz, hi xyz
+    double* sbox = nullptr;      // [n_super][6] boxes of 64 consecutive chunks
+    int64_t n_super = 0;
 };
 
 namespace {
 
-constexpr int PF_TRI_CHUNK = 256;
+constexpr int PF_TRI_CHUNK = 64;  // one triangle per lane and scan
 
 inline unsigned nblk(int64_t n) { return (unsigned)((n + PF_BLOCK - 1) / PF_BLOCK); }
 
@@ -121,6 +128,24 @@ __global__ __launch_bounds__(PF_WAVE) void k_chunk_boxes(const double* __restric
     }
 }
 
+// one wave per super-chunk: union of its 64 chunk boxes
+__global__ __launch_bounds__(PF_WAVE) void k_super_boxes(const double* __restrict__ box, int64_t n_chunks, double* __restrict__ sbox) {
+    const int64_t c = (int64_t)blockIdx.x * PF_WAVE + threadIdx.x;
+    const double inf = std::numeric_limits<double>::infinity();
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        double lo = c < n_chunks ? box[6 * c + a] : inf, hi = c < n_chunks ? box[6 * c + 3 + a] : -inf;
+        for (int off = PF_WAVE / 2; off > 0; off >>= 1) {
+            lo = fmin(lo, __shfl_xor(lo, off, PF_WAVE));
+            hi = fmax(hi, __shfl_xor(hi, off, PF_WAVE));
+        }
+        if (threadIdx.x == 0) {
+            sbox[6 * (int64_t)blockIdx.x + a] = lo;
+            sbox[6 * (int64_t)blockIdx.x + 3 + a] = hi;
+        }
+    }
+}
+
 __device__ __forceinline__ double dot3(const double a[3], const double b[3]) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
 
 // Ericson, Real-Time Collision Detection 5.1.5; same operation order as oracle/icp_port.py.
@@ -198,24 +223,32 @@ __device__ __forceinline__ bool better(double d2, int32_t orig, double bd2, int3
     return d2 < bd2 || (d2 == bd2 && orig < borig);
 }
 
-__device__ __forceinline__ void scan_chunk(const double* __restrict__ tri, const int32_t* __restrict__ tri_orig, int64_t n_tri,
-                                           int64_t c, int lane, const double p[3], Best& best) {
-    const int64_t end = (c + 1) * PF_TRI_CHUNK < n_tri ? (c + 1) * PF_TRI_CHUNK : n_tri;
-    for (int64_t s = c * PF_TRI_CHUNK + lane; s < end; s += PF_WAVE) {
-        double a[3], b[3], cc[3], q[3];
+// One triangle per lane from each of NB chunks: all loads are issued before the arithmetic, so the NB memory
+// latencies overlap (the kernel is latency-bound: few waves, dependent loads).  Slots past the end of the mesh or
+// repeated chunk indices re-evaluate a triangle that is already accounted for, which changes nothing.
+template <int NB>
+__device__ __forceinline__ void scan_chunks(const double* __restrict__ tri, const int32_t* __restrict__ tri_orig, int64_t n_tri,
+                                            const int64_t (&chunk)[NB], int lane, const double p[3], Best& best) {
+    double v[NB][9];
+    int32_t orig[NB];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            a[k] = tri[(int64_t)k * n_tri + s];
-            b[k] = tri[(int64_t)(3 + k) * n_tri + s];
-            cc[k] = tri[(int64_t)(6 + k) * n_tri + s];
-        }
-        closest_on_triangle(p, a, b, cc, q);
+    for (int b = 0; b < NB; ++b) {
+        int64_t s = chunk[b] * PF_TRI_CHUNK + lane;
+        s = s < n_tri ? s : n_tri - 1;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) v[b][k] = tri[(int64_t)k * n_tri + s];
+        orig[b] = tri_orig[s];
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const double a[3] = {v[b][0], v[b][1], v[b][2]}, bb[3] = {v[b][3], v[b][4], v[b][5]}, cc[3] = {v[b][6], v[b][7], v[b][8]};
+        double q[3];
+        closest_on_triangle(p, a, bb, cc, q);
         const double dx = p[0] - q[0], dy = p[1] - q[1], dz = p[2] - q[2];
         const double d2 = dx * dx + dy * dy + dz * dz;
-        const int32_t orig = tri_orig[s];
-        if (better(d2, orig, best.d2, best.orig)) {  // NaN distances compare false: never win
+        if (better(d2, orig[b], best.d2, best.orig)) {  // NaN distances compare false: never win
             best.d2 = d2;
-            best.orig = orig;
+            best.orig = orig[b];
             best.pt[0] = q[0], best.pt[1] = q[1], best.pt[2] = q[2];
         }
     }
@@ -228,51 +261,84 @@ __device__ __forceinline__ double wave_min(double v) {
 
 constexpr double PF_BOX_SLACK = 1.0 + 1e-9;  // the box test must never reject on a rounding error
 
+// one block (4 waves) per query point
 __global__ __launch_bounds__(PF_BLOCK) void k_closest(const double* __restrict__ tri, const int32_t* __restrict__ tri_orig,
-                                                      const double* __restrict__ box, int64_t n_tri, int64_t n_chunks,
+                                                      const double* __restrict__ box, const double* __restrict__ sbox,
+                                                      int64_t n_tri, int64_t n_chunks, int64_t n_super,
                                                       const double* __restrict__ qry, int64_t n_qry, int32_t per_face,
                                                       double* __restrict__ out_pt, int32_t* __restrict__ out_face,
                                                       double* __restrict__ out_d2) {
-    const int lane = threadIdx.x & (PF_WAVE - 1);
-    const int64_t qi = (int64_t)blockIdx.x * (PF_BLOCK / PF_WAVE) + (threadIdx.x >> 6);
-    if (qi >= n_qry) return;  // whole wave
+    constexpr int NW = PF_BLOCK / PF_WAVE;
+    constexpr int NB = 4;  // chunks scanned per step of a wave
+    __shared__ double w_d2[NW], w_pt[NW][3];
+    __shared__ int32_t w_orig[NW];
+    const int lane = threadIdx.x & (PF_WAVE - 1), wave = threadIdx.x >> 6;
+    const int64_t qi = blockIdx.x;
     const double p[3] = {qry[3 * qi], qry[3 * qi + 1], qry[3 * qi + 2]};
     const double inf = std::numeric_limits<double>::infinity();
 
-    // (1) nearest chunk by box distance
+    // (1) nearest super-chunk, nearest chunk inside it (by box distance; lowest index on ties) — every wave, same result
+    auto wave_argmin = [&](double& d, int64_t& i) {
+        for (int off = PF_WAVE / 2; off > 0; off >>= 1) {
+            const double od = __shfl_xor(d, off, PF_WAVE);
+            const int64_t oi = __shfl_xor(i, off, PF_WAVE);
+            if (od < d || (od == d && oi < i)) d = od, i = oi;
+        }
+    };
     double nd = inf;
-    int64_t nc = n_chunks;  // sentinel: none
-    for (int64_t c = lane; c < n_chunks; c += PF_WAVE) {
-        const double d = box_dist2(p, box + 6 * c);
-        if (d < nd) nd = d, nc = c;
+    int64_t ns = n_super;  // sentinel: none
+    for (int64_t s = lane; s < n_super; s += PF_WAVE) {
+        const double d = box_dist2(p, sbox + 6 * s);
+        if (d < nd) nd = d, ns = s;
     }
-    for (int off = PF_WAVE / 2; off > 0; off >>= 1) {
-        const double od = __shfl_xor(nd, off, PF_WAVE);
-        const int64_t oc = __shfl_xor(nc, off, PF_WAVE);
-        if (od < nd || (od == nd && oc < nc)) nd = od, nc = oc;
+    wave_argmin(nd, ns);
+    int64_t c0 = n_chunks;
+    if (ns < n_super) {
+        c0 = ns * PF_WAVE + lane;
+        nd = c0 < n_chunks ? box_dist2(p, box + 6 * c0) : inf;
+        if (!(nd < inf)) c0 = n_chunks;
+        wave_argmin(nd, c0);
     }
     Best best;
     best.d2 = inf, best.orig = 0x7fffffff, best.pt[0] = best.pt[1] = best.pt[2] = 0.0;
-    const int64_t c0 = nc;
-    if (c0 < n_chunks) scan_chunk(tri, tri_orig, n_tri, c0, lane, p, best);
+    if (c0 < n_chunks) {
+        const int64_t one[1] = {c0};
+        scan_chunks<1>(tri, tri_orig, n_tri, one, lane, p, best);
+    }
     double bound = wave_min(best.d2);
 
-    // (2) every chunk whose box is within the bound
-    for (int64_t base = 0; base < n_chunks; base += PF_WAVE) {
-        const int64_t c = base + lane;
-        const bool pass = c < n_chunks && c != c0 && box_dist2(p, box + 6 * c) <= bound * PF_BOX_SLACK;
-        unsigned long long mask = __ballot(pass);
-        while (mask) {
-            const int bit = __ffsll((long long)mask) - 1;
-            mask &= mask - 1;
-            const int64_t cc = base + bit;
-            if (box_dist2(p, box + 6 * cc) > bound * PF_BOX_SLACK) continue;  // the bound has shrunk since the ballot
-            scan_chunk(tri, tri_orig, n_tri, cc, lane, p, best);
-            bound = wave_min(best.d2);
+    // (2) every chunk whose box is within the bound, super-chunk by super-chunk; of a super-chunk's surviving
+    // chunks, wave w takes those at positions w, w+4, ... and scans NB of them per step
+    const unsigned long long mine = 0x1111111111111111ull << wave;
+    for (int64_t sb = 0; sb < n_super; sb += PF_WAVE) {
+        const int64_t s = sb + lane;
+        unsigned long long smask = __ballot(s < n_super && box_dist2(p, sbox + 6 * s) <= bound * PF_BOX_SLACK);
+        while (smask) {
+            const int64_t ss = sb + __ffsll((long long)smask) - 1;
+            smask &= smask - 1;
+            if (box_dist2(p, sbox + 6 * ss) > bound * PF_BOX_SLACK) continue;  // the bound has shrunk since the ballot
+            const int64_t c = ss * PF_WAVE + lane;
+            unsigned long long mask = __ballot(c < n_chunks && c != c0 && box_dist2(p, box + 6 * c) <= bound * PF_BOX_SLACK) & mine;
+            while (mask) {
+                int64_t batch[NB];
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    if (mask) {
+                        batch[b] = ss * PF_WAVE + __ffsll((long long)mask) - 1;
+                        mask &= mask - 1;
+                    } else {
+                        batch[b] = batch[0];
+                    }
+                }
+                scan_chunks<NB>(tri, tri_orig, n_tri, batch, lane, p, best);
+                bound = wave_min(best.d2);
+                // drop the remaining chunks the tighter bound excludes (one box per lane, as in the ballot above)
+                mask &= __ballot(c < n_chunks && box_dist2(p, box + 6 * c) <= bound * PF_BOX_SLACK);
+            }
         }
     }
 
-    // winner: smallest distance, lowest triangle index
+    // winner of the wave, then of the block: smallest distance, lowest triangle index
     double wd = best.d2;
     int32_t wo = best.orig;
     for (int off = PF_WAVE / 2; off > 0; off >>= 1) {
@@ -280,14 +346,24 @@ __global__ __launch_bounds__(PF_BLOCK) void k_closest(const double* __restrict__
         const int32_t oo = __shfl_xor(wo, off, PF_WAVE);
         if (better(od, oo, wd, wo)) wd = od, wo = oo;
     }
-    if (best.orig == wo && best.d2 == wd && wo != 0x7fffffff) {  // exactly one lane holds (wd, wo)
-        out_pt[3 * qi] = best.pt[0], out_pt[3 * qi + 1] = best.pt[1], out_pt[3 * qi + 2] = best.pt[2];
-        out_face[qi] = wo / per_face;
-        out_d2[qi] = wd;
-    } else if (wo == 0x7fffffff && lane == 0) {  // NaN query or no finite triangle
-        out_pt[3 * qi] = out_pt[3 * qi + 1] = out_pt[3 * qi + 2] = __longlong_as_double(0x7ff8000000000000ll);
-        out_face[qi] = -1;
-        out_d2[qi] = inf;
+    if (lane == 0) w_d2[wave] = wd, w_orig[wave] = wo;
+    if (best.orig == wo && best.d2 == wd && wo != 0x7fffffff) {  // the lane(s) holding (wd, wo) hold the same point
+        w_pt[wave][0] = best.pt[0], w_pt[wave][1] = best.pt[1], w_pt[wave][2] = best.pt[2];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int win = 0;
+        for (int w = 1; w < NW; ++w)
+            if (better(w_d2[w], w_orig[w], w_d2[win], w_orig[win])) win = w;
+        if (w_orig[win] != 0x7fffffff) {
+            out_pt[3 * qi] = w_pt[win][0], out_pt[3 * qi + 1] = w_pt[win][1], out_pt[3 * qi + 2] = w_pt[win][2];
+            out_face[qi] = w_orig[win] / per_face;
+            out_d2[qi] = w_d2[win];
+        } else {  // NaN query or no finite triangle
+            out_pt[3 * qi] = out_pt[3 * qi + 1] = out_pt[3 * qi + 2] = __longlong_as_double(0x7ff8000000000000ll);
+            out_face[qi] = -1;
+            out_d2[qi] = inf;
+        }
     }
 }
 
@@ -303,6 +379,7 @@ void pf_surface_free(pf_surface* s) {
     pf_free(st, s->tri);
     pf_free(st, s->tri_orig);
     pf_free(st, s->box);
+    pf_free(st, s->sbox);
     delete s;
 }
 
@@ -334,6 +411,7 @@ int pf_surface_create(pf_ctx* ctx, const double* pts, int64_t n, const int32_t* 
     s->n_points = n, s->n_faces = n_faces, s->vpf = vpf;
     s->n_tri = n_faces * (vpf - 2);
     s->n_chunks = (s->n_tri + PF_TRI_CHUNK - 1) / PF_TRI_CHUNK;
+    s->n_super = (s->n_chunks + PF_WAVE - 1) / PF_WAVE;
     const int64_t T = s->n_tri;
     double* d_pts = nullptr;
     int32_t* d_faces = nullptr;
@@ -352,6 +430,7 @@ int pf_surface_create(pf_ctx* ctx, const double* pts, int64_t n, const int32_t* 
         if ((e = pf_malloc(st, (void**)&s->tri, sizeof(double) * 9 * T)) != hipSuccess) break;
         if ((e = pf_malloc(st, (void**)&s->tri_orig, sizeof(int32_t) * T)) != hipSuccess) break;
         if ((e = pf_malloc(st, (void**)&s->box, sizeof(double) * 6 * s->n_chunks)) != hipSuccess) break;
+        if ((e = pf_malloc(st, (void**)&s->sbox, sizeof(double) * 6 * s->n_super)) != hipSuccess) break;
         if ((e = hipMemcpyAsync(d_pts, pts, sizeof(double) * 3 * n, hipMemcpyHostToDevice, st)) != hipSuccess) break;
         if ((e = hipMemcpyAsync(d_faces, faces, sizeof(int32_t) * n_faces * vpf, hipMemcpyHostToDevice, st)) != hipSuccess) break;
         k_tri_keys<<<nblk(T), PF_BLOCK, 0, st>>>(d_pts, d_faces, vpf, T, bb, k0, v0);
@@ -361,6 +440,7 @@ int pf_surface_create(pf_ctx* ctx, const double* pts, int64_t n, const int32_t* 
         if ((e = hipcub::DeviceRadixSort::SortPairs(tmp, need, k0, k1, v0, v1, (int)T, 0, 30, st)) != hipSuccess) break;
         k_tri_gather<<<nblk(T), PF_BLOCK, 0, st>>>(d_pts, d_faces, vpf, T, v1, s->tri, s->tri_orig);
         k_chunk_boxes<<<(unsigned)s->n_chunks, PF_WAVE, 0, st>>>(s->tri, T, s->box);
+        k_super_boxes<<<(unsigned)s->n_super, PF_WAVE, 0, st>>>(s->box, s->n_chunks, s->sbox);
         if ((e = hipGetLastError()) != hipSuccess) break;
         e = hipStreamSynchronize(st);  // the host arrays may go away after the call
     } while (0);
@@ -395,9 +475,8 @@ int pf_surface_closest(pf_surface* s, const double* qry, int64_t n_qry, double* 
         if ((e = pf_malloc(st, (void**)&d_d2, sizeof(double) * n_qry)) != hipSuccess) break;
         if ((e = pf_malloc(st, (void**)&d_face, sizeof(int32_t) * n_qry)) != hipSuccess) break;
         if ((e = hipMemcpyAsync(d_q, qry, sizeof(double) * 3 * n_qry, hipMemcpyHostToDevice, st)) != hipSuccess) break;
-        const unsigned blocks = (unsigned)((n_qry + PF_BLOCK / PF_WAVE - 1) / (PF_BLOCK / PF_WAVE));
-        k_closest<<<blocks, PF_BLOCK, 0, st>>>(s->tri, s->tri_orig, s->box, s->n_tri, s->n_chunks, d_q, n_qry, s->vpf - 2, d_pt,
-                                               d_face, d_d2);
+        k_closest<<<(unsigned)n_qry, PF_BLOCK, 0, st>>>(s->tri, s->tri_orig, s->box, s->sbox, s->n_tri, s->n_chunks, s->n_super, d_q, n_qry,
+                                               s->vpf - 2, d_pt, d_face, d_d2);
         if ((e = hipGetLastError()) != hipSuccess) break;
         if (out_pts && (e = hipMemcpyAsync(out_pts, d_pt, sizeof(double) * 3 * n_qry, hipMemcpyDeviceToHost, st)) != hipSuccess) break;
         if (out_face && (e = hipMemcpyAsync(out_face, d_face, sizeof(int32_t) * n_qry, hipMemcpyDeviceToHost, st)) != hipSuccess) break;
