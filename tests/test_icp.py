@@ -131,13 +131,14 @@ def test_closest_points_quads_degenerate_and_nan(ctx):
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", ["rigid", "similarity"])
 def test_icp_equals_oracle_loop(golden, ctx, mode):
-    """The reference's configuration (100 iterations, 1000 landmarks, centroid start) on the 5k pair."""
+    """The reference's configuration (1000 landmarks, centroid start, no mean-distance test) on the 5k pair; 30
+    instead of 100 iterations keep the brute-force CPU side of the comparison under a minute."""
     from pyfocusr_amd import icp
 
     gt, gs = golden("target_mesh"), golden("source_mesh")
-    got = icp.icp_transform(gt["points"], gt["faces"], gs["points"], transform_mode=mode, ctx=ctx)
-    want = icp_port.icp(gt["points"], gt["faces"], gs["points"], mode=mode)
-    assert got.n_iterations == 100 and got.n_landmarks == 1000
+    got = icp.icp_transform(gt["points"], gt["faces"], gs["points"], numberOfIterations=30, transform_mode=mode, ctx=ctx)
+    want = icp_port.icp(gt["points"], gt["faces"], gs["points"], n_iterations=30, mode=mode)
+    assert got.n_iterations == 30 and got.n_landmarks == 1000
     np.testing.assert_allclose(got.matrix, want, rtol=0, atol=1e-12)
     R = got.matrix[:3, :3]
     scale = np.cbrt(np.linalg.det(R))
