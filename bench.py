@@ -321,6 +321,10 @@ def main():
             "breakdown_ms_per_step": {key: 1e3 * timers[key] / args.steps
                                       for key in ("assembly", "eigensolve", "eigsort", "knn")},
             "matvecs_per_step": timers["matvecs"] / args.steps,
+            # eigenpairs/s of the eigensolve alone (Laplacian on the device -> normalised eigenpairs in
+            # host memory), and the algorithmic bytes the operator kernel moved per step (sum over its launches)
+            "eigensolve_only_eigenpairs_per_s": 2 * args.k * world / (timers["eigensolve"] / args.steps),
+            "operator_algorithmic_bytes_per_step": tm["op_bytes"] / args.steps,
             "knn_kernel_ms": tm["knn_ms"],
             "max_eig_residual": float(max_res),
             "roofline": {"bound": "hbm", "kernel": "k_sell_op2/k_sell_op (fused SpMV + Chebyshev recurrence, SELL-64, f64; both graphs of the pair per launch)",

@@ -18,7 +18,7 @@ behind `get_smoothed_correspondences` (focusr.py:368-396) and the 3-NN query of
   target_coords, kind) -> new_target_coords` if given, else the third-party
   `cycpd` when importable (what the reference calls), else `pyfocusr_amd/cpd.py`
   (same algorithm, E-step and affinity products on the device);
-* Hungarian point correspondence (:340-349, O(N^3)) is not implemented.
+* Hungarian point correspondence (:340-349): scipy on the host, as in the reference.
 """
 import numpy as np
 
@@ -117,11 +117,8 @@ class Focusr(object):
         self.return_transformed_mesh = return_transformed_mesh
 
         for kind in (initial_correspondence_type, final_correspondence_type):
-            if kind == "hungarian":
-                raise NotImplementedError("Hungarian point correspondence (focusr.py:340-349) is O(N^3) on the host "
-                                          "and outside the MI355X hot path; use 'kd'")
-            if kind != "kd":
-                raise ValueError("correspondence type must be 'kd'")
+            if kind not in ("kd", "hungarian"):
+                raise ValueError("correspondence type must be 'kd' or 'hungarian'")
 
         print("Starting ICP")
         self._icp_transform = None
@@ -228,18 +225,38 @@ class Focusr(object):
         """focusr.py:351-353: nearest target point of every source point, on the GPU."""
         self.corresponding_target_idx_for_each_source_pt = self._ctx.knn1(target_pts, spectral_pts)
 
+    def get_hungarian_correspondence(self, target_pts, spectral_pts):
+        """focusr.py:340-349: optimal one-to-one assignment on the dense distance matrix — scipy on the host
+        exactly as the reference issues it (O(N^2) memory, O(N^3) time: small meshes only)."""
+        from scipy.optimize import linear_sum_assignment
+        from scipy.spatial.distance import cdist
+
+        _, target_idx = linear_sum_assignment(cdist(spectral_pts, target_pts))
+        self.corresponding_target_idx_for_each_source_pt = target_idx
+
     def get_initial_correspondences(self):
         """focusr.py:355-366."""
-        self.get_kd_correspondence(self.target_spectral_coords, self.source_spectral_coords)
+        if self.initial_correspondence_type == "hungarian":
+            self.get_hungarian_correspondence(self.target_spectral_coords, self.source_spectral_coords)
+        else:
+            self.get_kd_correspondence(self.target_spectral_coords, self.source_spectral_coords)
 
     def get_smoothed_correspondences(self):
         """focusr.py:368-396 (mean filters and the second NN query on the device)."""
         self.smoothed_target_coords = self.graph_target.mean_filter_graph(
             self.graph_target.points, iterations=self.graph_smoothing_iterations)
+        if (self.smoothed_target_coords.shape[0] != self.graph_source.n_points) & (
+                self.initial_correspondence_type == "hungarian"):  # focusr.py:377-385
+            raise Exception(
+                "If number vertices between source & target don't match, initial_correspondence_type must\n"
+                "be 'kd' and not 'hungarian'. Current type is: {}".format(self.initial_correspondence_type))
         self.source_projected_on_target = self.graph_source.mean_filter_graph(
             self.smoothed_target_coords[self.corresponding_target_idx_for_each_source_pt, :],
             iterations=self.projection_smooth_iterations)
-        self.get_kd_correspondence(self.smoothed_target_coords, self.source_projected_on_target)
+        if self.final_correspondence_type == "hungarian":  # focusr.py:391-396
+            self.get_hungarian_correspondence(self.smoothed_target_coords, self.source_projected_on_target)
+        else:
+            self.get_kd_correspondence(self.smoothed_target_coords, self.source_projected_on_target)
 
     def get_weighted_final_node_locations(self, n_closest_pts=3):
         """focusr.py:401-426: every source point goes to the inverse-distance-weighted average of the

@@ -677,3 +677,20 @@ def test_full_size_250k_properties(hip, ctx):
     sample = rng.choice(n, 300, replace=False)
     bidx, bd2 = orc.knn1_bruteforce(gr.eig_vecs, q[sample])
     assert np.array_equal(idx[sample], bidx) and np.array_equal(d2[sample], bd2)
+
+
+def test_hungarian_correspondence_small(golden, ctx):
+    """focusr.py:340-349 on a mesh small enough for the O(N^3) assignment: a permutation (one-to-one), each
+    source vertex close to its assigned target vertex in spectral space."""
+    from pyfocusr_amd import Focusr
+    from pyfocusr_amd.meshgen import blob_mesh
+
+    a, b = blob_mesh(600, seed=3), blob_mesh(600, seed=4)
+    reg = Focusr(a, b, icp_register_first=False, n_spectral_features=3, n_extra_spectral=0, list_features_to_calc=[],
+                 initial_correspondence_type="hungarian", final_correspondence_type="hungarian", ctx=ctx,
+                 registration=lambda src, tgt, kind: tgt)
+    reg.align_maps()
+    idx = reg.corresponding_target_idx_for_each_source_pt
+    assert sorted(idx.tolist()) == list(range(600))
+    with pytest.raises(ValueError):
+        Focusr(a, b, icp_register_first=False, initial_correspondence_type="nearest", ctx=ctx)
