@@ -202,6 +202,22 @@ void pf_cpd_free(pf_cpd* h);
 int pf_cpd_estep(pf_cpd* h, const double* TY, double sigma2, double w, double* P1, double* Pt1, double* PX);
 int pf_cpd_set_basis(pf_cpd* h, const double* Q, int32_t K);
 int pf_cpd_weighted_gram(pf_cpd* h, double* H);
+/* Device-resident EM iterations: after pf_cpd_estep(h, NULL, sigma2, w, NULL, NULL, NULL) the posterior sums stay
+ * on the device; only the small moment sums an M-step needs come back, and only the new parameters go in.
+ *   pf_cpd_affine_sums   shifts [32] = cx[16] | cy[16] (means of X and Y, the centre the sums are taken about);
+ *                        sums [2 d^2 + 3 d + 3], with xc = x - cx, yc = y - cy, PXc_m = PX_m - P1_m cx:
+ *                        sum P1 | sum PXc [d] | sum P1 yc [d] | sum PXc yc^T [d][d] | sum P1 yc yc^T [d][d] |
+ *                        sum Pt1 | sum Pt1 |xc|^2 | sum Pt1 xc [d]
+ *   pf_cpd_apply_affine  TY = Y B + t
+ *   pf_cpd_deform_sums   H [K][K] = Q^T diag(P1) Q,  R [K][d] = Q^T (PX - diag(P1) Y)      (needs pf_cpd_set_basis)
+ *   pf_cpd_apply_deform  TY = Y + Q C (C [K][d]), then sums [5] = sum P1 | sum P1 |ty|^2 | sum ty.PX | sum Pt1 |
+ *                        sum Pt1 |x|^2 with the new TY
+ *   pf_cpd_download      current TY [M][d] and the last posterior sums (each may be NULL) */
+int pf_cpd_affine_sums(pf_cpd* h, double* shifts, double* sums);
+int pf_cpd_apply_affine(pf_cpd* h, const double* B, const double* t);
+int pf_cpd_deform_sums(pf_cpd* h, double* H, double* R);
+int pf_cpd_apply_deform(pf_cpd* h, const double* C, double* sums);
+int pf_cpd_download(pf_cpd* h, double* TY, double* P1, double* Pt1, double* PX);
 int pf_cpd_gram(pf_ctx* ctx, const double* A, int64_t n_a, const double* B, int64_t n_b, int32_t d, double beta,
                 const double* V, int32_t n_cols, double* out);
 

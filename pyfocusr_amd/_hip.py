@@ -96,6 +96,11 @@ SIGNATURES = {
     "pf_cpd_estep": (C.c_int, [C.c_void_p, _f64p, C.c_double, C.c_double, _f64p, _f64p, _f64p]),
     "pf_cpd_set_basis": (C.c_int, [C.c_void_p, _f64p, C.c_int32]),
     "pf_cpd_weighted_gram": (C.c_int, [C.c_void_p, _f64p]),
+    "pf_cpd_affine_sums": (C.c_int, [C.c_void_p, _f64p, _f64p]),
+    "pf_cpd_apply_affine": (C.c_int, [C.c_void_p, _f64p, _f64p]),
+    "pf_cpd_deform_sums": (C.c_int, [C.c_void_p, _f64p, _f64p]),
+    "pf_cpd_apply_deform": (C.c_int, [C.c_void_p, _f64p, _f64p]),
+    "pf_cpd_download": (C.c_int, [C.c_void_p, _f64p, _f64p, _f64p, _f64p]),
     "pf_cpd_gram": (C.c_int, [C.c_void_p, _f64p, C.c_int64, _f64p, C.c_int64, C.c_int32, C.c_double, _f64p, C.c_int32, _f64p]),
 }
 
@@ -338,6 +343,44 @@ class DeviceCpd(object):
         _check(self._lib.pf_cpd_estep(self._h, _f64(TY), float(sigma2), float(w), _f64(self._P1), _f64(self._Pt1),
                                       _f64(self._PX)))
         return self._P1, self._Pt1, self._PX
+
+    # ---- device-resident iterations: the posterior sums stay in HBM, small moments out, parameters in
+    def estep_resident(self, sigma2, w=0.0):
+        _check(self._lib.pf_cpd_estep(self._h, None, float(sigma2), float(w), None, None, None))
+
+    def affine_sums(self):
+        """dict of the moment sums of `pf_cpd_affine_sums` (about the centres cx, cy)."""
+        D = self.D
+        shifts, sums = np.empty(32), np.empty(2 * D * D + 3 * D + 3)
+        _check(self._lib.pf_cpd_affine_sums(self._h, _f64(shifts), _f64(sums)))
+        o = 1 + 2 * D + 2 * D * D
+        return dict(cx=shifts[:D], cy=shifts[16:16 + D], Np=sums[0], sPX=sums[1:1 + D], sP1Y=sums[1 + D:1 + 2 * D],
+                    PXY=sums[1 + 2 * D:1 + 2 * D + D * D].reshape(D, D), YPY=sums[1 + 2 * D + D * D:o].reshape(D, D),
+                    sPt1=sums[o], sPt1XX=sums[o + 1], sPt1X=sums[o + 2:o + 2 + D])
+
+    def apply_affine(self, B, t):
+        B, t = _c_f64(B), _c_f64(t)
+        _check(self._lib.pf_cpd_apply_affine(self._h, _f64(B), _f64(t)))
+
+    def deform_sums(self):
+        """(H (K,K) = Q^T diag(P1) Q, R (K,d) = Q^T (PX - diag(P1) Y))."""
+        K = self._H.shape[0]
+        R = np.empty((K, self.D))
+        _check(self._lib.pf_cpd_deform_sums(self._h, _f64(self._H), _f64(R)))
+        return self._H, R
+
+    def apply_deform(self, Cmat):
+        """TY = Y + Q C; returns (Np, yPy, trPXY, sum Pt1, xPx) with the new TY."""
+        Cmat = _c_f64(Cmat)
+        sums = np.empty(5)
+        _check(self._lib.pf_cpd_apply_deform(self._h, _f64(Cmat), _f64(sums)))
+        return sums
+
+    def download(self):
+        """(TY, P1, Pt1, PX) as they stand on the device."""
+        TY = np.empty((self.M, self.D))
+        _check(self._lib.pf_cpd_download(self._h, _f64(TY), _f64(self._P1), _f64(self._Pt1), _f64(self._PX)))
+        return TY, self._P1, self._Pt1, self._PX
 
     def set_basis(self, Q):
         """Keep the low-rank basis Q (M,K) on the device for `weighted_gram`."""

@@ -15,8 +15,11 @@ derives from, see the docstrings) with its O(M*N) work on the MI355X:
   host work is a QR of an M x (num_eig+oversampling) block.
 * `transform_point_cloud` of all n points of the mesh: `pf_cpd_gram` again (n x M affinity).
 
-The M-steps are O(M d^2) (affine) and O(M K d + K^3) (deformable, Woodbury form) numpy on the
-host.  Parity with cycpd itself is unpinned (absent from the build image); `tests/test_cpd.py`
+The EM loop is device-resident: P1, Pt1, PX and the moving set never leave HBM; per iteration the
+M-step's moment sums (O(d^2) numbers for the affine model; the K x K matrix Q^T diag(P1) Q and K x d
+right-hand side for the Woodbury form of the deformable model) come back, the host solves the small
+dense system, and the new parameters go in (`pf_cpd_affine_sums / apply_affine / deform_sums /
+apply_deform`).  Parity with cycpd itself is unpinned (absent from the build image); `tests/test_cpd.py`
 checks this module against a dense CPU restatement of the same algorithm.
 """
 import numpy as np
@@ -59,27 +62,31 @@ class _ExpectationMaximisation(object):
         self.Np = 0.0
 
     def register(self, callback=lambda **kwargs: None):
-        dev = self._dev = _hip.DeviceCpd(self.X, self.Y, ctx=self._ctx)
+        """EM loop.  The posterior sums P1 / Pt1 / PX and the moving set TY stay on the device: per iteration
+        only the M-step's small moment sums come back and the new transform parameters go in."""
+        dev = _hip.DeviceCpd(self.X, self.Y, ctx=self._ctx)
         try:
             self._on_device(dev)
-            self.transform_point_cloud()
+            self._apply(dev)
             while self.iteration < self.max_iterations and self.diff > self.tolerance:
-                self.P1, self.Pt1, self.PX = dev.estep(self.TY, self.sigma2, self.w)
-                self.Np = float(self.P1.sum())
-                self.update_transform()
-                self.transform_point_cloud()
-                self.update_variance()
+                dev.estep_resident(self.sigma2, self.w)
+                self._maximisation(dev)
                 self.iteration += 1
                 if callable(callback):
                     callback(iteration=self.iteration, error=self.q, X=self.X, Y=self.TY)
                 if self.verbose:
                     print("CPD iteration %d: sigma2 %.3e, change %.3e" % (self.iteration, self.sigma2, self.diff))
+            self.TY, P1, Pt1, PX = dev.download()
+            self.P1, self.Pt1, self.PX = P1.copy(), Pt1.copy(), PX.copy()
+            self._finish()
         finally:
-            self._dev = None
             dev.close()
         return self.TY, self.get_registration_parameters()
 
     def _on_device(self, dev):
+        pass
+
+    def _finish(self):
         pass
 
 
@@ -91,32 +98,37 @@ class affine_registration(_ExpectationMaximisation):
         self.B = np.eye(self.D) if B is None else np.asarray(B, dtype=np.float64)
         self.t = np.zeros(self.D) if t is None else np.asarray(t, dtype=np.float64).reshape(self.D)
 
-    def update_transform(self):
-        muX = self.PX.sum(axis=0) / self.Np
-        muY = self.P1 @ self.Y / self.Np
-        self.X_hat = self.X - muX
-        Y_hat = self.Y - muY
-        self.A = (self.PX - self.P1[:, None] * muX[None, :]).T @ Y_hat  # X_hat^T P^T Y_hat
-        self.YPY = Y_hat.T @ (self.P1[:, None] * Y_hat)
+    def _apply(self, dev):
+        dev.apply_affine(self.B, self.t)
+
+    def _maximisation(self, dev):
+        # all sums are taken about fixed centres cx, cy (the means of X and Y), which keeps the expansions below
+        # free of cancellation: x - cx ~ (y - cy) B + t_c
+        m = dev.affine_sums()
+        self.Np = Np = float(m["Np"])
+        muX, muY = m["sPX"] / Np, m["sP1Y"] / Np
+        self.A = m["PXY"] - Np * np.outer(muX, muY)    # X_hat^T P^T Y_hat
+        self.YPY = m["YPY"] - Np * np.outer(muY, muY)  # Y_hat^T diag(P1) Y_hat
         self.B = np.linalg.solve(self.YPY.T, self.A.T)
-        self.t = muX - self.B.T @ muY
+        t_c = muX - self.B.T @ muY
+        self.t = t_c + m["cx"] - self.B.T @ m["cy"]
+        dev.apply_affine(self.B, self.t)
+        # update_variance
+        qprev = self.q
+        trAB = np.trace(self.A @ self.B)
+        xPx = m["sPt1XX"] - 2.0 * (muX @ m["sPt1X"]) + m["sPt1"] * (muX @ muX)
+        trBYPYP = np.trace(self.B @ self.YPY @ self.B)
+        self.q = (xPx - 2 * trAB + trBYPYP) / (2 * self.sigma2) + self.D * Np / 2 * np.log(self.sigma2)
+        self.diff = abs(self.q - qprev)
+        self.sigma2 = (xPx - trAB) / (Np * self.D)
+        if self.sigma2 <= 0:
+            self.sigma2 = self.tolerance / 10
 
     def transform_point_cloud(self, Y=None):
         if Y is None:
             self.TY = self.Y @ self.B + self.t
             return None
         return np.asarray(Y, dtype=np.float64) @ self.B + self.t
-
-    def update_variance(self):
-        qprev = self.q
-        trAB = np.trace(self.A @ self.B)
-        xPx = self.Pt1 @ np.sum(self.X_hat * self.X_hat, axis=1)
-        trBYPYP = np.trace(self.B @ self.YPY @ self.B)
-        self.q = (xPx - 2 * trAB + trBYPYP) / (2 * self.sigma2) + self.D * self.Np / 2 * np.log(self.sigma2)
-        self.diff = abs(self.q - qprev)
-        self.sigma2 = (xPx - trAB) / (self.Np * self.D)
-        if self.sigma2 <= 0:
-            self.sigma2 = self.tolerance / 10
 
     def get_registration_parameters(self):
         return self.B, self.t
@@ -197,35 +209,46 @@ class deformable_registration(_ExpectationMaximisation):
         self.W = np.zeros((self.M, self.D))
         self.Q, self.S = low_rank_affinity(self.Y, self.beta, self.num_eig, ctx=self._ctx)
         self.inv_S = 1.0 / self.S
+        self._C = np.zeros((len(self.S), self.D))  # S * (Q^T W): TY = Y + Q C
+        self._Z = np.zeros_like(self._C)
+        self._lam = self.alpha * self.sigma2
 
     def _on_device(self, dev):
         dev.set_basis(self.Q)
 
-    def update_transform(self):
-        # Woodbury form of (diag(P1) G + alpha sigma2 I) W = PX - diag(P1) Y with G = Q S Q^T
-        F = self.PX - self.P1[:, None] * self.Y
-        dPQ = self.P1[:, None] * self.Q
-        lam = self.alpha * self.sigma2
-        QtPQ = self._dev.weighted_gram() if getattr(self, "_dev", None) is not None else self.Q.T @ dPQ
-        Z = np.linalg.solve(lam * np.diag(self.inv_S) + QtPQ, self.Q.T @ F)
-        self.W = (F - dPQ @ Z) / lam
+    def _apply(self, dev):
+        dev.apply_deform(self._C)
 
-    def transform_point_cloud(self, Y=None):
-        if Y is None:
-            self.TY = self.Y + self.Q @ (self.S[:, None] * (self.Q.T @ self.W))
-            return None
-        Y = np.ascontiguousarray(Y, dtype=np.float64)
-        return Y + _hip.gaussian_gram_product(Y, self.Y, self.beta, self.W, ctx=self._ctx)
-
-    def update_variance(self):
+    def _maximisation(self, dev):
+        # Woodbury form of (diag(P1) G + alpha sigma2 I) W = F,  F = PX - diag(P1) Y,  G = Q S Q^T:
+        #   W = (F - diag(P1) Q Z) / lam,  (lam S^-1 + H) Z = R,  H = Q^T diag(P1) Q,  R = Q^T F
+        # and therefore Q^T W = (R - H Z) / lam — W itself (M x d) is only formed once, at the end.
+        H, R = dev.deform_sums()
+        self._lam = lam = self.alpha * self.sigma2
+        A = H.copy()
+        A[np.diag_indices_from(A)] += lam * self.inv_S
+        self._Z = np.linalg.solve(A, R)
+        self._C = self.S[:, None] * ((R - H @ self._Z) / lam)
+        Np, yPy, trPXY, _, xPx = dev.apply_deform(self._C)
+        self.Np = float(Np)
+        # update_variance
         qprev = self.sigma2
-        xPx = self.Pt1 @ np.sum(self.X * self.X, axis=1)
-        yPy = self.P1 @ np.sum(self.TY * self.TY, axis=1)
-        trPXY = np.sum(self.TY * self.PX)
-        self.sigma2 = (xPx - 2 * trPXY + yPy) / (self.Np * self.D)
+        self.sigma2 = (xPx - 2 * trPXY + yPy) / (Np * self.D)
         if self.sigma2 <= 0:
             self.sigma2 = self.tolerance / 10
         self.diff = abs(self.sigma2 - qprev)
+
+    def _finish(self):
+        if self.iteration:
+            F = self.PX - self.P1[:, None] * self.Y
+            self.W = (F - self.P1[:, None] * (self.Q @ self._Z)) / self._lam
+
+    def transform_point_cloud(self, Y=None):
+        if Y is None:
+            self.TY = self.Y + self.Q @ self._C
+            return None
+        Y = np.ascontiguousarray(Y, dtype=np.float64)
+        return Y + _hip.gaussian_gram_product(Y, self.Y, self.beta, self.W, ctx=self._ctx)
 
     def get_registration_parameters(self):
         return self.Q, self.S, self.W

@@ -35,6 +35,13 @@ struct pf_cpd {
     double* hpart = nullptr;  // [chunks_h][K][K]
     double* H = nullptr;      // [K][K]
     int32_t K = 0, chunks_h = 0;
+    // device-resident M-step support: moment sums of the E-step results (pf_cpd_affine_sums / pf_cpd_deform_sums /
+    // pf_cpd_variance_sums) and the transform kernels (pf_cpd_apply_affine / pf_cpd_apply_deform)
+    double* Y = nullptr;      // [M][D] moving set as given (TY is its transformed copy)
+    double* shift = nullptr;  // [3][16]: cx (mean of X), cy (mean of Y), zeros
+    double* mpart = nullptr;  // per-block partial sums of the moment kernels
+    double* msum = nullptr;   // their totals (device), also the staging area of small uploads
+    int64_t mpart_cap = 0, msum_cap = 0;
 };
 
 namespace {
@@ -209,6 +216,141 @@ __global__ __launch_bounds__(PF_BLOCK) void k_sum_chunks(const double* __restric
     out[i] = s;
 }
 
+// ---- moment sums for the device-resident M-steps.  One block per MOM_ROWS rows: the rows' data go to LDS, thread t
+// sums output t (, t + 256, ...) over them; block partials are added in block order by k_sum_chunks.
+constexpr int MOM_ROWS = 64;
+
+// m side, L = 1 + 2 D + 2 D^2 outputs with xc = x - cx, yc = y - cy, PXc_m = PX_m - P1_m cx:
+//   [0] sum P1 | [1..] sum PXc[d] | sum P1 yc[d] | sum PXc[d] yc[e] | sum P1 yc[d] yc[e]
+__global__ __launch_bounds__(PF_BLOCK) void k_affine_moments_m(const double* __restrict__ P1, const double* __restrict__ PX,
+                                                               const double* __restrict__ Y, const double* __restrict__ cx,
+                                                               const double* __restrict__ cy, int64_t M, int D,
+                                                               double* __restrict__ part) {
+    __shared__ double sp[MOM_ROWS], spx[MOM_ROWS * 16], sy[MOM_ROWS * 16];
+    const int64_t m0 = (int64_t)blockIdx.x * MOM_ROWS;
+    const int cnt = (int)(M - m0 < MOM_ROWS ? M - m0 : MOM_ROWS);
+    for (int k = threadIdx.x; k < cnt; k += PF_BLOCK) sp[k] = P1[m0 + k];
+    for (int k = threadIdx.x; k < cnt * D; k += PF_BLOCK) {
+        const int r = k / D, d = k - r * D;
+        spx[k] = PX[m0 * D + k] - P1[m0 + r] * cx[d];
+        sy[k] = Y[m0 * D + k] - cy[d];
+    }
+    __syncthreads();
+    const int L = 1 + 2 * D + 2 * D * D;
+    for (int o = threadIdx.x; o < L; o += PF_BLOCK) {
+        double acc = 0.0;
+        if (o == 0) {
+            for (int r = 0; r < cnt; ++r) acc += sp[r];
+        } else if (o < 1 + D) {
+            for (int r = 0; r < cnt; ++r) acc += spx[r * D + o - 1];
+        } else if (o < 1 + 2 * D) {
+            for (int r = 0; r < cnt; ++r) acc += sp[r] * sy[r * D + o - 1 - D];
+        } else if (o < 1 + 2 * D + D * D) {
+            const int q = o - 1 - 2 * D, d = q / D, e = q - d * D;
+            for (int r = 0; r < cnt; ++r) acc += spx[r * D + d] * sy[r * D + e];
+        } else {
+            const int q = o - 1 - 2 * D - D * D, d = q / D, e = q - d * D;
+            for (int r = 0; r < cnt; ++r) acc += sp[r] * sy[r * D + d] * sy[r * D + e];
+        }
+        part[(int64_t)blockIdx.x * L + o] = acc;
+    }
+}
+
+// n side, L = 2 + D outputs with xc = x - shift: [0] sum Pt1 | [1] sum Pt1 |xc|^2 | [2..] sum Pt1 xc[d]
+__global__ __launch_bounds__(PF_BLOCK) void k_moments_n(const double* __restrict__ Pt1, const double* __restrict__ X,
+                                                        const double* __restrict__ shift, int64_t N, int D, double* __restrict__ part) {
+    __shared__ double sp[MOM_ROWS], sx[MOM_ROWS * 16];
+    const int64_t n0 = (int64_t)blockIdx.x * MOM_ROWS;
+    const int cnt = (int)(N - n0 < MOM_ROWS ? N - n0 : MOM_ROWS);
+    for (int k = threadIdx.x; k < cnt; k += PF_BLOCK) sp[k] = Pt1[n0 + k];
+    for (int k = threadIdx.x; k < cnt * D; k += PF_BLOCK) sx[k] = X[n0 * D + k] - shift[k % D];
+    __syncthreads();
+    const int L = 2 + D;
+    for (int o = threadIdx.x; o < L; o += PF_BLOCK) {
+        double acc = 0.0;
+        if (o == 0) {
+            for (int r = 0; r < cnt; ++r) acc += sp[r];
+        } else if (o == 1) {
+            for (int r = 0; r < cnt; ++r) {
+                double q = 0.0;
+                for (int d = 0; d < D; ++d) q += sx[r * D + d] * sx[r * D + d];
+                acc += sp[r] * q;
+            }
+        } else {
+            for (int r = 0; r < cnt; ++r) acc += sp[r] * sx[r * D + o - 2];
+        }
+        part[(int64_t)blockIdx.x * L + o] = acc;
+    }
+}
+
+// m side of the deformable variance update, 3 outputs: [0] sum P1 | [1] sum P1 |ty|^2 | [2] sum ty . PX
+__global__ __launch_bounds__(PF_BLOCK) void k_variance_m(const double* __restrict__ P1, const double* __restrict__ PX,
+                                                         const double* __restrict__ TY, int64_t M, int D, double* __restrict__ part) {
+    __shared__ double red[3][PF_BLOCK];
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+    const int64_t m = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
+    if (m < M) {
+        double q = 0.0, t = 0.0;
+        for (int d = 0; d < D; ++d) {
+            const double ty = TY[m * D + d];
+            q += ty * ty;
+            t += ty * PX[m * D + d];
+        }
+        a0 = P1[m], a1 = P1[m] * q, a2 = t;
+    }
+    red[0][threadIdx.x] = a0, red[1][threadIdx.x] = a1, red[2][threadIdx.x] = a2;
+    __syncthreads();
+    for (int off = PF_BLOCK / 2; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off)
+            for (int k = 0; k < 3; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x < 3) part[(int64_t)blockIdx.x * 3 + threadIdx.x] = red[threadIdx.x][0];
+}
+
+// R[i][d] = sum_m Q[m][i] (PX[m][d] - P1[m] Y[m][d]) over the block's rows; output o = i * D + d
+__global__ __launch_bounds__(PF_BLOCK) void k_deform_rhs(const double* __restrict__ Q, const double* __restrict__ P1,
+                                                         const double* __restrict__ PX, const double* __restrict__ Y, int64_t M,
+                                                         int K, int D, double* __restrict__ part) {
+    __shared__ double sf[MOM_ROWS * 16];
+    const int64_t m0 = (int64_t)blockIdx.x * MOM_ROWS;
+    const int cnt = (int)(M - m0 < MOM_ROWS ? M - m0 : MOM_ROWS);
+    for (int k = threadIdx.x; k < cnt * D; k += PF_BLOCK) sf[k] = PX[m0 * D + k] - P1[m0 + k / D] * Y[m0 * D + k];
+    __syncthreads();
+    const int L = K * D;
+    for (int o = threadIdx.x; o < L; o += PF_BLOCK) {
+        const int i = o / D, d = o - i * D;
+        double acc = 0.0;
+        for (int r = 0; r < cnt; ++r) acc += Q[(m0 + r) * K + i] * sf[r * D + d];
+        part[(int64_t)blockIdx.x * L + o] = acc;
+    }
+}
+
+// TY = Y B + t
+__global__ __launch_bounds__(PF_BLOCK) void k_apply_affine(const double* __restrict__ Y, const double* __restrict__ Bt /* [D][D] | [D] */,
+                                                           int64_t M, int D, double* __restrict__ TY) {
+    const int64_t i = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
+    if (i >= M * D) return;
+    const int64_t m = i / D;
+    const int e = (int)(i - m * D);
+    double acc = Bt[D * D + e];
+    for (int d = 0; d < D; ++d) acc += Y[m * D + d] * Bt[d * D + e];
+    TY[i] = acc;
+}
+
+// TY = Y + Q C,  C [K][D]
+__global__ __launch_bounds__(PF_BLOCK) void k_apply_deform(const double* __restrict__ Y, const double* __restrict__ Q,
+                                                           const double* __restrict__ C, int64_t M, int K, int D,
+                                                           double* __restrict__ TY) {
+    const int64_t i = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
+    if (i >= M * D) return;
+    const int64_t m = i / D;
+    const int d = (int)(i - m * D);
+    double acc = 0.0;
+    for (int k = 0; k < K; ++k) acc += Q[m * K + k] * C[k * D + d];
+    TY[i] = Y[i] + acc;
+}
+
 template <int D>
 int run_estep(pf_cpd* h, double inv2s, double c) {
     hipStream_t st = h->ctx->stream;
@@ -281,6 +423,10 @@ void pf_cpd_free(pf_cpd* h) {
     pf_free(st, h->Q);
     pf_free(st, h->hpart);
     pf_free(st, h->H);
+    pf_free(st, h->Y);
+    pf_free(st, h->shift);
+    pf_free(st, h->mpart);
+    pf_free(st, h->msum);
     delete h;
 }
 
@@ -303,7 +449,21 @@ int pf_cpd_create(pf_ctx* ctx, const double* X, int64_t N, const double* Y, int6
         if ((e = pf_malloc(st, (void**)&h->den, sizeof(double) * N)) != hipSuccess) break;
         if ((e = pf_malloc(st, (void**)&h->part, sizeof(double) * part)) != hipSuccess) break;
         if ((e = pf_malloc(st, (void**)&h->out, sizeof(double) * (N + M + M * D))) != hipSuccess) break;
+        if ((e = pf_malloc(st, (void**)&h->Y, sizeof(double) * M * D)) != hipSuccess) break;
+        if ((e = pf_malloc(st, (void**)&h->shift, sizeof(double) * 48)) != hipSuccess) break;
+        h->mpart_cap = (std::max(N, M) / MOM_ROWS + 1) * (1 + 2 * 16 + 2 * 256);
+        h->msum_cap = 1 + 2 * 16 + 2 * 256 + 16;
+        if ((e = pf_malloc(st, (void**)&h->mpart, sizeof(double) * h->mpart_cap)) != hipSuccess) break;
+        if ((e = pf_malloc(st, (void**)&h->msum, sizeof(double) * h->msum_cap)) != hipSuccess) break;
+        double sh[48] = {0.0};
+        for (int64_t i = 0; i < N; ++i)
+            for (int d = 0; d < D; ++d) sh[d] += X[i * D + d];
+        for (int64_t i = 0; i < M; ++i)
+            for (int d = 0; d < D; ++d) sh[16 + d] += Y[i * D + d];
+        for (int d = 0; d < D; ++d) sh[d] /= (double)N, sh[16 + d] /= (double)M;
+        if ((e = hipMemcpyAsync(h->shift, sh, sizeof(sh), hipMemcpyHostToDevice, st)) != hipSuccess) break;
         if ((e = hipMemcpyAsync(h->X, X, sizeof(double) * N * D, hipMemcpyHostToDevice, st)) != hipSuccess) break;
+        if ((e = hipMemcpyAsync(h->Y, Y, sizeof(double) * M * D, hipMemcpyHostToDevice, st)) != hipSuccess) break;
         if ((e = hipMemcpyAsync(h->TY, Y, sizeof(double) * M * D, hipMemcpyHostToDevice, st)) != hipSuccess) break;
         e = hipStreamSynchronize(st);
     } while (0);
@@ -359,6 +519,106 @@ int pf_cpd_estep(pf_cpd* h, const double* TY, double sigma2, double w, double* P
     if (TY) PF_HIP(hipMemcpyAsync(h->TY, TY, sizeof(double) * h->M * h->D, hipMemcpyHostToDevice, st));
     const double c = std::pow(2.0 * M_PI * sigma2, 0.5 * h->D) * w / (1.0 - w) * (double)h->M / (double)h->N;
     PF_TRY(dispatch_estep(h, 1.0 / (2.0 * sigma2), c));
+    if (Pt1) PF_HIP(hipMemcpyAsync(Pt1, h->out, sizeof(double) * h->N, hipMemcpyDeviceToHost, st));
+    if (P1) PF_HIP(hipMemcpyAsync(P1, h->out + h->N, sizeof(double) * h->M, hipMemcpyDeviceToHost, st));
+    if (PX) PF_HIP(hipMemcpyAsync(PX, h->out + h->N + h->M, sizeof(double) * h->M * h->D, hipMemcpyDeviceToHost, st));
+    if (Pt1 || P1 || PX) PF_HIP(hipStreamSynchronize(st));  // device-resident loops read the results with the *_sums calls
+    return PF_OK;
+}
+
+// ---- device-resident M-steps: small sums out, small parameters in; P1 / Pt1 / PX / TY never leave the device
+int pf_cpd_affine_sums(pf_cpd* h, double* shifts, double* sums) {
+    PF_CHECK(h && shifts && sums, PF_E_ARG, "pf_cpd_affine_sums: NULL argument");
+    PF_HIP(hipSetDevice(h->ctx->device));
+    hipStream_t st = h->ctx->stream;
+    const int D = h->D, Lm = 1 + 2 * D + 2 * D * D, Ln = 2 + D;
+    const unsigned bm = (unsigned)((h->M + MOM_ROWS - 1) / MOM_ROWS), bn = (unsigned)((h->N + MOM_ROWS - 1) / MOM_ROWS);
+    double *Pt1 = h->out, *P1 = h->out + h->N, *PX = h->out + h->N + h->M;
+    k_affine_moments_m<<<bm, PF_BLOCK, 0, st>>>(P1, PX, h->Y, h->shift, h->shift + 16, h->M, D, h->mpart);
+    k_sum_chunks<<<nblk(Lm), PF_BLOCK, 0, st>>>(h->mpart, (int)bm, Lm, h->msum);
+    PF_HIP(hipMemcpyAsync(sums, h->msum, sizeof(double) * Lm, hipMemcpyDeviceToHost, st));
+    k_moments_n<<<bn, PF_BLOCK, 0, st>>>(Pt1, h->X, h->shift, h->N, D, h->mpart);
+    k_sum_chunks<<<nblk(Ln), PF_BLOCK, 0, st>>>(h->mpart, (int)bn, Ln, h->msum);
+    PF_HIP(hipGetLastError());
+    PF_HIP(hipMemcpyAsync(sums + Lm, h->msum, sizeof(double) * Ln, hipMemcpyDeviceToHost, st));
+    PF_HIP(hipMemcpyAsync(shifts, h->shift, sizeof(double) * 32, hipMemcpyDeviceToHost, st));
+    PF_HIP(hipStreamSynchronize(st));
+    return PF_OK;
+}
+
+int pf_cpd_apply_affine(pf_cpd* h, const double* B, const double* t) {
+    PF_CHECK(h && B && t, PF_E_ARG, "pf_cpd_apply_affine: NULL argument");
+    PF_HIP(hipSetDevice(h->ctx->device));
+    hipStream_t st = h->ctx->stream;
+    const int D = h->D;
+    PF_HIP(hipMemcpyAsync(h->msum, B, sizeof(double) * D * D, hipMemcpyHostToDevice, st));
+    PF_HIP(hipMemcpyAsync(h->msum + D * D, t, sizeof(double) * D, hipMemcpyHostToDevice, st));
+    k_apply_affine<<<nblk(h->M * D), PF_BLOCK, 0, st>>>(h->Y, h->msum, h->M, D, h->TY);
+    PF_HIP(hipGetLastError());
+    PF_HIP(hipStreamSynchronize(st));  // B and t are the caller's again
+    return PF_OK;
+}
+
+int pf_cpd_deform_sums(pf_cpd* h, double* H, double* R) {
+    PF_CHECK(h && H && R, PF_E_ARG, "pf_cpd_deform_sums: NULL argument");
+    PF_CHECK(h->K > 0, PF_E_STATE, "pf_cpd_deform_sums: no basis (pf_cpd_set_basis) on this handle");
+    PF_HIP(hipSetDevice(h->ctx->device));
+    hipStream_t st = h->ctx->stream;
+    const int D = h->D, K = h->K;
+    double *P1 = h->out + h->N, *PX = h->out + h->N + h->M;
+    const unsigned tiles = (unsigned)((K + GRAM_TILE - 1) / GRAM_TILE);
+    k_weighted_gram<<<dim3(tiles, tiles, (unsigned)h->chunks_h), GRAM_TILE * GRAM_TILE, 0, st>>>(h->Q, P1, h->M, K, h->hpart);
+    k_sum_chunks<<<nblk((int64_t)K * K), PF_BLOCK, 0, st>>>(h->hpart, h->chunks_h, (int64_t)K * K, h->H);
+    PF_HIP(hipMemcpyAsync(H, h->H, sizeof(double) * (size_t)K * K, hipMemcpyDeviceToHost, st));
+    const unsigned bm = (unsigned)((h->M + MOM_ROWS - 1) / MOM_ROWS);
+    const int64_t need = (int64_t)bm * K * D;
+    if (need > h->mpart_cap) {
+        pf_free(st, h->mpart);
+        h->mpart = nullptr, h->mpart_cap = 0;
+        PF_HIP(pf_malloc(st, (void**)&h->mpart, sizeof(double) * need));
+        h->mpart_cap = need;
+    }
+    if ((int64_t)K * D > h->msum_cap) {
+        pf_free(st, h->msum);
+        h->msum = nullptr, h->msum_cap = 0;
+        PF_HIP(pf_malloc(st, (void**)&h->msum, sizeof(double) * K * D));
+        h->msum_cap = (int64_t)K * D;
+    }
+    k_deform_rhs<<<bm, PF_BLOCK, 0, st>>>(h->Q, P1, PX, h->Y, h->M, K, D, h->mpart);
+    k_sum_chunks<<<nblk((int64_t)K * D), PF_BLOCK, 0, st>>>(h->mpart, (int)bm, (int64_t)K * D, h->msum);
+    PF_HIP(hipGetLastError());
+    PF_HIP(hipMemcpyAsync(R, h->msum, sizeof(double) * K * D, hipMemcpyDeviceToHost, st));
+    PF_HIP(hipStreamSynchronize(st));
+    return PF_OK;
+}
+
+int pf_cpd_apply_deform(pf_cpd* h, const double* C, double* sums) {
+    PF_CHECK(h && C && sums, PF_E_ARG, "pf_cpd_apply_deform: NULL argument");
+    PF_CHECK(h->K > 0, PF_E_STATE, "pf_cpd_apply_deform: no basis (pf_cpd_set_basis) on this handle");
+    PF_HIP(hipSetDevice(h->ctx->device));
+    hipStream_t st = h->ctx->stream;
+    const int D = h->D, K = h->K;
+    double *Pt1 = h->out, *P1 = h->out + h->N, *PX = h->out + h->N + h->M;
+    PF_HIP(hipMemcpyAsync(h->msum, C, sizeof(double) * K * D, hipMemcpyHostToDevice, st));
+    k_apply_deform<<<nblk(h->M * D), PF_BLOCK, 0, st>>>(h->Y, h->Q, h->msum, h->M, K, D, h->TY);
+    // variance sums with the new TY and the posterior of this iteration: [Np, yPy, trPXY | sum Pt1, xPx]
+    const unsigned bm = nblk(h->M), bn = (unsigned)((h->N + MOM_ROWS - 1) / MOM_ROWS);
+    k_variance_m<<<bm, PF_BLOCK, 0, st>>>(P1, PX, h->TY, h->M, D, h->mpart);
+    k_sum_chunks<<<1, PF_BLOCK, 0, st>>>(h->mpart, (int)bm, 3, h->msum);  // C has been consumed (stream order)
+    PF_HIP(hipMemcpyAsync(sums, h->msum, sizeof(double) * 3, hipMemcpyDeviceToHost, st));
+    k_moments_n<<<bn, PF_BLOCK, 0, st>>>(Pt1, h->X, h->shift + 32, h->N, D, h->mpart);
+    k_sum_chunks<<<1, PF_BLOCK, 0, st>>>(h->mpart, (int)bn, 2 + D, h->msum);
+    PF_HIP(hipGetLastError());
+    PF_HIP(hipMemcpyAsync(sums + 3, h->msum, sizeof(double) * 2, hipMemcpyDeviceToHost, st));
+    PF_HIP(hipStreamSynchronize(st));
+    return PF_OK;
+}
+
+int pf_cpd_download(pf_cpd* h, double* TY, double* P1, double* Pt1, double* PX) {
+    PF_CHECK(h != nullptr, PF_E_ARG, "pf_cpd_download: NULL handle");
+    PF_HIP(hipSetDevice(h->ctx->device));
+    hipStream_t st = h->ctx->stream;
+    if (TY) PF_HIP(hipMemcpyAsync(TY, h->TY, sizeof(double) * h->M * h->D, hipMemcpyDeviceToHost, st));
     if (Pt1) PF_HIP(hipMemcpyAsync(Pt1, h->out, sizeof(double) * h->N, hipMemcpyDeviceToHost, st));
     if (P1) PF_HIP(hipMemcpyAsync(P1, h->out + h->N, sizeof(double) * h->M, hipMemcpyDeviceToHost, st));
     if (PX) PF_HIP(hipMemcpyAsync(PX, h->out + h->N + h->M, sizeof(double) * h->M * h->D, hipMemcpyDeviceToHost, st));

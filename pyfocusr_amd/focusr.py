@@ -360,12 +360,10 @@ class Focusr(object):
         self.register_target_to_source("deformable")
 
         self.get_initial_correspondences()
-        print("Number of unique correspondences: {}".format(
-            len(np.unique(self.corresponding_target_idx_for_each_source_pt))))
+        print("Number of unique correspondences: {}".format(self._n_unique_correspondences()))
         if self.smooth_correspondences is True:
             self.get_smoothed_correspondences()
-            print("Number of unique correspondences after smoothing: {}".format(
-                len(np.unique(self.corresponding_target_idx_for_each_source_pt))))
+            print("Number of unique correspondences after smoothing: {}".format(self._n_unique_correspondences()))
         if self.return_average_final_points is True:
             if self.smoothed_target_coords is None:  # focusr.py:409 needs the smoothed coordinates
                 raise RuntimeError("return_average_final_points needs smooth_correspondences=True")
@@ -377,6 +375,11 @@ class Focusr(object):
                 self.get_source_mesh_transformed_weighted_avg()
             if self.return_nearest_final_points is True:
                 self.get_source_mesh_transformed_nearest_neighbour()
+
+    def _n_unique_correspondences(self):
+        """len(np.unique(idx)) (focusr.py:543-554) without the sort: target indices are small non-negative ints."""
+        idx = np.asarray(self.corresponding_target_idx_for_each_source_pt)
+        return int(np.count_nonzero(np.bincount(idx, minlength=self.graph_target.n_points)))
 
     @property
     def icp_transform(self):

@@ -359,6 +359,7 @@ def test_eigsort_and_focusr_host_logic(golden, pair, t, s, k, ns):
     reg._ctx = FakeCtx()
     reg.graph_target, reg.graph_source, reg.Q, reg.n_spectral_features = gt, gs, Q, ns
     reg.get_weighted_spectral_coords = True
+    reg.initial_correspondence_type = "kd"
     reg.calc_spectral_coords()
     reg.get_initial_correspondences()
     np.testing.assert_allclose(reg.spectral_weights, p["spectral_weights"], rtol=1e-12)

@@ -46,10 +46,15 @@ from pyfocusr_amd import cpd as cpd_mod  # noqa: E402
 
 timed(cpd_mod, "low_rank_affinity", "  cpd: low-rank affinity")
 timed(_hip.DeviceCpd, "estep", "  cpd: E-steps")
-timed(cpd_mod.affine_registration, "update_transform", "  cpd: affine M-steps")
-timed(cpd_mod.deformable_registration, "update_transform", "  cpd: deformable M-steps")
-timed(cpd_mod.deformable_registration, "transform_point_cloud", "  cpd: deformable transform (incl. all points)")
-timed(cpd_mod.deformable_registration, "update_variance", "  cpd: deformable variance")
+timed(_hip.DeviceCpd, "estep_resident", "  cpd: E-steps (enqueue only)")
+timed(cpd_mod.affine_registration, "_maximisation", "  cpd: affine M-steps (incl. waiting for the E-step)")
+timed(cpd_mod.deformable_registration, "_maximisation", "  cpd: deformable M-steps (incl. waiting for the E-step)")
+timed(cpd_mod.deformable_registration, "transform_point_cloud", "  cpd: deformable transform of all points")
+timed(_hip.DeviceCpd, "deform_sums", "    deform_sums")
+timed(_hip.DeviceCpd, "apply_deform", "    apply_deform")
+timed(_hip.DeviceCpd, "affine_sums", "    affine_sums")
+timed(_hip.DeviceCpd, "apply_affine", "    apply_affine")
+timed(cpd_mod.np.linalg, "solve", "    np.linalg.solve")
 _orig_register = cpd_mod._ExpectationMaximisation.register
 
 
