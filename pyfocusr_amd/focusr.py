@@ -251,7 +251,7 @@ class Focusr(object):
                 "If number vertices between source & target don't match, initial_correspondence_type must\n"
                 "be 'kd' and not 'hungarian'. Current type is: {}".format(self.initial_correspondence_type))
         self.source_projected_on_target = self.graph_source.mean_filter_graph(
-            self.smoothed_target_coords[self.corresponding_target_idx_for_each_source_pt, :],
+            np.take(self.smoothed_target_coords, self.corresponding_target_idx_for_each_source_pt, axis=0),
             iterations=self.projection_smooth_iterations)
         if self.final_correspondence_type == "hungarian":  # focusr.py:391-396
             self.get_hungarian_correspondence(self.smoothed_target_coords, self.source_projected_on_target)
@@ -267,10 +267,10 @@ class Focusr(object):
         pts = self.graph_target.points
         with np.errstate(divide="ignore", invalid="ignore"):
             w = 1.0 / dist
-            num = pts[idx[:, 0], :] * w[:, 0:1]
+            num = np.take(pts, idx[:, 0], axis=0) * w[:, 0:1]  # np.take: the fast path for whole-row gathers
             den = w[:, 0:1].copy()
             for j in range(1, idx.shape[1]):
-                num = num + pts[idx[:, j], :] * w[:, j:j + 1]
+                num = num + np.take(pts, idx[:, j], axis=0) * w[:, j:j + 1]
                 den = den + w[:, j:j + 1]
             out = num / den
         coincident = dist == 0.0
@@ -282,8 +282,8 @@ class Focusr(object):
 
     def get_nearest_neighbour_final_node_locations(self):
         """focusr.py:428-431."""
-        self.nearest_neighbor_transformed_points = self.graph_target.points[
-            self.corresponding_target_idx_for_each_source_pt, :]
+        self.nearest_neighbor_transformed_points = np.take(
+            self.graph_target.points, self.corresponding_target_idx_for_each_source_pt, axis=0)
 
     def _source_mesh_with_points(self, new_points):
         mesh = self.graph_source.vtk_mesh

@@ -68,3 +68,27 @@ for n in args.sizes:
         1e3 * best["sort"], 1e3 * best["knn"], 2 * k / total, cpu, best["res"]), flush=True)
     for m in meshes:
         m._pf_device_mesh.close()
+
+# KNN stress input of SURVEY 8d: two unrelated uniform clouds U(-0.5, 0.5)^(N x 5), seeds 0 / 1
+print()
+print("| KNN stress: U(-0.5,0.5)^(N x d), seeds 0/1 | d | GPU ms (incl. H2D/D2H) | kernel ms | scipy KDTree s (1 thread, 20k-query sample scaled) |")
+print("|---|---|---|---|---|")
+from scipy.spatial import KDTree  # noqa: E402
+
+for n, d in ((250000, 5), (1000000, 5), (250000, 10)):
+    ref = np.random.default_rng(0).uniform(-0.5, 0.5, (n, d))
+    qry = np.random.default_rng(1).uniform(-0.5, 0.5, (n, d))
+    best = None
+    for rep in range(3):
+        ctx.timing(reset=True)
+        t0 = time.perf_counter()
+        idx = ctx.knn1(ref, qry)
+        dt = time.perf_counter() - t0
+        best = dt if best is None or dt < best else best
+        kern = ctx.timing()["knn_ms"]
+    t0 = time.perf_counter()
+    tree = KDTree(ref)
+    ii = tree.query(qry[:20000])[1]
+    cpu = (time.perf_counter() - t0) * n / 20000
+    assert np.array_equal(ii, idx[:20000])
+    print("| %d x %d | %d | %.1f | %.1f | %.1f |" % (n, n, d, 1e3 * best, kern, cpu), flush=True)
