@@ -544,6 +544,7 @@ def test_eigsort_and_correspondence_from_golden_eigs(golden, ctx, pair, t, s, k,
 
     reg = object.__new__(Focusr)
     reg._ctx = ctx
+    reg.initial_correspondence_type = "kd"
     reg.graph_target, reg.graph_source, reg.Q, reg.n_spectral_features = gt, gs, Q, ns
     for tag, weighted in (("u", False), ("w", True)):
         reg.get_weighted_spectral_coords = weighted
