@@ -153,6 +153,34 @@ def test_deformable_registration_equals_oracle(ctx):
 
 
 @pytest.mark.gpu
+def test_tiny_and_ragged_sizes(ctx):
+    """One-point sets, sets smaller than one tile / one basis block, K clipped to M."""
+    from pyfocusr_amd import _hip, cpd
+
+    rng = np.random.default_rng(8)
+    for N, M, D in ((1, 1, 2), (3, 1, 1), (1, 7, 3), (5, 9, 4), (130, 3, 2)):
+        X, Y = rng.normal(size=(N, D)), rng.normal(size=(M, D))
+        dev = _hip.DeviceCpd(X, Y, ctx=ctx)
+        P1, Pt1, PX = dev.estep(Y, 0.7, 0.1)
+        wP1, wPt1, wPX, _ = cpd_port.expectation(X, Y, 0.7, 0.1)
+        np.testing.assert_allclose(P1, wP1, rtol=1e-12)
+        np.testing.assert_allclose(Pt1, wPt1, rtol=1e-12)
+        np.testing.assert_allclose(PX, wPX, rtol=1e-11, atol=1e-14)
+        dev.close()
+    X, Y = rng.normal(size=(40, 2)), rng.normal(size=(9, 2))
+    got = cpd.deformable_registration(X=X, Y=Y, alpha=1.0, beta=1.0, num_eig=100, max_iterations=10, tolerance=0.0, ctx=ctx)
+    TY, (Q, S, W) = got.register()
+    want = cpd_port.DeformableRegistration(X, Y, alpha=1.0, beta=1.0, num_eig=100, max_iterations=10, tolerance=0.0)
+    np.testing.assert_allclose(TY, want.register()[0], atol=1e-8)
+    assert Q.shape[0] == 9 and Q.shape[1] <= 9 and W.shape == (9, 2)
+    a = cpd.affine_registration(X=X, Y=Y, max_iterations=5, tolerance=0.0, ctx=ctx)
+    b = cpd_port.AffineRegistration(X, Y, max_iterations=5, tolerance=0.0)
+    np.testing.assert_allclose(a.register()[0], b.register()[0], atol=1e-10)
+    with pytest.raises(ValueError):
+        cpd.affine_registration(X=X, Y=rng.normal(size=(9, 3)), ctx=ctx)
+
+
+@pytest.mark.gpu
 def test_focusr_full_defaults_run_without_cycpd_or_vtk(golden, ctx):
     """`Focusr(target, source)` with EVERY argument at the reference's default (ICP first, curvature features
     requested but unused, affine + deformable CPD on 5000 sampled points, smoothing, both outputs), then

@@ -129,6 +129,23 @@ def test_closest_points_quads_degenerate_and_nan(ctx):
 
 
 @pytest.mark.gpu
+def test_closest_points_tiny_surfaces(ctx):
+    """One triangle; fewer triangles than a chunk; exactly one chunk; one more than a chunk / a super-chunk."""
+    from pyfocusr_amd import _hip
+
+    rng = np.random.default_rng(9)
+    for n_tri in (1, 5, 64, 65, 64 * 64, 64 * 64 + 1):
+        pts = rng.normal(size=(max(3, n_tri // 2 + 3), 3))
+        faces = rng.integers(0, len(pts), size=(n_tri, 3)).astype(np.int32)
+        q = rng.normal(size=(23, 3)) * 1.5
+        surf = _hip.DeviceSurface(pts, faces, ctx=ctx)
+        cp, face, d2 = surf.closest(q)
+        surf.close()
+        want_cp, want_face, want_d2 = icp_port.closest_points_on_surface(pts, faces, q)
+        assert np.array_equal(d2, want_d2) and np.array_equal(face, want_face) and np.array_equal(cp, want_cp), n_tri
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("mode", ["rigid", "similarity"])
 def test_icp_equals_oracle_loop(golden, ctx, mode):
     """The reference's configuration (1000 landmarks, centroid start, no mean-distance test) on the 5k pair; 30
