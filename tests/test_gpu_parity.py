@@ -312,6 +312,32 @@ def test_spectrum_vs_reference(golden, ctx, name, k):
     assert np.max(np.linalg.norm(R, axis=0)) < 1e-8
 
 
+@pytest.mark.parametrize("n,k,seed", [(2000, 1, 11), (2000, 12, 12), (7000, 3, 13), (7000, 8, 14), (20000, 5, 15),
+                                      (20000, 12, 16), (60000, 3, 17), (60000, 8, 18)])
+def test_spectrum_sweep_vs_oracle(ctx, n, k, seed):
+    """Sizes and k the bundled meshes do not cover: synthetic closed meshes against the oracle's scipy `eigs`
+    (the reference's call) — eigenvalues to 1e-8 relative, eigenvectors up to sign within the conditioning of
+    the pair (residual / gap), true residuals against the oracle's L."""
+    from pyfocusr_amd import Graph
+    from pyfocusr_amd.meshgen import blob_mesh
+
+    m = blob_mesh(n, seed=seed)
+    W, deg, d_inv, L = orc.graph_matrices(m.points, m.faces)
+    vals, vecs = orc.canonicalize(*orc.recursive_eig(L, k + 1, k))
+    gr = Graph(m, n_spectral_features=k, norm_eig_vecs=False, n_rand_samples=10**9, ctx=ctx, verbose=False)
+    gr.get_graph_spectrum()
+    assert gr.eig_vals.shape == vals.shape
+    np.testing.assert_allclose(gr.eig_vals, vals, rtol=1e-8)
+    R = L @ gr.eig_vecs - gr.eig_vecs * gr.eig_vals[None, :]
+    assert np.max(np.linalg.norm(R, axis=0)) < 1e-10
+    Rref = L @ vecs - vecs * vals[None, :]
+    gaps = np.minimum(np.diff(np.concatenate(([0.0], vals))), np.diff(np.concatenate((vals, [np.inf]))))
+    gaps[-1] = vals[-1] - vals[-2] if k > 1 else vals[-1]  # the next eigenvalue up is unknown: use the gap below
+    play = (np.linalg.norm(R, axis=0) + np.linalg.norm(Rref, axis=0)) / gaps
+    err = np.max(np.abs(gr.eig_vecs - vecs), axis=0)
+    assert np.all(err < 10 * play + 1e-12), (err, play)
+
+
 def test_tiny_meshes(ctx):
     """n = 4 and n = 6: far below one wavefront; the solver runs unfiltered (scipy eigs refuses k >= n-1)."""
     from pyfocusr_amd import Graph, PolyMesh
