@@ -407,6 +407,51 @@ def test_open_mesh_complex_spectrum(ctx):
     assert np.all(np.isfinite(gr.eig_vecs)) and gr.eig_vecs.min() == -0.5 and gr.eig_vecs.max() == 0.5
 
 
+@pytest.mark.parametrize("case", ["blob_with_holes", "four_components_and_strays", "thin_strip", "asymmetric_few"])
+def test_spectrum_messy_meshes_vs_oracle(ctx, case):
+    """Non-closed, multi-component and slightly asymmetric inputs at sizes where the automatic paths of the solver
+    switch (null-vector locking, widen-and-retry, Arnoldi with complex outliers, ellipse filter): the eigenvalues
+    the reference returns (scipy `eigs` in the oracle), in its column count."""
+    from pyfocusr_amd import Graph, PolyMesh
+    from pyfocusr_amd.meshgen import blob_mesh
+
+    rng = np.random.default_rng(21)
+    k = 5
+    if case == "blob_with_holes":  # closed blob with three caps cut out: 59 one-way boundary edges and 32 vertices
+        m = blob_mesh(8000, seed=5)  # left without faces (each one a null vector the reference widens k for: larger
+        pts, faces = m.points, m.faces  # holes keep scipy's eigs busy for minutes)
+        c = pts[faces].mean(axis=1)
+        keep = np.ones(len(faces), dtype=bool)
+        for centre in pts[[10, 2000, 7000]]:
+            keep &= np.linalg.norm(c - centre, axis=1) > 3.0
+        faces = faces[keep]
+    elif case == "four_components_and_strays":
+        parts = [blob_mesh(n, seed=30 + i) for i, n in enumerate((9000, 4000, 2500, 600))]
+        pts = np.concatenate([p.points + 300.0 * i for i, p in enumerate(parts)] + [rng.normal(size=(4, 3))])
+        off = np.cumsum([0] + [len(p.points) for p in parts])
+        faces = np.concatenate([p.faces + off[i] for i, p in enumerate(parts)])
+    elif case == "thin_strip":  # 400 x 12 open strip: long thin domain, many boundary edges
+        nx, ny = 400, 12
+        x, y = np.meshgrid(np.arange(nx, dtype=float), np.arange(ny, dtype=float), indexing="ij")
+        pts = np.stack([x, y, 0.5 * np.sin(x / 9.0)], -1).reshape(-1, 3) + 0.03 * rng.normal(size=(nx * ny, 3))
+        idx = np.arange(nx * ny).reshape(nx, ny)
+        a, b, c, d = idx[:-1, :-1].ravel(), idx[1:, :-1].ravel(), idx[1:, 1:].ravel(), idx[:-1, 1:].ravel()
+        faces = np.concatenate([np.stack([a, b, c], 1), np.stack([a, c, d], 1)])
+    else:  # a closed mesh with a handful of faces removed: a few one-way edges, Arnoldi with a real low spectrum
+        m = blob_mesh(12000, seed=6)
+        pts, faces = m.points, np.delete(m.faces, [5, 900, 4000, 4001, 20000], axis=0)
+    ref = orc.graph_spectrum(pts, faces, k)
+    gr = Graph(PolyMesh(pts, faces), n_spectral_features=k, n_rand_samples=10**9, ctx=ctx, verbose=False)
+    gr.get_graph_spectrum()
+    m_ = min(len(gr.eig_vals), len(ref["eig_vals"]))
+    assert m_ >= k
+    if case == "four_components_and_strays":
+        assert gr.device.n_components == 4 and gr.device.n_isolated == 4
+        assert gr.eig_vals.shape == ref["eig_vals"].shape
+    np.testing.assert_allclose(gr.eig_vals[:m_], ref["eig_vals"][:m_], rtol=2e-7)
+    assert np.all(np.isfinite(gr.eig_vecs)) and gr.eig_vecs.min() >= -0.5 and gr.eig_vecs.max() <= 0.5
+
+
 def test_paired_spectra_equal_single(golden, ctx):
     """Two graphs per kernel launch (pf_cheb2, different sizes and degrees) give bit-identical
     results to one graph per launch."""
