@@ -119,3 +119,44 @@ class NumpyOps(object):
 
     def resnorm(self, ax, x, lam):
         return float(np.linalg.norm(self.ws[:, ax] - lam * self.ws[:, x]))
+
+    # -- primitives the row-partitioned solver adds (pyfocusr_amd/rowpart.py)
+    def op_step(self, x, prev, out, alpha, c, beta):
+        """out = alpha (c x - A x) - beta prev; `out` may be the `prev` slot."""
+        y = alpha * (c * self.ws[:, x] - self.A @ self.ws[:, x])
+        if prev is not None:
+            y = y - beta * self.ws[:, prev]
+        self.ws[:, out] = y
+        self.launches += 1
+
+    def axpy(self, w, first, count, coef):
+        self.ws[:, w] += self.ws[:, first : first + count] @ np.asarray(coef, dtype=np.float64)
+
+    def rows_create(self, idx):
+        return np.asarray(idx, dtype=np.int64).copy()
+
+    def rows_gather(self, slot, rows):
+        return self.ws[rows, slot].copy()
+
+    def rows_scatter(self, slot, rows, values):
+        self.ws[rows, slot] = values
+
+    def rows_fill(self, slot, rows, value):
+        self.ws[rows, slot] = value
+
+
+class MatrixOps(NumpyOps):
+    """Test double over a general symmetric matrix (the local operator of one rank of the row-partitioned solve)."""
+
+    def __init__(self, A):
+        A = A.tocsr()
+        self.n = A.shape[0]
+        self.A = self.S = A
+        self.symmetric = True
+        self.isolated = np.zeros(self.n, dtype=bool)
+        self.n_isolated = 0
+        self.ws = np.zeros((self.n, 0), order="F")
+        self.launches = 0
+
+    def lock_null_vectors(self):
+        return 0

@@ -1,0 +1,120 @@
+"""Row-partitioned eigensolve: host-side layout logic, and the whole distributed solve
+under gloo with the CPU test double as the per-rank local operator (world sizes 2 and 3); on the GPU box the same
+code runs with `_hip.DeviceLaplacian` local operators (`-m gpu`, ranks sharing the one MI355X)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (REPO, os.path.join(REPO, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _mesh_operator(n, seed):
+    from oracle import reference_port as orc
+    from pyfocusr_amd import rowpart
+    from pyfocusr_amd.meshgen import blob_mesh
+
+    m = blob_mesh(n, seed=seed)
+    W, deg, d_inv, L = orc.graph_matrices(m.points, m.faces)
+    Wc = W.tocsr()
+    Wc.sort_indices()
+    S, sg = rowpart.symmetric_operator(Wc.indptr, Wc.indices, Wc.data, deg)
+    return m, L, S, sg
+
+
+def test_layouts_cover_and_ghost_zone_is_exact():
+    """Own sets partition the rows; ring r is exactly the set at graph distance r; and `s` steps of the three-term
+    recurrence on chunk + s rings reproduce the global recurrence on the own rows (the property the scheme rests on)."""
+    from _numpy_ops import MatrixOps
+    from pyfocusr_amd import rowpart
+    from scipy.sparse.csgraph import shortest_path
+
+    m, L, S, sg = _mesh_operator(1500, 2)
+    order = rowpart.morton_order(m.points)
+    assert sorted(order.tolist()) == list(range(1500))
+    for world, s in ((2, 3), (3, 5), (5, 2)):
+        layouts = rowpart.build_all_layouts(S, order, world, s)
+        owned = np.concatenate([lay.local[: lay.n_own] for lay in layouts])
+        assert sorted(owned.tolist()) == list(range(1500))
+        pattern = (S != 0).astype(np.float64)
+        for lay in layouts:
+            dist = shortest_path(pattern, unweighted=True, indices=lay.local[: lay.n_own]).min(axis=0)
+            for r in range(len(lay.ring_ptr) - 1):
+                ring = lay.local[lay.ring_ptr[r]: lay.ring_ptr[r + 1]]
+                assert np.all(dist[ring] == r + 1)
+            assert abs(lay.S_local - S[lay.local][:, lay.local]).max() == 0
+            assert np.all(lay.publish < lay.n_own)
+            for q, (src, dst) in lay.fill.items():
+                assert np.all(dst >= lay.n_own)
+                assert np.array_equal(layouts[q].local[layouts[q].publish][src], lay.local[dst])
+        # s steps without communication are exact on the own rows
+        x = np.random.default_rng(0).standard_normal(1500)
+        y0, y1 = x, (x - S @ x)
+        for _ in range(s - 1):
+            y0, y1 = y1, 2.0 * (y1 - S @ y1) - y0
+        for lay in layouts:
+            o = MatrixOps(lay.S_local)
+            o.ws_ensure(3)
+            o.ws[:, 0] = x[lay.local]
+            o.op_step(0, None, 1, 1.0, 1.0, 0.0)
+            prev, cur = 0, 1
+            for _ in range(s - 1):
+                o.op_step(cur, prev, prev, 2.0, 1.0, 1.0)
+                prev, cur = cur, prev
+            np.testing.assert_allclose(o.ws[: lay.n_own, cur], y1[lay.local[: lay.n_own]], rtol=0, atol=1e-12 * np.abs(y1).max())
+
+
+def _worker(rank, world, port, out_dir, s):
+    import torch
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from _numpy_ops import MatrixOps
+    from oracle import reference_port as orc
+    from pyfocusr_amd import _krylov, rowpart
+
+    m, L, S, sg = _mesh_operator(3000, 7)
+    k = 4
+    comm = rowpart.Comm(dist, torch)
+    order = rowpart.morton_order(m.points)
+    local, n_own, ring_ptr, S_local, spans, pos = rowpart.build_layout(S, order, world, rank, s)
+    ghosts = [g[:, 0].astype(np.int64) for g in comm.allgather_ragged(local[n_own:].astype(np.float64)[:, None])]
+    layout = rowpart.finish_layout(rank, world, local, n_own, ring_ptr, S_local, spans, pos, ghosts)
+    ops = rowpart.RowPartitionedOps(MatrixOps(layout.S_local), layout, comm, S.shape[0], s)
+    vals, first, stats = _krylov.filtered_eigs(ops, k + 1, True)
+    vals = vals[:k]
+    ref_vals, ref_vecs = orc.canonicalize(*orc.recursive_eig(L, k + 1, k))
+    np.testing.assert_allclose(vals, ref_vals, rtol=1e-8)
+    own = layout.local[:n_own]
+    vecs = np.stack([ops.local.rows_gather(first + j, np.arange(n_own)) for j in range(k)], axis=1) * sg[own, None]
+    nrm = np.sqrt(comm.allreduce_sum(np.sum(vecs * vecs, axis=0)))
+    vecs = vecs / nrm
+    sign = np.sign(comm.allreduce_sum(np.sum(vecs * ref_vecs[own], axis=0)))
+    assert np.max(np.abs(vecs * sign - ref_vecs[own])) < 1e-7
+    assert ops.exchanges > 0 and stats.matvecs > 0
+    dist.barrier()
+    dist.destroy_process_group()
+    open(os.path.join(out_dir, "ok%d" % rank), "w").close()
+
+
+@pytest.mark.parametrize("world,s", [(2, 6), (3, 16)])
+def test_row_partitioned_solve_gloo(tmp_path, world, s):
+    import torch.multiprocessing as mp
+
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), s), nprocs=world, join=True)
+    assert all(os.path.exists(tmp_path / ("ok%d" % r)) for r in range(world))
