@@ -168,6 +168,22 @@ int pf_knn_upload(pf_ctx* ctx, const double* ref, int64_t n_ref, const double* q
 int pf_knn_run(pf_ctx* ctx);
 int pf_knn_download(pf_ctx* ctx, int64_t* idx_out, double* d2_out);
 
+/* ---- primitives of the row-partitioned solve (one large mesh over several GPUs; SURVEY 8e / BASELINE config C5).
+ * The reference has no counterpart (scipy eigs on one core, graph.py:357-389).  pyfocusr_amd/rowpart.py drives them.
+ *   pf_op_step     one step of a three-term recurrence: out = alpha (shift x - A x) - beta prev   (slots; prev = -1:
+ *                  no prev term; out may be the prev slot)
+ *   pf_axpy        slot w += sum_i coef[i] * slot (first + i)
+ *   pf_rows_*      a fixed subset of rows (mesh-order indices): gather its values of a slot to the host, scatter
+ *                  host values into it, or fill it with a constant — the boundary / ghost rows of a partition. */
+typedef struct pf_rows pf_rows;
+int pf_op_step(pf_graph* g, int32_t op, int32_t x, int32_t prev, int32_t out, double alpha, double shift, double beta);
+int pf_axpy(pf_graph* g, int32_t w, int32_t first, int32_t count, const double* coef);
+int pf_rows_create(pf_graph* g, const int64_t* rows, int64_t n, pf_rows** out);
+void pf_rows_free(pf_rows* r);
+int pf_rows_gather(pf_rows* r, int32_t slot, double* out);
+int pf_rows_scatter(pf_rows* r, int32_t slot, const double* in);
+int pf_rows_fill(pf_rows* r, int32_t slot, double value);
+
 /* ---- closest point on a triangulated surface (ICP pre-alignment, "next" row f3) --------------------------
  * Replaces the vtkCellLocator::FindClosestPoint loop inside vtkIterativeClosestPointTransform, which the
  * reference runs through vtk_functions.py:12-29 (called from focusr.py:110-131).  Polygons with more than three

@@ -88,6 +88,13 @@ SIGNATURES = {
     "pf_knn_upload": (C.c_int, [C.c_void_p, _f64p, C.c_int64, _f64p, C.c_int64, C.c_int32]),
     "pf_knn_run": (C.c_int, [C.c_void_p]),
     "pf_knn_download": (C.c_int, [C.c_void_p, _i64p, _f64p]),
+    "pf_op_step": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double]),
+    "pf_axpy": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, _f64p]),
+    "pf_rows_create": (C.c_int, [C.c_void_p, _i64p, C.c_int64, C.POINTER(C.c_void_p)]),
+    "pf_rows_free": (None, [C.c_void_p]),
+    "pf_rows_gather": (C.c_int, [C.c_void_p, C.c_int32, _f64p]),
+    "pf_rows_scatter": (C.c_int, [C.c_void_p, C.c_int32, _f64p]),
+    "pf_rows_fill": (C.c_int, [C.c_void_p, C.c_int32, C.c_double]),
     "pf_surface_create": (C.c_int, [C.c_void_p, _f64p, C.c_int64, _i32p, C.c_int64, C.c_int32, C.POINTER(C.c_void_p)]),
     "pf_surface_free": (None, [C.c_void_p]),
     "pf_surface_closest": (C.c_int, [C.c_void_p, _f64p, C.c_int64, _f64p, _i32p, _f64p]),
@@ -419,6 +426,18 @@ def gaussian_gram_product(A, B, beta, V, ctx=None):
     return out
 
 
+class _Rows(object):
+    """A fixed subset of a graph's rows on the device (`pf_rows_*`)."""
+
+    def __init__(self, owner, h, n):
+        self._lib, self._h, self.n = owner._lib, h, n
+
+    def close(self):
+        if self._h:
+            self._lib.pf_rows_free(self._h)
+            self._h = None
+
+
 class DeviceLaplacian(object):
     """Device-resident graph of one mesh: CSR(W), deg, SELL-64 operators, workspace.
     Also the `ops` object the Krylov driver (`_krylov.filtered_eigs`) drives."""
@@ -461,9 +480,12 @@ class DeviceLaplacian(object):
         self.max_degree = int(info.max_degree)
         self.n_oneway = int(info.n_oneway)
         self.op = PF_OP_SYM if self.symmetric else PF_OP_RW
+        self._rows = []
 
     def close(self):
         if getattr(self, "_h", None):
+            for rows in getattr(self, "_rows", []):
+                rows.close()
             self._lib.pf_graph_free(self._h)
             self._h = None
 
@@ -573,6 +595,36 @@ class DeviceLaplacian(object):
         y = np.empty(self.n, dtype=np.float64)
         _check(self._lib.pf_spmv_host(self._h, self.op if op is None else int(op), _f64(x), _f64(y)))
         return y
+
+    # ---- primitives of the row-partitioned solve (pyfocusr_amd/rowpart.py)
+    def op_step(self, x, prev, out, alpha, c, beta, op=None):
+        """out = alpha (c x - A x) - beta prev (slots; prev None: no prev term; out may be the prev slot)."""
+        _check(self._lib.pf_op_step(self._h, self.op if op is None else int(op), int(x), -1 if prev is None else int(prev),
+                                    int(out), float(alpha), float(c), float(beta)))
+
+    def axpy(self, w, first, count, coef):
+        coef = _c_f64(coef)
+        _check(self._lib.pf_axpy(self._h, int(w), int(first), int(count), _f64(coef)))
+
+    def rows_create(self, idx):
+        idx = np.ascontiguousarray(idx, dtype=np.int64)
+        h = C.c_void_p()
+        _check(self._lib.pf_rows_create(self._h, idx.ctypes.data_as(_i64p), len(idx), C.byref(h)))
+        rows = _Rows(self, h, len(idx))
+        self._rows.append(rows)
+        return rows
+
+    def rows_gather(self, slot, rows):
+        out = np.empty(rows.n)
+        _check(self._lib.pf_rows_gather(rows._h, int(slot), _f64(out)))
+        return out
+
+    def rows_scatter(self, slot, rows, values):
+        values = _c_f64(values, (rows.n,))
+        _check(self._lib.pf_rows_scatter(rows._h, int(slot), _f64(values)))
+
+    def rows_fill(self, slot, rows, value):
+        _check(self._lib.pf_rows_fill(rows._h, int(slot), float(value)))
 
     def mean_filter(self, values, iterations):
         v = _c_f64(values)

@@ -468,6 +468,28 @@ __global__ __launch_bounds__(PF_BLOCK) void k_rows_out(const double* __restrict_
     dst[t] = src[(int64_t)iperm[old] * ncols + (t - old * ncols)];
 }
 
+// ---- row subsets (pf_rows_*): boundary / ghost rows of a row-partitioned solve, addressed in solver order
+__global__ __launch_bounds__(PF_BLOCK) void k_rows_to_new(const int64_t* __restrict__ old_idx, const int32_t* __restrict__ iperm,
+                                                          int64_t cnt, int32_t* __restrict__ new_idx) {
+    const int64_t t = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
+    if (t < cnt) new_idx[t] = iperm[old_idx[t]];
+}
+__global__ __launch_bounds__(PF_BLOCK) void k_rows_gather(const double* __restrict__ x, const int32_t* __restrict__ idx, int64_t cnt,
+                                                          double* __restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
+    if (t < cnt) out[t] = x[idx[t]];
+}
+__global__ __launch_bounds__(PF_BLOCK) void k_rows_scatter(double* __restrict__ x, const int32_t* __restrict__ idx, int64_t cnt,
+                                                           const double* __restrict__ in) {
+    const int64_t t = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
+    if (t < cnt) x[idx[t]] = in[t];
+}
+__global__ __launch_bounds__(PF_BLOCK) void k_rows_fill(double* __restrict__ x, const int32_t* __restrict__ idx, int64_t cnt,
+                                                        double value) {
+    const int64_t t = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
+    if (t < cnt) x[idx[t]] = value;
+}
+
 int stage_ensure(pf_graph* g, int64_t elems) {
     if (elems <= g->stage_cap) return PF_OK;
     pf_free(g->ctx->stream, g->stage);
@@ -967,6 +989,117 @@ int pf_mean_filter(pf_graph* g, const double* values, int32_t ncols, int32_t ite
     pf_free(st, b);
     PF_HIP(e);
     PF_HIP(e2);
+    return PF_OK;
+}
+
+// ---- primitives of the row-partitioned solve (pyfocusr_amd/rowpart.py)
+int pf_op_step(pf_graph* g, int32_t op, int32_t x, int32_t prev, int32_t out, double alpha, double shift, double beta) {
+    PF_TRY(check_slots(g, x, 1, "pf_op_step"));
+    PF_TRY(check_slots(g, out, 1, "pf_op_step"));
+    if (prev >= 0) PF_TRY(check_slots(g, prev, 1, "pf_op_step"));
+    const double* vals = op_values(g, op);
+    PF_CHECK(vals != nullptr && x != out, PF_E_ARG, "pf_op_step: operator %d unavailable or x == out", op);
+    OpTimer t(g->ctx, 1, (double)op_bytes(g));
+    PF_TRY(launch_op(g, vals, pf_slot(g, x), prev >= 0 ? pf_slot(g, prev) : nullptr, pf_slot(g, out), alpha, shift, beta));
+    return t.finish();
+}
+
+int pf_axpy(pf_graph* g, int32_t w, int32_t first, int32_t count, const double* coef) {
+    PF_TRY(check_slots(g, w, 1, "pf_axpy"));
+    PF_TRY(check_slots(g, first, count, "pf_axpy"));
+    PF_CHECK(coef != nullptr || count == 0, PF_E_ARG, "pf_axpy: coef is NULL");
+    PF_CHECK(w < first || w >= first + count, PF_E_ARG, "pf_axpy: w inside the basis range");
+    if (count == 0) return PF_OK;
+    hipStream_t st = g->ctx->stream;
+    PF_TRY(pf_reduce_ensure(g, count));
+    std::vector<double> neg(coef, coef + count);
+    for (double& v : neg) v = -v;  // k_multi_axpy subtracts
+    PF_HIP(hipMemcpyAsync(g->coef, neg.data(), sizeof(double) * count, hipMemcpyHostToDevice, st));
+    k_multi_axpy<<<nblk(g->n_pad / 2), PF_BLOCK, 0, st>>>(g->ws, g->n_pad, first, count, w, g->coef);
+    PF_HIP(hipGetLastError());
+    PF_HIP(hipStreamSynchronize(st));  // neg goes out of scope
+    return PF_OK;
+}
+
+struct pf_rows {
+    pf_graph* g = nullptr;
+    int32_t* idx = nullptr;  // solver-order row of every entry
+    double* buf = nullptr;   // device staging [n]
+    int64_t n = 0;
+};
+
+void pf_rows_free(pf_rows* r) {
+    if (!r) return;
+    hipSetDevice(r->g->ctx->device);
+    hipStream_t st = r->g->ctx->stream;
+    hipStreamSynchronize(st);
+    pf_free(st, r->idx);
+    pf_free(st, r->buf);
+    delete r;
+}
+
+int pf_rows_create(pf_graph* g, const int64_t* rows, int64_t n, pf_rows** out) {
+    PF_CHECK(g && out && (rows || n == 0) && n >= 0, PF_E_ARG, "pf_rows_create: bad argument");
+    for (int64_t i = 0; i < n; ++i)
+        PF_CHECK(rows[i] >= 0 && rows[i] < g->n, PF_E_ARG, "pf_rows_create: row %lld outside [0, %lld)", (long long)rows[i],
+                 (long long)g->n);
+    PF_HIP(hipSetDevice(g->ctx->device));
+    hipStream_t st = g->ctx->stream;
+    pf_rows* r = new pf_rows();
+    r->g = g;
+    r->n = n;
+    if (n > 0) {
+        int64_t* tmp = nullptr;
+        hipError_t e = pf_malloc(st, (void**)&r->idx, sizeof(int32_t) * n);
+        if (e == hipSuccess) e = pf_malloc(st, (void**)&r->buf, sizeof(double) * n);
+        if (e == hipSuccess) e = pf_malloc(st, (void**)&tmp, sizeof(int64_t) * n);
+        if (e == hipSuccess) e = hipMemcpyAsync(tmp, rows, sizeof(int64_t) * n, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) {
+            k_rows_to_new<<<nblk(n), PF_BLOCK, 0, st>>>(tmp, g->iperm, n, r->idx);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        pf_free(st, tmp);
+        if (e != hipSuccess) {
+            pf_set_error("pf_rows_create: %s", hipGetErrorString(e));
+            pf_rows_free(r);
+            return PF_E_HIP;
+        }
+    }
+    *out = r;
+    return PF_OK;
+}
+
+int pf_rows_gather(pf_rows* r, int32_t slot, double* out) {
+    PF_CHECK(r && (out || r->n == 0), PF_E_ARG, "pf_rows_gather: NULL argument");
+    PF_TRY(check_slots(r->g, slot, 1, "pf_rows_gather"));
+    if (r->n == 0) return PF_OK;
+    hipStream_t st = r->g->ctx->stream;
+    k_rows_gather<<<nblk(r->n), PF_BLOCK, 0, st>>>(pf_slot(r->g, slot), r->idx, r->n, r->buf);
+    PF_HIP(hipGetLastError());
+    PF_HIP(hipMemcpyAsync(out, r->buf, sizeof(double) * r->n, hipMemcpyDeviceToHost, st));
+    PF_HIP(hipStreamSynchronize(st));
+    return PF_OK;
+}
+
+int pf_rows_scatter(pf_rows* r, int32_t slot, const double* in) {
+    PF_CHECK(r && (in || r->n == 0), PF_E_ARG, "pf_rows_scatter: NULL argument");
+    PF_TRY(check_slots(r->g, slot, 1, "pf_rows_scatter"));
+    if (r->n == 0) return PF_OK;
+    hipStream_t st = r->g->ctx->stream;
+    PF_HIP(hipMemcpyAsync(r->buf, in, sizeof(double) * r->n, hipMemcpyHostToDevice, st));
+    k_rows_scatter<<<nblk(r->n), PF_BLOCK, 0, st>>>(pf_slot(r->g, slot), r->idx, r->n, r->buf);
+    PF_HIP(hipGetLastError());
+    PF_HIP(hipStreamSynchronize(st));  // `in` is the caller's again
+    return PF_OK;
+}
+
+int pf_rows_fill(pf_rows* r, int32_t slot, double value) {
+    PF_CHECK(r != nullptr, PF_E_ARG, "pf_rows_fill: NULL argument");
+    PF_TRY(check_slots(r->g, slot, 1, "pf_rows_fill"));
+    if (r->n == 0) return PF_OK;
+    k_rows_fill<<<nblk(r->n), PF_BLOCK, 0, r->g->ctx->stream>>>(pf_slot(r->g, slot), r->idx, r->n, value);
+    PF_HIP(hipGetLastError());
     return PF_OK;
 }
 

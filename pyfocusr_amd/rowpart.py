@@ -294,8 +294,9 @@ def row_partitioned_eigs(points, faces, k, comm, make_local, s=16, device_graph=
     stats, ops)."""
     from . import _krylov
 
-    rowptr, col, w, _, deg, _, _ = device_graph.download()
-    S, sg = symmetric_operator(rowptr, col, w, deg)
+    d = device_graph.download()
+    S, sg = symmetric_operator(d["rowptr"], d["colidx"], d["w"], d["deg"])
+    deg = d["deg"]
     if abs(S - S.T).max() > 1e-12 * abs(S).max():
         raise NotImplementedError("row-partitioned solve needs a symmetric adjacency (no one-way edges)")
     order = morton_order(points)

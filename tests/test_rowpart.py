@@ -118,3 +118,52 @@ def test_row_partitioned_solve_gloo(tmp_path, world, s):
 
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), s), nprocs=world, join=True)
     assert all(os.path.exists(tmp_path / ("ok%d" % r)) for r in range(world))
+
+
+def _gpu_worker(rank, world, port, out_dir, n, k, s):
+    import torch
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)  # ranks share GPU 0; collectives on the host
+    from oracle import reference_port as orc
+    from pyfocusr_amd import _hip, rowpart
+    from pyfocusr_amd.meshgen import blob_mesh
+
+    ctx = _hip.Context(0)
+    m = blob_mesh(n, seed=9)
+    full = _hip.DeviceLaplacian(m.points, m.faces, ctx=ctx)
+    comm = rowpart.Comm(dist, torch)
+
+    def make_local(S_local):
+        return _hip.DeviceLaplacian(matrix=(S_local.indptr, S_local.indices, S_local.data), ctx=ctx)
+
+    vals, vecs, own, stats, ops = rowpart.row_partitioned_eigs(m.points, m.faces, k, comm, make_local, s=s, device_graph=full)
+    W, deg, d_inv, L = orc.graph_matrices(m.points, m.faces)
+    ref_vals, ref_vecs = orc.canonicalize(*orc.recursive_eig(L, k + 1, k))
+    np.testing.assert_allclose(vals, ref_vals, rtol=1e-8)
+    sign = np.sign(comm.allreduce_sum(np.sum(vecs * ref_vecs[own], axis=0)))
+    assert np.max(np.abs(vecs * sign - ref_vecs[own])) < 1e-7
+    # true residual of the assembled eigenvectors against the oracle's L (needs all rows: gather)
+    parts = comm.allgather_ragged(np.concatenate([own[:, None].astype(np.float64), vecs], axis=1))
+    allv = np.zeros((n, k))
+    for p in parts:
+        allv[p[:, 0].astype(np.int64)] = p[:, 1:]
+    R = L @ allv - allv * vals[None, :]
+    assert np.max(np.linalg.norm(R, axis=0)) < 1e-9
+    assert ops.exchanges >= stats.matvecs // s  # one refresh per s steps (plus the Rayleigh-Ritz products)
+    dist.barrier()
+    dist.destroy_process_group()
+    open(os.path.join(out_dir, "ok%d" % rank), "w").close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,n,k,s", [(2, 20000, 5, 8), (3, 60000, 4, 16)])
+def test_row_partitioned_solve_on_device(tmp_path, world, n, k, s):
+    """Ranks share the one MI355X (gloo for the collectives): every rank holds chunk + ghost rows as its own
+    device graph; eigenpairs equal the oracle's."""
+    import torch.multiprocessing as mp
+
+    mp.spawn(_gpu_worker, args=(world, _free_port(), str(tmp_path), n, k, s), nprocs=world, join=True)
+    assert all(os.path.exists(tmp_path / ("ok%d" % r)) for r in range(world))
