@@ -156,6 +156,34 @@ def bundled_15k_pair(ctx, k=5, reps=3):
                 max_rel_eigenvalue_error_vs_reference=err)
 
 
+def row_partition_step(ctx, dist, torch, mesh, k, s):
+    """BASELINE config C5 layout (opt-in, `--row-partition S`): ONE mesh's rows split over all ranks, ghost zones of
+    depth S, the Chebyshev recurrence exchanging boundary rows every S steps (pyfocusr_amd/rowpart.py).  Returns
+    (seconds of the eigensolve, seconds of the setup, stats)."""
+    from pyfocusr_amd import _hip, rowpart
+
+    comm = rowpart.Comm(dist, torch)
+    t0 = time.perf_counter()
+    full = _hip.DeviceLaplacian(mesh.points, mesh.faces, ctx=ctx)
+    made = []
+
+    def make_local(S_local):
+        made.append(_hip.DeviceLaplacian(matrix=(S_local.indptr, S_local.indices, S_local.data), ctx=ctx))
+        return made[-1]
+
+    marks = {}  # row_partitioned_eigs records the seconds of the eigensolve proper under "solve"
+    vals, vecs, own, stats, ops = rowpart.row_partitioned_eigs(mesh.points, mesh.faces, k, comm, make_local, s=s,
+                                                               device_graph=full, timing=marks)
+    ctx.sync()
+    total = time.perf_counter() - t0
+    out = dict(solve_s=marks.get("solve", float("nan")), setup_s=total - marks.get("solve", 0.0), matvecs=int(stats.matvecs),
+               exchanges=int(ops.exchanges), rows_own=int(len(own)), rows_local=int(ops.layout.n_local), eig_vals=vals.tolist())
+    for g in made:
+        g.close()
+    full.close()
+    return out
+
+
 def split_pair_step(ctx, dist, torch, tdev, rank, mesh, k, n_samples):
     """BASELINE config C4: rank 0 = target, rank 1 = source; all-gather of the normalised
     eigenvectors (n x k f64) over RCCL/xGMI; eigsort replicated (k x k work); KNN sharded by
@@ -199,6 +227,9 @@ def main():
     ap.add_argument("--no-extras", action="store_true",
                     help="only the headline workload (no bundled-15k-pair measurement): keeps rocprofv3 kernel statistics "
                          "to the 250k launches")
+    ap.add_argument("--row-partition", type=int, default=0, metavar="S",
+                    help="opt-in extra at N > 1: additionally solve ONE mesh with its rows split over all ranks, ghost "
+                         "zones of depth S (BASELINE config C5 layout); reported under 'row_partitioned'")
     ap.add_argument("--pair", choices=("on", "off"), default="on",
                     help="on: the target and source recurrences share kernel launches (pf_cheb2, the library default); "
                          "off: one graph per launch, the two solves one after the other")
@@ -288,6 +319,38 @@ def main():
                               "coordinates, query-sharded KNN" % args.n, ms=1e3 * float(t.item()),
                      eigenpairs_per_s=2 * args.k / float(t.item()), scaling="strong")
 
+    rowp = None
+    if world > 1 and args.row_partition > 0:
+        try:
+            mesh_rp = mesh_t if rank == 0 else blob_mesh(args.n, seed=0)  # every rank needs the SAME mesh here
+            barrier()
+            r = row_partition_step(ctx, dist, torch, mesh_rp, args.k, args.row_partition)
+            barrier()
+            t = torch.tensor([r["solve_s"], r["setup_s"]], dtype=torch.float64, device=tdev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            rows = torch.tensor([float(r["rows_local"])], dtype=torch.float64, device=tdev)
+            dist.all_reduce(rows, op=dist.ReduceOp.MAX)
+            rowp = dict(workload="C5 layout: ONE %d-vertex mesh, rows split over %d ranks, ghost depth %d, k=%d"
+                                 % (args.n, world, args.row_partition, args.k),
+                        eigensolve_ms=1e3 * float(t[0]), setup_ms=1e3 * float(t[1]), matvecs=r["matvecs"],
+                        exchanges=r["exchanges"], rows_own_rank0=r["rows_own"], max_rows_with_ghosts=int(rows.item()),
+                        eig_vals=r["eig_vals"])
+            if rank == 0:  # the same mesh on one device, for comparison
+                from pyfocusr_amd import Graph
+
+                t0 = time.perf_counter()
+                g1 = Graph(mesh_t, n_spectral_features=args.k, n_rand_samples=args.samples, ctx=ctx, verbose=False)
+                _ = g1.device
+                ctx.sync()
+                t1 = time.perf_counter()
+                g1.get_graph_spectrum()
+                rowp["single_device_eigensolve_ms"] = 1e3 * (time.perf_counter() - t1)
+                rowp["max_rel_eigenvalue_diff_vs_single_device"] = float(
+                    np.max(np.abs(np.array(r["eig_vals"]) - g1.eig_vals[:args.k]) / g1.eig_vals[:args.k]))
+                g1.device.close()
+        except Exception as exc:  # noqa: BLE001 - an opt-in extra must never cost the headline line
+            rowp = dict(error="%s: %s" % (type(exc).__name__, exc))
+
     if rank == 0:
         n = args.n
         kernel_us = 1e3 * tm["op_ms"] / max(tm["op_launches"], 1)
@@ -339,6 +402,8 @@ def main():
             out["roofline"]["frac_of_achievable_copy"] = achieved / copy_gbs
         if split is not None:
             out["split_pair"] = split
+        if rowp is not None:
+            out["row_partitioned"] = rowp
         if world == 1 and not args.no_extras:
             c2 = bundled_15k_pair(ctx, 5)
             if c2 is not None:

@@ -172,11 +172,17 @@ int pf_knn_download(pf_ctx* ctx, int64_t* idx_out, double* d2_out);
  * The reference has no counterpart (scipy eigs on one core, graph.py:357-389).  pyfocusr_amd/rowpart.py drives them.
  *   pf_op_step     one step of a three-term recurrence: out = alpha (shift x - A x) - beta prev   (slots; prev = -1:
  *                  no prev term; out may be the prev slot)
+ *   pf_cheb_steps  steps k_first .. k_first+n_steps-1 of the Chebyshev recurrence of pf_cheb on explicit state: slot
+ *                  `cur` holds y_{k_first-1}, slot `prev` holds y_{k_first-2} (ignored and overwritten when
+ *                  k_first = 1); each step writes y_k over y_{k-2}; *out_cur / *out_prev tell where y_last and
+ *                  y_{last-1} ended up
  *   pf_axpy        slot w += sum_i coef[i] * slot (first + i)
  *   pf_rows_*      a fixed subset of rows (mesh-order indices): gather its values of a slot to the host, scatter
  *                  host values into it, or fill it with a constant — the boundary / ghost rows of a partition. */
 typedef struct pf_rows pf_rows;
 int pf_op_step(pf_graph* g, int32_t op, int32_t x, int32_t prev, int32_t out, double alpha, double shift, double beta);
+int pf_cheb_steps(pf_graph* g, int32_t op, int32_t prev, int32_t cur, int32_t k_first, int32_t n_steps, double c, double e,
+                  double rho, int32_t* out_prev, int32_t* out_cur);
 int pf_axpy(pf_graph* g, int32_t w, int32_t first, int32_t count, const double* coef);
 int pf_rows_create(pf_graph* g, const int64_t* rows, int64_t n, pf_rows** out);
 void pf_rows_free(pf_rows* r);

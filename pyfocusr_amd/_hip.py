@@ -89,6 +89,8 @@ SIGNATURES = {
     "pf_knn_run": (C.c_int, [C.c_void_p]),
     "pf_knn_download": (C.c_int, [C.c_void_p, _i64p, _f64p]),
     "pf_op_step": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double]),
+    "pf_cheb_steps": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double,
+                                C.c_double, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "pf_axpy": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, _f64p]),
     "pf_rows_create": (C.c_int, [C.c_void_p, _i64p, C.c_int64, C.POINTER(C.c_void_p)]),
     "pf_rows_free": (None, [C.c_void_p]),
@@ -601,6 +603,13 @@ class DeviceLaplacian(object):
         """out = alpha (c x - A x) - beta prev (slots; prev None: no prev term; out may be the prev slot)."""
         _check(self._lib.pf_op_step(self._h, self.op if op is None else int(op), int(x), -1 if prev is None else int(prev),
                                     int(out), float(alpha), float(c), float(beta)))
+
+    def cheb_steps(self, prev, cur, k_first, n_steps, c, e, rho=1.0, op=None):
+        """Steps k_first.. of the Chebyshev recurrence on explicit state slots; returns (prev, cur) afterwards."""
+        op_, oc = C.c_int32(), C.c_int32()
+        _check(self._lib.pf_cheb_steps(self._h, self.op if op is None else int(op), int(prev), int(cur), int(k_first),
+                                       int(n_steps), float(c), float(e), float(rho), C.byref(op_), C.byref(oc)))
+        return op_.value, oc.value
 
     def axpy(self, w, first, count, coef):
         coef = _c_f64(coef)

@@ -1004,6 +1004,26 @@ int pf_op_step(pf_graph* g, int32_t op, int32_t x, int32_t prev, int32_t out, do
     return t.finish();
 }
 
+int pf_cheb_steps(pf_graph* g, int32_t op, int32_t prev, int32_t cur, int32_t k_first, int32_t n_steps, double c, double e,
+                  double rho, int32_t* out_prev, int32_t* out_cur) {
+    PF_TRY(check_slots(g, prev, 1, "pf_cheb_steps"));
+    PF_TRY(check_slots(g, cur, 1, "pf_cheb_steps"));
+    const double* vals = op_values(g, op);
+    PF_CHECK(vals != nullptr && prev != cur && out_prev && out_cur, PF_E_ARG, "pf_cheb_steps: bad operator / slots");
+    PF_CHECK(k_first >= 1 && n_steps >= 0 && e > 0.0 && rho >= 1.0, PF_E_ARG, "pf_cheb_steps: k_first %d / n_steps %d invalid",
+             k_first, n_steps);
+    OpTimer t(g->ctx, n_steps, (double)n_steps * op_bytes(g));
+    int32_t a = prev, b = cur;  // b holds y_{k-1} of the step about to run, a receives y_k (step 1: a is overwritten, no prev term)
+    for (int32_t k = k_first; k < k_first + n_steps; ++k) {
+        if (k == 1) PF_TRY(launch_op(g, vals, pf_slot(g, b), nullptr, pf_slot(g, a), 1.0 / (e * rho), c, 0.0));
+        else PF_TRY(launch_op(g, vals, pf_slot(g, b), pf_slot(g, a), pf_slot(g, a), 2.0 / (e * rho), c, 1.0 / (rho * rho)));
+        std::swap(a, b);
+    }
+    *out_prev = a;
+    *out_cur = b;
+    return t.finish();
+}
+
 int pf_axpy(pf_graph* g, int32_t w, int32_t first, int32_t count, const double* coef) {
     PF_TRY(check_slots(g, w, 1, "pf_axpy"));
     PF_TRY(check_slots(g, first, count, "pf_axpy"));

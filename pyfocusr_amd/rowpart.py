@@ -255,19 +255,13 @@ class RowPartitionedOps(object):
         coefficients as the single-device `pf_cheb` (first step alpha = 1/(e rho), then 2/(e rho) and 1/rho^2)."""
         loc, s = self.local, self.s
         a, b = self._scratch, self._scratch + 1
-        loc.copy(src, a, 1)  # y_0 (ghosts are zero: refreshed below)
-        prev, cur = None, a
-        done = 0
+        loc.copy(src, b, 1)  # y_0 (its ghost rows are refreshed below)
+        prev, cur, done = a, b, 0
         while done < p:
-            self._refresh_ghosts([cur] if prev is None else [cur, prev])
-            for _ in range(min(s, p - done)):
-                if prev is None:
-                    loc.op_step(cur, None, b, 1.0 / (e * rho), c, 0.0)
-                    prev, cur = a, b
-                else:
-                    loc.op_step(cur, prev, prev, 2.0 / (e * rho), c, 1.0 / (rho * rho))  # y_{k+1} over y_{k-1}
-                    prev, cur = cur, prev
-                done += 1
+            self._refresh_ghosts([cur] if done == 0 else [cur, prev])
+            n_steps = min(s, p - done)
+            prev, cur = loc.cheb_steps(prev, cur, done + 1, n_steps, c, e, rho)
+            done += n_steps
         loc.copy(cur, dst, 1)
         self._zero_ghosts(dst)
 
@@ -285,7 +279,8 @@ def symmetric_operator(rowptr, col, w, deg):
     return S, sg
 
 
-def row_partitioned_eigs(points, faces, k, comm, make_local, s=16, device_graph=None, verbose=False, **solver_kw):
+def row_partitioned_eigs(points, faces, k, comm, make_local, s=16, device_graph=None, verbose=False, timing=None,
+                         **solver_kw):
     """Lowest `k` non-null eigenpairs of the mesh Laplacian with the rows split over `comm.world` ranks.
 
     `make_local(S_local)` builds the rank's local operator object; `device_graph` (a `DeviceLaplacian` of the
@@ -306,7 +301,12 @@ def row_partitioned_eigs(points, faces, k, comm, make_local, s=16, device_graph=
     ghosts = [g[:, 0].astype(np.int64) for g in ghosts]
     layout = finish_layout(rank, world, local, n_own, ring_ptr, S_local, spans, pos, ghosts)
     ops = RowPartitionedOps(make_local(layout.S_local), layout, comm, len(deg), s)
+    import time
+
+    t0 = time.perf_counter()
     vals, first, stats = _krylov.filtered_eigs(ops, k + 1, True, verbose=verbose, **solver_kw)  # + the null vector
+    if timing is not None:
+        timing["solve"] = time.perf_counter() - t0
     keep = vals > 1e-10  # graph.py:381
     vals = vals[keep][:k]
     slots = (np.arange(len(keep))[keep] + first)[:k]

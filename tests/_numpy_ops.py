@@ -129,6 +129,16 @@ class NumpyOps(object):
         self.ws[:, out] = y
         self.launches += 1
 
+    def cheb_steps(self, prev, cur, k_first, n_steps, c, e, rho=1.0):
+        a, b = prev, cur
+        for k in range(k_first, k_first + n_steps):
+            if k == 1:
+                self.op_step(b, None, a, 1.0 / (e * rho), c, 0.0)
+            else:
+                self.op_step(b, a, a, 2.0 / (e * rho), c, 1.0 / (rho * rho))
+            a, b = b, a
+        return a, b
+
     def axpy(self, w, first, count, coef):
         self.ws[:, w] += self.ws[:, first : first + count] @ np.asarray(coef, dtype=np.float64)
 
