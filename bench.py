@@ -173,7 +173,8 @@ def row_partition_step(ctx, dist, torch, mesh, k, s):
 
     marks = {}  # row_partitioned_eigs records the seconds of the eigensolve proper under "solve"
     vals, vecs, own, stats, ops = rowpart.row_partitioned_eigs(mesh.points, mesh.faces, k, comm, make_local, s=s,
-                                                               device_graph=full, timing=marks)
+                                                               device_graph=full, timing=marks,
+                                                               device_exchange=dist.get_backend() == "nccl")
     ctx.sync()
     total = time.perf_counter() - t0
     out = dict(solve_s=marks.get("solve", float("nan")), setup_s=total - marks.get("solve", 0.0), matvecs=int(stats.matvecs),

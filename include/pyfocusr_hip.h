@@ -188,6 +188,8 @@ int pf_rows_create(pf_graph* g, const int64_t* rows, int64_t n, pf_rows** out);
 void pf_rows_free(pf_rows* r);
 int pf_rows_gather(pf_rows* r, int32_t slot, double* out);
 int pf_rows_scatter(pf_rows* r, int32_t slot, const double* in);
+int pf_rows_gather_dev(pf_rows* r, int32_t slot, double* dst_device);        /* device buffers of the caller (e.g. a */
+int pf_rows_scatter_dev(pf_rows* r, int32_t slot, const double* src_device); /* tensor RCCL sends / received); no sync */
 int pf_rows_fill(pf_rows* r, int32_t slot, double value);
 
 /* ---- closest point on a triangulated surface (ICP pre-alignment, "next" row f3) --------------------------

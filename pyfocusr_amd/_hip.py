@@ -96,6 +96,8 @@ SIGNATURES = {
     "pf_rows_free": (None, [C.c_void_p]),
     "pf_rows_gather": (C.c_int, [C.c_void_p, C.c_int32, _f64p]),
     "pf_rows_scatter": (C.c_int, [C.c_void_p, C.c_int32, _f64p]),
+    "pf_rows_gather_dev": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
+    "pf_rows_scatter_dev": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
     "pf_rows_fill": (C.c_int, [C.c_void_p, C.c_int32, C.c_double]),
     "pf_surface_create": (C.c_int, [C.c_void_p, _f64p, C.c_int64, _i32p, C.c_int64, C.c_int32, C.POINTER(C.c_void_p)]),
     "pf_surface_free": (None, [C.c_void_p]),
@@ -631,6 +633,16 @@ class DeviceLaplacian(object):
     def rows_scatter(self, slot, rows, values):
         values = _c_f64(values, (rows.n,))
         _check(self._lib.pf_rows_scatter(rows._h, int(slot), _f64(values)))
+
+    def rows_gather_dev(self, slot, rows, device_ptr):
+        """Values of the row subset into a device buffer of the caller (int address); no host sync."""
+        _check(self._lib.pf_rows_gather_dev(rows._h, int(slot), C.c_void_p(int(device_ptr))))
+
+    def rows_scatter_dev(self, slot, rows, device_ptr):
+        _check(self._lib.pf_rows_scatter_dev(rows._h, int(slot), C.c_void_p(int(device_ptr))))
+
+    def sync(self):
+        self.ctx.sync()
 
     def rows_fill(self, slot, rows, value):
         _check(self._lib.pf_rows_fill(rows._h, int(slot), float(value)))

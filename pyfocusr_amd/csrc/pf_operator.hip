@@ -1114,6 +1114,27 @@ int pf_rows_scatter(pf_rows* r, int32_t slot, const double* in) {
     return PF_OK;
 }
 
+// device-pointer forms: `dst` / `src` are device buffers of r->n doubles owned by the caller (e.g. a torch tensor that
+// RCCL sends / has received).  Enqueued on the ctx stream without a host sync: the caller orders the two streams
+// (pf_sync before the peer library reads dst; the peer library's own sync before src is read here).
+int pf_rows_gather_dev(pf_rows* r, int32_t slot, double* dst) {
+    PF_CHECK(r && (dst || r->n == 0), PF_E_ARG, "pf_rows_gather_dev: NULL argument");
+    PF_TRY(check_slots(r->g, slot, 1, "pf_rows_gather_dev"));
+    if (r->n == 0) return PF_OK;
+    k_rows_gather<<<nblk(r->n), PF_BLOCK, 0, r->g->ctx->stream>>>(pf_slot(r->g, slot), r->idx, r->n, dst);
+    PF_HIP(hipGetLastError());
+    return PF_OK;
+}
+
+int pf_rows_scatter_dev(pf_rows* r, int32_t slot, const double* src) {
+    PF_CHECK(r && (src || r->n == 0), PF_E_ARG, "pf_rows_scatter_dev: NULL argument");
+    PF_TRY(check_slots(r->g, slot, 1, "pf_rows_scatter_dev"));
+    if (r->n == 0) return PF_OK;
+    k_rows_scatter<<<nblk(r->n), PF_BLOCK, 0, r->g->ctx->stream>>>(pf_slot(r->g, slot), r->idx, r->n, src);
+    PF_HIP(hipGetLastError());
+    return PF_OK;
+}
+
 int pf_rows_fill(pf_rows* r, int32_t slot, double value) {
     PF_CHECK(r != nullptr, PF_E_ARG, "pf_rows_fill: NULL argument");
     PF_TRY(check_slots(r->g, slot, 1, "pf_rows_fill"));

@@ -164,6 +164,51 @@ class Comm(object):
             return [np.ascontiguousarray(arr, dtype=np.float64)]
         return all_gather_rows(self.dist, self.torch, arr)
 
+    def allgather_device(self, send, recv):
+        """recv[q] <- rank q's `send` (CUDA tensors of equal shape): one RCCL all-gather, no host staging."""
+        self.torch.cuda.synchronize()
+        self.dist.all_gather_into_tensor(recv, send)
+        self.torch.cuda.synchronize()
+
+
+class ThreadComm(object):
+    """The same two collectives between THREADS of one process (one "rank" per thread, each with its own HIP
+    stream on the same device): the harness the tests use to run every rank of the solve on the one-GPU box,
+    including the device-buffer exchange that RCCL serves on a multi-GPU node."""
+
+    class Shared(object):
+        def __init__(self, world):
+            import threading
+
+            self.world = world
+            self.barrier = threading.Barrier(world)
+            self.slots = [None] * world
+
+    def __init__(self, shared, rank, torch=None):
+        self.shared, self.rank, self.world, self.torch = shared, rank, shared.world, torch
+
+    def _exchange(self, item):
+        sh = self.shared
+        sh.slots[self.rank] = item
+        sh.barrier.wait()
+        items = list(sh.slots)
+        sh.barrier.wait()  # nobody overwrites its slot before everybody has read
+        return items
+
+    def allreduce_sum(self, arr):
+        return np.sum(self._exchange(np.ascontiguousarray(arr, dtype=np.float64)), axis=0)
+
+    def allgather_ragged(self, arr):
+        return self._exchange(np.ascontiguousarray(arr, dtype=np.float64))
+
+    def allgather_device(self, send, recv):
+        """recv[q] <- rank q's `send` (device tensors, equal shapes)."""
+        self.torch.cuda.synchronize()
+        for q, t in enumerate(self._exchange(send)):
+            recv[q].copy_(t)
+        self.torch.cuda.synchronize()
+        self.shared.barrier.wait()  # every copy out of `send` is done before its owner refills it
+
 
 class RowPartitionedOps(object):
     """The `ops` object of `_krylov.filtered_eigs` for a row-partitioned operator.
@@ -171,7 +216,7 @@ class RowPartitionedOps(object):
     `local` is a per-rank operator object over chunk + ghost rows (a `_hip.DeviceLaplacian` built from the local
     submatrix, or the CPU test double) offering the single-device ops plus `op_step`, `axpy`, `rows_*`."""
 
-    def __init__(self, local, layout, comm, n_global, s):
+    def __init__(self, local, layout, comm, n_global, s, device_exchange=False):
         self.local, self.layout, self.comm = local, layout, comm
         self.n, self.n_isolated, self.s = int(n_global), 0, int(s)
         self._pub = local.rows_create(layout.publish)
@@ -179,12 +224,45 @@ class RowPartitionedOps(object):
         self._fill = {q: (src, local.rows_create(dst)) for q, (src, dst) in layout.fill.items()}
         self.exchanges = 0
         self._pending = None
+        self._dev = None
+        if device_exchange and comm.world > 1:
+            # boundary values travel device buffer -> collective -> device buffer (RCCL over xGMI on a GPU node)
+            torch = comm.torch
+            n_pub = int(np.max(comm.allreduce_sum(np.eye(comm.world)[comm.rank] * len(layout.publish))))
+            dev = torch.device("cuda", torch.cuda.current_device())
+            self._dev = dict(torch=torch, send=torch.zeros((2, max(n_pub, 1)), dtype=torch.float64, device=dev),
+                             recv=torch.zeros((comm.world, 2, max(n_pub, 1)), dtype=torch.float64, device=dev),
+                             src={q: torch.from_numpy(src).to(dev) for q, (src, _) in layout.fill.items()})
 
     # ---- communication
+    def _refresh_ghosts_device(self, slots):
+        d, loc = self._dev, self.local
+        n_pub = len(self.layout.publish)
+        for j, sl in enumerate(slots):
+            loc.rows_gather_dev(sl, self._pub, d["send"][j].data_ptr())
+        loc.sync()  # the gathers have landed before the collective reads `send`
+        self.comm.allgather_device(d["send"], d["recv"])
+        keep = []
+        for q, (_, dst) in self._fill.items():
+            for j, sl in enumerate(slots):
+                vals = d["recv"][q, j].index_select(0, d["src"][q]).contiguous()
+                keep.append(vals)
+        d["torch"].cuda.synchronize()  # index_select ran on torch's stream
+        i = 0
+        for q, (_, dst) in self._fill.items():
+            for j, sl in enumerate(slots):
+                loc.rows_scatter_dev(sl, dst, keep[i].data_ptr())
+                i += 1
+        loc.sync()  # the scatters have read `keep` before it is released
+        del n_pub
+        self.exchanges += 1
+
     def _refresh_ghosts(self, slots):
         """Owners publish their boundary rows of `slots`; every rank overwrites its ghost rows."""
         if self.comm.world == 1:
             return
+        if self._dev is not None:
+            return self._refresh_ghosts_device(slots)
         mine = np.stack([self.local.rows_gather(sl, self._pub) for sl in slots], axis=1)  # (n_pub, len(slots))
         parts = self.comm.allgather_ragged(mine)
         for q, (src, dst) in self._fill.items():
@@ -280,7 +358,7 @@ def symmetric_operator(rowptr, col, w, deg):
 
 
 def row_partitioned_eigs(points, faces, k, comm, make_local, s=16, device_graph=None, verbose=False, timing=None,
-                         **solver_kw):
+                         device_exchange=False, **solver_kw):
     """Lowest `k` non-null eigenpairs of the mesh Laplacian with the rows split over `comm.world` ranks.
 
     `make_local(S_local)` builds the rank's local operator object; `device_graph` (a `DeviceLaplacian` of the
@@ -300,7 +378,7 @@ def row_partitioned_eigs(points, faces, k, comm, make_local, s=16, device_graph=
     ghosts = comm.allgather_ragged(local[n_own:].astype(np.float64)[:, None])
     ghosts = [g[:, 0].astype(np.int64) for g in ghosts]
     layout = finish_layout(rank, world, local, n_own, ring_ptr, S_local, spans, pos, ghosts)
-    ops = RowPartitionedOps(make_local(layout.S_local), layout, comm, len(deg), s)
+    ops = RowPartitionedOps(make_local(layout.S_local), layout, comm, len(deg), s, device_exchange=device_exchange)
     import time
 
     t0 = time.perf_counter()

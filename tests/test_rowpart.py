@@ -167,3 +167,94 @@ def test_row_partitioned_solve_on_device(tmp_path, world, n, k, s):
 
     mp.spawn(_gpu_worker, args=(world, _free_port(), str(tmp_path), n, k, s), nprocs=world, join=True)
     assert all(os.path.exists(tmp_path / ("ok%d" % r)) for r in range(world))
+
+
+def _thread_ranks(world, target):
+    """Run `target(rank, comm_shared)` in `world` threads; re-raise the first failure."""
+    import threading
+
+    from pyfocusr_amd import rowpart
+
+    shared = rowpart.ThreadComm.Shared(world)
+    errors = []
+
+    def run(rank):
+        try:
+            target(rank, shared)
+        except BaseException as exc:  # noqa: BLE001
+            errors.append(exc)
+            shared.barrier.abort()
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if errors:
+        raise errors[0]
+
+
+def test_row_partitioned_solve_threads_cpu():
+    """The in-process communicator (threads as ranks) with the CPU test double: same answer as under gloo."""
+    from _numpy_ops import MatrixOps
+    from oracle import reference_port as orc
+    from pyfocusr_amd import _krylov, rowpart
+
+    m, L, S, sg = _mesh_operator(2500, 4)
+    ref_vals, _ = orc.canonicalize(*orc.recursive_eig(L, 4, 3))
+    order = rowpart.morton_order(m.points)
+    layouts = rowpart.build_all_layouts(S, order, 3, 5)
+    out = {}
+
+    def rank_main(rank, shared):
+        comm = rowpart.ThreadComm(shared, rank)
+        ops = rowpart.RowPartitionedOps(MatrixOps(layouts[rank].S_local), layouts[rank], comm, S.shape[0], 5)
+        vals, first, stats = _krylov.filtered_eigs(ops, 4, True)
+        out[rank] = vals[:3]
+
+    _thread_ranks(3, rank_main)
+    for r in range(3):
+        np.testing.assert_allclose(out[r], ref_vals, rtol=1e-8)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("device_exchange", [False, True])
+def test_row_partitioned_solve_threads_on_device(device_exchange):
+    """Three ranks as threads of one process, one HIP stream each on the one MI355X.  With `device_exchange` the
+    boundary rows go device buffer -> collective -> device buffer (torch CUDA tensors; RCCL's role on a GPU node is
+    played by device-to-device copies here) — the path a multi-GPU node runs, minus the RCCL call itself."""
+    import torch
+
+    from oracle import reference_port as orc
+    from pyfocusr_amd import _hip, rowpart
+    from pyfocusr_amd.meshgen import blob_mesh
+
+    n, k, s, world = 40000, 5, 12, 3
+    m = blob_mesh(n, seed=12)
+    W, deg, d_inv, L = orc.graph_matrices(m.points, m.faces)
+    ref_vals, ref_vecs = orc.canonicalize(*orc.recursive_eig(L, k + 1, k))
+    out = {}
+
+    def rank_main(rank, shared):
+        ctx = _hip.Context(0)
+        comm = rowpart.ThreadComm(shared, rank, torch=torch)
+        full = _hip.DeviceLaplacian(m.points, m.faces, ctx=ctx)
+
+        def make_local(S_local):
+            return _hip.DeviceLaplacian(matrix=(S_local.indptr, S_local.indices, S_local.data), ctx=ctx)
+
+        vals, vecs, own, stats, ops = rowpart.row_partitioned_eigs(m.points, m.faces, k, comm, make_local, s=s,
+                                                                   device_graph=full, device_exchange=device_exchange)
+        out[rank] = (vals, vecs, own, ops.exchanges)
+
+    _thread_ranks(world, rank_main)
+    allv = np.zeros((n, k))
+    for r in range(world):
+        vals, vecs, own, exchanges = out[r]
+        np.testing.assert_allclose(vals, ref_vals, rtol=1e-8)
+        allv[own] = vecs
+        assert exchanges > 0
+    sign = np.sign(np.sum(allv * ref_vecs, axis=0))
+    assert np.max(np.abs(allv * sign - ref_vecs)) < 1e-7
+    R = L @ allv - allv * ref_vals[None, :]
+    assert np.max(np.linalg.norm(R, axis=0)) < 1e-9
