@@ -72,6 +72,7 @@ int pf_device_count(void);
 int pf_create(int device, pf_ctx** out);
 void pf_destroy(pf_ctx* ctx);
 int pf_sync(pf_ctx* ctx);
+void* pf_stream(pf_ctx* ctx); /* the ctx's hipStream_t, so that a peer library (RCCL through torch) can enqueue on it */
 int pf_timing_enable(pf_ctx* ctx, int on);            /* time operator launches with HIP events on the ctx stream */
 int pf_timing_get(pf_ctx* ctx, pf_timing* out, int reset);
 
@@ -190,6 +191,12 @@ int pf_rows_gather(pf_rows* r, int32_t slot, double* out);
 int pf_rows_scatter(pf_rows* r, int32_t slot, const double* in);
 int pf_rows_gather_dev(pf_rows* r, int32_t slot, double* dst_device);        /* device buffers of the caller (e.g. a */
 int pf_rows_scatter_dev(pf_rows* r, int32_t slot, const double* src_device); /* tensor RCCL sends / received); no sync */
+/* one launch each way for BOTH vectors of a boundary exchange: dst[t] = slot_a[row t], dst[stride + t] = slot_b[row t]
+ * (slot_b = -1: only a);  slot_a[row t] = src[off t], slot_b[row t] = src[off t + stride] with the per-row offsets
+ * of pf_rows_set_sources (where each ghost row's value sits in the all-gathered receive buffer) */
+int pf_rows_set_sources(pf_rows* r, const int64_t* offsets);
+int pf_rows_gather2_dev(pf_rows* r, int32_t slot_a, int32_t slot_b, double* dst_device, int64_t stride);
+int pf_rows_scatter2_dev(pf_rows* r, int32_t slot_a, int32_t slot_b, const double* src_device, int64_t stride);
 int pf_rows_fill(pf_rows* r, int32_t slot, double value);
 
 /* ---- closest point on a triangulated surface (ICP pre-alignment, "next" row f3) --------------------------

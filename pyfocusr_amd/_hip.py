@@ -52,6 +52,7 @@ SIGNATURES = {
     "pf_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
     "pf_destroy": (None, [C.c_void_p]),
     "pf_sync": (C.c_int, [C.c_void_p]),
+    "pf_stream": (C.c_void_p, [C.c_void_p]),
     "pf_timing_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "pf_timing_get": (C.c_int, [C.c_void_p, C.POINTER(Timing), C.c_int]),
     "pf_graph_build": (C.c_int, [C.c_void_p, _f64p, C.c_int64, _i32p, C.c_int64, C.c_int32, C.POINTER(C.c_void_p)]),
@@ -98,6 +99,9 @@ SIGNATURES = {
     "pf_rows_scatter": (C.c_int, [C.c_void_p, C.c_int32, _f64p]),
     "pf_rows_gather_dev": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
     "pf_rows_scatter_dev": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
+    "pf_rows_set_sources": (C.c_int, [C.c_void_p, _i64p]),
+    "pf_rows_gather2_dev": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int64]),
+    "pf_rows_scatter2_dev": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int64]),
     "pf_rows_fill": (C.c_int, [C.c_void_p, C.c_int32, C.c_double]),
     "pf_surface_create": (C.c_int, [C.c_void_p, _f64p, C.c_int64, _i32p, C.c_int64, C.c_int32, C.POINTER(C.c_void_p)]),
     "pf_surface_free": (None, [C.c_void_p]),
@@ -196,6 +200,12 @@ class Context(object):
 
     def sync(self):
         _check(self._lib.pf_sync(self._h))
+
+    @property
+    def stream_ptr(self):
+        """Address of the ctx's hipStream_t (for `torch.cuda.ExternalStream`: a collective enqueued on it is ordered
+        with the library's kernels without any host synchronisation)."""
+        return int(self._lib.pf_stream(self._h) or 0)
 
     def timing_enable(self, on=True):
         _check(self._lib.pf_timing_enable(self._h, int(bool(on))))
@@ -640,6 +650,20 @@ class DeviceLaplacian(object):
 
     def rows_scatter_dev(self, slot, rows, device_ptr):
         _check(self._lib.pf_rows_scatter_dev(rows._h, int(slot), C.c_void_p(int(device_ptr))))
+
+    def rows_set_sources(self, rows, offsets):
+        offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+        if len(offsets) != rows.n:
+            raise ValueError("one offset per row")
+        _check(self._lib.pf_rows_set_sources(rows._h, offsets.ctypes.data_as(_i64p)))
+
+    def rows_gather2_dev(self, slot_a, slot_b, rows, device_ptr, stride):
+        _check(self._lib.pf_rows_gather2_dev(rows._h, int(slot_a), -1 if slot_b is None else int(slot_b),
+                                             C.c_void_p(int(device_ptr)), int(stride)))
+
+    def rows_scatter2_dev(self, slot_a, slot_b, rows, device_ptr, stride):
+        _check(self._lib.pf_rows_scatter2_dev(rows._h, int(slot_a), -1 if slot_b is None else int(slot_b),
+                                              C.c_void_p(int(device_ptr)), int(stride)))
 
     def sync(self):
         self.ctx.sync()

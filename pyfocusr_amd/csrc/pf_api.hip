@@ -138,6 +138,8 @@ void pf_destroy(pf_ctx* c) {
     delete c;
 }
 
+void* pf_stream(pf_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
 int pf_sync(pf_ctx* c) {
     PF_CHECK(c != nullptr, PF_E_ARG, "pf_sync: ctx is NULL");
     PF_HIP(hipStreamSynchronize(c->stream));

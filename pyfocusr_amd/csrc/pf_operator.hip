@@ -484,6 +484,26 @@ __global__ __launch_bounds__(PF_BLOCK) void k_rows_scatter(double* __restrict__ 
     const int64_t t = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
     if (t < cnt) x[idx[t]] = in[t];
 }
+// both recurrence vectors of a boundary exchange in one launch each way
+__global__ __launch_bounds__(PF_BLOCK) void k_rows_gather2(const double* __restrict__ xa, const double* __restrict__ xb,
+                                                           const int32_t* __restrict__ idx, int64_t cnt, int64_t stride,
+                                                           double* __restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
+    if (t >= cnt) return;
+    const int32_t r = idx[t];
+    out[t] = xa[r];
+    if (xb) out[stride + t] = xb[r];
+}
+__global__ __launch_bounds__(PF_BLOCK) void k_rows_scatter2(double* __restrict__ xa, double* __restrict__ xb,
+                                                            const int32_t* __restrict__ idx, const int64_t* __restrict__ off,
+                                                            int64_t cnt, int64_t stride, const double* __restrict__ src) {
+    const int64_t t = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
+    if (t >= cnt) return;
+    const int32_t r = idx[t];
+    const int64_t o = off[t];
+    xa[r] = src[o];
+    if (xb) xb[r] = src[o + stride];
+}
 __global__ __launch_bounds__(PF_BLOCK) void k_rows_fill(double* __restrict__ x, const int32_t* __restrict__ idx, int64_t cnt,
                                                         double value) {
     const int64_t t = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
@@ -1045,6 +1065,7 @@ struct pf_rows {
     pf_graph* g = nullptr;
     int32_t* idx = nullptr;  // solver-order row of every entry
     double* buf = nullptr;   // device staging [n]
+    int64_t* off = nullptr;  // optional: where each row's value sits in a receive buffer (pf_rows_set_sources)
     int64_t n = 0;
 };
 
@@ -1055,6 +1076,7 @@ void pf_rows_free(pf_rows* r) {
     hipStreamSynchronize(st);
     pf_free(st, r->idx);
     pf_free(st, r->buf);
+    pf_free(st, r->off);
     delete r;
 }
 
@@ -1131,6 +1153,40 @@ int pf_rows_scatter_dev(pf_rows* r, int32_t slot, const double* src) {
     PF_TRY(check_slots(r->g, slot, 1, "pf_rows_scatter_dev"));
     if (r->n == 0) return PF_OK;
     k_rows_scatter<<<nblk(r->n), PF_BLOCK, 0, r->g->ctx->stream>>>(pf_slot(r->g, slot), r->idx, r->n, src);
+    PF_HIP(hipGetLastError());
+    return PF_OK;
+}
+
+int pf_rows_set_sources(pf_rows* r, const int64_t* offsets) {
+    PF_CHECK(r && (offsets || r->n == 0), PF_E_ARG, "pf_rows_set_sources: NULL argument");
+    if (r->n == 0) return PF_OK;
+    hipStream_t st = r->g->ctx->stream;
+    PF_HIP(hipSetDevice(r->g->ctx->device));
+    if (!r->off) PF_HIP(pf_malloc(st, (void**)&r->off, sizeof(int64_t) * r->n));
+    PF_HIP(hipMemcpyAsync(r->off, offsets, sizeof(int64_t) * r->n, hipMemcpyHostToDevice, st));
+    PF_HIP(hipStreamSynchronize(st));
+    return PF_OK;
+}
+
+int pf_rows_gather2_dev(pf_rows* r, int32_t slot_a, int32_t slot_b, double* dst, int64_t stride) {
+    PF_CHECK(r && (dst || r->n == 0) && stride >= r->n, PF_E_ARG, "pf_rows_gather2_dev: bad argument");
+    PF_TRY(check_slots(r->g, slot_a, 1, "pf_rows_gather2_dev"));
+    if (slot_b >= 0) PF_TRY(check_slots(r->g, slot_b, 1, "pf_rows_gather2_dev"));
+    if (r->n == 0) return PF_OK;
+    k_rows_gather2<<<nblk(r->n), PF_BLOCK, 0, r->g->ctx->stream>>>(pf_slot(r->g, slot_a), slot_b >= 0 ? pf_slot(r->g, slot_b) : nullptr,
+                                                                  r->idx, r->n, stride, dst);
+    PF_HIP(hipGetLastError());
+    return PF_OK;
+}
+
+int pf_rows_scatter2_dev(pf_rows* r, int32_t slot_a, int32_t slot_b, const double* src, int64_t stride) {
+    PF_CHECK(r && (src || r->n == 0), PF_E_ARG, "pf_rows_scatter2_dev: NULL argument");
+    PF_CHECK(r->off || r->n == 0, PF_E_STATE, "pf_rows_scatter2_dev: no source offsets (pf_rows_set_sources)");
+    PF_TRY(check_slots(r->g, slot_a, 1, "pf_rows_scatter2_dev"));
+    if (slot_b >= 0) PF_TRY(check_slots(r->g, slot_b, 1, "pf_rows_scatter2_dev"));
+    if (r->n == 0) return PF_OK;
+    k_rows_scatter2<<<nblk(r->n), PF_BLOCK, 0, r->g->ctx->stream>>>(pf_slot(r->g, slot_a), slot_b >= 0 ? pf_slot(r->g, slot_b) : nullptr,
+                                                                   r->idx, r->off, r->n, stride, src);
     PF_HIP(hipGetLastError());
     return PF_OK;
 }

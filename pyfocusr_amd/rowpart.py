@@ -164,11 +164,17 @@ class Comm(object):
             return [np.ascontiguousarray(arr, dtype=np.float64)]
         return all_gather_rows(self.dist, self.torch, arr)
 
-    def allgather_device(self, send, recv):
-        """recv[q] <- rank q's `send` (CUDA tensors of equal shape): one RCCL all-gather, no host staging."""
-        self.torch.cuda.synchronize()
-        self.dist.all_gather_into_tensor(recv, send)
-        self.torch.cuda.synchronize()
+    def allgather_device(self, send, recv, stream, local):
+        """recv[q] <- rank q's `send` (CUDA tensors of equal shape): one RCCL all-gather enqueued on the library's
+        stream (`stream` = torch.cuda.ExternalStream over it), i.e. after the gather kernel and before the scatter
+        kernel, with no host synchronisation."""
+        if stream is None:
+            local.sync()
+            self.dist.all_gather_into_tensor(recv, send)
+            self.torch.cuda.synchronize()
+            return
+        with self.torch.cuda.stream(stream):
+            self.dist.all_gather_into_tensor(recv, send)
 
 
 class ThreadComm(object):
@@ -201,9 +207,10 @@ class ThreadComm(object):
     def allgather_ragged(self, arr):
         return self._exchange(np.ascontiguousarray(arr, dtype=np.float64))
 
-    def allgather_device(self, send, recv):
-        """recv[q] <- rank q's `send` (device tensors, equal shapes)."""
-        self.torch.cuda.synchronize()
+    def allgather_device(self, send, recv, stream, local):
+        """recv[q] <- rank q's `send` (device tensors, equal shapes).  Threads stand in for ranks, so the ordering
+        RCCL gets from the stream is made with host synchronisation here."""
+        local.sync()  # this rank's gather kernel has filled `send`
         for q, t in enumerate(self._exchange(send)):
             recv[q].copy_(t)
         self.torch.cuda.synchronize()
@@ -226,35 +233,30 @@ class RowPartitionedOps(object):
         self._pending = None
         self._dev = None
         if device_exchange and comm.world > 1:
-            # boundary values travel device buffer -> collective -> device buffer (RCCL over xGMI on a GPU node)
+            # Boundary values travel device buffer -> collective -> device buffer (RCCL over xGMI on a GPU node):
+            # ONE gather launch for both recurrence vectors, one all-gather, ONE scatter launch for every owner —
+            # all enqueued on the library's own stream (torch sees it as an ExternalStream), no host synchronisation.
             torch = comm.torch
-            n_pub = int(np.max(comm.allreduce_sum(np.eye(comm.world)[comm.rank] * len(layout.publish))))
+            sizes = comm.allreduce_sum(np.eye(comm.world)[comm.rank] * len(layout.publish))
+            n_pub = int(max(np.max(sizes), 1))
             dev = torch.device("cuda", torch.cuda.current_device())
-            self._dev = dict(torch=torch, send=torch.zeros((2, max(n_pub, 1)), dtype=torch.float64, device=dev),
-                             recv=torch.zeros((comm.world, 2, max(n_pub, 1)), dtype=torch.float64, device=dev),
-                             src={q: torch.from_numpy(src).to(dev) for q, (src, _) in layout.fill.items()})
+            dst = np.concatenate([d for _, (_, d) in sorted(layout.fill.items())]) if layout.fill else np.zeros(0, np.int64)
+            off = np.concatenate([q * 2 * n_pub + src for q, (src, _) in sorted(layout.fill.items())]) \
+                if layout.fill else np.zeros(0, np.int64)
+            rows = local.rows_create(dst)
+            local.rows_set_sources(rows, off)
+            stream = torch.cuda.ExternalStream(local.ctx.stream_ptr) if getattr(local, "ctx", None) is not None else None
+            self._dev = dict(torch=torch, n_pub=n_pub, rows=rows, stream=stream,
+                             send=torch.zeros((2, n_pub), dtype=torch.float64, device=dev),
+                             recv=torch.zeros((comm.world, 2, n_pub), dtype=torch.float64, device=dev))
 
     # ---- communication
     def _refresh_ghosts_device(self, slots):
         d, loc = self._dev, self.local
-        n_pub = len(self.layout.publish)
-        for j, sl in enumerate(slots):
-            loc.rows_gather_dev(sl, self._pub, d["send"][j].data_ptr())
-        loc.sync()  # the gathers have landed before the collective reads `send`
-        self.comm.allgather_device(d["send"], d["recv"])
-        keep = []
-        for q, (_, dst) in self._fill.items():
-            for j, sl in enumerate(slots):
-                vals = d["recv"][q, j].index_select(0, d["src"][q]).contiguous()
-                keep.append(vals)
-        d["torch"].cuda.synchronize()  # index_select ran on torch's stream
-        i = 0
-        for q, (_, dst) in self._fill.items():
-            for j, sl in enumerate(slots):
-                loc.rows_scatter_dev(sl, dst, keep[i].data_ptr())
-                i += 1
-        loc.sync()  # the scatters have read `keep` before it is released
-        del n_pub
+        second = slots[1] if len(slots) > 1 else None
+        loc.rows_gather2_dev(slots[0], second, self._pub, d["send"].data_ptr(), d["n_pub"])
+        self.comm.allgather_device(d["send"], d["recv"], d["stream"], loc)
+        loc.rows_scatter2_dev(slots[0], second, d["rows"], d["recv"].data_ptr(), d["n_pub"])
         self.exchanges += 1
 
     def _refresh_ghosts(self, slots):
