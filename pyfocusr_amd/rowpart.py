@@ -237,6 +237,9 @@ class RowPartitionedOps(object):
             # ONE gather launch for both recurrence vectors, one all-gather, ONE scatter launch for every owner —
             # all enqueued on the library's own stream (torch sees it as an ExternalStream), no host synchronisation.
             torch = comm.torch
+            if not torch.cuda.is_available():
+                raise RuntimeError("device_exchange needs torch.cuda; if a GPU is present, import torch BEFORE pyfocusr_amd "
+                                   "loads libpyfocusr_hip.so (both must share one copy of the HIP runtime)")
             sizes = comm.allreduce_sum(np.eye(comm.world)[comm.rank] * len(layout.publish))
             n_pub = int(max(np.max(sizes), 1))
             dev = torch.device("cuda", torch.cuda.current_device())

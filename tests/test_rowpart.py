@@ -7,6 +7,8 @@ import sys
 
 import numpy as np
 import pytest
+import torch  # noqa: F401  (first: torch and libpyfocusr_hip.so must share ONE HIP runtime — whichever copy of
+#                libamdhip64 is loaded first serves both, and torch.cuda only comes up on its own copy)
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (REPO, os.path.join(REPO, "tests")):
