@@ -122,6 +122,10 @@ int pf_spmv(pf_graph* g, int32_t op, int32_t src, int32_t dst);           /* dst
 /* dst = T_degree((c I - A)/e) src / rho^degree : `degree` launches of the fused SpMV + three-term
  * recurrence kernel (scaled by rho >= 1 per step so that high degrees cannot overflow; rho = 1 is the
  * plain Chebyshev polynomial).  src is preserved; dst != src. */
+/* Experimental, OFF by default: pf_cheb / pf_cheb2 can run TWO recurrence steps per kernel launch (windows of 1024
+ * rows with ghost rows, pf_twostep.hip; results bit-identical to one step per launch).  Measured slower than two
+ * one-step launches on MI355X, see that file.  1 switches it on (also: environment PF_TWO_STEP=1); process-wide. */
+int pf_two_step_enable(int on);
 int pf_cheb(pf_graph* g, int32_t op, int32_t src, int32_t dst, int32_t degree, double c, double e, double rho);
 /* Two independent recurrences (graphs a and b of one ctx) advanced in lockstep: step k of both in
  * ONE launch while both have steps left, the longer one alone afterwards. */

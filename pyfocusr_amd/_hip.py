@@ -71,6 +71,7 @@ SIGNATURES = {
     "pf_mask_isolated": (C.c_int, [C.c_void_p, C.c_int32]),
     "pf_lock_null_vectors": (C.c_int, [C.c_void_p, C.c_int32, _i32p]),
     "pf_spmv": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
+    "pf_two_step_enable": (C.c_int, [C.c_int]),
     "pf_cheb": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double]),
     "pf_cheb2": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double,
                            C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double]),
@@ -152,6 +153,12 @@ def load_library():
             fn.argtypes = args
         _lib = lib
         return lib
+
+
+def two_step_enable(on=True):
+    """Process-wide switch of the experimental two-steps-per-launch Chebyshev kernel (off by default: measured slower
+    than two one-step launches, see csrc/pf_twostep.hip)."""
+    _check(load_library().pf_two_step_enable(int(bool(on))))
 
 
 def _check(code):

@@ -427,6 +427,7 @@ void pf_graph_free(pf_graph* g) {
     pf_free(st, g->diag);
     pf_free(st, g->mf_col);
     pf_free(st, g->mf_val);
+    pf_twostep_free(g);
     pf_free(st, g->ws);
     pf_free(st, g->partials);
     pf_free(st, g->coef);

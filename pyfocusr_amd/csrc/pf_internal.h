@@ -37,6 +37,9 @@ constexpr int PF_WAVE = 64;        // gfx950 wavefront
 constexpr int PF_BLOCK = 256;      // 4 waves: one per SIMD of a CU
 constexpr int PF_DOT_CHUNK = 4096; // rows per block in the reduction kernels
 constexpr int PF_MAX_ROOTS = 4096; // components tracked explicitly
+constexpr int PF_TS_ROWS = 1024;   // rows per window of the two-step operator kernel (= degree-sort window of pf_reorder)
+constexpr int PF_TS_GHOSTS = 1024; // ghost rows a window may have
+constexpr int PF_WS_TMPS = 4;      // temporaries behind the workspace slots (Chebyshev rotation)
 
 struct pf_ctx {
     int device = 0;
@@ -115,6 +118,18 @@ struct pf_graph {
     // with slice s at slice_ptr[s] + 64 s and width + 1 entries per row, in DESCENDING mesh column order
     int32_t* mf_col = nullptr;    // [sell_entries + n_pad]
     double* mf_val = nullptr;
+    // two Chebyshev steps per launch (pf_twostep.hip, built on first use): windows of PF_TS_ROWS solver-order rows,
+    // each with the list of outside rows its rows touch (ghosts), those rows' matrix entries, and the window-local
+    // position of every column of its own entries
+    int32_t two_step = -1;        // -1 not tried, 0 unavailable for this graph, 1 ready
+    int32_t ts_width = 0;         // entries kept per ghost row (>= widest SELL slice)
+    int64_t ts_windows = 0;
+    int32_t* ts_scol2 = nullptr;  // [sell_entries] window-local slot of scol: < PF_TS_ROWS own row, else PF_TS_ROWS + ghost index
+    int32_t* ts_gh_cnt = nullptr; // [windows]
+    int32_t* ts_gh_row = nullptr; // [windows][PF_TS_GHOSTS]
+    int32_t* ts_gh_col = nullptr; // [windows][ts_width][PF_TS_GHOSTS]
+    double* ts_gh_rw = nullptr;   // same shape: values of the RW operator
+    double* ts_gh_sym = nullptr;  // same shape: values of the SYM operator (symmetric graphs)
     int32_t is_symmetric = 0, n_isolated = 0, n_components = 0, max_degree = 0, n_oneway = 0;
     std::vector<int32_t> roots; // roots of components with >= 2 vertices, ascending
     // workspace: n_slots vectors + 2 Chebyshev temporaries, stride n_pad
@@ -164,3 +179,18 @@ int pf_reduce_ensure(pf_graph* g, int32_t count);
 
 // pf_reorder.hip
 int pf_compute_order(pf_graph* g, const double* d_pts);
+
+// pf_twostep.hip: two steps of  y <- alpha (shift y - A y) - beta y_prev  per launch, for one or two graphs
+struct pf_ts_args {
+    pf_graph* g;
+    const double* vals;   // SELL values of the operator
+    const double* ghvals; // ghost-row values of the same operator
+    const double* p;      // y_{k-1}
+    const double* x;      // y_k
+    double* z1;           // y_{k+1}
+    double* z2;           // y_{k+2}
+    double alpha, shift, beta;
+};
+int pf_twostep_prepare(pf_graph* g);  // builds the window structures once; g->two_step tells whether they exist
+int pf_twostep_launch(const pf_ts_args* a, const pf_ts_args* b /* nullable */);
+void pf_twostep_free(pf_graph* g);

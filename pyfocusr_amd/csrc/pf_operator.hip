@@ -9,6 +9,7 @@
 // instruction), x gathered through L2.  Reductions are two-stage and atomic-free, so results
 // are bitwise reproducible run to run.
 #include <math.h>
+#include <stdlib.h>
 
 #include <algorithm>
 #include <vector>
@@ -565,31 +566,72 @@ int launch_op2(pf_graph* ga, const OpArgs& a, const OpArgs& b, bool has_prev) {
     return PF_OK;
 }
 
-// Rotating buffers of one Chebyshev recurrence: y0 = src; y1 = (c y0 - A y0)/e;
-// y_{k+1} = (2/e)(c y_k - A y_k) - y_{k-1}.  y_{k+1} overwrites y_{k-1} element-wise (thread i reads
-// prev[i] then writes out[i]); the caller's src is never overwritten; the last step lands in dst.
-struct ChebState {
+// One Chebyshev recurrence: y0 = src; y1 = (c y0 - A y0)/(e rho); y_{k+1} = (2/(e rho))(c y_k - A y_k) - y_{k-1}/rho^2
+// (rho > 1: scaled by rho^-k, so the result is T_p(.)/rho^p and high degrees cannot overflow).  Steps run one per
+// launch (sell_op_block) or two per launch (pf_twostep.hip) through four rotating temporaries; the caller's src is
+// never overwritten and the last step lands in dst.
+struct ChebRun {
     pf_graph* g;
     const double* vals;
-    const double* y_prev;
-    const double* y_cur;
-    double* bufs[2];
+    const double* ghvals;  // ghost-row values of the same operator, or nullptr: one step per launch only
+    const double* src;
     double* dst;
     int32_t degree;
-    double c, e, rho;  // rho > 1: recurrence scaled by rho^-k, so the result is T_p(.) / rho^p (no overflow at high degree)
-    OpArgs step(int32_t k) {  // arguments of step k (1-based); advances the rotation
-        double* target;
-        if (k == degree) target = dst;
-        else if (k == 1) target = bufs[0];
-        else if (k == 2) target = bufs[1];
-        else target = const_cast<double*>(y_prev);
-        OpArgs a = k == 1 ? op_args(g, vals, y_prev, nullptr, target, 1.0 / (e * rho), c, 0.0)
-                          : op_args(g, vals, y_cur, y_prev, target, 2.0 / (e * rho), c, 1.0 / (rho * rho));
-        if (k > 1) y_prev = y_cur;
-        y_cur = target;
+    double c, e, rho;
+    const double* yp = nullptr;  // y_{done-1}
+    const double* yc = nullptr;  // y_done
+    int32_t done = 0;
+
+    int32_t left() const { return degree - done; }
+    bool can_double() const { return ghvals != nullptr && done >= 1 && left() >= 2; }
+    double* free_tmp(int which) const {  // the which-th temporary that holds neither y_{done-1} nor y_done
+        for (int t = 0; t < PF_WS_TMPS; ++t) {
+            double* b = pf_tmp(g, t);
+            if (b != yp && b != yc && which-- == 0) return b;
+        }
+        return nullptr;
+    }
+    OpArgs first() {  // step 1
+        double* target = degree == 1 ? dst : pf_tmp(g, 0);
+        const OpArgs a = op_args(g, vals, src, nullptr, target, 1.0 / (e * rho), c, 0.0);
+        yp = src, yc = target, done = 1;
+        return a;
+    }
+    OpArgs single() {  // one step k > 1
+        double* target = left() == 1 ? dst : free_tmp(0);
+        const OpArgs a = op_args(g, vals, yc, yp, target, 2.0 / (e * rho), c, 1.0 / (rho * rho));
+        yp = yc, yc = target, done += 1;
+        return a;
+    }
+    pf_ts_args twin() {  // two steps k, k+1 > 1
+        double* z1 = free_tmp(0);
+        double* z2 = left() == 2 ? dst : free_tmp(1);
+        const pf_ts_args a{g, vals, ghvals, yp, yc, z1, z2, 2.0 / (e * rho), c, 1.0 / (rho * rho)};
+        yp = z1, yc = z2, done += 2;
         return a;
     }
 };
+
+// Two steps per launch is OFF by default: measured slower than two one-step launches on MI355X (10.3 vs 9.0 us at
+// 250k rows, 39.5 vs 33 us at 1M; see pf_twostep.hip).  -1: not decided (environment PF_TWO_STEP=1 enables), 0 off,
+// 1 on; pf_two_step_enable overrides.
+int g_two_step = -1;
+
+bool two_step_enabled() {
+    if (g_two_step < 0) {
+        const char* v = getenv("PF_TWO_STEP");
+        g_two_step = (v && v[0] == '1') ? 1 : 0;
+    }
+    return g_two_step == 1;
+}
+
+// ghost-row values matching `vals` if the two-step structures of g exist (built on first use), else nullptr
+const double* two_step_values(pf_graph* g, const double* vals, int32_t degree) {
+    if (!two_step_enabled() || degree < 3) return nullptr;
+    if (g->two_step < 0 && pf_twostep_prepare(g) != PF_OK) return nullptr;
+    if (g->two_step != 1) return nullptr;
+    return vals == g->sval_sym ? g->ts_gh_sym : g->ts_gh_rw;
+}
 
 struct OpTimer {
     pf_ctx* c;
@@ -658,7 +700,7 @@ int pf_ws_ensure(pf_graph* g, int32_t n_slots) {
     PF_HIP(hipSetDevice(g->ctx->device));
     hipStream_t st = g->ctx->stream;
     double* nw = nullptr;
-    const size_t bytes = sizeof(double) * (size_t)(n_slots + 2) * (size_t)g->n_pad;
+    const size_t bytes = sizeof(double) * (size_t)(n_slots + PF_WS_TMPS) * (size_t)g->n_pad;
     PF_HIP(pf_malloc(st, (void**)&nw, bytes));
     PF_HIP(hipMemsetAsync(nw, 0, bytes, st));
     if (g->ws && g->n_slots > 0)
@@ -755,18 +797,35 @@ int pf_spmv(pf_graph* g, int32_t op, int32_t src, int32_t dst) {
     return t.finish();
 }
 
+int pf_two_step_enable(int on) {
+    g_two_step = on ? 1 : 0;
+    return PF_OK;
+}
+
 int pf_cheb(pf_graph* g, int32_t op, int32_t src, int32_t dst, int32_t degree, double c, double e, double rho) {
     PF_TRY(check_slots(g, src, 1, "pf_cheb"));
     PF_TRY(check_slots(g, dst, 1, "pf_cheb"));
     const double* vals = op_values(g, op);
     PF_CHECK(vals != nullptr && src != dst, PF_E_ARG, "pf_cheb: operator %d unavailable or src == dst", op);
     PF_CHECK(degree >= 1 && e > 0.0 && rho >= 1.0, PF_E_ARG, "pf_cheb: degree %d / half-width %g / rho %g invalid", degree, e, rho);
+    ChebRun r{g, vals, two_step_values(g, vals, degree), pf_slot(g, src), pf_slot(g, dst), degree, c, e, rho};
     OpTimer t(g->ctx, degree, (double)degree * op_bytes(g));
-    ChebState st{g, vals, pf_slot(g, src), pf_slot(g, src), {pf_tmp(g, 0), pf_tmp(g, 1)}, pf_slot(g, dst), degree, c, e, rho};
-    for (int32_t k = 1; k <= degree; ++k) {
-        const OpArgs a = st.step(k);
+    int64_t launches = 1;
+    {
+        const OpArgs a = r.first();
         PF_TRY(launch_op(g, a.sval, a.x, a.prev, a.out, a.alpha, a.shift, a.beta));
     }
+    while (r.left() > 0) {
+        if (r.can_double()) {
+            const pf_ts_args a = r.twin();
+            PF_TRY(pf_twostep_launch(&a, nullptr));
+        } else {
+            const OpArgs a = r.single();
+            PF_TRY(launch_op(g, a.sval, a.x, a.prev, a.out, a.alpha, a.shift, a.beta));
+        }
+        ++launches;
+    }
+    t.launches = launches;
     return t.finish();
 }
 
@@ -782,19 +841,34 @@ int pf_cheb2(pf_graph* ga, int32_t op_a, int32_t src_a, int32_t dst_a, int32_t d
     PF_CHECK(va && vb && src_a != dst_a && src_b != dst_b, PF_E_ARG, "pf_cheb2: operator unavailable or src == dst");
     PF_CHECK(degree_a >= 1 && degree_b >= 1 && e_a > 0.0 && e_b > 0.0 && rho_a >= 1.0 && rho_b >= 1.0, PF_E_ARG,
              "pf_cheb2: bad degree / half-width / rho");
-    const int32_t joint = std::min(degree_a, degree_b), longest = std::max(degree_a, degree_b);
-    OpTimer t(ga->ctx, longest, (double)degree_a * op_bytes(ga) + (double)degree_b * op_bytes(gb));
-    ChebState sa{ga, va, pf_slot(ga, src_a), pf_slot(ga, src_a), {pf_tmp(ga, 0), pf_tmp(ga, 1)}, pf_slot(ga, dst_a), degree_a, c_a, e_a, rho_a};
-    ChebState sb{gb, vb, pf_slot(gb, src_b), pf_slot(gb, src_b), {pf_tmp(gb, 0), pf_tmp(gb, 1)}, pf_slot(gb, dst_b), degree_b, c_b, e_b, rho_b};
-    for (int32_t k = 1; k <= joint; ++k) {
-        const OpArgs a = sa.step(k), b = sb.step(k);
-        PF_TRY(launch_op2(ga, a, b, k > 1));
+    ChebRun ra{ga, va, two_step_values(ga, va, degree_a), pf_slot(ga, src_a), pf_slot(ga, dst_a), degree_a, c_a, e_a, rho_a};
+    ChebRun rb{gb, vb, two_step_values(gb, vb, degree_b), pf_slot(gb, src_b), pf_slot(gb, dst_b), degree_b, c_b, e_b, rho_b};
+    OpTimer t(ga->ctx, std::max(degree_a, degree_b), (double)degree_a * op_bytes(ga) + (double)degree_b * op_bytes(gb));
+    int64_t launches = 1;
+    {
+        const OpArgs a = ra.first(), b = rb.first();
+        PF_TRY(launch_op2(ga, a, b, false));
     }
-    for (int32_t k = joint + 1; k <= longest; ++k) {  // the longer recurrence finishes alone
-        ChebState& s1 = degree_a > degree_b ? sa : sb;
-        const OpArgs a = s1.step(k);
-        PF_TRY(launch_op(s1.g, a.sval, a.x, a.prev, a.out, a.alpha, a.shift, a.beta));
+    while (ra.left() > 0 || rb.left() > 0) {
+        if (ra.can_double() && rb.can_double()) {  // both graphs: two steps in one launch
+            const pf_ts_args a = ra.twin(), b = rb.twin();
+            PF_TRY(pf_twostep_launch(&a, &b));
+        } else if (ra.left() > 0 && rb.left() > 0) {
+            const OpArgs a = ra.single(), b = rb.single();
+            PF_TRY(launch_op2(ga, a, b, true));
+        } else {  // the longer recurrence finishes alone
+            ChebRun& r = ra.left() > 0 ? ra : rb;
+            if (r.can_double()) {
+                const pf_ts_args a = r.twin();
+                PF_TRY(pf_twostep_launch(&a, nullptr));
+            } else {
+                const OpArgs a = r.single();
+                PF_TRY(launch_op(r.g, a.sval, a.x, a.prev, a.out, a.alpha, a.shift, a.beta));
+            }
+        }
+        ++launches;
     }
+    t.launches = launches;
     return t.finish();
 }
 

@@ -1,0 +1,349 @@
+// Two steps of the three-term recurrence per launch — EVALUATED AND NOT USED BY DEFAULT (pf_two_step_enable(1) or
+// PF_TWO_STEP=1 switches it on; tests keep it bit-identical to the one-step path).
+//
+// Measured on MI355X, one graph, per launch of two steps vs two one-step launches: 10.3 vs 9.0 us at 250k rows, 39.5 vs
+// 33 us at 1M.  Break-down at 250k (variants with parts compiled out): own rows of step k+1 in 1024-thread blocks 5.1 us
+// (the 256-thread one-step kernel: 4.5), step k+2 from LDS + L2 1.5 us, ghost rows 3.8 us.  The ghost rows are 22 % of a
+// step's rows but their entries are a private copy (81 MB per 250k graph) that nothing else reads — streamed from
+// HBM/Infinity Cache while the window's own entries hit L2 — and their gathers are scattered; spreading those
+// gathers over the whole block did not change the time, so it is traffic, not latency.  The saved launch boundary
+// (~1.7 us) does not pay for it.  Kept as a documented experiment and as the in-kernel twin of the multi-GPU ghost-zone
+// scheme (pyfocusr_amd/rowpart.py), where the same redundancy buys 16 steps per exchange instead of 2 per launch.
+//
+// A Chebyshev step on 250k rows is a ~4 us kernel behind a ~1.7 us launch boundary (the previous kernel must drain and
+// its writes become visible before the next may read them), and a filter application is 145 dependent steps.  The
+// boundary is the one cost more bandwidth cannot buy back, so this kernel halves the number of boundaries:
+//
+//   * a block owns a WINDOW of 1024 consecutive solver-order rows (Morton order: a compact patch of the surface);
+//   * step k+1 is computed for the window's rows AND for its ghost rows — the ~220 outside rows its rows touch — from
+//     the global y_k, y_{k-1}; both results stay in LDS (own rows also go to global memory: the recurrence needs them);
+//   * after one __syncthreads, step k+2 is computed for the window's rows from LDS alone.
+//
+// Step k+2 re-reads the window's matrix entries, which the block has just pulled through its XCD's L2.  Redundant work:
+// the ghost rows' step (~22 % of a step at 1024 rows per window).  The arithmetic of every row is the same sequence
+// of operations as in the one-step kernel (diag first, entries in SELL order, same epilogue), so results are
+// bit-identical to two one-step launches.
+//
+// Built once per graph (pf_twostep_prepare): per window the sorted ghost list, the ghost rows' entries in ELL form
+// (coalesced across ghosts) and, for every own entry, the window-local slot of its column (own row index or
+// 1024 + ghost index).  Graphs with a slice wider than 16 entries or a window with more than 1024 ghosts keep the
+// one-step kernel.
+#include <algorithm>
+#include <climits>
+
+#include "pf_internal.h"
+
+namespace {
+
+constexpr int TS_CAP = 4096;    // outside-column candidates of a window before deduplication
+constexpr int TS_MAX_WIDTH = 16;
+
+// ---- preprocessing: one block per window
+__global__ __launch_bounds__(PF_TS_ROWS) void k_ts_build(const int64_t* __restrict__ slice_ptr, const int32_t* __restrict__ scol,
+                                                         const double* __restrict__ sval_rw, const double* __restrict__ sval_sym,
+                                                         int32_t width_cap, int32_t* __restrict__ scol2, int32_t* __restrict__ gh_cnt,
+                                                         int32_t* __restrict__ gh_row, int32_t* __restrict__ gh_col,
+                                                         double* __restrict__ gh_rw, double* __restrict__ gh_sym,
+                                                         int32_t* __restrict__ flags) {
+    __shared__ int32_t cand[TS_CAP];
+    __shared__ int32_t ghost[PF_TS_GHOSTS];
+    __shared__ int32_t cnt, hcount;
+    const int tid = threadIdx.x;
+    const int64_t w = blockIdx.x;
+    const int64_t r0 = w * PF_TS_ROWS, row = r0 + tid;
+    const int64_t s = row >> 6;
+    const int lane = tid & (PF_WAVE - 1);
+    const int64_t base = slice_ptr[s];
+    const int32_t width = (int32_t)((slice_ptr[s + 1] - base) >> 6);
+    if (tid == 0) cnt = 0, hcount = 0;
+    for (int k = tid; k < TS_CAP; k += PF_TS_ROWS) cand[k] = INT_MAX;
+    __syncthreads();
+    for (int32_t j = 0; j < width; ++j) {
+        const int32_t c = scol[pf_sell_index(base, width, j, lane)];
+        if (c < r0 || c >= r0 + PF_TS_ROWS) {
+            const int p = atomicAdd(&cnt, 1);
+            if (p < TS_CAP) cand[p] = c;
+        }
+    }
+    __syncthreads();
+    if (cnt > TS_CAP) {  // block-uniform
+        if (tid == 0) atomicOr(flags, 1);
+        return;
+    }
+    // bitonic sort of cand[0, TS_CAP) ascending (INT_MAX padding sorts to the end)
+    for (int k = 2; k <= TS_CAP; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < TS_CAP; i += PF_TS_ROWS) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const int32_t a = cand[i], b = cand[ixj];
+                    const bool up = (i & k) == 0;
+                    if ((a > b) == up) {
+                        cand[i] = b;
+                        cand[ixj] = a;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (tid == 0) {  // unique, serial: <= 4096 steps once per window
+        int h = 0;
+        int32_t last = -1;
+        for (int i = 0; i < TS_CAP; ++i) {
+            const int32_t c = cand[i];
+            if (c == INT_MAX) break;
+            if (c != last) {
+                if (h < PF_TS_GHOSTS) ghost[h] = c;
+                ++h;
+                last = c;
+            }
+        }
+        hcount = h;
+    }
+    __syncthreads();
+    const int h = hcount;
+    if (h > PF_TS_GHOSTS) {
+        if (tid == 0) atomicOr(flags, 1);
+        return;
+    }
+    if (tid == 0) gh_cnt[w] = h;
+    // ghost rows: ids and their SELL entries, ELL layout [window][entry j][ghost i]
+    for (int i = tid; i < PF_TS_GHOSTS; i += PF_TS_ROWS) {
+        const bool real = i < h;
+        const int32_t g = real ? ghost[i] : 0;
+        gh_row[w * PF_TS_GHOSTS + i] = g;
+        int64_t bg = 0;
+        int32_t wg = 0;
+        const int lg = g & (PF_WAVE - 1);
+        if (real) {
+            bg = slice_ptr[g >> 6];
+            wg = (int32_t)((slice_ptr[(g >> 6) + 1] - bg) >> 6);
+            if (wg > width_cap) {
+                atomicOr(flags, 1);
+                wg = width_cap;
+            }
+        }
+        for (int32_t j = 0; j < width_cap; ++j) {
+            const int64_t o = (w * width_cap + j) * PF_TS_GHOSTS + i;
+            if (j < wg) {
+                const int64_t idx = pf_sell_index(bg, wg, j, lg);
+                gh_col[o] = scol[idx];
+                gh_rw[o] = sval_rw[idx];
+                if (gh_sym) gh_sym[o] = sval_sym[idx];
+            } else {
+                gh_col[o] = g;  // zero weight on an in-range column, as the SELL padding does
+                gh_rw[o] = 0.0;
+                if (gh_sym) gh_sym[o] = 0.0;
+            }
+        }
+    }
+    // window-local slot of every own entry's column
+    for (int32_t j = 0; j < width; ++j) {
+        const int64_t idx = pf_sell_index(base, width, j, lane);
+        const int32_t c = scol[idx];
+        int32_t slot;
+        if (c >= r0 && c < r0 + PF_TS_ROWS) {
+            slot = (int32_t)(c - r0);
+        } else {
+            int lo = 0, hi = h;  // lower bound in the sorted ghost list (c is in it)
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (ghost[mid] < c) lo = mid + 1;
+                else hi = mid;
+            }
+            slot = PF_TS_ROWS + lo;
+        }
+        scol2[idx] = slot;
+    }
+}
+
+struct TsDev {
+    const int64_t* slice_ptr;
+    const int32_t* scol;
+    const int32_t* scol2;
+    const double* sval;
+    const double* diag;
+    const int32_t* gh_cnt;
+    const int32_t* gh_row;
+    const int32_t* gh_col;
+    const double* gh_val;
+    const double* p;
+    const double* x;
+    double* z1;
+    double* z2;
+    double alpha, shift, beta;
+    int32_t width_cap;
+    unsigned n_windows, grid;  // grid = 8 * ceil(n_windows / 8)
+};
+
+__device__ __forceinline__ double ts_epilogue(double alpha, double shift, double beta, double xi, double acc, double prev) {
+#pragma clang fp contract(fast)
+    double r = alpha * (shift * xi - acc);
+    r -= beta * prev;
+    return r;
+}
+
+constexpr int TS_GX = 4096;  // doubles of LDS for the ghost rows' gathered x values
+
+__device__ __forceinline__ void ts_window(const TsDev& a, unsigned bid, double* __restrict__ y1, double* __restrict__ gx) {
+#pragma clang fp contract(fast)
+    // XCD-aware placement as in the one-step kernel: each XCD owns a contiguous eighth of the windows
+    const unsigned per_xcd = a.grid >> 3;
+    const unsigned w = (bid & 7u) * per_xcd + (bid >> 3);
+    if (w >= a.n_windows) return;  // block-uniform
+    const int tid = threadIdx.x;
+    const int64_t r0 = (int64_t)w * PF_TS_ROWS, row = r0 + tid;
+    const int64_t s = row >> 6;
+    const int lane = tid & (PF_WAVE - 1);
+    const int64_t base = a.slice_ptr[s];
+    const int width = (int)((a.slice_ptr[s + 1] - base) >> 6);
+    const int pairs = width >> 1;
+    const double2* __restrict__ vp2 = reinterpret_cast<const double2*>(a.sval + base) + lane;
+    const int2* __restrict__ cp2 = reinterpret_cast<const int2*>(a.scol + base) + lane;
+    const double* __restrict__ x = a.x;
+    const double dg = a.diag[row];
+    // ---- step k+1, own row (same operation order as sell_op_block)
+    const double xi = x[row];
+    double acc = dg * xi;
+    for (int j = 0; j < pairs; ++j) {
+        const int2 c0 = cp2[(int64_t)j * PF_WAVE];
+        const double2 v0 = vp2[(int64_t)j * PF_WAVE];
+        acc += v0.x * x[c0.x];
+        acc += v0.y * x[c0.y];
+    }
+    if (width & 1) {
+        const int64_t t = base + (int64_t)pairs * (2 * PF_WAVE) + lane;
+        acc += a.sval[t] * x[a.scol[t]];
+    }
+    const double y1i = ts_epilogue(a.alpha, a.shift, a.beta, xi, acc, a.p[row]);
+    a.z1[row] = y1i;
+    y1[tid] = y1i;
+    // ---- step k+1, ghost rows.  Their x gathers are spread over the whole block (a ghost row alone would walk its
+    // entries one dependent L2 round trip after the other, on 4 of the block's 16 waves); the sums then run from LDS
+    // in the owner's order (diag first, entries in SELL order: same bits as the owner block computes).
+    const int h = a.gh_cnt[w];
+    const int W = a.width_cap;
+    const int per_batch = TS_GX / W;
+    for (int g0 = 0; g0 < h; g0 += per_batch) {  // block-uniform; one batch unless a window has > ~450 ghosts
+        const int nb = h - g0 < per_batch ? h - g0 : per_batch;
+        const int64_t o = (int64_t)w * W * PF_TS_GHOSTS + g0;
+        for (int e = tid; e < nb * W; e += PF_TS_ROWS) {
+            const int j = e / nb, i = e - j * nb;
+            gx[e] = x[a.gh_col[o + (int64_t)j * PF_TS_GHOSTS + i]];
+        }
+        __syncthreads();
+        for (int i = tid; i < nb; i += PF_TS_ROWS) {
+            const int32_t g = a.gh_row[(int64_t)w * PF_TS_GHOSTS + g0 + i];
+            const double xg = x[g];
+            double ag = a.diag[g] * xg;
+            for (int j = 0; j < W; ++j) ag += a.gh_val[o + (int64_t)j * PF_TS_GHOSTS + i] * gx[j * nb + i];
+            y1[PF_TS_ROWS + g0 + i] = ts_epilogue(a.alpha, a.shift, a.beta, xg, ag, a.p[g]);
+        }
+        if (g0 + per_batch < h) __syncthreads();  // gx is refilled
+    }
+    __syncthreads();
+    // ---- step k+2, own row, from LDS
+    const int2* __restrict__ lp2 = reinterpret_cast<const int2*>(a.scol2 + base) + lane;
+    double acc2 = dg * y1i;
+    for (int j = 0; j < pairs; ++j) {
+        const int2 c0 = lp2[(int64_t)j * PF_WAVE];
+        const double2 v0 = vp2[(int64_t)j * PF_WAVE];
+        acc2 += v0.x * y1[c0.x];
+        acc2 += v0.y * y1[c0.y];
+    }
+    if (width & 1) {
+        const int64_t t = base + (int64_t)pairs * (2 * PF_WAVE) + lane;
+        acc2 += a.sval[t] * y1[a.scol2[t]];
+    }
+    a.z2[row] = ts_epilogue(a.alpha, a.shift, a.beta, y1i, acc2, xi);
+}
+
+__global__ __launch_bounds__(PF_TS_ROWS) void k_sell_two_step(TsDev a) {
+    __shared__ double y1[PF_TS_ROWS + PF_TS_GHOSTS];
+    __shared__ double gx[TS_GX];
+    ts_window(a, blockIdx.x, y1, gx);
+}
+
+__global__ __launch_bounds__(PF_TS_ROWS) void k_sell_two_step2(TsDev a, TsDev b) {
+    __shared__ double y1[PF_TS_ROWS + PF_TS_GHOSTS];
+    __shared__ double gx[TS_GX];
+    if (blockIdx.x < a.grid) ts_window(a, blockIdx.x, y1, gx);
+    else ts_window(b, blockIdx.x - a.grid, y1, gx);
+}
+
+TsDev ts_dev(const pf_ts_args& a) {
+    pf_graph* g = a.g;
+    const unsigned nw = (unsigned)g->ts_windows;
+    return TsDev{g->slice_ptr, g->scol, g->ts_scol2, a.vals, g->diag, g->ts_gh_cnt, g->ts_gh_row, g->ts_gh_col, a.ghvals,
+                 a.p, a.x, a.z1, a.z2, a.alpha, a.shift, a.beta, g->ts_width, nw, 8u * ((nw + 7u) / 8u)};
+}
+
+}  // namespace
+
+void pf_twostep_free(pf_graph* g) {
+    hipStream_t st = g->ctx->stream;
+    pf_free(st, g->ts_scol2);
+    pf_free(st, g->ts_gh_cnt);
+    pf_free(st, g->ts_gh_row);
+    pf_free(st, g->ts_gh_col);
+    pf_free(st, g->ts_gh_rw);
+    pf_free(st, g->ts_gh_sym);
+    g->ts_scol2 = g->ts_gh_cnt = g->ts_gh_row = g->ts_gh_col = nullptr;
+    g->ts_gh_rw = g->ts_gh_sym = nullptr;
+}
+
+int pf_twostep_prepare(pf_graph* g) {
+    if (g->two_step >= 0) return PF_OK;
+    g->two_step = 0;
+    if (g->max_degree > TS_MAX_WIDTH || g->n_pad % PF_TS_ROWS != 0 || g->sell_entries <= 0) return PF_OK;
+    hipStream_t st = g->ctx->stream;
+    const int64_t nw = g->n_pad / PF_TS_ROWS;
+    int32_t width = std::max(1, g->max_degree);
+    int32_t* flags = nullptr;
+    const size_t gh = (size_t)nw * width * PF_TS_GHOSTS;
+    hipError_t e = pf_malloc(st, (void**)&flags, sizeof(int32_t));
+    if (e == hipSuccess) e = pf_malloc(st, (void**)&g->ts_scol2, sizeof(int32_t) * (size_t)g->sell_entries);
+    if (e == hipSuccess) e = pf_malloc(st, (void**)&g->ts_gh_cnt, sizeof(int32_t) * nw);
+    if (e == hipSuccess) e = pf_malloc(st, (void**)&g->ts_gh_row, sizeof(int32_t) * nw * PF_TS_GHOSTS);
+    if (e == hipSuccess) e = pf_malloc(st, (void**)&g->ts_gh_col, sizeof(int32_t) * gh);
+    if (e == hipSuccess) e = pf_malloc(st, (void**)&g->ts_gh_rw, sizeof(double) * gh);
+    if (e == hipSuccess && g->sval_sym) e = pf_malloc(st, (void**)&g->ts_gh_sym, sizeof(double) * gh);
+    if (e == hipSuccess) e = hipMemsetAsync(flags, 0, sizeof(int32_t), st);
+    if (e == hipSuccess) e = hipMemsetAsync(g->ts_gh_cnt, 0, sizeof(int32_t) * nw, st);
+    int32_t h_flag = 1;
+    if (e == hipSuccess) {
+        k_ts_build<<<(unsigned)nw, PF_TS_ROWS, 0, st>>>(g->slice_ptr, g->scol, g->sval_rw, g->sval_sym, width, g->ts_scol2, g->ts_gh_cnt,
+                                                        g->ts_gh_row, g->ts_gh_col, g->ts_gh_rw, g->ts_gh_sym, flags);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(&h_flag, flags, sizeof(int32_t), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    pf_free(st, flags);
+    if (e != hipSuccess) {
+        pf_twostep_free(g);
+        pf_set_error("pf_twostep_prepare: %s", hipGetErrorString(e));
+        return PF_E_HIP;
+    }
+    if (h_flag) {  // a window the scheme does not cover: keep the one-step kernel for this graph
+        pf_twostep_free(g);
+        return PF_OK;
+    }
+    g->ts_width = width;
+    g->ts_windows = nw;
+    g->two_step = 1;
+    return PF_OK;
+}
+
+int pf_twostep_launch(const pf_ts_args* a, const pf_ts_args* b) {
+    hipStream_t st = a->g->ctx->stream;
+    const TsDev da = ts_dev(*a);
+    if (b) {
+        const TsDev db = ts_dev(*b);
+        k_sell_two_step2<<<da.grid + db.grid, PF_TS_ROWS, 0, st>>>(da, db);
+    } else {
+        k_sell_two_step<<<da.grid, PF_TS_ROWS, 0, st>>>(da);
+    }
+    PF_HIP(hipGetLastError());
+    return PF_OK;
+}

@@ -766,3 +766,41 @@ def test_hungarian_correspondence_small(golden, ctx):
     assert sorted(idx.tolist()) == list(range(600))
     with pytest.raises(ValueError):
         Focusr(a, b, icp_register_first=False, initial_correspondence_type="nearest", ctx=ctx)
+
+
+def test_two_step_kernel_bit_identical(golden, hip, ctx):
+    """Two recurrence steps per launch (windows + ghost rows, pf_twostep.hip) against one step per launch: the
+    filter output must be the same bits, for both operators, single and paired, even and odd degrees."""
+    from pyfocusr_amd.meshgen import blob_mesh
+
+    rng = np.random.default_rng(3)
+    m = blob_mesh(30000, seed=8)
+    graphs = [hip.DeviceLaplacian(golden("target_mesh")["points"], golden("target_mesh")["faces"], ctx=ctx),
+              hip.DeviceLaplacian(golden("source_mesh_15k")["points"], golden("source_mesh_15k")["faces"], ctx=ctx),  # RW operator
+              hip.DeviceLaplacian(m.points, m.faces, ctx=ctx)]
+    try:
+        for g in graphs:
+            g.ws_ensure(4)
+            g.upload(0, rng.standard_normal(g.n))
+
+        def run(on):
+            hip.two_step_enable(on)
+            out = []
+            for g in graphs:
+                for p, rho in ((1, 1.0), (2, 1.0), (3, 1.0), (4, 1.0), (7, 1.0), (40, 1.0), (145, 1.02)):
+                    g.cheb(0, 1, p, 1.03, 0.98, rho)
+                    out.append(g.download_slots(1, 1).copy())
+            for pa, pb in ((6, 6), (9, 4), (1, 5), (33, 40)):
+                graphs[0].cheb2((0, 2, pa, 1.0, 1.0, 1.0), graphs[2], (0, 2, pb, 1.01, 0.99, 1.0))
+                out.append(graphs[0].download_slots(2, 1).copy())
+                out.append(graphs[2].download_slots(2, 1).copy())
+            return out
+
+        a, b = run(False), run(True)
+        assert len(a) == len(b)
+        for i, (x, y) in enumerate(zip(a, b)):
+            assert np.all(np.isfinite(x)) and np.array_equal(x, y), i
+    finally:
+        hip.two_step_enable(False)  # the default
+        for g in graphs:
+            g.close()
