@@ -27,7 +27,7 @@ else:
 
 reg = pyfocusr.Focusr(
     mesh_target, mesh_source,
-    icp_register_first=False,            # the notebook's ICP step needs the vtk wheel
+    icp_register_first=True,             # as in the notebook; runs without the vtk wheel (pyfocusr_amd/icp.py)
     n_spectral_features=3, n_extra_spectral=3,
     get_weighted_spectral_coords=False,
     list_features_to_calc=[],
