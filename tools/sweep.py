@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Size sweep of the hot path: per mesh size, GPU assembly / eigensolve / KNN times,
-SpMV launch time and roofline fraction, and the oracle's scipy `eigs` time on the host for
+SpMV launch time and roofline fraction, and the reference's scipy `eigs` call timed on the host for
 comparison.  python tools/sweep.py [--cpu-max 250000] n1 n2 ...   -> markdown table on stdout."""
 import argparse
 import os
@@ -10,7 +10,8 @@ import time
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from oracle import reference_port as orc  # noqa: E402  (comparison column only)
+from scipy import sparse  # noqa: E402
+from scipy.sparse.linalg import eigs  # noqa: E402  (comparison column: the reference's call, graph.py:372)
 from pyfocusr_amd import Graph, _hip, eigsort  # noqa: E402
 from pyfocusr_amd.graph import compute_spectra  # noqa: E402
 from pyfocusr_amd.meshgen import blob_mesh  # noqa: E402
@@ -58,9 +59,13 @@ for n in args.sizes:
             best = row
     cpu = ""
     if n <= args.cpu_max:
-        W, deg, d_inv, L = orc.graph_matrices(meshes[0].points, meshes[0].faces)
+        dev = _hip.DeviceLaplacian(meshes[0].points, meshes[0].faces, ctx=ctx)
+        d = dev.download()
+        dev.close()
+        W = sparse.csr_matrix((d["w"], d["colidx"], d["rowptr"]), shape=(n, n))
+        L = (sparse.diags(1.0 / (d["deg"] + 1e-8)) @ (sparse.diags(d["deg"]) - W)).tocsr()
         t0 = time.perf_counter()
-        orc.recursive_eig(L, k + 1, k)
+        eigs(L, k=k + 1, sigma=1e-10, which="LM", ncv=4 * (k + 1))
         cpu = "%.2f" % (time.perf_counter() - t0)
     total = best["asm"] + best["eig"] + best["sort"] + best["knn"]
     print("| %d | %d | %.2f | %.2f | %d | %.2f | %.0f | %.1f | %.2f | %.2f | %.1f | %s | %.1e |" % (
