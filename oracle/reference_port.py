@@ -2,9 +2,8 @@
 
 CPU restatement (numpy / scipy) of the reference's spectral hot path
 (`/root/reference/pyfocusr/graph.py`, `eigsort.py`, `focusr.py:351-366,459-508`).
-Only `tests/`, `__graft_entry__.smoke()`, `tools/make_golden.py` and
-`bench.py`'s `cpu_baseline` leg may import this module; nothing under
-`pyfocusr_amd/` does.
+Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg
+may import this module; nothing under `pyfocusr_amd/` (or `tools/`) does.
 
 Parity pin: every function below is checked against the reference itself,
 imported in the build container with stub `vtk`/`itkwidgets`/`cycpd` modules
