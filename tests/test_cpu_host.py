@@ -64,6 +64,12 @@ def test_product_does_not_import_oracle():
                 src = open(os.path.join(root, f)).read()
                 assert "oracle" not in src.replace("oracle-", ""), f
                 assert "_numpy_ops" not in src, f
+    # tools/ and examples/ are product-side too: no `import oracle`, no `from oracle ...`
+    for folder in ("tools", "examples"):
+        for f in os.listdir(os.path.join(REPO, folder)):
+            if f.endswith(".py"):
+                src = open(os.path.join(REPO, folder, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src, f
 
 
 # ------------------------------------------------------------------------------- mesh I/O
