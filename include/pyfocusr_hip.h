@@ -173,6 +173,29 @@ int pf_knn_upload(pf_ctx* ctx, const double* ref, int64_t n_ref, const double* q
 int pf_knn_run(pf_ctx* ctx);
 int pf_knn_download(pf_ctx* ctx, int64_t* idx_out, double* d2_out);
 
+/* ---- the whole eigensolve in one call --------------------------------------------------------------------------
+ * Replaces scipy.sparse.linalg.eigs(L, k, sigma=1e-10, which="LM", ncv=4k) at graph.py:372 (called from
+ * recursive_eig, graph.py:357-389) for callers that bind the C-ABI without the Python driver: the n_wanted lowest
+ * eigenpairs with eigenvalue > 1e-10 (graph.py:381) of the graph's random-walk Laplacian, ascending; vecs is
+ * [n][*n_out] row-major, unit 2-norm, sign fixed (largest-|entry| positive), min-max normalised to [-0.5, 0.5] when
+ * minmax != 0 (graph.py:254-257).  The reference's widen-and-retry rule (graph.py:369-384) only changes HOW MANY pairs
+ * it asks for: a caller that wants its column count asks for k_final - #nulls, with #nulls = n_components +
+ * n_isolated of pf_graph_get_info.  Covers symmetric W (no one-way edges) and graphs of at least ~100 vertices;
+ * PF_E_STATE otherwise — pyfocusr_amd/_krylov.py is the general driver (asymmetric W, complex spectra, two graphs per
+ * launch).  vals needs room for n_wanted values, vecs for n * n_wanted. */
+typedef struct pf_eigs_stats {
+    int64_t matvecs;      /* SpMV-equivalent launches */
+    int32_t outer_steps;  /* Lanczos steps */
+    int32_t restarts;
+    int32_t filter_resets;
+    int32_t degree;       /* of the last Chebyshev filter */
+    int32_t n_null;       /* eigenvalues <= 1e-10 found among the computed ones (= locked null vectors) */
+    double cut;           /* lower end of the damped interval */
+    double max_residual;  /* max ||S x - lambda x||_2 of the returned pairs */
+} pf_eigs_stats;
+int pf_eigs_smallest(pf_graph* g, int32_t n_wanted, int32_t minmax, double* vals, double* vecs, int32_t* n_out,
+                     pf_eigs_stats* stats);
+
 /* ---- primitives of the row-partitioned solve (one large mesh over several GPUs; SURVEY 8e / BASELINE config C5).
  * The reference has no counterpart (scipy eigs on one core, graph.py:357-389).  pyfocusr_amd/rowpart.py drives them.
  *   pf_op_step     one step of a three-term recurrence: out = alpha (shift x - A x) - beta prev   (slots; prev = -1:

@@ -39,6 +39,11 @@ class GraphInfo(C.Structure):
                 ("max_degree", C.c_int32), ("sell_entries", C.c_int64), ("n_pad", C.c_int64), ("n_oneway", C.c_int64)]
 
 
+class EigsStats(C.Structure):
+    _fields_ = [("matvecs", C.c_int64), ("outer_steps", C.c_int32), ("restarts", C.c_int32), ("filter_resets", C.c_int32),
+                ("degree", C.c_int32), ("n_null", C.c_int32), ("cut", C.c_double), ("max_residual", C.c_double)]
+
+
 class Timing(C.Structure):
     _fields_ = [("op_ms", C.c_double), ("op_launches", C.c_int64), ("op_bytes", C.c_double), ("knn_ms", C.c_double),
                 ("build_ms", C.c_double)]
@@ -90,6 +95,7 @@ SIGNATURES = {
     "pf_knn_upload": (C.c_int, [C.c_void_p, _f64p, C.c_int64, _f64p, C.c_int64, C.c_int32]),
     "pf_knn_run": (C.c_int, [C.c_void_p]),
     "pf_knn_download": (C.c_int, [C.c_void_p, _i64p, _f64p]),
+    "pf_eigs_smallest": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _f64p, _f64p, C.POINTER(C.c_int32), C.POINTER(EigsStats)]),
     "pf_op_step": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double]),
     "pf_cheb_steps": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double,
                                 C.c_double, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
@@ -616,6 +622,17 @@ class DeviceLaplacian(object):
         y = np.empty(self.n, dtype=np.float64)
         _check(self._lib.pf_spmv_host(self._h, self.op if op is None else int(op), _f64(x), _f64(y)))
         return y
+
+    def eigs_smallest(self, n_wanted, minmax=False):
+        """`pf_eigs_smallest`: the eigensolve as ONE C call (symmetric W only) -> (vals, vecs (n, m), stats dict)."""
+        vals = np.empty(int(n_wanted))
+        vecs = np.empty((self.n, int(n_wanted)))
+        n_out, st = C.c_int32(), EigsStats()
+        _check(self._lib.pf_eigs_smallest(self._h, int(n_wanted), int(bool(minmax)), _f64(vals), _f64(vecs), C.byref(n_out),
+                                          C.byref(st)))
+        m = n_out.value
+        out = np.ascontiguousarray(vecs.reshape(-1)[: self.n * m].reshape(self.n, m))
+        return vals[:m].copy(), out, {f: getattr(st, f) for f, _ in EigsStats._fields_}
 
     # ---- primitives of the row-partitioned solve (pyfocusr_amd/rowpart.py)
     def op_step(self, x, prev, out, alpha, c, beta, op=None):

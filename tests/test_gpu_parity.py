@@ -804,3 +804,51 @@ def test_two_step_kernel_bit_identical(golden, hip, ctx):
         hip.two_step_enable(False)  # the default
         for g in graphs:
             g.close()
+
+
+def test_eigs_smallest_single_c_call(golden, hip, ctx):
+    """`pf_eigs_smallest` (the eigensolve as ONE C call, symmetric W) against the golden eigenpairs of the reference,
+    the oracle on synthetic and multi-component meshes, and its documented refusals."""
+    from pyfocusr_amd import PolyMesh  # noqa: F401
+    from pyfocusr_amd.meshgen import blob_mesh
+
+    for name in ("target_mesh", "source_mesh"):
+        g = golden(name)
+        dev = hip.DeviceLaplacian(g["points"], g["faces"], ctx=ctx)
+        vals, vecs, st = dev.eigs_smallest(6, minmax=True)
+        np.testing.assert_allclose(vals, g["k6_eig_vals"], rtol=1e-8)
+        assert np.max(np.abs(vecs - g["k6_eig_vecs"])) < 2e-9
+        assert st["max_residual"] < 1e-10 and st["n_null"] == 1 and st["matvecs"] > 0
+        raw = dev.eigs_smallest(3)[1]
+        assert np.max(np.abs(raw - g["k3_eig_vecs_raw"])) < 2e-9
+        dev.close()
+    # two blobs + stray points: two locked null vectors, isolated vertices masked
+    a, b = blob_mesh(3000, seed=3), blob_mesh(2000, seed=4)
+    pts = np.concatenate([a.points, b.points + 200.0, np.zeros((3, 3))])
+    faces = np.concatenate([a.faces, b.faces + 3000])
+    dev = hip.DeviceLaplacian(pts, faces, ctx=ctx)
+    ref = orc.graph_spectrum(pts, faces, 4)
+    vals, vecs, st = dev.eigs_smallest(4)
+    np.testing.assert_allclose(vals, ref["eig_vals"][:4], rtol=1e-8)
+    assert st["n_null"] == 2 and vecs.shape == (5003, 4) and np.all(vecs[-3:] == 0)
+    dev.close()
+    # larger: against the oracle's L
+    m = blob_mesh(60000, seed=21)
+    dev = hip.DeviceLaplacian(m.points, m.faces, ctx=ctx)
+    vals, vecs, st = dev.eigs_smallest(5)
+    W, deg, d_inv, L = orc.graph_matrices(m.points, m.faces)
+    R = L @ vecs - vecs * vals[None, :]
+    assert np.max(np.linalg.norm(R, axis=0)) < 1e-10 and np.all(np.diff(vals) > 0)
+    np.testing.assert_allclose(np.linalg.norm(vecs, axis=0), 1.0, rtol=1e-12)
+    dev.close()
+    # refusals: one-way edges, tiny graphs
+    g15 = golden("source_mesh_15k")
+    dev = hip.DeviceLaplacian(g15["points"], g15["faces"], ctx=ctx)
+    with pytest.raises(hip.PfError):
+        dev.eigs_smallest(5)
+    dev.close()
+    t = blob_mesh(40, seed=1)
+    dev = hip.DeviceLaplacian(t.points, t.faces, ctx=ctx)
+    with pytest.raises(hip.PfError):
+        dev.eigs_smallest(5)
+    dev.close()
