@@ -32,6 +32,7 @@ reg = pyfocusr.Focusr(
     get_weighted_spectral_coords=False,
     list_features_to_calc=[],
     n_coords_spectral_ordering=10000, n_coords_spectral_registration=1000,
+    initial_correspondence_type="hungarian", final_correspondence_type="kd",   # the notebook's choice (cell 2)
     graph_smoothing_iterations=300, projection_smooth_iterations=40,
 )
 print("target eigenvalues:", reg.graph_target.eig_vals)   # notebook cell 2: 8.39246263e-04 1.63007145e-03 ...
