@@ -26,7 +26,7 @@ from . import _hip
 from .eigsort import eigsort
 from .graph import Graph, compute_spectra
 from .main import print_header
-from .vtk_functions import PolyMesh, apply_transform, icp_transform, vtk_deep_copy
+from .vtk_functions import PolyMesh, apply_transform, icp_transform, set_mesh_scalars, vtk_deep_copy
 
 from . import cpd as _native_cpd
 
@@ -302,6 +302,23 @@ class Focusr(object):
     def get_source_mesh_transformed_weighted_avg(self):
         """focusr.py:603-613."""
         self.weighted_avg_transformed_mesh = self._source_mesh_with_points(self.weighted_avg_transformed_points)
+
+    # ------------------------------------------------------------------ mesh scalars for visualisation (focusr.py:572-599)
+    def set_transformed_source_scalars_to_corresp_target_idx(self):
+        for mesh in (getattr(self, "weighted_avg_transformed_mesh", None), getattr(self, "nearest_neighbour_transformed_mesh", None)):
+            if mesh is not None:
+                set_mesh_scalars(mesh, self.corresponding_target_idx_for_each_source_pt)
+
+    def set_source_scalars_to_corresp_target_idx(self):
+        set_mesh_scalars(self.graph_source.vtk_mesh, self.corresponding_target_idx_for_each_source_pt)
+
+    def set_target_scalars_to_corresp_target_idx(self):
+        set_mesh_scalars(self.graph_target.vtk_mesh, np.arange(self.graph_target.n_points))
+
+    def set_all_mesh_scalars_to_corresp_target_idx(self):
+        self.set_target_scalars_to_corresp_target_idx()
+        self.set_source_scalars_to_corresp_target_idx()
+        self.set_transformed_source_scalars_to_corresp_target_idx()
 
     def get_average_shape(self, align_type="weighted"):
         """focusr.py:433-453: mean of each source vertex and its image on the target."""

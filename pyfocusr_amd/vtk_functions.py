@@ -217,6 +217,21 @@ def mesh_arrays(mesh):
     return pts, np.asarray(cells, dtype=np.int32).reshape(-1, v)
 
 
+def set_mesh_scalars(mesh, values, name="scalars"):
+    """`mesh.GetPointData().SetScalars(numpy_to_vtk(values))` (focusr.py:576-599) for either kind of mesh: a real
+    vtkPolyData gets VTK scalars; a `PolyMesh` gets / replaces the point-data array `name` (also `mesh.scalars`)."""
+    values = np.asarray(values)
+    if _is_vtk_polydata(mesh):
+        from vtk.util.numpy_support import numpy_to_vtk
+
+        mesh.GetPointData().SetScalars(numpy_to_vtk(values))
+        return
+    if len(values) != mesh.GetNumberOfPoints():
+        raise ValueError("one scalar per point expected")
+    mesh.point_data = [(n, v) for n, v in getattr(mesh, "point_data", []) if n != name] + [(name, values.copy())]
+    mesh.scalars = mesh.point_data[-1][1]
+
+
 def _need_vtk(what):
     if _vtk is None:
         raise NotImplementedError(

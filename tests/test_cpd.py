@@ -201,6 +201,9 @@ def test_focusr_full_defaults_run_without_cycpd_or_vtk(golden, ctx):
     assert after < before
     assert reg.weighted_avg_transformed_points.shape == (5000, 3)
     assert reg.nearest_neighbor_transformed_points.shape == (5000, 3)
+    reg.set_all_mesh_scalars_to_corresp_target_idx()   # focusr.py:572-599
+    assert np.array_equal(reg.graph_source.vtk_mesh.scalars, idx) and np.array_equal(reg.weighted_avg_transformed_mesh.scalars, idx)
+    assert np.array_equal(reg.graph_target.vtk_mesh.scalars, np.arange(5000))
     # two meshes of the same bone: corresponding points lie within a few percent of the bone's size
     d = np.linalg.norm(reg.weighted_avg_transformed_points - reg.graph_source.points, axis=1)
     assert np.median(d) < 0.05 * np.ptp(gt["points"])
