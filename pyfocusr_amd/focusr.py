@@ -320,6 +320,15 @@ class Focusr(object):
         self.set_source_scalars_to_corresp_target_idx()
         self.set_transformed_source_scalars_to_corresp_target_idx()
 
+    # ------------------------------------------------------------------ viewers (focusr.py:646-795): itkwidgets, not built
+    def _no_viewer(self, *args, **kwargs):
+        raise ImportError("itkwidgets viewers are not part of the MI355X hot path; the arrays they display are "
+                          "`source_spectral_coords`, `target_spectral_coords`, `corresponding_target_idx_for_each_source_pt`, "
+                          "`weighted_avg_transformed_mesh` and `nearest_neighbour_transformed_mesh`")
+
+    view_aligned_spectral_coords = view_meshes_colored_by_spectral_correspondences = _no_viewer
+    view_aligned_smoothed_spectral_coords = view_meshes = _no_viewer
+
     def get_average_shape(self, align_type="weighted"):
         """focusr.py:433-453: mean of each source vertex and its image on the target."""
         if align_type == "nearest":
