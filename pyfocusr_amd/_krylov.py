@@ -234,7 +234,8 @@ def filtered_eigs_gen(ops, n_wanted, symmetric, ellipse=None, **kw):
             return (yield from _solve_gen(ops, n_wanted, symmetric, half_height=half_height, **kw))
         except _NeedEllipse:
             half_height *= 1.6  # outliers above the assumed strip: make the ellipse taller
-    raise RuntimeError("filtered Krylov-Schur: could not enclose the complex spectrum in an ellipse")
+    raise RuntimeError("filtered Krylov-Schur: could not enclose the complex spectrum of this non-normal Laplacian in an "
+                       "ellipse (one-way edges: an open or non-manifold mesh); the eigenpairs were NOT computed")
 
 
 def _solve_gen(ops, n_wanted, symmetric, null_slots=0, cut=None, tol=1e-12, m_max=None,
@@ -447,6 +448,15 @@ def _solve_gen(ops, n_wanted, symmetric, null_slots=0, cut=None, tol=1e-12, m_ma
     lam = lam[keep]
     R = R[:, keep]
     nk = len(keep)
+    if nk == 0:
+        # The dominant subspace of the filtered operator held nothing but (numerically) null directions.  Seen on
+        # strongly non-normal Laplacians (a large hole: hundreds of one-way boundary edges next to >1000 stranded
+        # vertices), where Ritz values of the filter keep growing instead of converging.  A taller ellipse may
+        # still enclose the spectrum; if not, say so instead of handing an empty block to the device.
+        if not symmetric:
+            raise _NeedEllipse()
+        raise RuntimeError("filtered Krylov-Schur converged onto the null space only (no eigenvalue > 1e-10 among "
+                           "%d Ritz values)" % q)
     X0, AX0 = B0 + q, A0 + q
     if X0 + nk > 2 * reg or AX0 + nk > reg:
         raise RuntimeError("workspace too small for Ritz extraction")

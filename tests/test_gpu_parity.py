@@ -852,3 +852,27 @@ def test_eigs_smallest_single_c_call(golden, hip, ctx):
     with pytest.raises(hip.PfError):
         dev.eigs_smallest(5)
     dev.close()
+
+
+def test_large_hole_needs_taller_ellipse(ctx):
+    """Regression (found by a randomised sweep): a 150k blob with one large cap removed — 156 one-way boundary edges next
+    to 1279 stranded vertices.  The first ellipse is too flat, the dominant subspace of the filter then holds only null
+    directions; the solver must retry with a taller ellipse instead of handing an empty block to the device.  (The
+    reference's widen-and-retry loop would need k > 1280 here.)"""
+    from pyfocusr_amd import Graph, PolyMesh
+    from pyfocusr_amd.meshgen import blob_mesh
+
+    m = blob_mesh(150000, seed=118838)
+    faces = m.faces[np.linalg.norm(m.points[m.faces].mean(1) - m.points[0], axis=1) > 6.0]
+    gr = Graph(PolyMesh(m.points, faces), n_spectral_features=5, norm_eig_vecs=False, n_rand_samples=10**9, ctx=ctx, verbose=False)
+    gr.get_graph_spectrum()
+    assert gr.device.n_isolated == 1279 and not gr.device.symmetric
+    assert len(gr.eig_vals) >= 5 and np.all(gr.eig_vals > 1e-10) and np.all(np.diff(gr.eig_vals) >= 0)
+    gr.get_laplacian_matrix()
+    R = gr.laplacian_matrix @ gr.eig_vecs - gr.eig_vecs * gr.eig_vals[None, :]
+    res = np.linalg.norm(R, axis=0)
+    real = np.ones(len(res), dtype=bool)  # a complex pair is reported as a repeated real part (reference semantics)
+    dup = np.isclose(gr.eig_vals[:-1], gr.eig_vals[1:], rtol=1e-9)
+    real[:-1] &= ~dup
+    real[1:] &= ~dup
+    assert np.all(res[real] < 1e-9)
