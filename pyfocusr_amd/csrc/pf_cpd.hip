@@ -491,6 +491,21 @@ int pf_cpd_set_basis(pf_cpd* h, const double* Q, int32_t K) {
     PF_HIP(pf_malloc(st, (void**)&h->hpart, sizeof(double) * (size_t)h->chunks_h * K * K));
     PF_HIP(pf_malloc(st, (void**)&h->H, sizeof(double) * (size_t)K * K));
     PF_HIP(hipMemcpyAsync(h->Q, Q, sizeof(double) * h->M * K, hipMemcpyHostToDevice, st));
+    // scratch of the device-resident M-step: K x d coefficients / right-hand side and their per-block partial sums
+    const int64_t need_sum = std::max<int64_t>(h->msum_cap, (int64_t)K * h->D);
+    const int64_t need_part = std::max<int64_t>(h->mpart_cap, ((h->M + MOM_ROWS - 1) / MOM_ROWS) * (int64_t)K * h->D);
+    if (need_sum > h->msum_cap) {
+        pf_free(st, h->msum);
+        h->msum = nullptr, h->msum_cap = 0;
+        PF_HIP(pf_malloc(st, (void**)&h->msum, sizeof(double) * need_sum));
+        h->msum_cap = need_sum;
+    }
+    if (need_part > h->mpart_cap) {
+        pf_free(st, h->mpart);
+        h->mpart = nullptr, h->mpart_cap = 0;
+        PF_HIP(pf_malloc(st, (void**)&h->mpart, sizeof(double) * need_part));
+        h->mpart_cap = need_part;
+    }
     PF_HIP(hipStreamSynchronize(st));
     h->K = K;
     return PF_OK;
@@ -595,6 +610,7 @@ int pf_cpd_deform_sums(pf_cpd* h, double* H, double* R) {
 int pf_cpd_apply_deform(pf_cpd* h, const double* C, double* sums) {
     PF_CHECK(h && C && sums, PF_E_ARG, "pf_cpd_apply_deform: NULL argument");
     PF_CHECK(h->K > 0, PF_E_STATE, "pf_cpd_apply_deform: no basis (pf_cpd_set_basis) on this handle");
+    PF_CHECK((int64_t)h->K * h->D <= h->msum_cap, PF_E_STATE, "pf_cpd_apply_deform: scratch smaller than K x d");
     PF_HIP(hipSetDevice(h->ctx->device));
     hipStream_t st = h->ctx->stream;
     const int D = h->D, K = h->K;

@@ -15,6 +15,7 @@ void pf_set_error(const char* fmt, ...);
         hipError_t e_ = (call);                                                               \
         if (e_ != hipSuccess) {                                                               \
             pf_set_error("%s:%d %s: %s", __FILE__, __LINE__, #call, hipGetErrorString(e_));   \
+            (void)hipGetLastError(); /* clear the sticky error: later, unrelated calls must not report it again */ \
             return PF_E_HIP;                                                                  \
         }                                                                                     \
     } while (0)

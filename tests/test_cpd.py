@@ -207,3 +207,20 @@ def test_focusr_full_defaults_run_without_cycpd_or_vtk(golden, ctx):
     # two meshes of the same bone: corresponding points lie within a few percent of the bone's size
     d = np.linalg.norm(reg.weighted_avg_transformed_points - reg.graph_source.points, axis=1)
     assert np.median(d) < 0.05 * np.ptp(gt["points"])
+
+
+@pytest.mark.gpu
+def test_deformable_with_wide_coordinates(ctx):
+    """Regression (randomised pipeline sweep): K x d above the initial scratch size (100 eigenvectors x 8 coordinates,
+    i.e. spectral coordinates + xyz) must not overflow the device-resident M-step's buffers."""
+    from pyfocusr_amd import cpd
+
+    rng = np.random.default_rng(12)
+    X = rng.normal(size=(900, 8))
+    Y = X[:700] + 0.05 * rng.normal(size=(700, 8))
+    kw = dict(alpha=0.5, beta=1.2, num_eig=100, max_iterations=8, tolerance=0.0)
+    got = cpd.deformable_registration(X=X, Y=Y, ctx=ctx, **kw)
+    TY, (Q, S, W) = got.register()
+    want = cpd_port.DeformableRegistration(X, Y, low_rank=True, **kw)
+    np.testing.assert_allclose(TY, want.register()[0], atol=1e-7)
+    assert Q.shape[1] * 8 > 561
