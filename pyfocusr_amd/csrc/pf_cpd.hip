@@ -93,9 +93,12 @@ __global__ __launch_bounds__(PF_BLOCK) void k_cpd_colfinish(const double* __rest
     if (n >= N) return;
     double s = 0.0;
     for (int k = 0; k < chunks; ++k) s += part[(int64_t)k * N + n];
-    const double d = 1.0 / ((s == 0.0 ? 2.220446049250313e-16 : s) + c);
-    den[n] = d;
-    Pt1[n] = s * d;
+    // den[n] > 0: the reciprocal of the column sum (+ c).  A column whose Gaussians all underflow to denormals has a
+    // sum whose reciprocal overflows; it is stored as -sum instead and the row pass divides (e / sum <= 1 is exact
+    // enough and finite, as in numpy's P / den).
+    const double total = (s == 0.0 ? 2.220446049250313e-16 : s) + c;
+    den[n] = total >= 1e-280 ? 1.0 / total : -total;
+    Pt1[n] = s / total;
 }
 
 // pass 2: part[chunk][m][0] = sum_n P_mn, part[chunk][m][1 + c] = sum_n P_mn x_nc over the chunk's n
@@ -121,7 +124,8 @@ __global__ __launch_bounds__(PF_BLOCK) void k_cpd_rowsum(const double* __restric
         for (int k = threadIdx.x; k < cnt; k += PF_BLOCK) tden[k] = den[t0 + k];
         __syncthreads();
         for (int r = 0; r < cnt; ++r) {
-            const double p = exp(-sqdist<D>(y, tile + r * D) * inv2s) * tden[r];
+            const double ev = exp(-sqdist<D>(y, tile + r * D) * inv2s), dn = tden[r];
+            const double p = dn > 0.0 ? ev * dn : ev / -dn;
             p1 += p;
 #pragma unroll
             for (int c = 0; c < D; ++c) px[c] += p * tile[r * D + c];

@@ -224,3 +224,29 @@ def test_deformable_with_wide_coordinates(ctx):
     want = cpd_port.DeformableRegistration(X, Y, low_rank=True, **kw)
     np.testing.assert_allclose(TY, want.register()[0], atol=1e-7)
     assert Q.shape[1] * 8 > 561
+
+
+@pytest.mark.gpu
+def test_estep_denormal_column_sums(ctx):
+    """Regression (randomised sweep): column sums in the denormal range (far-apart clouds in many dimensions, small
+    sigma2, w = 0) must not turn into inf * 0 = NaN: numpy's P / den stays finite there."""
+    from pyfocusr_amd import _hip
+
+    rng = np.random.default_rng(4)
+    found = False
+    for trial in range(40):
+        D = int(rng.integers(8, 17))
+        X, Y = rng.normal(size=(300, D)) * 0.3, rng.normal(size=(200, D)) * 0.3 + rng.uniform(-1, 1)
+        s2 = float(10 ** rng.uniform(-2.6, -1.2))
+        wP1, wPt1, wPX, _ = cpd_port.expectation(X, Y, s2, 0.0)
+        col = np.exp(-np.sum((X[None] - Y[:, None]) ** 2, axis=2) / (2 * s2)).sum(axis=0)
+        tiny = np.any((col > 0) & (col < 1e-300))
+        dev = _hip.DeviceCpd(X, Y, ctx=ctx)
+        P1, Pt1, PX = dev.estep(Y, s2, 0.0)
+        dev.close()
+        assert np.all(np.isfinite(P1)) and np.all(np.isfinite(Pt1)) and np.all(np.isfinite(PX))
+        if tiny:
+            found = True
+            np.testing.assert_allclose(Pt1, wPt1, rtol=1e-6, atol=1e-300)
+            np.testing.assert_allclose(P1, wP1, rtol=1e-6, atol=1e-12)
+    assert found, "no trial reached the denormal range: adjust the generator"
