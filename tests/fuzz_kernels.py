@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised sweep of the "next"-row kernels against their CPU restatements: CPD (E-step, affine and deformable
-registrations), closest point on a surface, graph mean filter.  Uses oracle/ as the checker, so it lives next to the
-tests conceptually; run from the repo root:  python -m tools.fuzz_kernels SEED N   (or python tools/fuzz_kernels.py)"""
+registrations), closest point on a surface, graph mean filter.  Uses oracle/ as the checker, hence lives under tests/
+(not collected by pytest):  python tests/fuzz_kernels.py SEED N_ROUNDS   on the GPU box."""
 import os
 import sys
 import time
@@ -11,10 +11,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
-import test_cpd as _t  # noqa: E402,F401  (brings the checker modules in the way the tests do)
-from test_cpd import cpd_port  # noqa: E402
-from test_icp import icp_port  # noqa: E402
+from oracle import cpd_port, icp_port  # noqa: E402
 from pyfocusr_amd import _hip, cpd  # noqa: E402
 from pyfocusr_amd.meshgen import blob_mesh  # noqa: E402
 
