@@ -240,7 +240,7 @@ def filtered_eigs_gen(ops, n_wanted, symmetric, ellipse=None, **kw):
 
 def _solve_gen(ops, n_wanted, symmetric, null_slots=0, cut=None, tol=1e-12, m_max=None,
                max_restarts=60, max_filter_resets=8, seed=0, strength=2.0, hi=2.0,
-               nonsym_degree_cap=128, half_height=None, verbose=False):
+               nonsym_degree_cap=128, half_height=None, verbose=False, adapt_cut=False):
     """Generator form of the solver: yields `(src, dst, degree, c, e)` whenever the Chebyshev
     filter has to be applied (the only expensive device operation) and receives nothing back;
     `drive` / `drive_pair` execute the requests (`(src, dst, degree, c, e, rho)`).  Its return value is the solver result.
@@ -360,6 +360,15 @@ def _solve_gen(ops, n_wanted, symmetric, null_slots=0, cut=None, tol=1e-12, m_ma
                         outcome = "range"  # complex outliers eat the dynamic range: lower the degree
                     elif (j >= q + 12 or exhausted) and theta_min < band:
                         outcome = "cut"  # wanted eigenvalues sit inside the damped band
+                    elif adapt_cut and j == m_max and not plain and not ellipse:
+                        # General matrices (no a-priori scale for the low end, unlike mesh Laplacians): if the filter
+                        # amplifies far more Ritz values than wanted, the wanted ones are crowded together near the top
+                        # of the filter's range and Lanczos separates them slowly — narrow the undamped interval to
+                        # just above the (q_target+1)-th lowest eigenvalue estimate.
+                        amp = sorted(_cheb_inverse(t.real, c, e, p) for t in theta if abs(t.imag) <= 1e-9 * abs(t) and t.real > band)
+                        if len(amp) >= 2 * q_target + 4 and amp[q_target] > 0 and 3.0 * amp[q_target] < cut:
+                            shrink_to = 3.0 * amp[q_target]
+                            outcome = "shrink"
                     elif exhausted:
                         outcome = "converged"
                     if outcome == "converged" and U is None:
@@ -394,6 +403,8 @@ def _solve_gen(ops, n_wanted, symmetric, null_slots=0, cut=None, tol=1e-12, m_ma
             raise RuntimeError("could not place the Chebyshev filter (cut %g, degree %d)" % (cut, p))
         if outcome == "range":
             degree_cap = max(16, p // 2)
+        elif outcome == "shrink":
+            cut = shrink_to
         else:
             lead = theta[:q]
             lam_est = [] if ellipse else sorted(_cheb_inverse(t.real, c, e, p) for t in lead

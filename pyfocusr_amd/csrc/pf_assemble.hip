@@ -615,6 +615,7 @@ int pf_graph_from_matrix(pf_ctx* ctx, int64_t n, const int32_t* rowptr, const in
     hipStream_t st = ctx->stream;
     pf_graph* g = new pf_graph();
     g->ctx = ctx;
+    g->unit_g = 1;
     g->n = n;
     g->n_pad = (n + 4095) / 4096 * 4096;
     g->n_slices = g->n_pad / PF_WAVE;

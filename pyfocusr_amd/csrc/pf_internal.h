@@ -132,6 +132,7 @@ struct pf_graph {
     double* ts_gh_rw = nullptr;   // same shape: values of the RW operator
     double* ts_gh_sym = nullptr;  // same shape: values of the SYM operator (symmetric graphs)
     int32_t is_symmetric = 0, n_isolated = 0, n_components = 0, max_degree = 0, n_oneway = 0;
+    int32_t unit_g = 0;  // graph handed in as a matrix (pf_graph_from_matrix): G = I, the operator is the matrix itself
     std::vector<int32_t> roots; // roots of components with >= 2 vertices, ascending
     // workspace: n_slots vectors + 2 Chebyshev temporaries, stride n_pad
     double* ws = nullptr;

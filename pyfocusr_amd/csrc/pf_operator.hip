@@ -225,6 +225,8 @@ __global__ __launch_bounds__(PF_BLOCK) void k_null_vector(double* __restrict__ x
                                                           const int32_t* __restrict__ rowptr,
                                                           const double* __restrict__ deg, const int32_t* __restrict__ perm,
                                                           int64_t n_pad, int32_t root, int32_t sym) {
+    // null vector of the iterated operator on one component: 1_C for L = G (D - W) and for a general matrix with zero
+    // row sums (G = I: sym == 0 is passed), G^-1/2 1_C = sqrt(deg + 1e-8) 1_C for S = G^1/2 (D - W) G^1/2 of a mesh graph
     const int64_t r = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
     if (r >= n_pad) return;
     const int32_t i = perm[r];
@@ -773,7 +775,7 @@ int pf_lock_null_vectors(pf_graph* g, int32_t op, int32_t* n_locked) {
     PF_TRY(pf_reduce_ensure(g, 1));
     for (int32_t c = 0; c < nc; ++c) {
         k_null_vector<<<nblk(g->n_pad), PF_BLOCK, 0, st>>>(pf_slot(g, c), g->label, g->rowptr, g->deg, g->perm, g->n_pad,
-                                                          g->roots[c], op == PF_OP_SYM);
+                                                          g->roots[c], op == PF_OP_SYM && !g->unit_g);
         PF_HIP(hipGetLastError());
         PF_TRY(dots_device(g, c, c, 1, g->coef, nullptr, 0));
         double nrm2 = 0.0;

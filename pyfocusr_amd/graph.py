@@ -395,7 +395,7 @@ def _device_from_matrix(matrix, ctx=None):
     offdiag = np.diff(A.indptr) - (A.diagonal() != 0)
     if np.any((offdiag == 0) & (A.diagonal() != 0)):
         raise NotImplementedError("rows whose only entry is a non-zero diagonal are not supported")
-    return dev, dict(hi=max(hi, 1e-300), cut=8.0 * (1 + 1) / max(n, 1) * max(hi, 1e-300) / 2.0)
+    return dev, dict(hi=max(hi, 1e-300), cut=8.0 * (1 + 1) / max(n, 1) * max(hi, 1e-300) / 2.0, adapt_cut=True)
 
 
 def recursive_eig(matrix, k, n_k_needed, k_buffer=1, sigma=1e-10, which="LM"):
@@ -406,7 +406,13 @@ def recursive_eig(matrix, k, n_k_needed, k_buffer=1, sigma=1e-10, which="LM"):
     place; any other scipy sparse matrix (the reference's signature) is uploaded with
     `pf_graph_from_matrix`.  `sigma`/`which` select ARPACK's shift-invert mode in the reference and have no
     counterpart here: the eigenvalues nearest zero of a positive semi-definite operator are always the
-    ones computed.  Returns raw (un-normalised, unit-2-norm) eigenvectors, sorted ascending."""
+    ones computed.  Returns raw (un-normalised, unit-2-norm) eigenvectors, sorted ascending.
+
+    General matrices: null vectors are locked analytically when the rows sum to zero (one per connected component);
+    the filter's undamped interval adapts itself when the low end of the spectrum is far below k/n of its top.
+    Known limitation: for a DISCONNECTED matrix WITHOUT null vectors (e.g. a shifted Laplacian), an eigenvalue shared
+    by several components may be returned with lower multiplicity (single-vector Krylov iteration; mesh Laplacians
+    are not affected: their only degenerate eigenvalue by construction is 0, handled through the components)."""
     dev = getattr(matrix, "_pf_device", None)
     solver_kw = {}
     owned = False

@@ -876,3 +876,40 @@ def test_large_hole_needs_taller_ellipse(ctx):
     real[:-1] &= ~dup
     real[1:] &= ~dup
     assert np.all(res[real] < 1e-9)
+
+
+@pytest.mark.parametrize("kind", ["unnormalised", "random_walk", "shifted"])
+def test_recursive_eig_on_non_mesh_matrices(kind):
+    """Regression (randomised sweep): `recursive_eig` on Laplacians that do not come from a mesh — widely varying
+    weights, a spectrum whose low end is far below k/n of its top (the filter narrows itself), G = I (the locked null
+    vector is the constant one), or no null vector at all."""
+    from scipy.sparse.linalg import eigs, eigsh
+    from scipy.spatial import cKDTree
+
+    from pyfocusr_amd import recursive_eig
+
+    rng = np.random.default_rng(31)
+    n, nn, k = 4000, 6, 5
+    P = rng.random((n, 2))
+    d, j = cKDTree(P).query(P, k=nn + 1)
+    W = sparse.csr_matrix((1.0 / (d[:, 1:].ravel() + 1e-3), (np.repeat(np.arange(n), nn), j[:, 1:].ravel())), shape=(n, n))
+    W = W.maximum(W.T)
+    far = rng.integers(0, n, size=(80, 2))
+    far = far[far[:, 0] != far[:, 1]]
+    E = sparse.csr_matrix((np.full(len(far), 0.05), (far[:, 0], far[:, 1])), shape=(n, n))
+    W = W + E.maximum(E.T)  # connected
+    deg = np.asarray(W.sum(axis=1))[:, 0]
+    if kind == "unnormalised":
+        A = (sparse.diags(deg) - W).tocsr()
+        ref = eigsh(A, k=k + 1, sigma=-1e-2, which="LM")[0]
+    elif kind == "random_walk":
+        A = (sparse.diags(1.0 / deg) @ (sparse.diags(deg) - W)).tocsr()
+        ref = np.real(eigs(A, k=k + 1, sigma=-1e-6, which="LM")[0])
+    else:
+        A = (sparse.diags(deg) - W + 0.37 * sparse.eye(n)).tocsr()
+        ref = eigsh(A, k=k + 1, sigma=-1e-2, which="LM")[0]
+    ref = np.sort(ref[ref > 1e-10])[:k]
+    vals, vecs = recursive_eig(A, k=k + 1, n_k_needed=k)
+    np.testing.assert_allclose(np.sort(vals)[:len(ref)], ref, rtol=1e-8)
+    R = A @ vecs - vecs * vals[None, :]
+    assert np.max(np.linalg.norm(R, axis=0)) < 1e-8 * abs(A).sum(axis=1).max()
