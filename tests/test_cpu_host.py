@@ -397,3 +397,38 @@ def test_focusr_constructor_surface():
     assert d["n_coords_spectral_ordering"] == 5000 and d["get_weighted_spectral_coords"] is True
     assert d["graph_smoothing_iterations"] == 300 and d["projection_smooth_iterations"] == 40
     assert d["list_features_to_calc"] == ["curvature"] and d["initial_correspondence_type"] == "kd"
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_eigsort_random_inputs_vs_oracle(seed):
+    """The eigsort mirror on random eigenmaps (different vertex counts, sampled subsets, both reference choices,
+    columns that need flips and permutations) against the oracle's restatement of eigsort.py:54-249."""
+    from pyfocusr_amd import Graph, PolyMesh, eigsort
+    from pyfocusr_amd.meshgen import blob_mesh
+
+    rng = np.random.default_rng(100 + seed)
+    k = int(rng.integers(2, 7))
+    nt, ns = int(rng.integers(200, 900)), int(rng.integers(200, 900))
+    n_samples = int(rng.choice([150, 10**9]))  # subset sampling / all points
+    target_ref = bool(rng.integers(0, 2))
+    graphs = []
+    for n in (nt, ns):
+        m = blob_mesh(n, seed=int(rng.integers(0, 10**6)))
+        gr = Graph(PolyMesh(m.points, m.faces), n_spectral_features=k, n_rand_samples=n_samples, ctx=FakeCtx(), verbose=False)
+        gr.eig_vals = np.sort(rng.uniform(1e-4, 5e-3, k + int(rng.integers(0, 3))))  # extra columns as after widening
+        base = rng.uniform(-0.5, 0.5, (n, 1)) * rng.uniform(0.2, 1.0, (1, len(gr.eig_vals))) + 0.2 * rng.uniform(-0.5, 0.5, (n, len(gr.eig_vals)))
+        base = (base - base.min(0)) / np.ptp(base, axis=0) - 0.5  # min-max normalised like graph.py:254-257
+        gr.eig_vecs = base * rng.choice([-1.0, 1.0], size=(1, base.shape[1]))
+        gr.eig_vecs = (gr.eig_vecs - gr.eig_vecs.min(0)) / np.ptp(gr.eig_vecs, axis=0) - 0.5
+        graphs.append(gr)
+    gt, gs = graphs
+    vt0, vs0 = gt.eig_vecs.copy(), gs.eig_vecs.copy()
+    ref = orc.sort_eigenmaps(gt.points, gs.points, gt.eig_vals, gs.eig_vals, vt0.copy(), vs0.copy(), gt.rand_idxs, gs.rand_idxs, k,
+                             target_as_reference=target_ref)
+    sorter = eigsort(gt, gs, k, target_as_reference=target_ref)
+    Q = sorter.sort_eigenmaps()
+    for name in ("c_lambda", "c_hist", "c_hist_f", "c_spatial", "c_spatial_f"):
+        np.testing.assert_allclose(getattr(sorter, name), ref[name], rtol=1e-12, atol=1e-300, err_msg=name)
+    np.testing.assert_allclose(Q, ref["Q"], rtol=1e-12)
+    assert np.array_equal(gt.eig_vecs, ref["eig_vecs_t"]) and np.array_equal(gs.eig_vecs, ref["eig_vecs_s"])
+    assert np.array_equal(gt.eig_vals, np.sort(gt.eig_vals))  # eigenvalues are never permuted (SURVEY A10)
