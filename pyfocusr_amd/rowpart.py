@@ -372,6 +372,10 @@ def row_partitioned_eigs(points, faces, k, comm, make_local, s=16, device_graph=
     stats, ops)."""
     from . import _krylov
 
+    if device_graph.n_isolated or device_graph.n_components != 1:
+        raise NotImplementedError("row-partitioned solve needs ONE connected component and no unreferenced vertices "
+                                  "(this mesh: %d components, %d isolated vertices); use the single-device solve"
+                                  % (device_graph.n_components, device_graph.n_isolated))
     d = device_graph.download()
     S, sg = symmetric_operator(d["rowptr"], d["colidx"], d["w"], d["deg"])
     deg = d["deg"]
