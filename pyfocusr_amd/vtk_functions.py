@@ -2,7 +2,7 @@
 
 Mirrors the part of the reference's VTK adapter the hot path consumes
 (`/root/reference/pyfocusr/vtk_functions.py:5-9` `read_vtk_mesh`) without needing
-the `vtk` wheel: an ASCII legacy-VTK POLYDATA reader that yields a `PolyMesh`,
+the `vtk` wheel: a legacy-VTK POLYDATA reader (ASCII and BINARY, file versions <= 4.2 and 5.1) that yields a `PolyMesh`,
 a light object that
 
 * exposes `points` (n,3) f64 and `faces` (F,v) i32 arrays directly (fast path
@@ -109,71 +109,128 @@ class PolyMesh(object):
         return _PointData(self.point_data)
 
 
-def _tokens(path):
-    with open(path, "r") as fh:
-        for line in fh:
-            for tok in line.split():
-                yield tok
+_VTK_TYPES = {"float": ">f4", "double": ">f8", "int": ">i4", "unsigned_int": ">u4", "long": ">i8", "unsigned_long": ">u8",
+              "vtktypeint32": ">i4", "vtktypeint64": ">i8", "short": ">i2", "unsigned_short": ">u2", "char": ">i1",
+              "unsigned_char": ">u1", "vtkidtype": ">i8"}
+
+
+class _LegacyVtkStream(object):
+    """Token / raw-block reader over a legacy VTK file (ASCII or BINARY: binary blocks are big-endian)."""
+
+    def __init__(self, data, binary):
+        self.data, self.pos, self.binary = data, 0, binary
+
+    def token(self):
+        d, n = self.data, len(self.data)
+        while self.pos < n and d[self.pos] in b" \t\r\n":
+            self.pos += 1
+        start = self.pos
+        while self.pos < n and d[self.pos] not in b" \t\r\n":
+            self.pos += 1
+        return d[start:self.pos].decode("ascii", "replace") if self.pos > start else None
+
+    def rest_of_line(self):
+        end = self.data.find(b"\n", self.pos)
+        end = len(self.data) if end < 0 else end
+        line = self.data[self.pos:end]
+        self.pos = min(end + 1, len(self.data))
+        return line.decode("ascii", "replace")
+
+    def array(self, count, vtk_type):
+        dt = _VTK_TYPES.get(vtk_type.lower())
+        if dt is None:
+            raise NotImplementedError("legacy VTK data type %r" % vtk_type)
+        if self.binary:
+            if self.pos < len(self.data) and self.data[self.pos:self.pos + 1] == b"\n":
+                self.pos += 1  # the newline that ends the header line of the block
+            nbytes = count * np.dtype(dt).itemsize
+            out = np.frombuffer(self.data, dtype=dt, count=count, offset=self.pos)
+            self.pos += nbytes
+            return out
+        vals = []
+        while len(vals) < count:
+            t = self.token()
+            if t is None:
+                raise ValueError("unexpected end of file inside a data block")
+            vals.append(t)
+        return np.array(vals, dtype=np.float64 if dt[1] == "f" else np.int64)
 
 
 def read_vtk_mesh(path_to_file):
-    """Read an ASCII legacy-VTK POLYDATA file (the format of the reference's
-    `data/*.vtk`) into a `PolyMesh`.
+    """Read a legacy-VTK POLYDATA file into a `PolyMesh`: ASCII or BINARY, file versions up to 4.2 (`POLYGONS n size`
+    followed by `v i0 .. iv-1` records, the format of the reference's `data/*.vtk`) and 5.1
+    (`OFFSETS` / `CONNECTIVITY` blocks, what current VTK writes).  Same call signature as `vtk_functions.py:5-9`.
+    Polygons of mixed size are rejected (all bundled data are triangles)."""
+    with open(path_to_file, "rb") as fh:
+        data = fh.read()
+    st = _LegacyVtkStream(data, False)
+    if not st.rest_of_line().startswith("# vtk DataFile"):
+        raise ValueError("not a legacy VTK file: %s" % path_to_file)
+    st.rest_of_line()  # title
+    fmt = st.rest_of_line().strip().upper()
+    if fmt not in ("ASCII", "BINARY"):
+        raise NotImplementedError("legacy VTK format %r" % fmt)
+    st.binary = fmt == "BINARY"
+    if (st.token() or "").upper() != "DATASET" or (st.token() or "").upper() != "POLYDATA":
+        raise NotImplementedError("only DATASET POLYDATA is supported")
 
-    Same call signature as `vtk_functions.py:5-9`.  Polygons of mixed size are
-    rejected (all bundled data are triangles)."""
-    with open(path_to_file, "r") as fh:
-        header = [fh.readline() for _ in range(4)]
-        if not header[0].startswith("# vtk DataFile"):
-            raise ValueError("not a legacy VTK file: %s" % path_to_file)
-        if header[2].strip().upper() != "ASCII":
-            raise NotImplementedError("only ASCII legacy VTK files are supported")
-        if header[3].split()[:2] != ["DATASET", "POLYDATA"]:
-            raise NotImplementedError("only DATASET POLYDATA is supported")
-        rest = fh.read().split()
-
-    pos = 0
-    points = None
-    faces = None
-    point_data = []
-    n_points = 0
-    while pos < len(rest):
-        key = rest[pos].upper()
+    points = faces = None
+    point_data, n_points, in_point_data = [], 0, False
+    while True:
+        key = st.token()
+        if key is None:
+            break
+        key = key.upper()
         if key == "POINTS":
-            n_points = int(rest[pos + 1])
-            pos += 3
-            points = np.array(rest[pos : pos + 3 * n_points], dtype=np.float64).reshape(n_points, 3)
-            pos += 3 * n_points
-        elif key == "POLYGONS":
-            n_cells = int(rest[pos + 1])
-            total = int(rest[pos + 2])
-            pos += 3
-            flat = np.array(rest[pos : pos + total], dtype=np.int64)
-            pos += total
-            if n_cells == 0:
-                faces = np.zeros((0, 3), dtype=np.int32)
-            else:
-                v = int(flat[0])
-                if total != n_cells * (v + 1) or np.any(flat.reshape(n_cells, v + 1)[:, 0] != v):
-                    raise NotImplementedError("mixed polygon sizes are not supported")
-                faces = flat.reshape(n_cells, v + 1)[:, 1:].astype(np.int32)
+            n_points = int(st.token())
+            points = np.asarray(st.array(3 * n_points, st.token()), dtype=np.float64).reshape(n_points, 3)
+        elif key in ("POLYGONS", "VERTICES", "LINES", "TRIANGLE_STRIPS"):
+            a, b = int(st.token()), int(st.token())
+            nxt_pos = st.pos
+            nxt = st.token()
+            if nxt is not None and nxt.upper() == "OFFSETS":  # version 5.1: a offsets (cells + 1), b connectivity entries
+                offs = np.asarray(st.array(a, st.token()), dtype=np.int64)
+                if (st.token() or "").upper() != "CONNECTIVITY":
+                    raise ValueError("OFFSETS without CONNECTIVITY")
+                conn = np.asarray(st.array(b, st.token()), dtype=np.int64)
+                if key == "POLYGONS":
+                    widths = np.diff(offs)
+                    if len(widths) == 0:
+                        faces = np.zeros((0, 3), dtype=np.int32)
+                    elif np.any(widths != widths[0]):
+                        raise NotImplementedError("mixed polygon sizes are not supported")
+                    else:
+                        faces = conn.reshape(len(widths), int(widths[0])).astype(np.int32)
+            else:  # versions <= 4.2: a cells, b integers in all
+                st.pos = nxt_pos
+                flat = np.asarray(st.array(b, "int"), dtype=np.int64)
+                if key == "POLYGONS":
+                    if a == 0:
+                        faces = np.zeros((0, 3), dtype=np.int32)
+                    else:
+                        v = int(flat[0])
+                        if b != a * (v + 1) or np.any(flat.reshape(a, v + 1)[:, 0] != v):
+                            raise NotImplementedError("mixed polygon sizes are not supported")
+                        faces = flat.reshape(a, v + 1)[:, 1:].astype(np.int32)
         elif key == "POINT_DATA":
-            pos += 2
+            st.token()
+            in_point_data = True
+        elif key == "CELL_DATA":
+            st.token()
+            in_point_data = False
         elif key == "SCALARS":
-            name = rest[pos + 1]
-            ncomp = 1
-            pos += 3
-            if pos < len(rest) and rest[pos].isdigit():
-                ncomp = int(rest[pos])
-                pos += 1
-            if rest[pos].upper() == "LOOKUP_TABLE":
-                pos += 2
-            vals = np.array(rest[pos : pos + n_points * ncomp], dtype=np.float64)
-            pos += n_points * ncomp
+            name, vtype = st.token(), st.token()
+            line = st.rest_of_line().split()
+            ncomp = int(line[0]) if line and line[0].isdigit() else 1
+            if (st.token() or "").upper() != "LOOKUP_TABLE":
+                raise ValueError("SCALARS without LOOKUP_TABLE")
+            st.token()
+            count = (n_points if in_point_data else 0) * ncomp
+            if not in_point_data:
+                raise NotImplementedError("cell SCALARS are not supported")
+            vals = np.asarray(st.array(count, vtype), dtype=np.float64)
             point_data.append((name, vals if ncomp == 1 else vals.reshape(n_points, ncomp)))
-        else:
-            # unknown section (VERTICES/LINES/CELL_DATA/...): not needed by the hot path.
-            pos += 1
+        # anything else (METADATA, NORMALS, FIELD, ...): tokens are skipped one by one; the hot path needs none of it
     if points is None or faces is None:
         raise ValueError("file has no POINTS/POLYGONS section: %s" % path_to_file)
     return PolyMesh(points, faces, point_data)

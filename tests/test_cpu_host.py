@@ -432,3 +432,42 @@ def test_eigsort_random_inputs_vs_oracle(seed):
     np.testing.assert_allclose(Q, ref["Q"], rtol=1e-12)
     assert np.array_equal(gt.eig_vecs, ref["eig_vecs_t"]) and np.array_equal(gs.eig_vecs, ref["eig_vecs_s"])
     assert np.array_equal(gt.eig_vals, np.sort(gt.eig_vals))  # eigenvalues are never permuted
+
+
+def test_vtk_reader_ascii_binary_and_version_5(tmp_path):
+    """Legacy VTK POLYDATA in the four flavours a user may have on disk: ASCII / BINARY (big-endian blocks), file
+    versions <= 4.2 (`POLYGONS n size` records) and 5.1 (`OFFSETS` / `CONNECTIVITY`), with point scalars."""
+    from pyfocusr_amd.vtk_functions import read_vtk_mesh
+
+    rng = np.random.default_rng(0)
+    pts = rng.normal(size=(7, 3))
+    faces = np.array([[0, 1, 2], [2, 3, 4], [4, 5, 6]], dtype=np.int32)
+    sc = rng.normal(size=7)
+    head = "# vtk DataFile Version %s\nvtk output\n%s\nDATASET POLYDATA\n"
+    files = {
+        "a42": (head % ("4.2", "ASCII") + "POINTS 7 float\n" + "\n".join(" ".join(repr(float(v)) for v in p) for p in pts)
+                + "\nPOLYGONS 3 12\n" + "\n".join("3 %d %d %d" % tuple(f) for f in faces)
+                + "\n\nPOINT_DATA 7\nSCALARS thickness double\nLOOKUP_TABLE default\n" + " ".join(repr(float(v)) for v in sc) + "\n").encode(),
+        "a51": (head % ("5.1", "ASCII") + "POINTS 7 double\n" + " ".join(repr(float(v)) for v in pts.ravel())
+                + "\n\nMETADATA\nINFORMATION 0\n\nPOLYGONS 4 9\nOFFSETS vtktypeint64\n0 3 6 9\nCONNECTIVITY vtktypeint64\n"
+                + " ".join(str(int(v)) for v in faces.ravel()) + "\n").encode(),
+        "b42": (head % ("4.2", "BINARY")).encode() + b"POINTS 7 float\n" + pts.astype(">f4").tobytes() + b"\nPOLYGONS 3 12\n"
+        + np.hstack([np.full((3, 1), 3), faces]).astype(">i4").tobytes()
+        + b"\nPOINT_DATA 7\nSCALARS thickness double\nLOOKUP_TABLE default\n" + sc.astype(">f8").tobytes() + b"\n",
+        "b51": (head % ("5.1", "BINARY")).encode() + b"POINTS 7 double\n" + pts.astype(">f8").tobytes()
+        + b"\nPOLYGONS 4 9\nOFFSETS vtktypeint64\n" + np.array([0, 3, 6, 9]).astype(">i8").tobytes()
+        + b"\nCONNECTIVITY vtktypeint64\n" + faces.astype(">i8").ravel().tobytes() + b"\n",
+    }
+    for name, blob in files.items():
+        path = tmp_path / (name + ".vtk")
+        path.write_bytes(blob)
+        m = read_vtk_mesh(str(path))
+        want = pts.astype(np.float32).astype(np.float64) if name == "b42" else pts
+        np.testing.assert_allclose(m.points, want, rtol=1e-15 if name != "a42" else 1e-12, err_msg=name)
+        assert np.array_equal(m.faces, faces), name
+        if name in ("a42", "b42"):
+            assert m.point_data[0][0] == "thickness" and np.allclose(m.point_data[0][1], sc)
+    bad = tmp_path / "bad.vtk"
+    bad.write_bytes(b"# vtk DataFile Version 4.2\nx\nASCII\nDATASET UNSTRUCTURED_GRID\n")
+    with pytest.raises(NotImplementedError):
+        read_vtk_mesh(str(bad))
