@@ -10,6 +10,6 @@ from . import vtk_functions
 from .eigsort import eigsort
 from .focusr import *  # noqa: F401,F403
 from .graph import *  # noqa: F401,F403
-from .vtk_functions import PolyMesh, read_vtk_mesh
+from .vtk_functions import PolyMesh, read_vtk_mesh, write_vtk_mesh
 
 __version__ = "0.1.0"

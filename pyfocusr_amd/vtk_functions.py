@@ -236,6 +236,26 @@ def read_vtk_mesh(path_to_file):
     return PolyMesh(points, faces, point_data)
 
 
+def write_vtk_mesh(mesh, path_to_file, title="pyfocusr_amd"):
+    """Write a mesh (a `PolyMesh`, or anything `mesh_arrays` accepts) as an ASCII legacy-VTK 4.2 POLYDATA file with its
+    scalar point-data arrays — e.g. the transformed source meshes of `Focusr` with the correspondence indices set by
+    `set_all_mesh_scalars_to_corresp_target_idx`.  Coordinates are written with 17 significant digits (round trip exact)."""
+    pts, faces = mesh_arrays(mesh)
+    with open(path_to_file, "w") as fh:
+        fh.write("# vtk DataFile Version 4.2\n%s\nASCII\nDATASET POLYDATA\nPOINTS %d double\n" % (title, len(pts)))
+        for p in pts:
+            fh.write("%.17g %.17g %.17g\n" % (p[0], p[1], p[2]))
+        fh.write("POLYGONS %d %d\n" % (len(faces), len(faces) * (faces.shape[1] + 1)))
+        for f in faces:
+            fh.write("%d %s\n" % (len(f), " ".join(str(int(v)) for v in f)))
+        arrays = [(n, np.asarray(v)) for n, v in getattr(mesh, "point_data", []) if np.asarray(v).ndim == 1 and len(v) == len(pts)]
+        if arrays:
+            fh.write("POINT_DATA %d\n" % len(pts))
+            for name, vals in arrays:
+                fh.write("SCALARS %s double\nLOOKUP_TABLE default\n" % str(name).replace(" ", "_"))
+                fh.write("\n".join("%.17g" % float(v) for v in vals) + "\n")
+
+
 def mesh_arrays(mesh):
     """(points (n,3) f64, faces (F,v) i32) of any mesh object the reference
     accepts.  Fast paths: `PolyMesh`, objects with `.points/.faces`; fallback: the

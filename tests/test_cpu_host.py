@@ -467,6 +467,15 @@ def test_vtk_reader_ascii_binary_and_version_5(tmp_path):
         assert np.array_equal(m.faces, faces), name
         if name in ("a42", "b42"):
             assert m.point_data[0][0] == "thickness" and np.allclose(m.point_data[0][1], sc)
+    # writer round trip (coordinates exact, scalars kept)
+    from pyfocusr_amd.vtk_functions import PolyMesh, set_mesh_scalars, write_vtk_mesh
+
+    mesh = PolyMesh(pts, faces)
+    set_mesh_scalars(mesh, np.arange(7))
+    write_vtk_mesh(mesh, str(tmp_path / "out.vtk"))
+    back = read_vtk_mesh(str(tmp_path / "out.vtk"))
+    assert np.array_equal(back.points, pts) and np.array_equal(back.faces, faces)
+    assert back.point_data[0][0] == "scalars" and np.array_equal(back.point_data[0][1], np.arange(7.0))
     bad = tmp_path / "bad.vtk"
     bad.write_bytes(b"# vtk DataFile Version 4.2\nx\nASCII\nDATASET UNSTRUCTURED_GRID\n")
     with pytest.raises(NotImplementedError):
