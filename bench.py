@@ -245,6 +245,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.k < 2:
+        raise SystemExit("bench.py: --k must be >= 2 (with a single eigenmap the reference's eigenvalue-gap cost, "
+                         "eigsort.py:149-158, is the mean of an empty difference: NaN)")
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
 
