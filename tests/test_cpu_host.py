@@ -480,3 +480,29 @@ def test_vtk_reader_ascii_binary_and_version_5(tmp_path):
     bad.write_bytes(b"# vtk DataFile Version 4.2\nx\nASCII\nDATASET UNSTRUCTURED_GRID\n")
     with pytest.raises(NotImplementedError):
         read_vtk_mesh(str(bad))
+
+
+def test_header_is_plain_c_and_links_from_c(tmp_path):
+    """The drop-in boundary is a C-ABI: `include/pyfocusr_hip.h` must compile as C99 and a C program must link against
+    the in-tree library and call into it (no GPU needed for pf_version / pf_device_count)."""
+    import shutil
+    import subprocess
+
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("gcc not available")
+    from pyfocusr_amd import _hip
+
+    header = os.path.join(REPO, "include", "pyfocusr_hip.h")
+    subprocess.run([gcc, "-std=c99", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-x", "c", header], check=True)
+    if not os.path.exists(_hip.LIB_PATH):
+        pytest.skip("library not built")
+    src = tmp_path / "abi.c"
+    src.write_text('#include "pyfocusr_hip.h"\\n#include <stdio.h>\\n'
+                   'int main(void) { printf("%d %d\\\\n", pf_version(), pf_device_count() >= 0); return 0; }\\n')
+    exe = tmp_path / "abi"
+    libdir = os.path.dirname(_hip.LIB_PATH)
+    subprocess.run([gcc, "-std=c99", "-I", os.path.join(REPO, "include"), str(src), "-o", str(exe), "-L", libdir,
+                    "-l:" + os.path.basename(_hip.LIB_PATH), "-Wl,-rpath," + libdir], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()
+    assert int(out[0]) >= 1 and out[1] == "1"
