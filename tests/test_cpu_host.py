@@ -498,8 +498,8 @@ def test_header_is_plain_c_and_links_from_c(tmp_path):
     if not os.path.exists(_hip.LIB_PATH):
         pytest.skip("library not built")
     src = tmp_path / "abi.c"
-    src.write_text('#include "pyfocusr_hip.h"\\n#include <stdio.h>\\n'
-                   'int main(void) { printf("%d %d\\\\n", pf_version(), pf_device_count() >= 0); return 0; }\\n')
+    src.write_text('#include "pyfocusr_hip.h"\n#include <stdio.h>\n'
+                   'int main(void) { printf("%d %d\\n", pf_version(), pf_device_count() >= 0); return 0; }\n')
     exe = tmp_path / "abi"
     libdir = os.path.dirname(_hip.LIB_PATH)
     subprocess.run([gcc, "-std=c99", "-I", os.path.join(REPO, "include"), str(src), "-o", str(exe), "-L", libdir,
