@@ -67,6 +67,8 @@ __device__ __forceinline__ double pick(const double (&q)[D], int axis) {
 
 // per-axis [min, max] of the reference set (order-preserving integer encoding + 64-bit atomics)
 __global__ __launch_bounds__(PF_BLOCK) void k_extent(const double* __restrict__ pts, int64_t n, int d, unsigned long long* ext /* [2][16] */) {
+    __shared__ unsigned long long part[PF_BLOCK / PF_WAVE][32];
+    const int wave = threadIdx.x / PF_WAVE;
     for (int a = 0; a < d; ++a) {
         unsigned long long lo = ~0ull, hi = 0ull;
         for (int64_t i = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * PF_BLOCK) {
@@ -80,9 +82,23 @@ __global__ __launch_bounds__(PF_BLOCK) void k_extent(const double* __restrict__ 
             hi = h2 > hi ? h2 : hi;
         }
         if ((threadIdx.x & (PF_WAVE - 1)) == 0) {
-            atomicMin(&ext[a], lo);
-            atomicMax(&ext[16 + a], hi);
+            part[wave][a] = lo;
+            part[wave][16 + a] = hi;
         }
+    }
+    __syncthreads();  // block-level merge first: the 64-bit atomics of a whole grid on neighbouring addresses serialise
+    if ((int)threadIdx.x < 2 * d) {
+        const bool is_hi = (int)threadIdx.x >= d;
+        const int a = is_hi ? (int)threadIdx.x - d + 16 : (int)threadIdx.x;
+        unsigned long long v = part[0][a];
+        for (int w = 1; w < PF_BLOCK / PF_WAVE; ++w) {
+            const unsigned long long o = part[w][a];
+            v = is_hi ? (o > v ? o : v) : (o < v ? o : v);
+        }
+        if (is_hi)
+            atomicMax(&ext[a], v);
+        else
+            atomicMin(&ext[a], v);
     }
 }
 

@@ -46,10 +46,28 @@ __global__ __launch_bounds__(PF_BLOCK) void k_bbox(const double* __restrict__ pt
             lo[a] = l2 < lo[a] ? l2 : lo[a];
             hi[a] = h2 > hi[a] ? h2 : hi[a];
         }
-        if ((threadIdx.x & (PF_WAVE - 1)) == 0) {
-            atomicMin(&bbox[a], lo[a]);
-            atomicMax(&bbox[3 + a], hi[a]);
+    }
+    // block-level merge first: 64-bit atomics on six neighbouring addresses serialise, one set per block is enough
+    __shared__ unsigned long long part[PF_BLOCK / PF_WAVE][6];
+    const int wave = threadIdx.x / PF_WAVE;
+    if ((threadIdx.x & (PF_WAVE - 1)) == 0) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            part[wave][a] = lo[a];
+            part[wave][3 + a] = hi[a];
         }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        unsigned long long v = part[0][threadIdx.x];
+        for (int w = 1; w < PF_BLOCK / PF_WAVE; ++w) {
+            const unsigned long long o = part[w][threadIdx.x];
+            v = threadIdx.x < 3 ? (o < v ? o : v) : (o > v ? o : v);
+        }
+        if (threadIdx.x < 3)
+            atomicMin(&bbox[threadIdx.x], v);
+        else
+            atomicMax(&bbox[threadIdx.x], v);
     }
 }
 

@@ -103,6 +103,38 @@ def test_assembly_errors(hip, ctx):
     hip.DeviceLaplacian(dup, np.array([[0, 1, 2], [4, 5, 6]], dtype=np.int32), ctx=ctx).close()  # duplicates not joined: fine
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_component_labels_random_soups(hip, ctx, seed):
+    """Weakly connected components of random triangle soups (many small components, one-way edges, chains that
+    snake through the index range, from_matrix graphs): every vertex is labelled with the smallest vertex index of
+    its component, exactly as scipy's connected_components partitions it."""
+    rng = np.random.default_rng(100 + seed)
+    kind = seed % 3
+    n = int(rng.integers(50, 8000 if kind == 0 else 40000))  # the library tracks at most 4096 components
+    pts = rng.normal(size=(n, 3))
+    if kind == 0:  # sparse soup: thousands of little components
+        faces = rng.integers(0, n, size=(max(n // 4, 4), 3))
+    elif kind == 1:  # strip in a random vertex order: one long chain through the index range + strays
+        order = rng.permutation(n)[: n - n // 10]
+        faces = np.stack([order[:-2], order[1:-1], order[2:]], axis=1)
+    else:  # clusters joined by single triangles
+        faces = rng.integers(0, n // 8, size=(n // 2, 3)) + (rng.integers(0, 8, size=(n // 2, 1)) * (n // 8))
+        faces = np.concatenate([faces, rng.integers(0, n, size=(3, 3))])
+    faces = faces[(faces[:, 0] != faces[:, 1]) & (faces[:, 1] != faces[:, 2]) & (faces[:, 0] != faces[:, 2])].astype(np.int32)
+    dev = hip.DeviceLaplacian(pts, faces, ctx=ctx)
+    h = dev.download(labels=True)
+    W = sparse.csr_matrix((h["w"], h["colidx"], h["rowptr"]), shape=(n, n))
+    ncomp, lab = sparse.csgraph.connected_components(W, directed=True, connection="weak")
+    smallest = np.full(ncomp, n, dtype=np.int64)
+    np.minimum.at(smallest, lab, np.arange(n))
+    assert np.array_equal(h["labels"], smallest[lab])
+    sizes = np.bincount(lab)
+    has_row = np.diff(h["rowptr"]) > 0
+    assert dev.n_components == int(np.sum(has_row[smallest]))  # components whose representative has a row of L
+    assert dev.n_isolated == int(np.sum(~has_row))
+    dev.close()
+
+
 def test_assembly_quads_and_duplicates(hip, ctx):
     """Polygons with 4 vertices (VTK edge order) and a face listed twice (set semantics)."""
     rng = np.random.default_rng(1)
