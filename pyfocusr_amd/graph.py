@@ -243,9 +243,8 @@ class Graph(object):
         return self.eig_vecs[self.rand_idxs, :]
 
     def get_rand_normalized_points(self):
-        return (
-            self.points[self.rand_idxs, :] - np.min(self.points[self.rand_idxs, :], axis=0)
-        ) / np.ptp(self.points[self.rand_idxs, :], axis=0)
+        sample = self.points[self.rand_idxs, :]  # gathered once (the reference gathers the same rows three times)
+        return (sample - np.min(sample, axis=0)) / np.ptp(sample, axis=0)
 
     def get_list_rand_idxs(self, n_rand_samples, replace=False, force_randomization=False):
         if n_rand_samples > self.n_points:
