@@ -342,6 +342,13 @@ def _solve_gen(ops, n_wanted, symmetric, null_slots=0, cut=None, tol=1e-12, m_ma
                     yield (A0 + j + 1, A0 + j + 2, p, c, e, rho)
                     stats.matvecs += p
                 h, beta = ops.orth_end()
+                if not (np.isfinite(beta) and np.all(np.isfinite(h))):
+                    # eigenvalues outside the damped set grow like ratio^p: at high degree (small cut: k = 1 on a
+                    # large open mesh) even a modest outlier overflows before any Ritz value could expose it
+                    if not symmetric:
+                        raise _NeedEllipse()
+                    raise RuntimeError("filtered Krylov-Schur: the Chebyshev filter overflowed (degree %d): the operator "
+                                       "has eigenvalues above the assumed bound %g" % (p, hi))
                 H[:j + 1, j] = h
                 H[j, :j] = b[:j]
                 j += 1

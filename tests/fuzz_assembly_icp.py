@@ -8,6 +8,7 @@ import time
 import traceback
 
 import numpy as np
+from scipy.sparse.csgraph import connected_components
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import icp_port  # noqa: E402
@@ -31,12 +32,17 @@ for it in range(N):
         faces = faces[keep] if keep.any() else faces[:0]
         if len(faces):
             dev = _hip.DeviceLaplacian(pts, faces, ctx=ctx)
-            d = dev.download()
+            d = dev.download(labels=True)
             W, deg, d_inv, L = orc.graph_matrices(pts, faces)
             Wc = W.tocsr()
             Wc.sort_indices()
             assert np.array_equal(d["rowptr"], Wc.indptr) and np.array_equal(d["colidx"], Wc.indices), "pattern"
             assert np.array_equal(d["w"], Wc.data) and np.array_equal(d["deg"], deg), "values"
+            ncomp, lab = connected_components(Wc, directed=True, connection="weak")
+            smallest = np.full(ncomp, n, dtype=np.int64)
+            np.minimum.at(smallest, lab, np.arange(n))
+            if dev.n_components <= 4096:
+                assert np.array_equal(d["labels"], smallest[lab]), "component labels"
             dev.close()
         a, b = blob_mesh(int(rng.integers(200, 1500)), seed=int(rng.integers(0, 10**6))), blob_mesh(
             int(rng.integers(200, 1500)), seed=int(rng.integers(0, 10**6)))

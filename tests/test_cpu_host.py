@@ -181,6 +181,40 @@ def test_krylov_components_isolated_and_bad_cut():
     np.testing.assert_allclose(lam3, orc.graph_spectrum(a.points, a.faces, 4)["eig_vals"], rtol=1e-8)
 
 
+def test_filter_overflow_is_reported_not_propagated(monkeypatch):
+    """At very high degree (k = 1 on a large open mesh: a tiny cut inside a flat ellipse) an eigenvalue outside the
+    damped set overflows the filtered vector before a Ritz value can expose it (fuzz case: 150k vertices, hole with
+    2235 stranded vertices -> LinAlgError from numpy's eig on a NaN Hessenberg matrix).  Non-finite orthogonalisation
+    coefficients must send a non-symmetric solve to a taller ellipse and fail a symmetric one with the reason."""
+    from pyfocusr_amd import _krylov
+    from pyfocusr_amd.meshgen import blob_mesh
+
+    m = blob_mesh(1500, seed=2)
+    faces = m.faces[np.linalg.norm(m.points[m.faces].mean(1) - m.points[0], axis=1) > 8.0]  # open: asymmetric W
+    heights, poisoned = [], [0]
+    orig_solve, orig_end = _krylov._solve_gen, NumpyOps.orth_end
+
+    def spy(*a, **kw):
+        heights.append(kw.get("half_height"))
+        return (yield from orig_solve(*a, **kw))
+
+    def poisoned_end(self):
+        h, beta = orig_end(self)
+        if poisoned[0] == 0:  # the very first step of the first attempt overflows
+            poisoned[0] = 1
+            return h, np.inf
+        return h, beta
+
+    monkeypatch.setattr(_krylov, "_solve_gen", spy)
+    monkeypatch.setattr(NumpyOps, "orth_end", poisoned_end)
+    lam, X, st, ops = solve(m.points, faces, 2, ellipse=True)
+    assert not ops.symmetric and heights[:2] == [0.25, 0.4]
+    np.testing.assert_allclose(lam, np.sort(orc.graph_spectrum(m.points, faces, 2)["eig_vals"])[:2], rtol=1e-7)
+    poisoned[0] = 0
+    with pytest.raises(RuntimeError, match="overflowed"):
+        solve(m.points, m.faces, 2)
+
+
 TET = (np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1.3]], float), np.array([[0, 2, 1], [0, 1, 3], [1, 2, 3], [0, 3, 2]]))
 OCT = (np.array([[1, 0, 0], [-1, 0, 0], [0, 1.1, 0], [0, -1.2, 0], [0, 0, 1.3], [0, 0, -0.9]], float),
        np.array([[0, 2, 4], [2, 1, 4], [1, 3, 4], [3, 0, 4], [2, 0, 5], [1, 2, 5], [3, 1, 5], [0, 3, 5]]))
