@@ -77,6 +77,7 @@ SIGNATURES = {
     "pf_lock_null_vectors": (C.c_int, [C.c_void_p, C.c_int32, _i32p]),
     "pf_spmv": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
     "pf_two_step_enable": (C.c_int, [C.c_int]),
+    "pf_persist_enable": (C.c_int, [C.c_int]),
     "pf_cheb": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double]),
     "pf_cheb2": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double,
                            C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double]),
@@ -165,6 +166,13 @@ def two_step_enable(on=True):
     """Process-wide switch of the experimental two-steps-per-launch Chebyshev kernel (off by default: measured slower
     than two one-step launches, see csrc/pf_twostep.hip)."""
     _check(load_library().pf_two_step_enable(int(bool(on))))
+
+
+def persist_enable(on=True):
+    """Process-wide switch of the persistent Chebyshev kernel (operator resident in LDS, one kernel per filter
+    application; on by default for PAIRS of graphs (`cheb2`), see csrc/pf_persist.hip; `on=2` also routes single-graph
+    applications through it).  Results are bit-identical either way."""
+    _check(load_library().pf_persist_enable(2 if on == 2 else int(bool(on))))
 
 
 def _check(code):

@@ -132,6 +132,7 @@ void pf_destroy(pf_ctx* c) {
         hipEventDestroy(pr.first);
         hipEventDestroy(pr.second);
     }
+    if (c->persist_abort) hipHostFree(c->persist_abort);
     hipEventDestroy(c->ev0);
     hipEventDestroy(c->ev1);
     hipStreamDestroy(c->stream);
@@ -143,7 +144,7 @@ void* pf_stream(pf_ctx* c) { return c ? (void*)c->stream : nullptr; }
 int pf_sync(pf_ctx* c) {
     PF_CHECK(c != nullptr, PF_E_ARG, "pf_sync: ctx is NULL");
     PF_HIP(hipStreamSynchronize(c->stream));
-    return PF_OK;
+    return pf_persist_check(c);
 }
 
 int pf_timing_enable(pf_ctx* c, int on) {

@@ -47,6 +47,8 @@ struct pf_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timing = false;
+    uint32_t* persist_sync = nullptr;  // barrier counters of the persistent Chebyshev kernel (pf_persist.hip)
+    int32_t* persist_abort = nullptr;  // pinned host word: a barrier wait ran out
     double op_ms = 0.0;
     int64_t op_launches = 0;
     double op_bytes = 0.0;
@@ -131,6 +133,11 @@ struct pf_graph {
     int32_t* ts_gh_col = nullptr; // [windows][ts_width][PF_TS_GHOSTS]
     double* ts_gh_rw = nullptr;   // same shape: values of the RW operator
     double* ts_gh_sym = nullptr;  // same shape: values of the SYM operator (symmetric graphs)
+    // persistent Chebyshev kernel (pf_persist.hip): host copy of slice_ptr and the LDS need of the fullest block
+    std::vector<int64_t> h_slice_ptr;
+    double* persist_ring = nullptr;  // [256][n_pad] result buffers, each written once per launch
+    int32_t persist_grid = 0;
+    int64_t persist_lds = 0;
     int32_t is_symmetric = 0, n_isolated = 0, n_components = 0, max_degree = 0, n_oneway = 0;
     int32_t unit_g = 0;  // graph handed in as a matrix (pf_graph_from_matrix): G = I, the operator is the matrix itself
     std::vector<int32_t> roots; // roots of components with >= 2 vertices, ascending
@@ -193,6 +200,18 @@ struct pf_ts_args {
     double* z2;           // y_{k+2}
     double alpha, shift, beta;
 };
+// pf_persist.hip: a whole recurrence T_degree((c - A)/e)/rho^degree src -> dst in one cooperative kernel
+struct pf_persist_args {
+    pf_graph* g;
+    const double* vals;
+    const double* src;
+    double* dst;
+    int32_t degree;
+    double c, e, rho;
+};
+int pf_persist_cheb(const pf_persist_args* a, const pf_persist_args* b /* nullable */, int* done);
+int pf_persist_check(pf_ctx* ctx);  // PF_E_HIP if a barrier of an earlier launch timed out
+int pf_persist_set(int on);
 int pf_twostep_prepare(pf_graph* g);  // builds the window structures once; g->two_step tells whether they exist
 int pf_twostep_launch(const pf_ts_args* a, const pf_ts_args* b /* nullable */);
 void pf_twostep_free(pf_graph* g);

@@ -735,7 +735,7 @@ int pf_ws_download(pf_graph* g, int32_t first, int32_t count, double* out) {
     PF_HIP(hipGetLastError());
     PF_HIP(hipMemcpyAsync(out, g->stage, sizeof(double) * (size_t)count * g->n, hipMemcpyDeviceToHost, st));
     PF_HIP(hipStreamSynchronize(st));
-    return PF_OK;
+    return pf_persist_check(g->ctx);
 }
 
 int pf_ws_copy(pf_graph* g, int32_t src, int32_t dst, int32_t count) {
@@ -810,8 +810,17 @@ int pf_cheb(pf_graph* g, int32_t op, int32_t src, int32_t dst, int32_t degree, d
     const double* vals = op_values(g, op);
     PF_CHECK(vals != nullptr && src != dst, PF_E_ARG, "pf_cheb: operator %d unavailable or src == dst", op);
     PF_CHECK(degree >= 1 && e > 0.0 && rho >= 1.0, PF_E_ARG, "pf_cheb: degree %d / half-width %g / rho %g invalid", degree, e, rho);
-    ChebRun r{g, vals, two_step_values(g, vals, degree), pf_slot(g, src), pf_slot(g, dst), degree, c, e, rho};
     OpTimer t(g->ctx, degree, (double)degree * op_bytes(g));
+    {  // the whole recurrence in one kernel with the operator in LDS, when it fits (pf_persist.hip)
+        const pf_persist_args pa{g, vals, pf_slot(g, src), pf_slot(g, dst), degree, c, e, rho};
+        int done = 0;
+        PF_TRY(pf_persist_cheb(&pa, nullptr, &done));
+        if (done) {
+            t.launches = 1;
+            return t.finish();
+        }
+    }
+    ChebRun r{g, vals, two_step_values(g, vals, degree), pf_slot(g, src), pf_slot(g, dst), degree, c, e, rho};
     int64_t launches = 1;
     {
         const OpArgs a = r.first();
@@ -843,9 +852,19 @@ int pf_cheb2(pf_graph* ga, int32_t op_a, int32_t src_a, int32_t dst_a, int32_t d
     PF_CHECK(va && vb && src_a != dst_a && src_b != dst_b, PF_E_ARG, "pf_cheb2: operator unavailable or src == dst");
     PF_CHECK(degree_a >= 1 && degree_b >= 1 && e_a > 0.0 && e_b > 0.0 && rho_a >= 1.0 && rho_b >= 1.0, PF_E_ARG,
              "pf_cheb2: bad degree / half-width / rho");
+    OpTimer t(ga->ctx, std::max(degree_a, degree_b), (double)degree_a * op_bytes(ga) + (double)degree_b * op_bytes(gb));
+    {
+        const pf_persist_args pa{ga, va, pf_slot(ga, src_a), pf_slot(ga, dst_a), degree_a, c_a, e_a, rho_a};
+        const pf_persist_args pb{gb, vb, pf_slot(gb, src_b), pf_slot(gb, dst_b), degree_b, c_b, e_b, rho_b};
+        int done = 0;
+        PF_TRY(pf_persist_cheb(&pa, &pb, &done));
+        if (done) {
+            t.launches = 1;
+            return t.finish();
+        }
+    }
     ChebRun ra{ga, va, two_step_values(ga, va, degree_a), pf_slot(ga, src_a), pf_slot(ga, dst_a), degree_a, c_a, e_a, rho_a};
     ChebRun rb{gb, vb, two_step_values(gb, vb, degree_b), pf_slot(gb, src_b), pf_slot(gb, dst_b), degree_b, c_b, e_b, rho_b};
-    OpTimer t(ga->ctx, std::max(degree_a, degree_b), (double)degree_a * op_bytes(ga) + (double)degree_b * op_bytes(gb));
     int64_t launches = 1;
     {
         const OpArgs a = ra.first(), b = rb.first();
@@ -935,6 +954,7 @@ int pf_orth_end(pf_graph* g, double* h, double* nrm) {
     PF_HIP(hipSetDevice(g->ctx->device));
     PF_HIP(hipEventSynchronize(g->orth_ev));
     g->orth_pending = -1;
+    PF_TRY(pf_persist_check(g->ctx));
     for (int32_t b = 0; b < count; ++b) h[b] = g->orth_host[b];
     const double v = g->orth_host[count];
     *nrm = sqrt(v > 0.0 ? v : 0.0);

@@ -1,0 +1,365 @@
+// A whole Chebyshev recurrence in ONE kernel: the operator stays in LDS, only the vectors travel.
+//
+// One step per launch (pf_operator.hip) streams the SELL-64 matrix of the graph(s) through the chip on every step:
+// 26 MB per 250k-vertex mesh, ~5 us, and the L2s do not keep it from one launch to the next (PMC: the fetched bytes
+// per launch equal the algorithmic bytes).  But 1/256 of that matrix is ~74 KB - less than the 160 KB of LDS a CU
+// has.  So: 256 blocks (one per CU, 1024 threads), each copies its contiguous run of SELL slices of both graphs into
+// LDS once, then the steps of  y_{k+1} = (2/(e rho)) (c y_k - A y_k) - y_{k-1}/rho^2  run inside the kernel with a
+// grid-wide barrier between steps.  Per step only x (gathered through L2), y_{k-1}, the diagonal and the output cross
+// the fabric: 8 MB instead of 26 MB per graph.  The arithmetic per row is the one of sell_op_block, operation for
+// operation: results are bit-identical to the one-step-per-launch path (tests/test_gpu_parity.py).
+//
+// Coherence.  The 8 XCDs have private L2s and every CU a private L1; neither snoops the others.  Measured on MI355X
+// (250k rows, per step): compute 2.3 us; a barrier of atomics 1.5 us; but an agent-scope release (L2 write-back) and
+// acquire (L2 + L1 invalidate) by every block 5.8 + 3.7 us, and `buffer_inv sc0` does not drop the L1.  Two measures
+// remove all invalidation and all but one write-back per XCD:
+//   * every step writes its result to a buffer NOBODY HAS READ OR WRITTEN in this kernel (a ring of PS_RING vectors per
+//     graph, at most PS_RING - 2 steps per launch): no cache can hold a stale copy of a line that was never touched,
+//     so readers need no invalidate; kernel boundaries (which do invalidate) recycle the ring;
+//   * writers: every wave waits for its stores to be acknowledged by the L2 before the block arrives at the XCD's
+//     counter; the LAST block of an XCD to arrive therefore knows all of that XCD's results are in its L2, writes the
+//     L2 back once (agent-scope release) and only then joins the device-wide count that everybody polls.
+// Every wait is bounded: a block that waits longer than a few seconds raises the abort flag, every other block sees
+// it in its own wait loop, and the kernel drains; the host reports PF_E_HIP at its next synchronisation.  The kernel
+// is launched cooperatively (all blocks resident, or the launch fails and the classic path is used).
+#include <stdlib.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "pf_internal.h"
+
+namespace {
+
+constexpr int PS_THREADS = 1024;
+constexpr int PS_SYNC_STRIDE = 32;       // uint32 words between counters (128 B: one cache line each)
+constexpr int PS_SYNC_WORDS = 10 * PS_SYNC_STRIDE;  // 8 XCD counters, device counter, abort flag
+constexpr int PS_RING = 256;             // result buffers per graph; a launch runs at most PS_RING - 2 steps
+constexpr unsigned PS_SPIN_LIMIT = 4000000u;
+constexpr size_t PS_LDS_LIMIT = 160 * 1024 - 256;  // static __shared__ of the kernel lives in the remainder
+
+struct PsGraph {
+    const int64_t* slice_ptr;
+    const int32_t* scol;
+    const double* sval;
+    const double* diag;
+    const double* y_prev;  // y_{k_begin-2} (unused when k_begin == 1)
+    const double* y_cur;   // y_{k_begin-1}
+    double* dst;           // y_degree
+    double* ring;          // [PS_RING][n_pad]: y_k lives in ring[(k-1) % PS_RING] for k < degree
+    int64_t n_pad;
+    int64_t n_slices;
+    int32_t k_begin, k_end;  // steps of this launch (1-based, inclusive); k_end < k_begin: nothing left for this graph
+    int32_t degree;
+    double a1, a2, shift, beta;  // step 1: a1 (c x - A x); later: a2 (c x - A x) - beta prev
+};
+
+struct PsArgs {
+    PsGraph g[2];
+    uint32_t* sync;
+    int32_t* host_abort;  // pinned: set to 1 when a barrier wait ran out
+};
+
+// Bounded wait for *word >= target; false (and the abort flag raised) if it ran out or another block gave up.
+__device__ __forceinline__ bool wait_for(uint32_t* word, unsigned target, uint32_t* abort_flag) {
+    unsigned spins = 0;
+    while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        if (++spins > PS_SPIN_LIMIT || __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+            __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(2);
+    }
+    return true;
+}
+
+// Grid barrier; the last block of each XCD writes that XCD's L2 back before it joins the device-wide count.
+__device__ __forceinline__ bool grid_barrier(uint32_t* sync, unsigned xcd, unsigned per_xcd, unsigned epoch, int* s_state) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's results have been acknowledged by the L2
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t* xc = sync + xcd * PS_SYNC_STRIDE;
+        uint32_t* dc = sync + 8 * PS_SYNC_STRIDE;
+        uint32_t* ab = sync + 9 * PS_SYNC_STRIDE;
+        if (atomicAdd(xc, 1u) + 1u == per_xcd * epoch) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // buffer_wbl2: the XCD's results reach memory
+            atomicAdd(dc, 1u);
+        }
+        *s_state = wait_for(dc, 8u * epoch, ab) ? 0 : 1;
+    }
+    __syncthreads();
+    return *s_state == 0;
+}
+
+template <int NG>
+__global__ __launch_bounds__(PS_THREADS) void k_sell_persist(PsArgs a) {
+    // The floating-point operations are spelled out (and contraction is off) so that they are the ones the compiler
+    // forms for sell_op_block: acc = d x; acc = fma(v, x, acc)...; t = fma(c, x, -acc); r = fma(alpha, t, -(beta prev)).
+#pragma clang fp contract(off)
+    extern __shared__ __align__(16) unsigned char lds[];
+    __shared__ int s_state;
+    const unsigned G = gridDim.x, per_xcd = G >> 3;
+    const unsigned xcd = blockIdx.x & 7u;
+    const unsigned blk = xcd * per_xcd + (blockIdx.x >> 3);  // every XCD owns one contiguous run of (Morton-ordered) rows
+    const int tid = threadIdx.x;
+    const int lane = tid & (PF_WAVE - 1);
+
+    // ---- stage this block's slices: values, then columns, then slice offsets
+    int64_t s_lo[2] = {0, 0};
+    int32_t n_sl[2] = {0, 0};
+    double* lval[2] = {nullptr, nullptr};
+    int32_t* lcol[2] = {nullptr, nullptr};
+    int32_t* lbase[2] = {nullptr, nullptr};
+    size_t off = 0;
+#pragma unroll
+    for (int q = 0; q < NG; ++q) {
+        const PsGraph& g = a.g[q];
+        s_lo[q] = (int64_t)blk * g.n_slices / G;
+        n_sl[q] = (int32_t)((int64_t)(blk + 1) * g.n_slices / G - s_lo[q]);
+        const int64_t e_lo = g.slice_ptr[s_lo[q]];
+        const int64_t cnt = g.slice_ptr[s_lo[q] + n_sl[q]] - e_lo;
+        lval[q] = reinterpret_cast<double*>(lds + off);
+        off += (size_t)cnt * sizeof(double);
+        for (int64_t i = tid; i < cnt; i += PS_THREADS) lval[q][i] = g.sval[e_lo + i];
+    }
+#pragma unroll
+    for (int q = 0; q < NG; ++q) {
+        const PsGraph& g = a.g[q];
+        const int64_t e_lo = g.slice_ptr[s_lo[q]];
+        const int64_t cnt = g.slice_ptr[s_lo[q] + n_sl[q]] - e_lo;
+        lcol[q] = reinterpret_cast<int32_t*>(lds + off);
+        off += (size_t)cnt * sizeof(int32_t);
+        for (int64_t i = tid; i < cnt; i += PS_THREADS) lcol[q][i] = g.scol[e_lo + i];
+    }
+#pragma unroll
+    for (int q = 0; q < NG; ++q) {
+        const PsGraph& g = a.g[q];
+        const int64_t e_lo = g.slice_ptr[s_lo[q]];
+        lbase[q] = reinterpret_cast<int32_t*>(lds + off);
+        off += (size_t)(n_sl[q] + 1) * sizeof(int32_t);
+        for (int i = tid; i <= n_sl[q]; i += PS_THREADS) lbase[q][i] = (int32_t)(g.slice_ptr[s_lo[q] + i] - e_lo);
+    }
+    __syncthreads();
+
+    int32_t n_steps = a.g[0].k_end - a.g[0].k_begin + 1;
+    if (NG > 1 && a.g[1].k_end - a.g[1].k_begin + 1 > n_steps) n_steps = a.g[1].k_end - a.g[1].k_begin + 1;
+
+    for (int32_t t = 0; t < n_steps; ++t) {
+#pragma unroll
+        for (int q = 0; q < NG; ++q) {
+            const PsGraph& g = a.g[q];
+            const int32_t k = g.k_begin + t;
+            if (k > g.k_end) continue;
+            const double* x = t == 0 ? g.y_cur : g.ring + (int64_t)((k - 2) % PS_RING) * g.n_pad;
+            const double* prev = k == 1 ? nullptr : (t == 0 ? g.y_prev : (t == 1 ? g.y_cur : g.ring + (int64_t)((k - 3) % PS_RING) * g.n_pad));
+            double* out = k == g.degree ? g.dst : g.ring + (int64_t)((k - 1) % PS_RING) * g.n_pad;
+            const double alpha = k == 1 ? g.a1 : g.a2;
+            const int32_t rows = n_sl[q] * PF_WAVE;
+            for (int32_t r = tid; r < rows; r += PS_THREADS) {
+                const int32_t sl = r >> 6;
+                const int64_t row = (s_lo[q] << 6) + r;
+                const int32_t base = lbase[q][sl];
+                const int width = (lbase[q][sl + 1] - base) >> 6;
+                const double xi = x[row];
+                double acc = g.diag[row] * xi;
+                const int pairs = width >> 1;
+                const double2* vp2 = reinterpret_cast<const double2*>(lval[q] + base) + lane;
+                const int2* cp2 = reinterpret_cast<const int2*>(lcol[q] + base) + lane;
+                for (int j = 0; j < pairs; ++j) {
+                    const int2 c0 = cp2[j * PF_WAVE];
+                    const double2 v0 = vp2[j * PF_WAVE];
+                    const double x0 = x[c0.x], x1 = x[c0.y];
+                    acc = __builtin_fma(v0.x, x0, acc);
+                    acc = __builtin_fma(v0.y, x1, acc);
+                }
+                if (width & 1) {
+                    const int32_t e = base + pairs * (2 * PF_WAVE) + lane;
+                    acc = __builtin_fma(lval[q][e], x[lcol[q][e]], acc);
+                }
+                const double u = __builtin_fma(g.shift, xi, -acc);
+                double res;
+                if (prev) {
+                    const double w = g.beta * prev[row];
+                    res = __builtin_fma(alpha, u, -w);
+                } else {
+                    res = alpha * u;
+                }
+                out[row] = res;
+            }
+        }
+        if (t + 1 < n_steps && !grid_barrier(a.sync, xcd, per_xcd, (unsigned)(t + 1), &s_state)) {
+            if (tid == 0) *a.host_abort = 1;
+            return;
+        }
+    }
+}
+
+// -1 undecided (environment PF_PERSIST=0 disables), 0 off, 1 on
+int g_persist = -1;
+
+bool persist_enabled() {
+    if (g_persist < 0) {
+        const char* v = getenv("PF_PERSIST");
+        g_persist = (v && v[0] == '0') ? 0 : 1;
+    }
+    return g_persist >= 1;
+}
+
+struct DeviceFacts {
+    int grid = 0;  // 0: persistent path unavailable on this device
+    bool ready = false;
+};
+DeviceFacts g_facts[64];
+
+int device_grid(int device) {
+    if (device < 0 || device >= 64) return 0;
+    DeviceFacts& f = g_facts[device];
+    if (!f.ready) {
+        f.ready = true;
+        hipDeviceProp_t prop;
+        int coop = 0;
+        if (hipGetDeviceProperties(&prop, device) != hipSuccess) return 0;
+        if (hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, device) != hipSuccess || !coop) return 0;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_sell_persist<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)PS_LDS_LIMIT) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(k_sell_persist<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)PS_LDS_LIMIT) != hipSuccess) {
+            (void)hipGetLastError();
+            return 0;
+        }
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_sell_persist<2>, PS_THREADS, PS_LDS_LIMIT) != hipSuccess || per_cu < 1) {
+            (void)hipGetLastError();
+            return 0;
+        }
+        f.grid = std::min(prop.multiProcessorCount, 256) & ~7;  // one block per CU, a multiple of the 8 XCDs
+    }
+    return f.grid;
+}
+
+// LDS bytes the fullest block needs for g when the slices are split over `grid` blocks
+int64_t lds_need(pf_graph* g, int grid) {
+    if (g->h_slice_ptr.empty()) {
+        g->h_slice_ptr.resize((size_t)g->n_slices + 1);
+        if (hipMemcpyAsync(g->h_slice_ptr.data(), g->slice_ptr, sizeof(int64_t) * (g->n_slices + 1), hipMemcpyDeviceToHost,
+                           g->ctx->stream) != hipSuccess ||
+            hipStreamSynchronize(g->ctx->stream) != hipSuccess) {
+            (void)hipGetLastError();
+            g->h_slice_ptr.clear();
+            return -1;
+        }
+        g->persist_grid = 0;
+    }
+    if (g->persist_grid != grid) {
+        int64_t worst = 0;
+        for (int b = 0; b < grid; ++b) {
+            const int64_t lo = (int64_t)b * g->n_slices / grid, hi = (int64_t)(b + 1) * g->n_slices / grid;
+            const int64_t cnt = g->h_slice_ptr[(size_t)hi] - g->h_slice_ptr[(size_t)lo];
+            worst = std::max(worst, cnt * 12 + (hi - lo + 1) * 4);
+        }
+        g->persist_lds = worst;
+        g->persist_grid = grid;
+    }
+    return g->persist_lds;
+}
+
+}  // namespace
+
+int pf_persist_set(int on) {
+    g_persist = on == 2 ? 2 : (on ? 1 : 0);
+    return PF_OK;
+}
+
+extern "C" int pf_persist_enable(int on) { return pf_persist_set(on); }
+
+// Runs the recurrence(s) in one kernel if the device, the sizes and the switch allow it.  *done = 1 when it was
+// launched; 0 means "use the one-step-per-launch path" (never an error by itself).
+int pf_persist_cheb(const pf_persist_args* a, const pf_persist_args* b, int* done) {
+    *done = 0;
+    if (!persist_enabled()) return PF_OK;
+    pf_graph* ga = a->g;
+    pf_ctx* ctx = ga->ctx;
+    const int32_t longest = std::max(a->degree, b ? b->degree : 0);
+    if (longest < 8) return PF_OK;  // staging the matrix must pay for itself
+    // One graph alone gains nothing (250k rows: 5.0 us per step here, 4.7 us per launch there: the barrier costs what
+    // the matrix traffic saves); two graphs share every barrier (7.0 vs 10.1 us).  pf_persist_enable(2) forces it.
+    if (!b && g_persist != 2) return PF_OK;
+    const int grid = device_grid(ctx->device);
+    if (grid < 8) return PF_OK;
+    if (ga->n_slices < grid || (b && b->g->n_slices < grid)) return PF_OK;
+    int64_t need = lds_need(ga, grid);
+    if (need < 0) return PF_OK;
+    if (b) {
+        const int64_t nb = lds_need(b->g, grid);
+        if (nb < 0) return PF_OK;
+        need += nb;
+    }
+    if ((size_t)need + 64 > PS_LDS_LIMIT) return PF_OK;
+    hipStream_t st = ctx->stream;
+    if (!ctx->persist_sync) {
+        PF_HIP(pf_malloc(st, (void**)&ctx->persist_sync, sizeof(uint32_t) * PS_SYNC_WORDS));
+        PF_HIP(hipHostMalloc((void**)&ctx->persist_abort, sizeof(int32_t), hipHostMallocDefault));
+        *ctx->persist_abort = 0;
+    }
+    const pf_persist_args* in[2] = {a, b};
+    const int ng = b ? 2 : 1;
+    for (int q = 0; q < ng; ++q) {
+        pf_graph* g = in[q]->g;
+        if (!g->persist_ring) PF_HIP(pf_malloc(st, (void**)&g->persist_ring, sizeof(double) * (size_t)PS_RING * (size_t)g->n_pad));
+    }
+    int32_t finished[2] = {0, 0};
+    bool launched = false;
+    while (finished[0] < a->degree || (b && finished[1] < b->degree)) {
+        PsArgs args{};
+        for (int q = 0; q < ng; ++q) {
+            pf_graph* g = in[q]->g;
+            PsGraph& p = args.g[q];
+            auto where = [&](int32_t k) -> const double* {  // y_k: the caller's src, or its ring slot
+                return k == 0 ? in[q]->src : g->persist_ring + (int64_t)((k - 1) % PS_RING) * g->n_pad;
+            };
+            p.slice_ptr = g->slice_ptr;
+            p.scol = g->scol;
+            p.sval = in[q]->vals;
+            p.diag = g->diag;
+            p.k_begin = finished[q] + 1;
+            p.k_end = std::min(in[q]->degree, finished[q] + PS_RING - 2);
+            p.y_cur = where(p.k_begin - 1);
+            p.y_prev = p.k_begin >= 2 ? where(p.k_begin - 2) : nullptr;
+            p.dst = in[q]->dst;
+            p.ring = g->persist_ring;
+            p.n_pad = g->n_pad;
+            p.n_slices = g->n_slices;
+            p.degree = in[q]->degree;
+            p.a1 = 1.0 / (in[q]->e * in[q]->rho);
+            p.a2 = 2.0 / (in[q]->e * in[q]->rho);
+            p.shift = in[q]->c;
+            p.beta = 1.0 / (in[q]->rho * in[q]->rho);
+            finished[q] = std::max(finished[q], p.k_end);
+        }
+        args.sync = ctx->persist_sync;
+        args.host_abort = ctx->persist_abort;
+        PF_HIP(hipMemsetAsync(ctx->persist_sync, 0, sizeof(uint32_t) * PS_SYNC_WORDS, st));
+        void* kargs[] = {&args};
+        const void* fn = b ? reinterpret_cast<const void*>(k_sell_persist<2>) : reinterpret_cast<const void*>(k_sell_persist<1>);
+        const hipError_t err = hipLaunchCooperativeKernel(fn, dim3((unsigned)grid), dim3(PS_THREADS), kargs, (unsigned)(need + 64), st);
+        if (err != hipSuccess) {
+            (void)hipGetLastError();
+            g_facts[ctx->device].grid = 0;  // not resident-able (or unsupported): the classic path from now on
+            PF_CHECK(!launched, PF_E_HIP, "persistent Chebyshev kernel: launch of a later segment failed: %s", hipGetErrorString(err));
+            return PF_OK;
+        }
+        launched = true;
+    }
+    *done = 1;
+    return PF_OK;
+}
+
+int pf_persist_check(pf_ctx* ctx) {
+    if (ctx->persist_abort && *ctx->persist_abort) {
+        *ctx->persist_abort = 0;
+        g_persist = 0;  // whatever kept the blocks apart, do not try again in this process
+        PF_CHECK(false, PF_E_HIP, "persistent Chebyshev kernel: a grid barrier timed out (the results of that filter "
+                                  "application are invalid); the one-step-per-launch path is used from now on");
+    }
+    return PF_OK;
+}

@@ -815,6 +815,8 @@ def test_two_step_kernel_bit_identical(golden, hip, ctx):
             g.ws_ensure(4)
             g.upload(0, rng.standard_normal(g.n))
 
+        hip.persist_enable(False)  # compare the two multi-launch paths with each other
+
         def run(on):
             hip.two_step_enable(on)
             out = []
@@ -833,7 +835,50 @@ def test_two_step_kernel_bit_identical(golden, hip, ctx):
         for i, (x, y) in enumerate(zip(a, b)):
             assert np.all(np.isfinite(x)) and np.array_equal(x, y), i
     finally:
-        hip.two_step_enable(False)  # the default
+        hip.two_step_enable(False)  # the defaults
+        hip.persist_enable(True)
+        for g in graphs:
+            g.close()
+
+
+def test_persistent_kernel_bit_identical(golden, hip, ctx):
+    """The whole recurrence in one cooperative kernel (operator in LDS, grid barrier between steps, pf_persist.hip)
+    against one step per launch: same bits for both operators, single and paired, equal and unequal degrees, from
+    graphs with one slice per block (15k) to the bench size (250k pair: the fullest LDS)."""
+    from pyfocusr_amd.meshgen import blob_mesh
+
+    rng = np.random.default_rng(4)
+    big = [blob_mesh(250000, seed=s) for s in (0, 1)]
+    m = blob_mesh(60000, seed=8)
+    graphs = [hip.DeviceLaplacian(golden("source_mesh_15k")["points"], golden("source_mesh_15k")["faces"], ctx=ctx),  # RW
+              hip.DeviceLaplacian(golden("target_mesh_15k")["points"], golden("target_mesh_15k")["faces"], ctx=ctx),
+              hip.DeviceLaplacian(m.points, m.faces, ctx=ctx),
+              hip.DeviceLaplacian(big[0].points, big[0].faces, ctx=ctx),
+              hip.DeviceLaplacian(big[1].points, big[1].faces, ctx=ctx)]
+    try:
+        for g in graphs:
+            g.ws_ensure(4)
+            g.upload(0, rng.standard_normal(g.n))
+
+        def run(on):
+            hip.persist_enable(2 if on else 0)  # 2: single-graph applications too
+            out = []
+            for g in graphs:
+                for p, rho in ((8, 1.0), (9, 1.0), (10, 1.0), (41, 1.0), (145, 1.02), (255, 1.02), (600, 1.03)):  # > 254 steps: several launches
+                    g.cheb(0, 1, p, 1.03, 0.98, rho)
+                    out.append(g.download_slots(1, 1).copy())
+            for ia, ib, pa, pb in ((2, 1, 12, 12), (2, 0, 9, 30), (3, 4, 145, 145), (3, 4, 150, 139), (4, 2, 20, 64), (3, 4, 300, 520)):
+                graphs[ia].cheb2((0, 2, pa, 1.0, 1.0, 1.0), graphs[ib], (0, 2, pb, 1.01, 0.99, 1.0))
+                out.append(graphs[ia].download_slots(2, 1).copy())
+                out.append(graphs[ib].download_slots(2, 1).copy())
+            return out
+
+        a, b = run(False), run(True)
+        assert len(a) == len(b)
+        for i, (x, y) in enumerate(zip(a, b)):
+            assert np.all(np.isfinite(x)) and np.array_equal(x, y), i
+    finally:
+        hip.persist_enable(True)  # the default
         for g in graphs:
             g.close()
 
