@@ -127,11 +127,12 @@ int pf_spmv(pf_graph* g, int32_t op, int32_t src, int32_t dst);           /* dst
  * one-step launches on MI355X, see that file.  1 switches it on (also: environment PF_TWO_STEP=1); process-wide. */
 int pf_two_step_enable(int on);
 /* ON by default for pf_cheb2: when the SELL slices of both graphs fit the LDS of the device split over one block per
- * CU (a 250k-vertex pair on MI355X), the WHOLE recurrence runs in one cooperative kernel with the operators resident
+ * CU (a 250k-vertex pair on MI355X), the WHOLE recurrence runs in one persistent kernel (one block per CU) with the operators resident
  * in LDS and a grid barrier between steps (pf_persist.hip; 7.0 instead of 10.1 us per step of the pair); results are
  * bit-identical to one step per launch.  0 switches it off (also: environment PF_PERSIST=0), 2 also routes pf_cheb
  * (one graph: no gain measured) through it; process-wide.  Needs 256 x n_pad doubles of scratch per graph.  A barrier
- * that times out is reported as PF_E_HIP at the next synchronising call and switches the path off. */
+ * that times out is reported as PF_E_HIP at the next synchronising call and switches the path off.  One ctx per
+ * process uses the path at a time (the first to get there, until it is destroyed). */
 int pf_persist_enable(int on);
 int pf_cheb(pf_graph* g, int32_t op, int32_t src, int32_t dst, int32_t degree, double c, double e, double rho);
 /* Two independent recurrences (graphs a and b of one ctx) advanced in lockstep: step k of both in

@@ -132,6 +132,7 @@ void pf_destroy(pf_ctx* c) {
         hipEventDestroy(pr.first);
         hipEventDestroy(pr.second);
     }
+    pf_persist_release(c);
     if (c->persist_abort) hipHostFree(c->persist_abort);
     hipEventDestroy(c->ev0);
     hipEventDestroy(c->ev1);

@@ -212,6 +212,7 @@ struct pf_persist_args {
 int pf_persist_cheb(const pf_persist_args* a, const pf_persist_args* b /* nullable */, int* done);
 int pf_persist_check(pf_ctx* ctx);  // PF_E_HIP if a barrier of an earlier launch timed out
 int pf_persist_set(int on);
+void pf_persist_release(pf_ctx* ctx);  // pf_destroy: another ctx may take the persistent path over
 int pf_twostep_prepare(pf_graph* g);  // builds the window structures once; g->two_step tells whether they exist
 int pf_twostep_launch(const pf_ts_args* a, const pf_ts_args* b /* nullable */);
 void pf_twostep_free(pf_graph* g);

@@ -20,16 +20,21 @@
 //     counter; the LAST block of an XCD to arrive therefore knows all of that XCD's results are in its L2, writes the
 //     L2 back once (agent-scope release) and only then joins the device-wide count that everybody polls.
 // Every wait is bounded: a block that waits longer than a few seconds raises the abort flag, every other block sees
-// it in its own wait loop, and the kernel drains; the host reports PF_E_HIP at its next synchronisation.  The kernel
-// is launched cooperatively (all blocks resident, or the launch fails and the classic path is used).
+// it in its own wait loop, and the kernel drains; the host reports PF_E_HIP at its next synchronisation.  One block
+// per CU (grid <= CU count, checked against the occupancy query) makes all blocks resident on an idle device.
 #include <stdlib.h>
 
 #include <algorithm>
+#include <atomic>
 #include <vector>
 
 #include "pf_internal.h"
 
 namespace {
+
+// Two persistent kernels in flight on different streams could each be given part of the CUs and wait for the rest
+// forever (until the bounded waits give up): only one ctx of the process uses this path at a time.
+std::atomic<pf_ctx*> g_owner{nullptr};
 
 constexpr int PS_THREADS = 1024;
 constexpr int PS_SYNC_STRIDE = 32;       // uint32 words between counters (128 B: one cache line each)
@@ -217,9 +222,7 @@ int device_grid(int device) {
     if (!f.ready) {
         f.ready = true;
         hipDeviceProp_t prop;
-        int coop = 0;
         if (hipGetDeviceProperties(&prop, device) != hipSuccess) return 0;
-        if (hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, device) != hipSuccess || !coop) return 0;
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_sell_persist<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)PS_LDS_LIMIT) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void*>(k_sell_persist<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -295,6 +298,10 @@ int pf_persist_cheb(const pf_persist_args* a, const pf_persist_args* b, int* don
         need += nb;
     }
     if ((size_t)need + 64 > PS_LDS_LIMIT) return PF_OK;
+    {
+        pf_ctx* expected = nullptr;
+        if (!g_owner.compare_exchange_strong(expected, ctx) && expected != ctx) return PF_OK;  // another ctx owns the path
+    }
     hipStream_t st = ctx->stream;
     if (!ctx->persist_sync) {
         PF_HIP(pf_malloc(st, (void**)&ctx->persist_sync, sizeof(uint32_t) * PS_SYNC_WORDS));
@@ -339,12 +346,17 @@ int pf_persist_cheb(const pf_persist_args* a, const pf_persist_args* b, int* don
         args.sync = ctx->persist_sync;
         args.host_abort = ctx->persist_abort;
         PF_HIP(hipMemsetAsync(ctx->persist_sync, 0, sizeof(uint32_t) * PS_SYNC_WORDS, st));
-        void* kargs[] = {&args};
-        const void* fn = b ? reinterpret_cast<const void*>(k_sell_persist<2>) : reinterpret_cast<const void*>(k_sell_persist<1>);
-        const hipError_t err = hipLaunchCooperativeKernel(fn, dim3((unsigned)grid), dim3(PS_THREADS), kargs, (unsigned)(need + 64), st);
+        // A plain launch, not hipLaunchCooperativeKernel: one block per CU is resident-able by construction (grid <=
+        // CU count, the occupancy query above says one block fits a CU), a block that has to wait for a CU another
+        // stream is using starts as soon as that kernel ends, and every barrier wait is bounded anyway.  (The
+        // cooperative entry point runs on a separate queue whose teardown crashes rocprofv3 at process exit.)
+        if (b)
+            k_sell_persist<2><<<dim3((unsigned)grid), dim3(PS_THREADS), (size_t)(need + 64), st>>>(args);
+        else
+            k_sell_persist<1><<<dim3((unsigned)grid), dim3(PS_THREADS), (size_t)(need + 64), st>>>(args);
+        const hipError_t err = hipGetLastError();
         if (err != hipSuccess) {
-            (void)hipGetLastError();
-            g_facts[ctx->device].grid = 0;  // not resident-able (or unsupported): the classic path from now on
+            g_facts[ctx->device].grid = 0;  // the classic path from now on
             PF_CHECK(!launched, PF_E_HIP, "persistent Chebyshev kernel: launch of a later segment failed: %s", hipGetErrorString(err));
             return PF_OK;
         }
@@ -352,6 +364,11 @@ int pf_persist_cheb(const pf_persist_args* a, const pf_persist_args* b, int* don
     }
     *done = 1;
     return PF_OK;
+}
+
+void pf_persist_release(pf_ctx* ctx) {
+    pf_ctx* expected = ctx;
+    g_owner.compare_exchange_strong(expected, nullptr);
 }
 
 int pf_persist_check(pf_ctx* ctx) {
