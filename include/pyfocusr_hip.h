@@ -63,6 +63,11 @@ typedef struct pf_timing {
     double op_bytes;     /* algorithmic bytes they moved: sum of 12 nnz + 20 n + 4 per graph and step */
     double knn_ms;       /* device time of the last pf_knn_run                                    */
     double build_ms;     /* device time of the last pf_graph_build (kernels only)                 */
+    /* the part of the above done by the persistent kernel (pf_persist_enable): one launch = a whole recurrence */
+    double persist_ms;
+    int64_t persist_launches;
+    int64_t persist_steps; /* recurrence steps those launches ran (the longer of the two graphs per launch) */
+    double persist_bytes;  /* algorithmic bytes, counted as for op_bytes                                   */
 } pf_timing;
 
 /* ---- context -------------------------------------------------------------------------- */

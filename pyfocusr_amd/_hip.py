@@ -46,7 +46,8 @@ class EigsStats(C.Structure):
 
 class Timing(C.Structure):
     _fields_ = [("op_ms", C.c_double), ("op_launches", C.c_int64), ("op_bytes", C.c_double), ("knn_ms", C.c_double),
-                ("build_ms", C.c_double)]
+                ("build_ms", C.c_double), ("persist_ms", C.c_double), ("persist_launches", C.c_int64),
+                ("persist_steps", C.c_int64), ("persist_bytes", C.c_double)]
 
 
 # name -> (restype, argtypes): every symbol include/pyfocusr_hip.h declares.
@@ -235,7 +236,8 @@ class Context(object):
         t = Timing()
         _check(self._lib.pf_timing_get(self._h, C.byref(t), int(bool(reset))))
         return dict(op_ms=t.op_ms, op_launches=int(t.op_launches), op_bytes=t.op_bytes, knn_ms=t.knn_ms,
-                    build_ms=t.build_ms)
+                    build_ms=t.build_ms, persist_ms=t.persist_ms, persist_launches=int(t.persist_launches),
+                    persist_steps=int(t.persist_steps), persist_bytes=t.persist_bytes)
 
     # ---- nearest neighbour -------------------------------------------------------------
     def knn1(self, ref, qry, return_d2=False):

@@ -69,6 +69,12 @@ int pf_timing_collect(pf_ctx* c) {
         c->op_ms += ms;
         c->op_launches += sp.launches;
         c->op_bytes += sp.bytes;
+        if (sp.persist_steps > 0) {
+            c->persist_ms += ms;
+            c->persist_launches += sp.launches;
+            c->persist_steps += sp.persist_steps;
+            c->persist_bytes += sp.bytes;
+        }
         c->spans_free.emplace_back(sp.e0, sp.e1);
     }
     c->spans_pending.clear();
@@ -162,7 +168,13 @@ int pf_timing_get(pf_ctx* c, pf_timing* out, int reset) {
     out->op_bytes = c->op_bytes;
     out->knn_ms = c->knn_ms;
     out->build_ms = c->build_ms;
+    out->persist_ms = c->persist_ms;
+    out->persist_launches = c->persist_launches;
+    out->persist_steps = c->persist_steps;
+    out->persist_bytes = c->persist_bytes;
     if (reset) {
+        c->persist_ms = c->persist_bytes = 0.0;
+        c->persist_launches = c->persist_steps = 0;
         c->op_ms = 0.0;
         c->op_launches = 0;
         c->op_bytes = 0.0;

@@ -52,6 +52,8 @@ struct pf_ctx {
     double op_ms = 0.0;
     int64_t op_launches = 0;
     double op_bytes = 0.0;
+    double persist_ms = 0.0, persist_bytes = 0.0;
+    int64_t persist_launches = 0, persist_steps = 0;
     double knn_ms = 0.0;
     double build_ms = 0.0;
     // nearest-neighbour state (pf_knn_upload / run / download)
@@ -82,6 +84,7 @@ struct pf_ctx {
         hipEvent_t e0, e1;
         int64_t launches;
         double bytes;
+        int64_t persist_steps;  // > 0: one launch of the persistent kernel that ran this many steps
     };
     std::vector<TimedSpan> spans_pending;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> spans_free;

@@ -640,6 +640,7 @@ struct OpTimer {
     int64_t launches;
     double bytes;
     bool on;
+    int64_t persist_steps = 0;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     OpTimer(pf_ctx* ctx, int64_t n, double b) : c(ctx), launches(n), bytes(b), on(ctx->timing) {
         if (!on) return;
@@ -657,7 +658,7 @@ struct OpTimer {
     int finish() {  // never blocks: the span is resolved in pf_timing_get
         if (!on) return PF_OK;
         PF_HIP(hipEventRecord(e1, c->stream));
-        c->spans_pending.push_back({e0, e1, launches, bytes});
+        c->spans_pending.push_back({e0, e1, launches, bytes, persist_steps});
         return PF_OK;
     }
 };
@@ -816,7 +817,8 @@ int pf_cheb(pf_graph* g, int32_t op, int32_t src, int32_t dst, int32_t degree, d
         int done = 0;
         PF_TRY(pf_persist_cheb(&pa, nullptr, &done));
         if (done) {
-            t.launches = 1;
+            t.launches = (degree + 253) / 254;  // at most 254 steps per launch (pf_persist.hip)
+            t.persist_steps = degree;
             return t.finish();
         }
     }
@@ -859,7 +861,8 @@ int pf_cheb2(pf_graph* ga, int32_t op_a, int32_t src_a, int32_t dst_a, int32_t d
         int done = 0;
         PF_TRY(pf_persist_cheb(&pa, &pb, &done));
         if (done) {
-            t.launches = 1;
+            t.launches = (std::max(degree_a, degree_b) + 253) / 254;
+            t.persist_steps = std::max(degree_a, degree_b);
             return t.finish();
         }
     }

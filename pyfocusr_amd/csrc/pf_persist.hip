@@ -12,13 +12,17 @@
 // Coherence.  The 8 XCDs have private L2s and every CU a private L1; neither snoops the others.  Measured on MI355X
 // (250k rows, per step): compute 2.3 us; a barrier of atomics 1.5 us; but an agent-scope release (L2 write-back) and
 // acquire (L2 + L1 invalidate) by every block 5.8 + 3.7 us, and `buffer_inv sc0` does not drop the L1.  Two measures
-// remove all invalidation and all but one write-back per XCD:
+// remove all invalidation and all write-backs:
 //   * every step writes its result to a buffer NOBODY HAS READ OR WRITTEN in this kernel (a ring of PS_RING vectors per
 //     graph, at most PS_RING - 2 steps per launch): no cache can hold a stale copy of a line that was never touched,
 //     so readers need no invalidate; kernel boundaries (which do invalidate) recycle the ring;
-//   * writers: every wave waits for its stores to be acknowledged by the L2 before the block arrives at the XCD's
-//     counter; the LAST block of an XCD to arrive therefore knows all of that XCD's results are in its L2, writes the
-//     L2 back once (agent-scope release) and only then joins the device-wide count that everybody polls.
+//   * writers store their results with agent scope (`global_store ... sc1`: written through the XCD's L2 to memory)
+//     and every wave waits for the acknowledgement before its block arrives at the barrier, so no L2 write-back is
+//     needed either (one `buffer_wbl2` per XCD and step by the last block to arrive was 0.4 us slower).
+// The barrier itself: blocks arrive on the counter of their XCD (32 arrivals each; same-address atomics serialise at
+// ~10 ns), the last arrival of an XCD bumps the device-wide counter, which everybody polls.  6.5 us per step of a
+// 250k-vertex pair, of which ~4 us are the x gathers (bound by the L1's line rate, not by latency: issuing both
+// graphs' gathers together changed nothing) and ~2.5 us the chain store-acknowledge -> arrive -> count -> poll.
 // Every wait is bounded: a block that waits longer than a few seconds raises the abort flag, every other block sees
 // it in its own wait loop, and the kernel drains; the host reports PF_E_HIP at its next synchronisation.  One block
 // per CU (grid <= CU count, checked against the occupancy query) makes all blocks resident on an idle device.
@@ -78,7 +82,7 @@ __device__ __forceinline__ bool wait_for(uint32_t* word, unsigned target, uint32
     return true;
 }
 
-// Grid barrier; the last block of each XCD writes that XCD's L2 back before it joins the device-wide count.
+// Grid barrier (results were stored write-through; this wave has waited for their acknowledgement).
 __device__ __forceinline__ bool grid_barrier(uint32_t* sync, unsigned xcd, unsigned per_xcd, unsigned epoch, int* s_state) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's results have been acknowledged by the L2
     __syncthreads();
@@ -86,10 +90,7 @@ __device__ __forceinline__ bool grid_barrier(uint32_t* sync, unsigned xcd, unsig
         uint32_t* xc = sync + xcd * PS_SYNC_STRIDE;
         uint32_t* dc = sync + 8 * PS_SYNC_STRIDE;
         uint32_t* ab = sync + 9 * PS_SYNC_STRIDE;
-        if (atomicAdd(xc, 1u) + 1u == per_xcd * epoch) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");  // buffer_wbl2: the XCD's results reach memory
-            atomicAdd(dc, 1u);
-        }
+        if (atomicAdd(xc, 1u) + 1u == per_xcd * epoch) atomicAdd(dc, 1u);
         *s_state = wait_for(dc, 8u * epoch, ab) ? 0 : 1;
     }
     __syncthreads();
@@ -149,47 +150,99 @@ __global__ __launch_bounds__(PS_THREADS) void k_sell_persist(PsArgs a) {
     int32_t n_steps = a.g[0].k_end - a.g[0].k_begin + 1;
     if (NG > 1 && a.g[1].k_end - a.g[1].k_begin + 1 > n_steps) n_steps = a.g[1].k_end - a.g[1].k_begin + 1;
 
+    constexpr int JP = 4;  // pairs of entries gathered up front per row (widths up to 9); wider rows finish in a loop
     for (int32_t t = 0; t < n_steps; ++t) {
+        // per-graph vectors of this step
+        const double* xq[NG];
+        const double* pq[NG];
+        double* oq[NG];
+        double alq[NG];
+        int32_t rows[NG];
+        int32_t most_rows = 0;
 #pragma unroll
         for (int q = 0; q < NG; ++q) {
             const PsGraph& g = a.g[q];
             const int32_t k = g.k_begin + t;
-            if (k > g.k_end) continue;
-            const double* x = t == 0 ? g.y_cur : g.ring + (int64_t)((k - 2) % PS_RING) * g.n_pad;
-            const double* prev = k == 1 ? nullptr : (t == 0 ? g.y_prev : (t == 1 ? g.y_cur : g.ring + (int64_t)((k - 3) % PS_RING) * g.n_pad));
-            double* out = k == g.degree ? g.dst : g.ring + (int64_t)((k - 1) % PS_RING) * g.n_pad;
-            const double alpha = k == 1 ? g.a1 : g.a2;
-            const int32_t rows = n_sl[q] * PF_WAVE;
-            for (int32_t r = tid; r < rows; r += PS_THREADS) {
-                const int32_t sl = r >> 6;
-                const int64_t row = (s_lo[q] << 6) + r;
-                const int32_t base = lbase[q][sl];
-                const int width = (lbase[q][sl + 1] - base) >> 6;
-                const double xi = x[row];
-                double acc = g.diag[row] * xi;
-                const int pairs = width >> 1;
-                const double2* vp2 = reinterpret_cast<const double2*>(lval[q] + base) + lane;
-                const int2* cp2 = reinterpret_cast<const int2*>(lcol[q] + base) + lane;
-                for (int j = 0; j < pairs; ++j) {
-                    const int2 c0 = cp2[j * PF_WAVE];
-                    const double2 v0 = vp2[j * PF_WAVE];
-                    const double x0 = x[c0.x], x1 = x[c0.y];
-                    acc = __builtin_fma(v0.x, x0, acc);
-                    acc = __builtin_fma(v0.y, x1, acc);
+            xq[q] = t == 0 ? g.y_cur : g.ring + (int64_t)((k - 2) % PS_RING) * g.n_pad;
+            pq[q] = k == 1 ? nullptr : (t == 0 ? g.y_prev : (t == 1 ? g.y_cur : g.ring + (int64_t)((k - 3) % PS_RING) * g.n_pad));
+            oq[q] = k == g.degree ? g.dst : g.ring + (int64_t)((k - 1) % PS_RING) * g.n_pad;
+            alq[q] = k == 1 ? g.a1 : g.a2;
+            rows[q] = k <= g.k_end ? n_sl[q] * PF_WAVE : 0;  // a graph whose recurrence is over sits the step out
+            most_rows = rows[q] > most_rows ? rows[q] : most_rows;
+        }
+        // The rows of BOTH graphs a thread owns are gathered before any of them is summed: the step is bound by the
+        // latency of the x gathers, and this keeps twice as many in flight.  Per row the operations and their order
+        // are those of sell_op_block.
+        for (int32_t r = tid; r < most_rows; r += PS_THREADS) {
+            bool act[NG];
+            int64_t row[NG];
+            int32_t base[NG];
+            int width[NG], pairs[NG];
+            double xi[NG], dg[NG], pv[NG];
+            double2 vv[NG][JP];
+            double xa[NG][JP], xb[NG][JP];
+            double vt[NG], xt[NG];
+#pragma unroll
+            for (int q = 0; q < NG; ++q) {
+                act[q] = r < rows[q];
+                const int32_t rr = act[q] ? r : lane;  // an idle lane reads (and discards) a row of the first slice
+                const int32_t sl = rr >> 6;
+                row[q] = (s_lo[q] << 6) + rr;
+                base[q] = lbase[q][sl];
+                width[q] = act[q] ? (lbase[q][sl + 1] - base[q]) >> 6 : 0;
+                pairs[q] = width[q] >> 1;
+                xi[q] = xq[q][row[q]];
+                dg[q] = a.g[q].diag[row[q]];
+                pv[q] = pq[q] ? pq[q][row[q]] : 0.0;
+#pragma unroll
+                for (int j = 0; j < JP; ++j) {
+                    const bool on = j < pairs[q];
+                    const int32_t e = on ? base[q] + j * (2 * PF_WAVE) + 2 * lane : 0;
+                    const int2 c0 = *reinterpret_cast<const int2*>(lcol[q] + e);
+                    vv[q][j] = *reinterpret_cast<const double2*>(lval[q] + e);
+                    xa[q][j] = xq[q][on ? c0.x : (int32_t)row[q]];
+                    xb[q][j] = xq[q][on ? c0.y : (int32_t)row[q]];
                 }
-                if (width & 1) {
-                    const int32_t e = base + pairs * (2 * PF_WAVE) + lane;
-                    acc = __builtin_fma(lval[q][e], x[lcol[q][e]], acc);
+                const bool odd = (width[q] & 1) && pairs[q] <= JP;
+                const int32_t e = odd ? base[q] + pairs[q] * (2 * PF_WAVE) + lane : 0;
+                vt[q] = lval[q][e];
+                xt[q] = xq[q][odd ? lcol[q][e] : (int32_t)row[q]];
+            }
+#pragma unroll
+            for (int q = 0; q < NG; ++q) {
+                double acc = dg[q] * xi[q];
+#pragma unroll
+                for (int j = 0; j < JP; ++j) {
+                    const double s0 = __builtin_fma(vv[q][j].x, xa[q][j], acc);
+                    const double s1 = __builtin_fma(vv[q][j].y, xb[q][j], s0);
+                    acc = j < pairs[q] ? s1 : acc;
                 }
-                const double u = __builtin_fma(g.shift, xi, -acc);
+                if (pairs[q] > JP) {  // wide rows: the remaining pairs (and the odd entry) in order
+                    const double2* vp2 = reinterpret_cast<const double2*>(lval[q] + base[q]) + lane;
+                    const int2* cp2 = reinterpret_cast<const int2*>(lcol[q] + base[q]) + lane;
+                    for (int j = JP; j < pairs[q]; ++j) {
+                        const int2 c0 = cp2[j * PF_WAVE];
+                        const double2 v0 = vp2[j * PF_WAVE];
+                        acc = __builtin_fma(v0.x, xq[q][c0.x], acc);
+                        acc = __builtin_fma(v0.y, xq[q][c0.y], acc);
+                    }
+                    if (width[q] & 1) {
+                        const int32_t e = base[q] + pairs[q] * (2 * PF_WAVE) + lane;
+                        acc = __builtin_fma(lval[q][e], xq[q][lcol[q][e]], acc);
+                    }
+                } else if (width[q] & 1) {
+                    acc = __builtin_fma(vt[q], xt[q], acc);
+                }
+                const double u = __builtin_fma(a.g[q].shift, xi[q], -acc);
                 double res;
-                if (prev) {
-                    const double w = g.beta * prev[row];
-                    res = __builtin_fma(alpha, u, -w);
+                if (pq[q]) {
+                    const double w = a.g[q].beta * pv[q];
+                    res = __builtin_fma(alq[q], u, -w);
                 } else {
-                    res = alpha * u;
+                    res = alq[q] * u;
                 }
-                out[row] = res;
+                // agent-scope store: written through the XCD's L2 to memory, so the barrier needs no L2 write-back
+                if (act[q]) __hip_atomic_store(&oq[q][row[q]], res, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
         if (t + 1 < n_steps && !grid_barrier(a.sync, xcd, per_xcd, (unsigned)(t + 1), &s_state)) {
