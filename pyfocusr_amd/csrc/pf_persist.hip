@@ -23,6 +23,9 @@
 // ~10 ns), the last arrival of an XCD bumps the device-wide counter, which everybody polls.  6.5 us per step of a
 // 250k-vertex pair, of which ~4 us are the x gathers (bound by the L1's line rate, not by latency: issuing both
 // graphs' gathers together changed nothing) and ~2.5 us the chain store-acknowledge -> arrive -> count -> poll.
+// Tried and dropped: one kernel per graph (512 threads, half the LDS, two blocks per CU) on two streams, hoping one
+// graph's barrier chain would hide behind the other graph's gathers: 6.9 us per step of the pair against 6.5 us for
+// both graphs in one kernel (bit-identical results either way).
 // Every wait is bounded: a block that waits longer than a few seconds raises the abort flag, every other block sees
 // it in its own wait loop, and the kernel drains; the host reports PF_E_HIP at its next synchronisation.  One block
 // per CU (grid <= CU count, checked against the occupancy query) makes all blocks resident on an idle device.
