@@ -607,6 +607,13 @@ class DeviceLaplacian(object):
         _check(self._lib.pf_orth_end(self._h, _f64(h), C.byref(nrm)))
         return h[: self._orth_count], float(nrm.value)
 
+    def orth_abandon(self):
+        """Collect and discard an orthogonalisation left in flight by a solve that was aborted."""
+        try:
+            self.orth_end()
+        except PfError:
+            pass
+
     def scale(self, slot, alpha):
         _check(self._lib.pf_scale(self._h, int(slot), float(alpha)))
 

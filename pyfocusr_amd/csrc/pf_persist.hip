@@ -402,6 +402,8 @@ int pf_persist_cheb(const pf_persist_args* a, const pf_persist_args* b, int* don
         args.sync = ctx->persist_sync;
         args.host_abort = ctx->persist_abort;
         PF_HIP(hipMemsetAsync(ctx->persist_sync, 0, sizeof(uint32_t) * PS_SYNC_WORDS, st));
+        if (getenv("PF_PERSIST_TEST_ABORT"))  // test hook: the first barrier finds the abort flag raised (tests/test_gpu_parity.py)
+            PF_HIP(hipMemsetAsync(ctx->persist_sync + 9 * PS_SYNC_STRIDE, 1, sizeof(uint32_t), st));
         // A plain launch, not hipLaunchCooperativeKernel: one block per CU is resident-able by construction (grid <=
         // CU count, the occupancy query above says one block fits a CU), a block that has to wait for a CU another
         // stream is using starts as soon as that kernel ends, and every barrier wait is bounded anyway.  (The

@@ -325,7 +325,18 @@ def _paired_spectra(ga, gb):
             print("Beginning Eigen Decomposition")
         gens.append(_device_eigs_gen(g.device, k=g.n_spectral_features + 1, n_k_needed=g.n_spectral_features,
                                      k_buffer=1, minmax=g.norm_eig_vecs is True, verbose=g.verbose))
-    ra, rb = drive_pair(gens[0], ga.device, gens[1], gb.device)
+    try:
+        ra, rb = drive_pair(gens[0], ga.device, gens[1], gb.device)
+    except _hip.PfError as exc:
+        # A grid barrier of the persistent filter kernel timed out (another tenant on the device?): the library has
+        # switched that path off and said so; the eigenpairs are computed again, one step per launch.
+        if "persistent Chebyshev kernel" not in str(exc):
+            raise
+        for g in (ga, gb):
+            g.device.orth_abandon()
+        gens = [_device_eigs_gen(g.device, k=g.n_spectral_features + 1, n_k_needed=g.n_spectral_features, k_buffer=1,
+                                 minmax=g.norm_eig_vecs is True, verbose=g.verbose) for g in (ga, gb)]
+        ra, rb = drive_pair(gens[0], ga.device, gens[1], gb.device)
     for g, (vals, vecs, stats) in ((ga, ra), (gb, rb)):
         g.eig_vals, g.eig_vecs, g.eigs_stats = vals, vecs, stats
         if g.verbose:

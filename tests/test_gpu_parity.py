@@ -883,6 +883,50 @@ def test_persistent_kernel_bit_identical(golden, hip, ctx):
             g.close()
 
 
+def test_persistent_kernel_timeout_is_survived(hip, ctx, monkeypatch):
+    """A barrier of the persistent kernel that gives up (forced here through the library's test hook) must not cost the
+    caller the result: the library reports it and switches the path off, and the pair is solved again one step per
+    launch."""
+    from pyfocusr_amd import Graph
+    from pyfocusr_amd.graph import compute_spectra
+    from pyfocusr_amd.meshgen import blob_mesh
+
+    meshes = [blob_mesh(60000, seed=s) for s in (3, 4)]
+
+    def spectra():
+        graphs = [Graph(m, n_spectral_features=4, n_rand_samples=10**9, ctx=ctx, verbose=False) for m in meshes]
+        compute_spectra(graphs)
+        vals = [g.eig_vals.copy() for g in graphs]
+        for g in graphs:
+            g.device.close()
+        return vals
+
+    try:
+        hip.persist_enable(True)
+        good = spectra()
+        monkeypatch.setenv("PF_PERSIST_TEST_ABORT", "1")
+        survived = spectra()  # first filter application aborts -> PfError inside -> solved again without the kernel
+        monkeypatch.delenv("PF_PERSIST_TEST_ABORT")
+        for a, b in zip(good, survived):
+            np.testing.assert_allclose(a, b, rtol=1e-9)
+        dev = hip.DeviceLaplacian(meshes[0].points, meshes[0].faces, ctx=ctx)
+        dev.ws_ensure(4)
+        dev.upload(0, np.ones(dev.n))
+        before = ctx.timing(reset=True)
+        dev2 = hip.DeviceLaplacian(meshes[1].points, meshes[1].faces, ctx=ctx)
+        dev2.ws_ensure(4)
+        dev2.upload(0, np.ones(dev2.n))
+        ctx.timing_enable(True)
+        dev.cheb2((0, 1, 20, 1.0, 1.0, 1.0), dev2, (0, 1, 20, 1.0, 1.0, 1.0))
+        assert ctx.timing(reset=True)["persist_launches"] == 0  # switched off by the timeout
+        ctx.timing_enable(False)
+        dev.close()
+        dev2.close()
+        del before
+    finally:
+        hip.persist_enable(True)
+
+
 def test_eigs_smallest_single_c_call(golden, hip, ctx):
     """`pf_eigs_smallest` (the eigensolve as ONE C call, symmetric W) against the golden eigenpairs of the reference,
     the oracle on synthetic and multi-component meshes, and its documented refusals."""
