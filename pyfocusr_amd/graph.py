@@ -334,6 +334,13 @@ def _paired_spectra(ga, gb):
             raise
         for g in (ga, gb):
             g.device.orth_abandon()
+        for _ in range(8):  # launches queued ahead of the report (speculative filter applications) may raise it again
+            try:
+                ga.device.ctx.sync()
+                break
+            except _hip.PfError as again:
+                if "persistent Chebyshev kernel" not in str(again):
+                    raise
         gens = [_device_eigs_gen(g.device, k=g.n_spectral_features + 1, n_k_needed=g.n_spectral_features, k_buffer=1,
                                  minmax=g.norm_eig_vecs is True, verbose=g.verbose) for g in (ga, gb)]
         ra, rb = drive_pair(gens[0], ga.device, gens[1], gb.device)
