@@ -162,6 +162,63 @@ __global__ __launch_bounds__(PF_BLOCK) void k_multi_axpy(double* __restrict__ ws
     *reinterpret_cast<double2*>(ws + (int64_t)wslot * n_pad + i) = acc;
 }
 
+// Fused forms for pf_orth_begin (one Gram-Schmidt pass = k_dot_partial + this; no separate finish launch):
+// every block finishes the per-chunk partial sums itself - in k_dot_finish's order, so all blocks (and the host) see
+// the same bits - then subtracts.  Block 0 also publishes the coefficients: hsum[b] (+)= h[b].
+constexpr int PF_ORTH_MAX = 256;
+__global__ __launch_bounds__(PF_BLOCK) void k_axpy_finishing(double* __restrict__ ws, int64_t n_pad, int32_t first, int32_t count,
+                                                             int32_t wslot, const double* __restrict__ partial, int64_t n_chunks,
+                                                             double* __restrict__ hsum, int accumulate) {
+    __shared__ double hs[PF_ORTH_MAX];
+    const int lane = threadIdx.x & (PF_WAVE - 1);
+    for (int b = threadIdx.x / PF_WAVE; b < count; b += PF_BLOCK / PF_WAVE) {
+        double s = 0.0;
+        for (int64_t k = lane; k < n_chunks; k += PF_WAVE) s += partial[(int64_t)b * n_chunks + k];
+#pragma unroll
+        for (int off = PF_WAVE / 2; off > 0; off >>= 1) s += __shfl_down(s, off, PF_WAVE);
+        if (lane == 0) hs[b] = s;
+    }
+    __syncthreads();
+    if (blockIdx.x == 0)
+        for (int b = threadIdx.x; b < count; b += PF_BLOCK) hsum[b] = accumulate ? hsum[b] + hs[b] : hs[b];
+    const int64_t i = 2 * ((int64_t)blockIdx.x * PF_BLOCK + threadIdx.x);
+    if (i >= n_pad) return;
+    double2 acc = *reinterpret_cast<double2*>(ws + (int64_t)wslot * n_pad + i);
+    for (int b = 0; b < count; ++b) {
+        const double hb = hs[b];
+        const double2 v = *reinterpret_cast<const double2*>(ws + (int64_t)(first + b) * n_pad + i);
+        acc.x -= hb * v.x;
+        acc.y -= hb * v.y;
+    }
+    *reinterpret_cast<double2*>(ws + (int64_t)wslot * n_pad + i) = acc;
+}
+
+// Last launch of pf_orth_begin: finishes ||w||^2 from its partial sums, normalises w if asked, and block 0 writes
+// the coefficients and the squared norm straight into the pinned host buffer (no device-to-host copies).
+__global__ __launch_bounds__(PF_BLOCK) void k_scale_finishing(double* __restrict__ x, int64_t n_pad, const double* __restrict__ partial,
+                                                              int64_t n_chunks, int normalize, const double* __restrict__ hsum,
+                                                              int32_t count, double* __restrict__ nrm2, double* __restrict__ host_out) {
+    __shared__ double s_v;
+    if (threadIdx.x < PF_WAVE) {
+        double s = 0.0;
+        for (int64_t k = threadIdx.x; k < n_chunks; k += PF_WAVE) s += partial[k];
+#pragma unroll
+        for (int off = PF_WAVE / 2; off > 0; off >>= 1) s += __shfl_down(s, off, PF_WAVE);
+        if (threadIdx.x == 0) s_v = s;
+    }
+    __syncthreads();
+    const double v = s_v;
+    if (blockIdx.x == 0) {
+        for (int b = threadIdx.x; b < count; b += PF_BLOCK) host_out[b] = hsum[b];
+        if (threadIdx.x == 0) {
+            *nrm2 = v;
+            host_out[count] = v;
+        }
+    }
+    const int64_t i = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
+    if (normalize && i < n_pad && v > 1e-280) x[i] *= 1.0 / sqrt(v);
+}
+
 __global__ __launch_bounds__(PF_BLOCK) void k_scale(double* __restrict__ x, int64_t n_pad, double alpha) {
     const int64_t i = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
     if (i < n_pad) x[i] *= alpha;
@@ -930,20 +987,35 @@ int pf_orth_begin(pf_graph* g, int32_t w, int32_t first, int32_t count, int32_t 
     double* hpass = g->coef;           // coefficients of the current pass
     double* hsum = g->coef + cap;      // h1 + h2
     double* nrm2 = g->coef + 2 * cap;  // ||w||^2
-    if (count > 0) {
+    if (count <= PF_ORTH_MAX) {
+        // 6 launches and no copies instead of 9 + 2: the finishing of every reduction rides in its consumer
+        for (int pass = 0; pass < 2 && count > 0; ++pass) {
+            dim3 grid((unsigned)g->n_chunks, (unsigned)count);
+            k_dot_partial<<<grid, PF_BLOCK, 0, st>>>(g->ws, g->n_pad, first, w, g->n_chunks, g->partials);
+            PF_HIP(hipGetLastError());
+            k_axpy_finishing<<<nblk(g->n_pad / 2), PF_BLOCK, 0, st>>>(g->ws, g->n_pad, first, count, w, g->partials, g->n_chunks,
+                                                                     hsum, pass);
+            PF_HIP(hipGetLastError());
+        }
+        k_dot_partial<<<dim3((unsigned)g->n_chunks, 1u), PF_BLOCK, 0, st>>>(g->ws, g->n_pad, w, w, g->n_chunks, g->partials);
+        PF_HIP(hipGetLastError());
+        k_scale_finishing<<<nblk(g->n_pad), PF_BLOCK, 0, st>>>(pf_slot(g, w), g->n_pad, g->partials, g->n_chunks, normalize ? 1 : 0,
+                                                              hsum, count, nrm2, g->orth_host);
+        PF_HIP(hipGetLastError());
+    } else {
         for (int pass = 0; pass < 2; ++pass) {
             PF_TRY(dots_device(g, w, first, count, hpass, hsum, pass));
             k_multi_axpy<<<nblk(g->n_pad / 2), PF_BLOCK, 0, st>>>(g->ws, g->n_pad, first, count, w, hpass);
             PF_HIP(hipGetLastError());
         }
+        PF_TRY(dots_device(g, w, w, 1, nrm2, nullptr, 0));
+        if (normalize) {
+            k_scale_rsqrt<<<nblk(g->n_pad), PF_BLOCK, 0, st>>>(pf_slot(g, w), g->n_pad, nrm2);
+            PF_HIP(hipGetLastError());
+        }
+        PF_HIP(hipMemcpyAsync(g->orth_host, hsum, sizeof(double) * count, hipMemcpyDeviceToHost, st));
+        PF_HIP(hipMemcpyAsync(g->orth_host + count, nrm2, sizeof(double), hipMemcpyDeviceToHost, st));
     }
-    PF_TRY(dots_device(g, w, w, 1, nrm2, nullptr, 0));
-    if (normalize) {
-        k_scale_rsqrt<<<nblk(g->n_pad), PF_BLOCK, 0, st>>>(pf_slot(g, w), g->n_pad, nrm2);
-        PF_HIP(hipGetLastError());
-    }
-    if (count > 0) PF_HIP(hipMemcpyAsync(g->orth_host, hsum, sizeof(double) * count, hipMemcpyDeviceToHost, st));
-    PF_HIP(hipMemcpyAsync(g->orth_host + count, nrm2, sizeof(double), hipMemcpyDeviceToHost, st));
     PF_HIP(hipEventRecord(g->orth_ev, st));
     g->orth_pending = count;
     return PF_OK;
