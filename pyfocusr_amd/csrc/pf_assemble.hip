@@ -455,6 +455,7 @@ void pf_graph_free(pf_graph* g) {
     hipSetDevice(g->ctx->device);
     hipStream_t st = g->ctx->stream;
     pf_free(st, g->persist_ring);
+    pf_window_slots_free(g);
     pf_free(st, g->rowptr);
     pf_free(st, g->col);
     pf_free(st, g->w);

@@ -139,6 +139,13 @@ struct pf_graph {
     // persistent Chebyshev kernel (pf_persist.hip): host copy of slice_ptr and the LDS need of the fullest block
     std::vector<int64_t> h_slice_ptr;
     double* persist_ring = nullptr;  // [256][n_pad] result buffers, each written once per launch
+    // windows of 1024 rows: window-local slot of every SELL column (own row, or 1024 + index into the window's sorted
+    // list of outside rows) for the persistent kernel that keeps x in LDS too
+    int32_t px_state = -1;
+    int32_t* px_slot = nullptr;    // [sell_entries]
+    int32_t* px_gh_cnt = nullptr;  // [windows]
+    int32_t* px_gh_row = nullptr;  // [windows][PF_TS_GHOSTS]
+    std::vector<int32_t> h_px_gh_cnt;
     int32_t persist_grid = 0;
     int64_t persist_lds = 0;
     int32_t is_symmetric = 0, n_isolated = 0, n_components = 0, max_degree = 0, n_oneway = 0;
@@ -216,6 +223,8 @@ int pf_persist_cheb(const pf_persist_args* a, const pf_persist_args* b /* nullab
 int pf_persist_check(pf_ctx* ctx);  // PF_E_HIP if a barrier of an earlier launch timed out
 int pf_persist_set(int on);
 void pf_persist_release(pf_ctx* ctx);  // pf_destroy: another ctx may take the persistent path over
+int pf_window_slots_prepare(pf_graph* g);  // pf_twostep.hip: px_* of the graph (see pf_graph)
+void pf_window_slots_free(pf_graph* g);
 int pf_twostep_prepare(pf_graph* g);  // builds the window structures once; g->two_step tells whether they exist
 int pf_twostep_launch(const pf_ts_args* a, const pf_ts_args* b /* nullable */);
 void pf_twostep_free(pf_graph* g);

@@ -255,6 +255,172 @@ __global__ __launch_bounds__(PS_THREADS) void k_sell_persist(PsArgs a) {
     }
 }
 
+// ---- variant with x in LDS as well ------------------------------------------------------------------------------
+// A block owns a WINDOW of 1024 consecutive rows (one row per thread and graph).  Besides the window's SELL entries
+// (columns as 16-bit window-local slots: own row, or 1024 + index into the window's sorted list of outside rows,
+// pf_window_slots_prepare) LDS holds the x values of the window's own rows - updated in place from the results, after
+// the barrier's first __syncthreads - and of its outside rows, fetched from global memory at the start of a step
+// (~220 values per window).  All gathers of a step are LDS reads; y_{k-1} of a row is the x the same thread used one
+// step earlier (a register); the diagonal is a register.  Per step a block reads only its outside rows from memory.
+// Same operations in the same order as sell_op_block: bit-identical results.
+struct PxGraph {
+    const int64_t* slice_ptr;
+    const int32_t* slot;     // [sell_entries] window-local slots
+    const int32_t* gh_cnt;   // [windows]
+    const int32_t* gh_row;   // [windows][PF_TS_GHOSTS]
+    const double* sval;
+    const double* diag;
+    const double* y_prev;
+    const double* y_cur;
+    double* dst;
+    double* ring;
+    int64_t n_pad;
+    int32_t n_windows;
+    int32_t k_begin, k_end, degree;
+    double a1, a2, shift, beta;
+};
+
+struct PxArgs {
+    PxGraph g[2];
+    uint32_t* sync;
+    int32_t* host_abort;
+};
+
+template <int NG>
+__global__ __launch_bounds__(PS_THREADS) void k_sell_persist_x(PxArgs a) {
+#pragma clang fp contract(off)
+    extern __shared__ __align__(16) unsigned char lds[];
+    __shared__ int s_state;
+    const unsigned G = gridDim.x, per_xcd = G >> 3;
+    const unsigned xcd = blockIdx.x & 7u;
+    const int32_t win = (int32_t)(xcd * per_xcd + (blockIdx.x >> 3));
+    const int tid = threadIdx.x;
+    const int lane = tid & (PF_WAVE - 1);
+    const int sl = tid >> 6;
+
+    bool have[NG];
+    int32_t ghosts[NG];
+    double* lval[NG];
+    double* xl[NG];
+    int32_t* lbase[NG];
+    unsigned short* lslot[NG];
+    const int32_t* ghr[NG];
+    int64_t row[NG];
+    double dg[NG], pv[NG];
+    size_t off = 0;
+#pragma unroll
+    for (int q = 0; q < NG; ++q) {
+        const PxGraph& g = a.g[q];
+        have[q] = win < g.n_windows;
+        const int64_t s0 = (int64_t)(have[q] ? win : 0) * (PF_TS_ROWS / PF_WAVE);
+        const int64_t e_lo = g.slice_ptr[s0];
+        const int64_t cnt = have[q] ? g.slice_ptr[s0 + PF_TS_ROWS / PF_WAVE] - e_lo : 0;
+        ghosts[q] = have[q] ? g.gh_cnt[win] : 0;
+        ghr[q] = g.gh_row + (int64_t)(have[q] ? win : 0) * PF_TS_GHOSTS;
+        row[q] = (int64_t)(have[q] ? win : 0) * PF_TS_ROWS + tid;
+        lval[q] = reinterpret_cast<double*>(lds + off);
+        off += (size_t)cnt * sizeof(double);
+        xl[q] = reinterpret_cast<double*>(lds + off);
+        off += (size_t)(have[q] ? PF_TS_ROWS + ghosts[q] : 0) * sizeof(double);
+        lbase[q] = reinterpret_cast<int32_t*>(lds + off);
+        off += (size_t)(PF_TS_ROWS / PF_WAVE + 2) * sizeof(int32_t);  // 18 words: keeps the 8-byte alignment
+        lslot[q] = reinterpret_cast<unsigned short*>(lds + off);
+        off = (off + (size_t)cnt * sizeof(unsigned short) + 15) & ~(size_t)15;  // the next graph's values: 16-byte aligned
+        for (int64_t i = tid; i < cnt; i += PS_THREADS) {
+            lval[q][i] = g.sval[e_lo + i];
+            lslot[q][i] = (unsigned short)g.slot[e_lo + i];
+        }
+        if (tid <= PF_TS_ROWS / PF_WAVE) lbase[q][tid] = have[q] ? (int32_t)(g.slice_ptr[s0 + tid] - e_lo) : 0;
+        dg[q] = have[q] ? g.diag[row[q]] : 0.0;
+        pv[q] = (have[q] && g.y_prev) ? g.y_prev[row[q]] : 0.0;
+        if (have[q]) xl[q][tid] = g.y_cur[row[q]];
+    }
+    __syncthreads();
+
+    int32_t n_steps = a.g[0].k_end - a.g[0].k_begin + 1;
+    if (NG > 1 && a.g[1].k_end - a.g[1].k_begin + 1 > n_steps) n_steps = a.g[1].k_end - a.g[1].k_begin + 1;
+    constexpr int JP = 4;
+
+    for (int32_t t = 0; t < n_steps; ++t) {
+        bool step[NG];
+        double res[NG], xi[NG];
+        // outside rows of this step: y_{k-1} of other windows, written (write-through) before the last barrier
+#pragma unroll
+        for (int q = 0; q < NG; ++q) {
+            const PxGraph& g = a.g[q];
+            const int32_t k = g.k_begin + t;
+            step[q] = have[q] && k <= g.k_end;
+            const double* xg = t == 0 ? g.y_cur : g.ring + (int64_t)((k - 2) % PS_RING) * g.n_pad;
+            if (step[q])
+                for (int h = tid; h < ghosts[q]; h += PS_THREADS) xl[q][PF_TS_ROWS + h] = xg[ghr[q][h]];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < NG; ++q) {
+            const PxGraph& g = a.g[q];
+            const int32_t k = g.k_begin + t;
+            const int32_t base = lbase[q][sl];
+            const int width = step[q] ? (lbase[q][sl + 1] - base) >> 6 : 0;
+            const int pairs = width >> 1;
+            xi[q] = step[q] ? xl[q][tid] : 0.0;
+            double acc = dg[q] * xi[q];
+#pragma unroll
+            for (int j = 0; j < JP; ++j) {
+                const bool on = j < pairs;
+                const int32_t e = on ? base + j * (2 * PF_WAVE) + 2 * lane : 0;
+                const unsigned int two = *reinterpret_cast<const unsigned int*>(lslot[q] + e);
+                const double2 v = *reinterpret_cast<const double2*>(lval[q] + e);
+                const double x0 = xl[q][on ? (two & 0xffffu) : 0], x1 = xl[q][on ? (two >> 16) : 0];
+                const double s0 = __builtin_fma(v.x, x0, acc);
+                const double s1 = __builtin_fma(v.y, x1, s0);
+                acc = on ? s1 : acc;
+            }
+            for (int j = JP; j < pairs; ++j) {  // wide rows
+                const int32_t e = base + j * (2 * PF_WAVE) + 2 * lane;
+                const unsigned int two = *reinterpret_cast<const unsigned int*>(lslot[q] + e);
+                const double2 v = *reinterpret_cast<const double2*>(lval[q] + e);
+                acc = __builtin_fma(v.x, xl[q][two & 0xffffu], acc);
+                acc = __builtin_fma(v.y, xl[q][two >> 16], acc);
+            }
+            if (width & 1) {
+                const int32_t e = base + pairs * (2 * PF_WAVE) + lane;
+                acc = __builtin_fma(lval[q][e], xl[q][lslot[q][e]], acc);
+            }
+            const double u = __builtin_fma(g.shift, xi[q], -acc);
+            if (k == 1) {
+                res[q] = g.a1 * u;
+            } else {
+                const double w = g.beta * pv[q];
+                res[q] = __builtin_fma(g.a2, u, -w);
+            }
+            double* out = k == g.degree ? g.dst : g.ring + (int64_t)((k - 1) % PS_RING) * g.n_pad;
+            if (step[q]) __hip_atomic_store(&out[row[q]], res[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (t + 1 == n_steps) break;
+        // ---- barrier, with the window's own x replaced by the results between its two block-level halves
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();  // every thread has finished reading xl for this step
+#pragma unroll
+        for (int q = 0; q < NG; ++q)
+            if (step[q]) {
+                xl[q][tid] = res[q];
+                pv[q] = xi[q];
+            }
+        if (tid == 0) {
+            uint32_t* xc = a.sync + xcd * PS_SYNC_STRIDE;
+            uint32_t* dc = a.sync + 8 * PS_SYNC_STRIDE;
+            uint32_t* ab = a.sync + 9 * PS_SYNC_STRIDE;
+            if (atomicAdd(xc, 1u) + 1u == per_xcd * (unsigned)(t + 1)) atomicAdd(dc, 1u);
+            s_state = wait_for(dc, 8u * (unsigned)(t + 1), ab) ? 0 : 1;
+        }
+        __syncthreads();
+        if (s_state != 0) {
+            if (tid == 0) *a.host_abort = 1;
+            return;
+        }
+    }
+}
+
 // -1 undecided (environment PF_PERSIST=0 disables), 0 off, 1 on
 int g_persist = -1;
 
@@ -282,6 +448,10 @@ int device_grid(int device) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_sell_persist<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)PS_LDS_LIMIT) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void*>(k_sell_persist<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)PS_LDS_LIMIT) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(k_sell_persist_x<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)PS_LDS_LIMIT) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(k_sell_persist_x<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)PS_LDS_LIMIT) != hipSuccess) {
             (void)hipGetLastError();
             return 0;
@@ -294,6 +464,40 @@ int device_grid(int device) {
         f.grid = std::min(prop.multiProcessorCount, 256) & ~7;  // one block per CU, a multiple of the 8 XCDs
     }
     return f.grid;
+}
+
+// -1 undecided (environment PF_PERSIST_X=0 disables the variant with x in LDS), 0 off, 1 on
+int g_x_state = -1;
+bool x_enabled() {
+    if (g_x_state < 0) {
+        const char* v = getenv("PF_PERSIST_X");
+        g_x_state = (v && v[0] == '0') ? 0 : 1;
+    }
+    return g_x_state == 1;
+}
+
+// LDS bytes of the fullest window for the x-in-LDS kernel (layout as in k_sell_persist_x), both graphs together
+int64_t lds_need_x(pf_graph* ga, pf_graph* gb) {
+    pf_graph* gs[2] = {ga, gb};
+    const int64_t wa = ga->n_pad / PF_TS_ROWS, wb = gb ? gb->n_pad / PF_TS_ROWS : 0;
+    int64_t worst = 0;
+    for (int64_t w = 0; w < std::max(wa, wb); ++w) {
+        int64_t need = 0;
+        for (int q = 0; q < 2; ++q) {
+            pf_graph* g = gs[q];
+            if (!g) continue;
+            if (g->h_slice_ptr.empty() || (int64_t)g->h_px_gh_cnt.size() * PF_TS_ROWS != g->n_pad) return -1;
+            need += (PF_TS_ROWS / PF_WAVE + 2) * 4;
+            if (w < g->n_pad / PF_TS_ROWS) {
+                const int64_t s0 = w * (PF_TS_ROWS / PF_WAVE);
+                const int64_t cnt = g->h_slice_ptr[(size_t)(s0 + PF_TS_ROWS / PF_WAVE)] - g->h_slice_ptr[(size_t)s0];
+                need += cnt * 8 + (PF_TS_ROWS + g->h_px_gh_cnt[(size_t)w]) * 8 + cnt * 2;
+            }
+            need = (need + 15) & ~(int64_t)15;
+        }
+        worst = std::max(worst, need);
+    }
+    return worst;
 }
 
 // LDS bytes the fullest block needs for g when the slices are split over `grid` blocks
@@ -343,17 +547,38 @@ int pf_persist_cheb(const pf_persist_args* a, const pf_persist_args* b, int* don
     // One graph alone gains nothing (250k rows: 5.0 us per step here, 4.7 us per launch there: the barrier costs what
     // the matrix traffic saves); two graphs share every barrier (7.0 vs 10.1 us).  pf_persist_enable(2) forces it.
     if (!b && g_persist != 2) return PF_OK;
-    const int grid = device_grid(ctx->device);
+    int grid = device_grid(ctx->device);
     if (grid < 8) return PF_OK;
-    if (ga->n_slices < grid || (b && b->g->n_slices < grid)) return PF_OK;
-    int64_t need = lds_need(ga, grid);
-    if (need < 0) return PF_OK;
-    if (b) {
-        const int64_t nb = lds_need(b->g, grid);
-        if (nb < 0) return PF_OK;
-        need += nb;
+    // Preferred: x in LDS as well (windows of 1024 rows; needs the window-local slots of the graph(s), built once)
+    int64_t need = 0;
+    bool use_x = false;
+    if (x_enabled()) {
+        PF_TRY(pf_window_slots_prepare(ga));
+        if (b) PF_TRY(pf_window_slots_prepare(b->g));
+        if (ga->px_state == 1 && (!b || b->g->px_state == 1)) {
+            const int64_t wa = ga->n_pad / PF_TS_ROWS, wb = b ? b->g->n_pad / PF_TS_ROWS : 0;
+            const int64_t gx = (std::max(wa, wb) + 7) & ~(int64_t)7;
+            if (gx >= 8 && gx <= grid) {
+                const int64_t nx = lds_need_x(ga, b ? b->g : nullptr);
+                if (nx > 0 && (size_t)nx + 64 <= PS_LDS_LIMIT) {
+                    use_x = true;
+                    need = nx;
+                    grid = (int)gx;
+                }
+            }
+        }
     }
-    if ((size_t)need + 64 > PS_LDS_LIMIT) return PF_OK;
+    if (!use_x) {
+        if (ga->n_slices < grid || (b && b->g->n_slices < grid)) return PF_OK;
+        need = lds_need(ga, grid);
+        if (need < 0) return PF_OK;
+        if (b) {
+            const int64_t nb = lds_need(b->g, grid);
+            if (nb < 0) return PF_OK;
+            need += nb;
+        }
+        if ((size_t)need + 64 > PS_LDS_LIMIT) return PF_OK;
+    }
     {
         pf_ctx* expected = nullptr;
         if (!g_owner.compare_exchange_strong(expected, ctx) && expected != ctx) return PF_OK;  // another ctx owns the path
@@ -374,6 +599,7 @@ int pf_persist_cheb(const pf_persist_args* a, const pf_persist_args* b, int* don
     bool launched = false;
     while (finished[0] < a->degree || (b && finished[1] < b->degree)) {
         PsArgs args{};
+        PxArgs xargs{};
         for (int q = 0; q < ng; ++q) {
             pf_graph* g = in[q]->g;
             PsGraph& p = args.g[q];
@@ -398,9 +624,29 @@ int pf_persist_cheb(const pf_persist_args* a, const pf_persist_args* b, int* don
             p.shift = in[q]->c;
             p.beta = 1.0 / (in[q]->rho * in[q]->rho);
             finished[q] = std::max(finished[q], p.k_end);
+            PxGraph& x = xargs.g[q];
+            x.slice_ptr = g->slice_ptr;
+            x.slot = g->px_slot;
+            x.gh_cnt = g->px_gh_cnt;
+            x.gh_row = g->px_gh_row;
+            x.sval = p.sval;
+            x.diag = p.diag;
+            x.y_prev = p.y_prev;
+            x.y_cur = p.y_cur;
+            x.dst = p.dst;
+            x.ring = p.ring;
+            x.n_pad = p.n_pad;
+            x.n_windows = (int32_t)(g->n_pad / PF_TS_ROWS);
+            x.k_begin = p.k_begin;
+            x.k_end = p.k_end;
+            x.degree = p.degree;
+            x.a1 = p.a1;
+            x.a2 = p.a2;
+            x.shift = p.shift;
+            x.beta = p.beta;
         }
-        args.sync = ctx->persist_sync;
-        args.host_abort = ctx->persist_abort;
+        args.sync = xargs.sync = ctx->persist_sync;
+        args.host_abort = xargs.host_abort = ctx->persist_abort;
         PF_HIP(hipMemsetAsync(ctx->persist_sync, 0, sizeof(uint32_t) * PS_SYNC_WORDS, st));
         if (getenv("PF_PERSIST_TEST_ABORT"))  // test hook: the first barrier finds the abort flag raised (tests/test_gpu_parity.py)
             PF_HIP(hipMemsetAsync(ctx->persist_sync + 9 * PS_SYNC_STRIDE, 1, sizeof(uint32_t), st));
@@ -408,7 +654,11 @@ int pf_persist_cheb(const pf_persist_args* a, const pf_persist_args* b, int* don
         // CU count, the occupancy query above says one block fits a CU), a block that has to wait for a CU another
         // stream is using starts as soon as that kernel ends, and every barrier wait is bounded anyway.  (The
         // cooperative entry point runs on a separate queue whose teardown crashes rocprofv3 at process exit.)
-        if (b)
+        if (use_x && b)
+            k_sell_persist_x<2><<<dim3((unsigned)grid), dim3(PS_THREADS), (size_t)(need + 64), st>>>(xargs);
+        else if (use_x)
+            k_sell_persist_x<1><<<dim3((unsigned)grid), dim3(PS_THREADS), (size_t)(need + 64), st>>>(xargs);
+        else if (b)
             k_sell_persist<2><<<dim3((unsigned)grid), dim3(PS_THREADS), (size_t)(need + 64), st>>>(args);
         else
             k_sell_persist<1><<<dim3((unsigned)grid), dim3(PS_THREADS), (size_t)(need + 64), st>>>(args);

@@ -108,11 +108,13 @@ __global__ __launch_bounds__(PF_TS_ROWS) void k_ts_build(const int64_t* __restri
         return;
     }
     if (tid == 0) gh_cnt[w] = h;
-    // ghost rows: ids and their SELL entries, ELL layout [window][entry j][ghost i]
+    // ghost rows: ids and (unless only the slots are wanted: gh_col == nullptr) their SELL entries, ELL layout
+    // [window][entry j][ghost i]
     for (int i = tid; i < PF_TS_GHOSTS; i += PF_TS_ROWS) {
         const bool real = i < h;
         const int32_t g = real ? ghost[i] : 0;
         gh_row[w * PF_TS_GHOSTS + i] = g;
+        if (!gh_col) continue;
         int64_t bg = 0;
         int32_t wg = 0;
         const int lg = g & (PF_WAVE - 1);
@@ -333,6 +335,50 @@ int pf_twostep_prepare(pf_graph* g) {
     g->ts_windows = nw;
     g->two_step = 1;
     return PF_OK;
+}
+
+// The window-local slots and ghost lists alone (no ghost-row entries): what the persistent kernel with x in LDS needs
+// (pf_persist.hip).  g->px_state: -1 not tried, 0 this graph is not covered, 1 ready (+ host copy of the ghost counts).
+int pf_window_slots_prepare(pf_graph* g) {
+    if (g->px_state >= 0) return PF_OK;
+    g->px_state = 0;
+    if (g->n_pad % PF_TS_ROWS != 0 || g->sell_entries <= 0) return PF_OK;
+    hipStream_t st = g->ctx->stream;
+    const int64_t nw = g->n_pad / PF_TS_ROWS;
+    int32_t* flags = nullptr;
+    hipError_t e = pf_malloc(st, (void**)&flags, sizeof(int32_t));
+    if (e == hipSuccess) e = pf_malloc(st, (void**)&g->px_slot, sizeof(int32_t) * (size_t)g->sell_entries);
+    if (e == hipSuccess) e = pf_malloc(st, (void**)&g->px_gh_cnt, sizeof(int32_t) * nw);
+    if (e == hipSuccess) e = pf_malloc(st, (void**)&g->px_gh_row, sizeof(int32_t) * nw * PF_TS_GHOSTS);
+    if (e == hipSuccess) e = hipMemsetAsync(flags, 0, sizeof(int32_t), st);
+    if (e == hipSuccess) e = hipMemsetAsync(g->px_gh_cnt, 0, sizeof(int32_t) * nw, st);
+    int32_t h_flag = 1;
+    g->h_px_gh_cnt.assign((size_t)nw, 0);
+    if (e == hipSuccess) {
+        k_ts_build<<<(unsigned)nw, PF_TS_ROWS, 0, st>>>(g->slice_ptr, g->scol, nullptr, nullptr, 0, g->px_slot, g->px_gh_cnt,
+                                                        g->px_gh_row, nullptr, nullptr, nullptr, flags);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(&h_flag, flags, sizeof(int32_t), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(g->h_px_gh_cnt.data(), g->px_gh_cnt, sizeof(int32_t) * nw, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    pf_free(st, flags);
+    if (e != hipSuccess || h_flag) {
+        (void)hipGetLastError();
+        pf_window_slots_free(g);
+        return PF_OK;  // not covered: the callers have other paths
+    }
+    g->px_state = 1;
+    return PF_OK;
+}
+
+void pf_window_slots_free(pf_graph* g) {
+    hipStream_t st = g->ctx->stream;
+    pf_free(st, g->px_slot);
+    pf_free(st, g->px_gh_cnt);
+    pf_free(st, g->px_gh_row);
+    g->px_slot = g->px_gh_cnt = g->px_gh_row = nullptr;
+    g->h_px_gh_cnt.clear();
 }
 
 int pf_twostep_launch(const pf_ts_args* a, const pf_ts_args* b) {
