@@ -46,9 +46,10 @@ std::atomic<pf_ctx*> g_owner{nullptr};
 constexpr int PS_THREADS = 1024;
 constexpr int PS_SYNC_STRIDE = 32;       // uint32 words between counters (128 B: one cache line each)
 constexpr int PS_SYNC_WORDS = 10 * PS_SYNC_STRIDE;  // 8 XCD counters, device counter, abort flag
+constexpr int PS_MAX_WINDOWS = 256;       // blocks of the x-in-LDS kernel (one window of 1024 rows each)
 constexpr int PS_RING = 256;             // result buffers per graph; a launch runs at most PS_RING - 2 steps
 constexpr unsigned PS_SPIN_LIMIT = 4000000u;
-constexpr size_t PS_LDS_LIMIT = 160 * 1024 - 256;  // static __shared__ of the kernel lives in the remainder
+constexpr size_t PS_LDS_LIMIT = 160 * 1024 - 2048;  // static __shared__ of the kernels (neighbour list, state) lives in the remainder
 
 struct PsGraph {
     const int64_t* slice_ptr;
@@ -335,7 +336,29 @@ __global__ __launch_bounds__(PS_THREADS) void k_sell_persist_x(PxArgs a) {
         pv[q] = (have[q] && g.y_prev) ? g.y_prev[row[q]] : 0.0;
         if (have[q]) xl[q][tid] = g.y_cur[row[q]];
     }
+    // the windows whose results this one reads (owners of its outside rows, either graph): the only blocks it has to
+    // wait for - no grid-wide barrier
+    __shared__ uint32_t nb_bits[PS_MAX_WINDOWS / 32];
+    __shared__ int32_t nb_list[PS_MAX_WINDOWS];
+    __shared__ int32_t nb_count;
+    if (tid < PS_MAX_WINDOWS / 32) nb_bits[tid] = 0u;
+    if (tid == 0) {
+        nb_count = 0;
+        s_state = 0;
+    }
     __syncthreads();
+#pragma unroll
+    for (int q = 0; q < NG; ++q)
+        for (int h = tid; h < ghosts[q]; h += PS_THREADS) {
+            const int32_t w = ghr[q][h] / PF_TS_ROWS;
+            atomicOr(&nb_bits[w >> 5], 1u << (w & 31));
+        }
+    __syncthreads();
+    if (tid < PS_MAX_WINDOWS && ((nb_bits[tid >> 5] >> (tid & 31)) & 1u)) nb_list[atomicAdd(&nb_count, 1)] = tid;
+    __syncthreads();
+    const int32_t n_nb = nb_count;
+    uint32_t* flags = a.sync + PS_SYNC_WORDS;            // [PS_MAX_WINDOWS] one 128-byte line each: steps finished
+    uint32_t* ab = a.sync + 9 * PS_SYNC_STRIDE;
 
     int32_t n_steps = a.g[0].k_end - a.g[0].k_begin + 1;
     if (NG > 1 && a.g[1].k_end - a.g[1].k_begin + 1 > n_steps) n_steps = a.g[1].k_end - a.g[1].k_begin + 1;
@@ -397,22 +420,20 @@ __global__ __launch_bounds__(PS_THREADS) void k_sell_persist_x(PxArgs a) {
             if (step[q]) __hip_atomic_store(&out[row[q]], res[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (t + 1 == n_steps) break;
-        // ---- barrier, with the window's own x replaced by the results between its two block-level halves
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();  // every thread has finished reading xl for this step
+        // ---- publish "step t done" and wait for the neighbours' (point to point: a window only ever reads the windows
+        // of its outside rows); the window's own x is replaced by the results in between.  Results are in buffers
+        // nobody touched before, so a window running a step ahead of a distant one harms nobody.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's results have been acknowledged
+        __syncthreads();  // ... every wave's; and every thread has finished reading xl for this step
 #pragma unroll
         for (int q = 0; q < NG; ++q)
             if (step[q]) {
                 xl[q][tid] = res[q];
                 pv[q] = xi[q];
             }
-        if (tid == 0) {
-            uint32_t* xc = a.sync + xcd * PS_SYNC_STRIDE;
-            uint32_t* dc = a.sync + 8 * PS_SYNC_STRIDE;
-            uint32_t* ab = a.sync + 9 * PS_SYNC_STRIDE;
-            if (atomicAdd(xc, 1u) + 1u == per_xcd * (unsigned)(t + 1)) atomicAdd(dc, 1u);
-            s_state = wait_for(dc, 8u * (unsigned)(t + 1), ab) ? 0 : 1;
-        }
+        if (tid == 0) __hip_atomic_store(flags + (int64_t)win * PS_SYNC_STRIDE, (uint32_t)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int i = tid; i < n_nb; i += PS_THREADS)
+            if (!wait_for(flags + (int64_t)nb_list[i] * PS_SYNC_STRIDE, (uint32_t)(t + 1), ab)) s_state = 1;
         __syncthreads();
         if (s_state != 0) {
             if (tid == 0) *a.host_abort = 1;
@@ -585,7 +606,7 @@ int pf_persist_cheb(const pf_persist_args* a, const pf_persist_args* b, int* don
     }
     hipStream_t st = ctx->stream;
     if (!ctx->persist_sync) {
-        PF_HIP(pf_malloc(st, (void**)&ctx->persist_sync, sizeof(uint32_t) * PS_SYNC_WORDS));
+        PF_HIP(pf_malloc(st, (void**)&ctx->persist_sync, sizeof(uint32_t) * (PS_SYNC_WORDS + PS_MAX_WINDOWS * PS_SYNC_STRIDE)));
         PF_HIP(hipHostMalloc((void**)&ctx->persist_abort, sizeof(int32_t), hipHostMallocDefault));
         *ctx->persist_abort = 0;
     }
@@ -647,7 +668,7 @@ int pf_persist_cheb(const pf_persist_args* a, const pf_persist_args* b, int* don
         }
         args.sync = xargs.sync = ctx->persist_sync;
         args.host_abort = xargs.host_abort = ctx->persist_abort;
-        PF_HIP(hipMemsetAsync(ctx->persist_sync, 0, sizeof(uint32_t) * PS_SYNC_WORDS, st));
+        PF_HIP(hipMemsetAsync(ctx->persist_sync, 0, sizeof(uint32_t) * (PS_SYNC_WORDS + (use_x ? PS_MAX_WINDOWS * PS_SYNC_STRIDE : 0)), st));
         if (getenv("PF_PERSIST_TEST_ABORT"))  // test hook: the first barrier finds the abort flag raised (tests/test_gpu_parity.py)
             PF_HIP(hipMemsetAsync(ctx->persist_sync + 9 * PS_SYNC_STRIDE, 1, sizeof(uint32_t), st));
         // A plain launch, not hipLaunchCooperativeKernel: one block per CU is resident-able by construction (grid <=
