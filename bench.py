@@ -364,8 +364,9 @@ def main():
         persistent = tm.get("persist_launches", 0) > 0 and tm["persist_ms"] > 0.5 * tm["op_ms"]
         if persistent:
             launches, kernel_ms, kernel_bytes = tm["persist_launches"], tm["persist_ms"], tm["persist_bytes"]
-            kernel_name = ("k_sell_persist<2> (the whole Chebyshev recurrence of both graphs of the pair in one launch: "
-                           "SELL-64 operators resident in LDS, grid barrier between steps, f64)")
+            kernel_name = ("k_sell_persist_x<2> (the whole Chebyshev recurrence of both graphs of the pair in one launch: SELL-64 "
+                           "operators and the x of each 1024-row window resident in LDS, neighbouring windows synchronise point to "
+                           "point between steps, f64)")
         else:
             launches, kernel_ms, kernel_bytes = tm["op_launches"], tm["op_ms"], tm["op_bytes"]
             kernel_name = ("k_sell_op2/k_sell_op (fused SpMV + Chebyshev recurrence, SELL-64, f64; both graphs of the pair "
@@ -419,8 +420,8 @@ def main():
             out["roofline"]["steps_per_launch"] = tm["persist_steps"] / max(launches, 1)
             out["roofline"]["us_per_step_of_the_pair"] = 1e3 * kernel_ms / max(tm["persist_steps"], 1)
             out["roofline"]["note"] = ("algorithmic bytes are what one step per launch would stream (12 nnz + 20 n + 4 per graph "
-                                       "and step); the operators stay in LDS here, so `traffic` (PMC) is far below them and "
-                                       "`achieved` is an effective rate, not HBM traffic")
+                                       "and step); the operators and x stay in LDS here, so `traffic` (PMC) is far below them and "
+                                       "`achieved` is an effective rate that can exceed the HBM peak, not HBM traffic")
         if not args.no_extras:
             copy_gbs = device_copy_gbs(torch, torch.device("cuda", local))
             out["roofline"]["achievable_copy"] = copy_gbs
