@@ -133,7 +133,8 @@ int pf_spmv(pf_graph* g, int32_t op, int32_t src, int32_t dst);           /* dst
 int pf_two_step_enable(int on);
 /* ON by default for pf_cheb2: when the SELL slices of both graphs fit the LDS of the device split over one block per
  * CU (a 250k-vertex pair on MI355X), the WHOLE recurrence runs in one persistent kernel (one block per CU) with the operators resident
- * in LDS and a grid barrier between steps (pf_persist.hip; 7.0 instead of 10.1 us per step of the pair); results are
+ * in LDS - and, when the 1024-row windows fit, x as well, with point-to-point synchronisation between neighbouring
+ * windows instead of a grid barrier - (pf_persist.hip; 4.3 instead of 10.1 us per step of the pair); results are
  * bit-identical to one step per launch.  0 switches it off (also: environment PF_PERSIST=0), 2 also routes pf_cheb
  * (one graph: no gain measured) through it; process-wide.  Needs 256 x n_pad doubles of scratch per graph.  A barrier
  * that times out is reported as PF_E_HIP at the next synchronising call and switches the path off.  One ctx per
