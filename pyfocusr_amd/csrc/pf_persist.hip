@@ -23,6 +23,10 @@
 // ~10 ns), the last arrival of an XCD bumps the device-wide counter, which everybody polls.  6.5 us per step of a
 // 250k-vertex pair, of which ~4 us are the x gathers (bound by the L1's line rate, not by latency: issuing both
 // graphs' gathers together changed nothing) and ~2.5 us the chain store-acknowledge -> arrive -> count -> poll.
+// Two kernels follow.  k_sell_persist is the scheme above as described (any partition of the slices over the blocks,
+// x gathered through L1/L2, grid barrier).  k_sell_persist_x, preferred when the graph's 1024-row windows fit, also
+// keeps x in LDS and replaces the barrier by point-to-point flags between neighbouring windows (4.3 us per step of the
+// pair); its own comment explains the differences.  Both write results to fresh ring buffers with write-through stores.
 // Tried and dropped: one kernel per graph (512 threads, half the LDS, two blocks per CU) on two streams, hoping one
 // graph's barrier chain would hide behind the other graph's gathers: 6.9 us per step of the pair against 6.5 us for
 // both graphs in one kernel (bit-identical results either way).
