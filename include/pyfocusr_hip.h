@@ -131,14 +131,16 @@ int pf_spmv(pf_graph* g, int32_t op, int32_t src, int32_t dst);           /* dst
  * rows with ghost rows, pf_twostep.hip; results bit-identical to one step per launch).  Measured slower than two
  * one-step launches on MI355X, see that file.  1 switches it on (also: environment PF_TWO_STEP=1); process-wide. */
 int pf_two_step_enable(int on);
-/* ON by default for pf_cheb2: when the SELL slices of both graphs fit the LDS of the device split over one block per
- * CU (a 250k-vertex pair on MI355X), the WHOLE recurrence runs in one persistent kernel (one block per CU) with the operators resident
- * in LDS - and, when the 1024-row windows fit, x as well, with point-to-point synchronisation between neighbouring
- * windows instead of a grid barrier - (pf_persist.hip; 4.3 instead of 10.1 us per step of the pair); results are
- * bit-identical to one step per launch.  0 switches it off (also: environment PF_PERSIST=0), 2 also routes pf_cheb
- * (one graph: no gain measured) through it; process-wide.  Needs 256 x n_pad doubles of scratch per graph.  A barrier
- * that times out is reported as PF_E_HIP at the next synchronising call and switches the path off.  One ctx per
- * process uses the path at a time (the first to get there, until it is destroyed). */
+/* ON by default: pf_cheb / pf_cheb2 run the WHOLE recurrence in one persistent kernel (one block per CU) when the
+ * graph(s) fit: each block keeps the SELL entries of a 1024-row window of every graph - and the window's x - in LDS,
+ * neighbouring windows synchronise point to point between steps (pf_persist.hip: 4.3 instead of 10.1 us per step of a
+ * 250k-vertex pair, 3.0 instead of 4.6 us for one such graph; graphs up to ~260k rows, a pair needs ~150 KB of LDS per
+ * block).  A pair whose windows do not fit with x falls back to a variant without x in LDS (any partition of the
+ * slices, grid barrier; 6.5 us), everything else to one step per launch.  Results are bit-identical in all cases.
+ * 0 switches it off (also: environment PF_PERSIST=0); 2 also routes single graphs through the variant without x (no
+ * gain measured); process-wide.  Needs 256 x n_pad doubles of scratch per graph.  A wait that times out is reported as
+ * PF_E_HIP at the next synchronising call and switches the path off.  One ctx per process uses the path at a time (the
+ * first to get there, until it is destroyed). */
 int pf_persist_enable(int on);
 int pf_cheb(pf_graph* g, int32_t op, int32_t src, int32_t dst, int32_t degree, double c, double e, double rho);
 /* Two independent recurrences (graphs a and b of one ctx) advanced in lockstep: step k of both in

@@ -452,7 +452,7 @@ int g_persist = -1;
 bool persist_enabled() {
     if (g_persist < 0) {
         const char* v = getenv("PF_PERSIST");
-        g_persist = (v && v[0] == '0') ? 0 : 1;
+        g_persist = (v && v[0] == '0') ? 0 : ((v && v[0] == '2') ? 2 : 1);
     }
     return g_persist >= 1;
 }
@@ -569,9 +569,6 @@ int pf_persist_cheb(const pf_persist_args* a, const pf_persist_args* b, int* don
     pf_ctx* ctx = ga->ctx;
     const int32_t longest = std::max(a->degree, b ? b->degree : 0);
     if (longest < 8) return PF_OK;  // staging the matrix must pay for itself
-    // One graph alone gains nothing (250k rows: 5.0 us per step here, 4.7 us per launch there: the barrier costs what
-    // the matrix traffic saves); two graphs share every barrier (7.0 vs 10.1 us).  pf_persist_enable(2) forces it.
-    if (!b && g_persist != 2) return PF_OK;
     int grid = device_grid(ctx->device);
     if (grid < 8) return PF_OK;
     // Preferred: x in LDS as well (windows of 1024 rows; needs the window-local slots of the graph(s), built once)
@@ -594,6 +591,10 @@ int pf_persist_cheb(const pf_persist_args* a, const pf_persist_args* b, int* don
         }
     }
     if (!use_x) {
+        // Without x in LDS one graph alone gains nothing (250k rows: 5.0 us per step here, 4.7 us per launch there: the
+        // barrier costs what the matrix traffic saves; with x in LDS it is 3.0 us); two graphs share every barrier
+        // (6.5 vs 10.1 us).  pf_persist_enable(2) forces it.
+        if (!b && g_persist != 2) return PF_OK;
         if (ga->n_slices < grid || (b && b->g->n_slices < grid)) return PF_OK;
         need = lds_need(ga, grid);
         if (need < 0) return PF_OK;
