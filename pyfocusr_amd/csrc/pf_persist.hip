@@ -569,6 +569,7 @@ int pf_persist_cheb(const pf_persist_args* a, const pf_persist_args* b, int* don
     pf_ctx* ctx = ga->ctx;
     const int32_t longest = std::max(a->degree, b ? b->degree : 0);
     if (longest < 8) return PF_OK;  // staging the matrix must pay for itself
+    PF_HIP(hipSetDevice(ctx->device));  // function attributes, occupancy queries and launches below are per device
     int grid = device_grid(ctx->device);
     if (grid < 8) return PF_OK;
     // Preferred: x in LDS as well (windows of 1024 rows; needs the window-local slots of the graph(s), built once)
