@@ -576,12 +576,15 @@ int pf_persist_cheb(const pf_persist_args* a, const pf_persist_args* b, int* don
     int64_t need = 0;
     bool use_x = false;
     if (x_enabled()) {
-        PF_TRY(pf_window_slots_prepare(ga));
-        if (b) PF_TRY(pf_window_slots_prepare(b->g));
-        if (ga->px_state == 1 && (!b || b->g->px_state == 1)) {
-            const int64_t wa = ga->n_pad / PF_TS_ROWS, wb = b ? b->g->n_pad / PF_TS_ROWS : 0;
-            const int64_t gx = (std::max(wa, wb) + 7) & ~(int64_t)7;
-            if (gx >= 8 && gx <= grid) {
+        const int64_t wa = ga->n_pad / PF_TS_ROWS, wb = b ? b->g->n_pad / PF_TS_ROWS : 0;
+        const int64_t gx = (std::max(wa, wb) + 7) & ~(int64_t)7;
+        const bool in_range = gx >= 8 && gx <= grid;  // (do not build window slots for graphs that cannot use them)
+        if (in_range) {
+            PF_TRY(pf_window_slots_prepare(ga));
+            if (b) PF_TRY(pf_window_slots_prepare(b->g));
+        }
+        if (in_range && ga->px_state == 1 && (!b || b->g->px_state == 1)) {
+            {
                 const int64_t nx = lds_need_x(ga, b ? b->g : nullptr);
                 if (nx > 0 && (size_t)nx + 64 <= PS_LDS_LIMIT) {
                     use_x = true;
