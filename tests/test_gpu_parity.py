@@ -745,6 +745,76 @@ def test_focusr_default_tail_of_align_maps(golden, ctx):
     assert reg.average_mesh.faces.shape == gs_["faces"].shape
 
 
+def test_tail_vs_reference_fixture(golden, ctx):
+    """SURVEY f1/f2 against outputs of the REFERENCE's own methods (tests/golden/tail_5k.npz, written by
+    tools/make_golden.py: tail_fixture): `Graph.mean_filter_graph` (graph.py:320-354, n x 3 and n x 1, 25 and 300
+    iterations), `get_smoothed_correspondences` (focusr.py:368-396), `get_weighted_final_node_locations` incl. the
+    coincident-point branch (focusr.py:401-426) and `get_nearest_neighbour_final_node_locations` (:428-431)."""
+    from pyfocusr_amd import Focusr, Graph
+
+    t, gt_, gs_ = golden("tail_5k"), golden("target_mesh"), golden("source_mesh")
+    gt = Graph(mesh_of(gt_), n_spectral_features=3, n_rand_samples=10**9, ctx=ctx, verbose=False)
+    gs = Graph(mesh_of(gs_), n_spectral_features=3, n_rand_samples=10**9, ctx=ctx, verbose=False)
+    for it in (25, 300):  # the device keeps scipy's summation order: bit-identical
+        assert np.array_equal(gt.mean_filter_graph(gt.points, iterations=it), t["mf_t_points_%d" % it])
+        assert np.array_equal(gs.mean_filter_graph(gs.points, iterations=it), t["mf_s_points_%d" % it])
+        got = np.asarray(gt.mean_filter_graph(t["scalar_in"][:, None], iterations=it)).reshape(-1, 1)
+        assert np.array_equal(got, t["mf_t_scalar_%d" % it])
+
+    reg = object.__new__(Focusr)
+    reg._ctx = ctx
+    reg.graph_target, reg.graph_source = gt, gs
+    reg.initial_correspondence_type = reg.final_correspondence_type = "kd"
+    reg.graph_smoothing_iterations, reg.projection_smooth_iterations = 300, 40  # focusr.py:49,55 defaults
+    reg.corresponding_target_idx_for_each_source_pt = t["idx_initial"].copy()
+    reg.get_smoothed_correspondences()
+    assert np.array_equal(reg.smoothed_target_coords, t["smoothed_target_coords"])
+    assert np.array_equal(reg.source_projected_on_target, t["source_projected_on_target"])
+    assert np.array_equal(reg.corresponding_target_idx_for_each_source_pt, t["idx_final"])
+    idx3, d2 = ctx.knn(reg.smoothed_target_coords, reg.source_projected_on_target, 3)
+    assert np.array_equal(idx3, t["final_top4_idx"][:, :3])
+    np.testing.assert_allclose(np.sqrt(d2), t["final_top4_dist"][:, :3], rtol=2e-16 * 4, atol=0)
+    reg.get_weighted_final_node_locations()
+    # same 3 neighbours, same distances; the average is summed pairwise here and by np.sum/sum() there
+    np.testing.assert_allclose(reg.weighted_avg_transformed_points, t["weighted_avg_transformed_points"],
+                               rtol=1e-14, atol=0)
+    reg.get_nearest_neighbour_final_node_locations()
+    assert np.array_equal(reg.nearest_neighbor_transformed_points, t["nearest_neighbor_transformed_points"])
+    reg.source_projected_on_target = t["coincident_projected"].copy()
+    reg.get_weighted_final_node_locations()
+    rows = t["coincident_rows"]
+    assert np.array_equal(reg.weighted_avg_transformed_points[rows], t["coincident_weighted_avg"][rows])
+    np.testing.assert_allclose(reg.weighted_avg_transformed_points, t["coincident_weighted_avg"], rtol=1e-14, atol=0)
+
+
+def test_focusr_end_to_end_15k(golden, ctx):
+    """BASELINE config C2 through the public API: own assembly (asymmetric W, isolated vertices) -> own
+    eigensolve (widen-and-retry: 9 columns for the source) -> eigsort flips / permutation (eigsort.py:54-140) ->
+    focusr.py:351-353 indices.  north_star: correspondence indices identical to the reference's — 0 of 14 996
+    may differ, weighted and un-weighted."""
+    from pyfocusr_amd import Focusr
+
+    p, gt_, gs_ = golden("pair_15k"), golden("target_mesh_15k"), golden("source_mesh_15k")
+    for tag, weighted in (("u", False), ("w", True)):
+        reg = Focusr(mesh_of(gt_), mesh_of(gs_), icp_register_first=False, n_spectral_features=5, n_extra_spectral=0,
+                     n_coords_spectral_ordering=20000, get_weighted_spectral_coords=weighted, list_features_to_calc=[],
+                     return_average_final_points=False, smooth_correspondences=False, ctx=ctx,
+                     registration=lambda src, tgt, kind: tgt)
+        np.testing.assert_allclose(reg.graph_target.eig_vals, gt_["k5_eig_vals"], rtol=1e-8)
+        np.testing.assert_allclose(reg.graph_source.eig_vals, gs_["k5_eig_vals"], rtol=1e-8)
+        assert reg.graph_source.eig_vecs.shape == gs_["k5_eig_vecs"].shape  # 9 columns
+        reg.align_maps()
+        np.testing.assert_allclose(reg.Q, p["Q"], rtol=1e-5)
+        assert np.max(np.abs(reg.graph_source.eig_vecs - p["eig_vecs_s_sorted"])) < 5e-7  # flips + permutation applied
+        if weighted:
+            np.testing.assert_allclose(reg.spectral_weights, p["spectral_weights"], rtol=1e-5)
+        got = reg.corresponding_target_idx_for_each_source_pt
+        bad = np.nonzero(got != p["knn_idx_" + tag])[0]
+        margins = p["knn_top2_" + tag][bad, 1] - p["knn_top2_" + tag][bad, 0] if len(bad) else []
+        assert len(bad) == 0, "%d of %d correspondences differ (%s); top-2 margins of the offenders: %s" % (
+            len(bad), len(got), tag, np.sort(margins)[:10])
+
+
 # ------------------------------------------------------------------------------- full size (C3)
 def test_full_size_250k_properties(hip, ctx):
     """BASELINE config C3 size: properties that do not need a CPU solve."""
@@ -780,6 +850,48 @@ def test_full_size_250k_properties(hip, ctx):
     idx, d2 = ctx.knn1(gr.eig_vecs, q, return_d2=True)
     sample = rng.choice(n, 300, replace=False)
     bidx, bd2 = orc.knn1_bruteforce(gr.eig_vecs, q[sample])
+    assert np.array_equal(idx[sample], bidx) and np.array_equal(d2[sample], bd2)
+
+
+def test_full_size_1m_k10_properties(hip, ctx):
+    """BASELINE config C5 size on one GPU (1M-vertex blob pair, k=10): the size-independent properties of
+    `test_full_size_250k_properties` — W bit-exact vs the oracle formula, residuals against the oracle's L,
+    eigenvalue order, paired solve == what the pair path returns, KNN (d=10) idempotence and sampled rows
+    against brute force."""
+    from pyfocusr_amd import Graph, compute_spectra
+    from pyfocusr_amd.meshgen import blob_mesh
+
+    n, k = 1000000, 10
+    meshes = [blob_mesh(n, seed=s) for s in (0, 1)]
+    graphs = [Graph(m, n_spectral_features=k, n_rand_samples=10**9, norm_eig_vecs=nrm, ctx=ctx, verbose=False)
+              for m, nrm in zip(meshes, (False, True))]
+    dev = graphs[0].device
+    assert dev.symmetric and dev.n_components == 1 and dev.n_isolated == 0
+    assert dev.nnz_w == 3 * len(meshes[0].faces) and dev.nnz_l == n + 3 * len(meshes[0].faces)
+    h = dev.download()
+    W = orc.weighted_adjacency(meshes[0].points, meshes[0].faces)
+    assert np.array_equal(h["rowptr"], W.indptr) and np.array_equal(h["colidx"], W.indices)
+    assert np.array_equal(h["w"], W.data)
+    compute_spectra(graphs)
+    for gr in graphs:
+        assert gr.eig_vals.shape == (k,) and np.all(np.diff(gr.eig_vals) > 0) and gr.eig_vals[0] > 1e-10
+        assert gr.eig_vecs.shape == (n, k)
+        assert gr.eigs_stats.residuals.max() < 1e-10
+    deg, d_inv = orc.degree_and_inverse(W)
+    L = orc.laplacian(W, deg, d_inv)
+    vecs, vals = graphs[0].eig_vecs, graphs[0].eig_vals  # raw unit-norm vectors of the seed-0 mesh
+    np.testing.assert_allclose(np.linalg.norm(vecs, axis=0), 1.0, rtol=1e-12)
+    R = L @ vecs - vecs * vals[None, :]
+    assert np.max(np.linalg.norm(R, axis=0)) < 1e-10
+    tv = graphs[1].eig_vecs
+    assert tv.min() == -0.5 and tv.max() == 0.5
+    idx, d2 = ctx.knn1(tv, tv, return_d2=True)
+    assert np.array_equal(idx, np.arange(n)) and np.all(d2 == 0)
+    sv = (vecs - vecs.min(axis=0)) / np.ptp(vecs, axis=0) - 0.5
+    idx, d2 = ctx.knn1(tv, sv, return_d2=True)  # focusr.py:351-353 at C5 size, d = 10
+    rng = np.random.default_rng(5)
+    sample = rng.choice(n, 96, replace=False)
+    bidx, bd2 = orc.knn1_bruteforce(tv, sv[sample], chunk=32)
     assert np.array_equal(idx[sample], bidx) and np.array_equal(d2[sample], bd2)
 
 

@@ -123,3 +123,31 @@ def test_set_semantics_properties():
         assert np.max(np.abs(np.asarray(L.sum(axis=1)))) < 1e-14  # random-walk Laplacian: rows sum to ~0
 
     run()
+
+
+def test_tail_fixture_mean_filter_and_final_locations(golden):
+    """"Next" rows f1/f2 pinned: oracle `mean_filter_graph` (graph.py:320-354), smoothed correspondences
+    (focusr.py:368-396) and weighted final locations incl. the coincident branch (focusr.py:401-426) against
+    outputs of the REFERENCE's own methods (tools/make_golden.py: tail_fixture -> tests/golden/tail_5k.npz)."""
+    t, gt, gs = golden("tail_5k"), golden("target_mesh"), golden("source_mesh")
+    nt, ns = len(gt["points"]), len(gs["points"])
+    Wt = sparse.csr_matrix((gt["W_data"], gt["W_indices"], gt["W_indptr"]), shape=(nt, nt))
+    Ws = sparse.csr_matrix((gs["W_data"], gs["W_indices"], gs["W_indptr"]), shape=(ns, ns))
+    for it in (25, 300):
+        assert np.array_equal(orc.mean_filter_graph(Wt, gt["points"], it), t["mf_t_points_%d" % it])
+        assert np.array_equal(orc.mean_filter_graph(Wt, t["scalar_in"][:, None], it), t["mf_t_scalar_%d" % it])
+        assert np.array_equal(orc.mean_filter_graph(Ws, gs["points"], it), t["mf_s_points_%d" % it])
+    assert np.array_equal(t["idx_initial"], golden("pair_5k")["knn_idx_w"])
+    sm, proj, idx = orc.smoothed_correspondences(Wt, Ws, gt["points"], t["idx_initial"], 300, 40)
+    assert np.array_equal(sm, t["smoothed_target_coords"])
+    assert np.array_equal(proj, t["source_projected_on_target"])
+    assert np.array_equal(idx, t["idx_final"])
+    assert np.array_equal(gt["points"][idx], t["nearest_neighbor_transformed_points"])
+    out = orc.weighted_final_node_locations(sm, proj, gt["points"])
+    assert np.array_equal(out, t["weighted_avg_transformed_points"])
+    out_c = orc.weighted_final_node_locations(sm, t["coincident_projected"], gt["points"])
+    assert np.array_equal(out_c, t["coincident_weighted_avg"])
+    rows = t["coincident_rows"]
+    hit = (rows * 13 + 5) % nt
+    hit[1] = hit[0]
+    assert np.array_equal(out_c[rows], gt["points"][hit])  # focusr.py:415-419: the coincident target point itself

@@ -147,12 +147,77 @@ def pair_fixture(ref, mesh_t, mesh_s, fix_t, fix_s, k, ns):
     return out
 
 
+def tail_fixture(ref, mesh_t, mesh_s, idx_initial):
+    """Reference outputs of the post-KNN tail ("next" rows f1/f2 of SURVEY §8f):
+    `Graph.mean_filter_graph` (graph.py:320-354) on n x 3 and n x 1 values for 25 and 300
+    iterations, `Focusr.get_smoothed_correspondences` (focusr.py:368-396, both correspondence
+    types "kd") and `Focusr.get_weighted_final_node_locations` (focusr.py:401-426) including
+    its coincident-point branch (:415-419), driven from the reference's own initial
+    correspondences `idx_initial` (pair fixture, `knn_idx_w`)."""
+    def graph(mesh):
+        g = ref.Graph(mesh, n_spectral_features=3, n_rand_samples=mesh.GetNumberOfPoints() + 1,
+                      feature_weights=np.eye(0))
+        quiet(g.get_weighted_adjacency_matrix)
+        return g
+
+    gt, gs = graph(mesh_t), graph(mesh_s)
+    out = {}
+    scalar = np.cos(3.0 * gt.normed_points[:, 0]) + gt.normed_points[:, 1] ** 2  # any n x 1 signal
+    out["scalar_in"] = scalar
+    for it in (25, 300):
+        out["mf_t_points_%d" % it] = np.asarray(gt.mean_filter_graph(gt.points, iterations=it))
+        out["mf_t_scalar_%d" % it] = np.asarray(gt.mean_filter_graph(scalar[:, None], iterations=it))
+        out["mf_s_points_%d" % it] = np.asarray(gs.mean_filter_graph(gs.points, iterations=it))
+
+    reg = object.__new__(ref.Focusr)  # drive focusr.py:368-426 without ICP / CPD
+    reg.graph_target, reg.graph_source = gt, gs
+    reg.initial_correspondence_type = "kd"
+    reg.final_correspondence_type = "kd"
+    reg.graph_smoothing_iterations = 300  # focusr.py:49 default
+    reg.projection_smooth_iterations = 40  # focusr.py:55 default
+    reg.corresponding_target_idx_for_each_source_pt = np.array(idx_initial)
+    out["idx_initial"] = np.asarray(idx_initial, dtype=np.int64)
+    reg.get_smoothed_correspondences()
+    out["smoothed_target_coords"] = np.asarray(reg.smoothed_target_coords)
+    out["source_projected_on_target"] = np.asarray(reg.source_projected_on_target)
+    out["idx_final"] = np.asarray(reg.corresponding_target_idx_for_each_source_pt, dtype=np.int64)
+    reg.get_weighted_final_node_locations()
+    out["weighted_avg_transformed_points"] = np.array(reg.weighted_avg_transformed_points)
+    reg.get_nearest_neighbour_final_node_locations()
+    out["nearest_neighbor_transformed_points"] = np.array(reg.nearest_neighbor_transformed_points)
+    d3, i3 = __import__("scipy.spatial", fromlist=["KDTree"]).KDTree(reg.smoothed_target_coords).query(
+        reg.source_projected_on_target, k=4)
+    out["final_top4_dist"], out["final_top4_idx"] = d3, i3  # tie margins of the 3-NN sets
+
+    # coincident-point branch (focusr.py:415-419): every 7th projected point is put exactly on a
+    # smoothed target point (a different one each time), two of them on the SAME target point.
+    proj = np.array(reg.source_projected_on_target)
+    hit = np.arange(0, len(proj), 7)
+    tgt = (hit * 13 + 5) % len(reg.smoothed_target_coords)
+    tgt[1] = tgt[0]
+    proj[hit, :] = reg.smoothed_target_coords[tgt, :]
+    reg.source_projected_on_target = proj
+    reg.get_weighted_final_node_locations()
+    out["coincident_projected"] = proj
+    out["coincident_rows"] = hit
+    out["coincident_weighted_avg"] = np.array(reg.weighted_avg_transformed_points)
+    return out
+
+
 def main():
     ref = import_reference()
     sys.path.insert(0, REPO)
     from pyfocusr_amd.vtk_functions import read_vtk_mesh
 
     os.makedirs(OUT, exist_ok=True)
+    if "--only-tail" in sys.argv:  # adds tail_5k.npz next to the existing fixtures, which stay as they are
+        mt = read_vtk_mesh(os.path.join(REF, "data", "target_mesh.vtk"))
+        ms = read_vtk_mesh(os.path.join(REF, "data", "source_mesh.vtk"))
+        idx = np.load(os.path.join(OUT, "pair_5k.npz"))["knn_idx_w"]
+        tf = tail_fixture(ref, mt, ms, idx)
+        np.savez_compressed(os.path.join(OUT, "tail_5k.npz"), **tf)
+        print("tail_5k", {k: v.shape for k, v in tf.items()})
+        return
     meshes, fixtures = {}, {}
     for name, ks in (("target_mesh", (3, 6)), ("source_mesh", (3, 6)),
                      ("target_mesh_15k", (5,)), ("source_mesh_15k", (5,))):
@@ -166,6 +231,9 @@ def main():
         pf = pair_fixture(ref, meshes[t], meshes[s], fixtures[t], fixtures[s], k, ns)
         np.savez_compressed(os.path.join(OUT, tag + ".npz"), **pf)
         print(tag, "Q", pf["Q"], "flipped", pf["flipped"], "matches", pf["source_matches"])
+        if tag == "pair_5k":
+            tf = tail_fixture(ref, meshes[t], meshes[s], pf["knn_idx_w"])
+            np.savez_compressed(os.path.join(OUT, "tail_5k.npz"), **tf)
 
 
 if __name__ == "__main__":
