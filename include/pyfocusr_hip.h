@@ -33,6 +33,10 @@ extern "C" {
 #define PF_E_HIP (-2)        /* HIP runtime error (allocation, launch, copy); see pf_last_error() */
 #define PF_E_DEGENERATE (-3) /* a face repeats a vertex: the reference would store W_ii = inf */
 #define PF_E_STATE (-4)      /* call order violated (e.g. knn run before upload) */
+#define PF_E_PERSIST_TIMEOUT (-5) /* a wait inside the resident Chebyshev kernel ran out (device shared?): the filter
+                                     applications since the last synchronising call are invalid; the stream has been
+                                     drained and the path switched off - repeat the solve (pf_eigs_smallest and the
+                                     Python drivers do so by themselves) */
 
 /* operator selector for the eigensolver kernels */
 #define PF_OP_RW 0  /* L = G (D - W), G = diag(1/(deg+1e-8))   graph.py:216-226 (as stored by the reference) */
@@ -127,21 +131,20 @@ int pf_spmv(pf_graph* g, int32_t op, int32_t src, int32_t dst);           /* dst
 /* dst = T_degree((c I - A)/e) src / rho^degree : `degree` launches of the fused SpMV + three-term
  * recurrence kernel (scaled by rho >= 1 per step so that high degrees cannot overflow; rho = 1 is the
  * plain Chebyshev polynomial).  src is preserved; dst != src. */
-/* Experimental, OFF by default: pf_cheb / pf_cheb2 can run TWO recurrence steps per kernel launch (windows of 1024
- * rows with ghost rows, pf_twostep.hip; results bit-identical to one step per launch).  Measured slower than two
- * one-step launches on MI355X, see that file.  1 switches it on (also: environment PF_TWO_STEP=1); process-wide. */
-int pf_two_step_enable(int on);
-/* ON by default: pf_cheb / pf_cheb2 run the WHOLE recurrence in one persistent kernel (one block per CU) when the
- * graph(s) fit: each block keeps the SELL entries of a 1024-row window of every graph - and the window's x - in LDS,
- * neighbouring windows synchronise point to point between steps (pf_persist.hip: 4.3 instead of 10.1 us per step of a
- * 250k-vertex pair, 3.0 instead of 4.6 us for one such graph; graphs up to ~260k rows, a pair needs ~150 KB of LDS per
- * block).  A pair whose windows do not fit with x falls back to a variant without x in LDS (any partition of the
- * slices, grid barrier; 6.5 us), everything else to one step per launch.  Results are bit-identical in all cases.
- * 0 switches it off (also: environment PF_PERSIST=0); 2 also routes single graphs through the variant without x (no
- * gain measured); process-wide.  Needs 256 x n_pad doubles of scratch per graph.  A wait that times out is reported as
- * PF_E_HIP at the next synchronising call and switches the path off.  One ctx per process uses the path at a time (the
- * first to get there, until it is destroyed). */
+/* ON by default: pf_cheb / pf_cheb2 run the WHOLE recurrence in one resident kernel (one block per CU) when the
+ * graph(s) fit: each block owns a window of 1024 / 2048 / 4096 consecutive rows of every graph, keeps the rows' entries
+ * in registers and the window's x in LDS, and neighbouring windows hand their boundary rows over through memory, one
+ * value per outside row, no flags (pf_persist.hip; graphs up to 256 windows: ~1M rows, pairs up to ~524k rows each).
+ * Everything else runs one step per launch.  Results are bit-identical in all cases.  0 switches it off (also:
+ * environment PF_PERSIST=0); process-wide.  Needs 4 x n_pad doubles of scratch per graph.  All blocks must be resident
+ * together (grid <= CU count; an idle device): a wait that runs out (another tenant on the device) is reported as
+ * PF_E_PERSIST_TIMEOUT at the next synchronising call, after the library has drained the stream and switched the path
+ * off for the process.  One ctx per process uses the path at a time (the first to get there, until it is destroyed);
+ * other ctxs run one step per launch. */
 int pf_persist_enable(int on);
+/* Test hook: the next n resident launches start with their abort flag raised (they give up at once and the
+ * PF_E_PERSIST_TIMEOUT recovery runs).  Never needed in production. */
+int pf_persist_test_hook(int n_launches);
 int pf_cheb(pf_graph* g, int32_t op, int32_t src, int32_t dst, int32_t degree, double c, double e, double rho);
 /* Two independent recurrences (graphs a and b of one ctx) advanced in lockstep: step k of both in
  * ONE launch while both have steps left, the longer one alone afterwards. */

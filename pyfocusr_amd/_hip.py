@@ -77,8 +77,8 @@ SIGNATURES = {
     "pf_mask_isolated": (C.c_int, [C.c_void_p, C.c_int32]),
     "pf_lock_null_vectors": (C.c_int, [C.c_void_p, C.c_int32, _i32p]),
     "pf_spmv": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
-    "pf_two_step_enable": (C.c_int, [C.c_int]),
     "pf_persist_enable": (C.c_int, [C.c_int]),
+    "pf_persist_test_hook": (C.c_int, [C.c_int]),
     "pf_cheb": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double]),
     "pf_cheb2": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double,
                            C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double]),
@@ -163,17 +163,18 @@ def load_library():
         return lib
 
 
-def two_step_enable(on=True):
-    """Process-wide switch of the experimental two-steps-per-launch Chebyshev kernel (off by default: measured slower
-    than two one-step launches, see csrc/pf_twostep.hip)."""
-    _check(load_library().pf_two_step_enable(int(bool(on))))
+PF_E_PERSIST_TIMEOUT = -5
 
 
 def persist_enable(on=True):
-    """Process-wide switch of the persistent Chebyshev kernel (operator resident in LDS, one kernel per filter
-    application; on by default for PAIRS of graphs (`cheb2`), see csrc/pf_persist.hip; `on=2` also routes single-graph
-    applications through it).  Results are bit-identical either way."""
-    _check(load_library().pf_persist_enable(2 if on == 2 else int(bool(on))))
+    """Process-wide switch of the resident Chebyshev kernel (operator in registers, x in LDS, one kernel per filter
+    application; on by default, see csrc/pf_persist.hip).  Results are bit-identical either way."""
+    _check(load_library().pf_persist_enable(int(bool(on))))
+
+
+def persist_test_hook(n_launches=1):
+    """Test hook: the next `n_launches` resident launches give up at once (PF_E_PERSIST_TIMEOUT recovery)."""
+    _check(load_library().pf_persist_test_hook(int(n_launches)))
 
 
 def _check(code):

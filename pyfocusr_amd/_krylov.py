@@ -169,22 +169,66 @@ def _select_dominant(ev, n_real, n_extra, count_all):
     return q, thr, int(min(cnt[-1], n_real)) if m else 0, order
 
 
+RETRY_CODE = -5  # PF_E_PERSIST_TIMEOUT of the C-ABI: filter applications in flight were invalid, repeat the solve
+MAX_RETRIES = 2
+
+
+def _retryable(exc):
+    return getattr(exc, "code", None) == RETRY_CODE
+
+
+def _abandon(ops):
+    """A solve was cut short: collect whatever orthogonalisation it left in flight."""
+    fn = getattr(ops, "orth_abandon", None)
+    if fn is not None:
+        fn()
+
+
 def drive(gen, ops):
-    """Run a solver generator to completion, executing each filter request on `ops`."""
-    try:
-        req = next(gen)
-        while True:
-            ops.cheb(*req)
-            req = gen.send(None)
-    except StopIteration as stop:
-        return stop.value
+    """Run a solver generator to completion, executing each filter request on `ops`.  `gen` is a generator, or a
+    zero-argument callable that makes one: then a solve whose filter applications the device library declared invalid
+    (error code RETRY_CODE: the library has drained its stream and switched to its other filter path by then) is
+    repeated from the start."""
+    make = gen if callable(gen) else None
+    for attempt in range(MAX_RETRIES + 1):
+        g = make() if make is not None else gen
+        try:
+            req = next(g)
+            while True:
+                ops.cheb(*req)
+                req = g.send(None)
+        except StopIteration as stop:
+            return stop.value
+        except Exception as exc:  # noqa: BLE001
+            if make is None or not _retryable(exc) or attempt == MAX_RETRIES:
+                raise
+            g.close()
+            _abandon(ops)
 
 
 def drive_pair(gen_a, ops_a, gen_b, ops_b):
     """Run two solver generators in lockstep: while both have a filter application pending,
     the two Chebyshev recurrences advance in shared kernel launches (`ops.cheb2`); once one
-    solver has finished the other continues alone.  Returns both results."""
-    gens, ops, reqs, results = [gen_a, gen_b], [ops_a, ops_b], [None, None], [None, None]
+    solver has finished the other continues alone.  Returns both results.  Generators or generator factories, as for
+    `drive` (with factories BOTH solves are repeated after a RETRY_CODE error: they share their launches)."""
+    makes = [gen_a if callable(gen_a) else None, gen_b if callable(gen_b) else None]
+    can_retry = makes[0] is not None and makes[1] is not None
+    for attempt in range(MAX_RETRIES + 1):
+        gens = [makes[0]() if makes[0] is not None else gen_a, makes[1]() if makes[1] is not None else gen_b]
+        try:
+            return _drive_pair_once(gens, [ops_a, ops_b])
+        except Exception as exc:  # noqa: BLE001
+            if not can_retry or not _retryable(exc) or attempt == MAX_RETRIES:
+                raise
+            for g in gens:
+                if g is not None:
+                    g.close()
+            _abandon(ops_a)
+            _abandon(ops_b)
+
+
+def _drive_pair_once(gens, ops):
+    reqs, results = [None, None], [None, None]
 
     def advance(i, first=False):
         try:
@@ -209,7 +253,7 @@ def drive_pair(gen_a, ops_a, gen_b, ops_b):
 def filtered_eigs(ops, n_wanted, symmetric, **kw):
     """Smallest `n_wanted` non-null eigenpairs of the Laplacian held by `ops`
     (see `filtered_eigs_gen` for arguments and return value)."""
-    return drive(filtered_eigs_gen(ops, n_wanted, symmetric, **kw), ops)
+    return drive(lambda: filtered_eigs_gen(ops, n_wanted, symmetric, **kw), ops)
 
 
 class _NeedEllipse(Exception):
@@ -482,4 +526,5 @@ def _solve_gen(ops, n_wanted, symmetric, null_slots=0, cut=None, tol=1e-12, m_ma
     ops.combine(A0, q, R, AX0)  # A X = (A Z) R
     # (for a complex pair the real part alone is not an eigenvector: its "residual" is |Im lambda| * |Im x|)
     stats.residuals = np.array([ops.resnorm(AX0 + i, X0 + i, lam[i]) for i in range(nk)])
+    ops.sync()  # nothing of this solve is left in flight (a speculative filter application that failed surfaces here)
     return lam, X0, stats

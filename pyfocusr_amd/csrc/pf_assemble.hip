@@ -283,7 +283,7 @@ __global__ __launch_bounds__(PF_BLOCK) void k_fill_sell(const int32_t* __restric
             sval_rw[idx] = -(gi * wv);  // L_ij = g_i * (0 - W_ij)
             if (sval_sym) sval_sym[idx] = -(wv * (si * sg[c]));
         } else {
-            scol[idx] = (int32_t)(row < n ? row : 0);  // padding: zero weight on an in-range, cached column
+            scol[idx] = (int32_t)row;  // padding: zero weight on the row's own (in-window) column
             sval_rw[idx] = 0.0;
             if (sval_sym) sval_sym[idx] = 0.0;
         }
@@ -415,7 +415,6 @@ int finish_graph(pf_graph* g, const double* d_pts, bool numeric_symmetry) {
     int32_t h_stats[6];
     PF_HIP(hipMemcpyAsync(h_stats, stats, sizeof(int32_t) * 5, hipMemcpyDeviceToHost, st));
     g->h_slice_ptr.resize((size_t)g->n_slices + 1);  // the persistent Chebyshev kernel sizes its LDS from this
-    g->persist_grid = 0;
     PF_HIP(hipMemcpyAsync(g->h_slice_ptr.data(), g->slice_ptr, sizeof(int64_t) * (g->n_slices + 1), hipMemcpyDeviceToHost, st));
     PF_HIP(hipMemcpyAsync(&g->sell_entries, g->slice_ptr + g->n_slices, sizeof(int64_t), hipMemcpyDeviceToHost, st));
     PF_HIP(hipStreamSynchronize(st));
@@ -474,7 +473,6 @@ void pf_graph_free(pf_graph* g) {
     pf_free(st, g->diag);
     pf_free(st, g->mf_col);
     pf_free(st, g->mf_val);
-    pf_twostep_free(g);
     pf_free(st, g->ws);
     pf_free(st, g->partials);
     pf_free(st, g->coef);
@@ -558,6 +556,7 @@ int pf_graph_build_device(pf_mesh* mesh, pf_graph** out) {
     g->n_faces = n_faces;
     g->vpf = vpf;
     g->n_pad = (n + 4095) / 4096 * 4096;  // whole blocks of up to 512 rows, a multiple of 8 of them (XCD remap)
+    g->win_rows = pf_window_rows(g->n_pad);
     g->n_slices = g->n_pad / PF_WAVE;
     g->n_chunks = (g->n_pad + PF_DOT_CHUNK - 1) / PF_DOT_CHUNK;
 
@@ -665,6 +664,7 @@ int pf_graph_from_matrix(pf_ctx* ctx, int64_t n, const int32_t* rowptr, const in
     g->unit_g = 1;
     g->n = n;
     g->n_pad = (n + 4095) / 4096 * 4096;
+    g->win_rows = pf_window_rows(g->n_pad);
     g->n_slices = g->n_pad / PF_WAVE;
     g->n_chunks = (g->n_pad + PF_DOT_CHUNK - 1) / PF_DOT_CHUNK;
     struct Guard {

@@ -91,10 +91,8 @@ void ritz_sorted(const std::vector<double>& H, int ld, int j, std::vector<double
     }
 }
 
-}  // namespace
-
-extern "C" int pf_eigs_smallest(pf_graph* g, int32_t n_wanted, int32_t minmax, double* vals, double* vecs, int32_t* n_out,
-                                pf_eigs_stats* stats_out) {
+int eigs_smallest_once(pf_graph* g, int32_t n_wanted, int32_t minmax, double* vals, double* vecs, int32_t* n_out,
+                       pf_eigs_stats* stats_out) {
     PF_CHECK(g && vals && vecs && n_out && n_wanted >= 1, PF_E_ARG, "pf_eigs_smallest: bad argument");
     PF_CHECK(g->is_symmetric, PF_E_STATE, "pf_eigs_smallest: W is not symmetric (one-way edges): use the Python driver");
     const double hi = 2.0, strength = 2.0, tol = 1e-12;
@@ -250,5 +248,19 @@ extern "C" int pf_eigs_smallest(pf_graph* g, int32_t n_wanted, int32_t minmax, d
     }
     *n_out = nk;
     if (stats_out) *stats_out = st;
-    return PF_OK;
+    return pf_sync(g->ctx);  // nothing of this solve is left in flight (and a late PF_E_PERSIST_TIMEOUT surfaces here)
+}
+
+}  // namespace
+
+// A wait of the resident filter kernel that ran out (PF_E_PERSIST_TIMEOUT: the stream is drained and the path switched
+// off by then) invalidates the filter applications in flight; the solve is simply repeated, one step per launch.
+extern "C" int pf_eigs_smallest(pf_graph* g, int32_t n_wanted, int32_t minmax, double* vals, double* vecs, int32_t* n_out,
+                                pf_eigs_stats* stats_out) {
+    int rc = PF_OK;
+    for (int attempt = 0; attempt < 3; ++attempt) {
+        rc = eigs_smallest_once(g, n_wanted, minmax, vals, vecs, n_out, stats_out);
+        if (rc != PF_E_PERSIST_TIMEOUT) break;
+    }
+    return rc;
 }

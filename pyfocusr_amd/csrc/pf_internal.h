@@ -38,8 +38,9 @@ constexpr int PF_WAVE = 64;        // gfx950 wavefront
 constexpr int PF_BLOCK = 256;      // 4 waves: one per SIMD of a CU
 constexpr int PF_DOT_CHUNK = 4096; // rows per block in the reduction kernels
 constexpr int PF_MAX_ROOTS = 4096; // components tracked explicitly
-constexpr int PF_TS_ROWS = 1024;   // rows per window of the two-step operator kernel (= degree-sort window of pf_reorder)
-constexpr int PF_TS_GHOSTS = 1024; // ghost rows a window may have
+constexpr int PF_WIN_THREADS = 1024; // threads of a window block of the resident Chebyshev kernel (pf_persist.hip)
+constexpr int PF_WIN_GHOSTS = 1024;  // outside rows a window may read (one per thread)
+constexpr int PF_WIN_MAX = 1024;     // windows per graph the window structures cover
 constexpr int PF_WS_TMPS = 4;      // temporaries behind the workspace slots (Chebyshev rotation)
 
 struct pf_ctx {
@@ -124,30 +125,20 @@ struct pf_graph {
     // with slice s at slice_ptr[s] + 64 s and width + 1 entries per row, in DESCENDING mesh column order
     int32_t* mf_col = nullptr;    // [sell_entries + n_pad]
     double* mf_val = nullptr;
-    // two Chebyshev steps per launch (pf_twostep.hip, built on first use): windows of PF_TS_ROWS solver-order rows,
-    // each with the list of outside rows its rows touch (ghosts), those rows' matrix entries, and the window-local
-    // position of every column of its own entries
-    int32_t two_step = -1;        // -1 not tried, 0 unavailable for this graph, 1 ready
-    int32_t ts_width = 0;         // entries kept per ghost row (>= widest SELL slice)
-    int64_t ts_windows = 0;
-    int32_t* ts_scol2 = nullptr;  // [sell_entries] window-local slot of scol: < PF_TS_ROWS own row, else PF_TS_ROWS + ghost index
-    int32_t* ts_gh_cnt = nullptr; // [windows]
-    int32_t* ts_gh_row = nullptr; // [windows][PF_TS_GHOSTS]
-    int32_t* ts_gh_col = nullptr; // [windows][ts_width][PF_TS_GHOSTS]
-    double* ts_gh_rw = nullptr;   // same shape: values of the RW operator
-    double* ts_gh_sym = nullptr;  // same shape: values of the SYM operator (symmetric graphs)
-    // persistent Chebyshev kernel (pf_persist.hip): host copy of slice_ptr and the LDS need of the fullest block
-    std::vector<int64_t> h_slice_ptr;
-    double* persist_ring = nullptr;  // [256][n_pad] result buffers, each written once per launch
-    // windows of 1024 rows: window-local slot of every SELL column (own row, or 1024 + index into the window's sorted
-    // list of outside rows) for the persistent kernel that keeps x in LDS too
-    int32_t px_state = -1;
-    int32_t* px_slot = nullptr;    // [sell_entries]
+    // windows of the resident Chebyshev kernel (pf_windows.hip / pf_persist.hip): win_rows (1024, 2048 or 4096, from
+    // n_pad) consecutive solver-order rows, boundary rows first (pf_reorder.hip).  Built on first use (px_state).
+    int32_t win_rows = 1024;
+    std::vector<int64_t> h_slice_ptr;  // host copy of slice_ptr (LDS sizing)
+    int32_t px_state = -1;         // -1 not tried, 0 this graph is not covered, 1 ready
+    int32_t* px_slot = nullptr;    // [sell_entries] window-local slot of every SELL column: own row, or win_rows + index
+                                   // into the window's sorted list of outside rows
     int32_t* px_gh_cnt = nullptr;  // [windows]
-    int32_t* px_gh_row = nullptr;  // [windows][PF_TS_GHOSTS]
+    int32_t* px_gh_row = nullptr;  // [windows][PF_WIN_GHOSTS]
+    int32_t* px_need = nullptr;    // [windows] leading rows of the window that other windows read (>= 1)
     std::vector<int32_t> h_px_gh_cnt;
-    int32_t persist_grid = 0;
-    int64_t persist_lds = 0;
+    double* persist_ring = nullptr;  // [4][n_pad] hand-off buffers of the windows' boundary rows (sentinel when empty)
+    int32_t persist_phase = 0;       // ring slot of step k of the next launch = (k + phase) & 3
+    uint64_t persist_epoch = 0;      // ring known good for this value of the library's abort epoch
     int32_t is_symmetric = 0, n_isolated = 0, n_components = 0, max_degree = 0, n_oneway = 0;
     int32_t unit_g = 0;  // graph handed in as a matrix (pf_graph_from_matrix): G = I, the operator is the matrix itself
     std::vector<int32_t> roots; // roots of components with >= 2 vertices, ascending
@@ -199,18 +190,11 @@ int pf_reduce_ensure(pf_graph* g, int32_t count);
 // pf_reorder.hip
 int pf_compute_order(pf_graph* g, const double* d_pts);
 
-// pf_twostep.hip: two steps of  y <- alpha (shift y - A y) - beta y_prev  per launch, for one or two graphs
-struct pf_ts_args {
-    pf_graph* g;
-    const double* vals;   // SELL values of the operator
-    const double* ghvals; // ghost-row values of the same operator
-    const double* p;      // y_{k-1}
-    const double* x;      // y_k
-    double* z1;           // y_{k+1}
-    double* z2;           // y_{k+2}
-    double alpha, shift, beta;
-};
-// pf_persist.hip: a whole recurrence T_degree((c - A)/e)/rho^degree src -> dst in one cooperative kernel
+// Rows per window of the resident Chebyshev kernel: one window per block, at most 256 blocks.
+static inline int32_t pf_window_rows(int64_t n_pad) { return n_pad <= 262144 ? 1024 : (n_pad <= 524288 ? 2048 : 4096); }
+
+// pf_persist.hip: a whole recurrence T_degree((c - A)/e)/rho^degree src -> dst in ONE kernel (operator in registers,
+// x in LDS, neighbouring windows hand their boundary rows over through memory)
 struct pf_persist_args {
     pf_graph* g;
     const double* vals;
@@ -220,11 +204,9 @@ struct pf_persist_args {
     double c, e, rho;
 };
 int pf_persist_cheb(const pf_persist_args* a, const pf_persist_args* b /* nullable */, int* done);
-int pf_persist_check(pf_ctx* ctx);  // PF_E_HIP if a barrier of an earlier launch timed out
+int pf_persist_check(pf_ctx* ctx);  // PF_E_PERSIST_TIMEOUT (stream drained, path switched off) if a wait of an earlier launch ran out
 int pf_persist_set(int on);
-void pf_persist_release(pf_ctx* ctx);  // pf_destroy: another ctx may take the persistent path over
-int pf_window_slots_prepare(pf_graph* g);  // pf_twostep.hip: px_* of the graph (see pf_graph)
+void pf_persist_release(pf_ctx* ctx);  // pf_destroy: another ctx may take the resident path over
+// pf_windows.hip
+int pf_window_slots_prepare(pf_graph* g);  // px_* of the graph (see pf_graph)
 void pf_window_slots_free(pf_graph* g);
-int pf_twostep_prepare(pf_graph* g);  // builds the window structures once; g->two_step tells whether they exist
-int pf_twostep_launch(const pf_ts_args* a, const pf_ts_args* b /* nullable */);
-void pf_twostep_free(pf_graph* g);

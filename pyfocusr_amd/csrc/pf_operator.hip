@@ -627,12 +627,11 @@ int launch_op2(pf_graph* ga, const OpArgs& a, const OpArgs& b, bool has_prev) {
 
 // One Chebyshev recurrence: y0 = src; y1 = (c y0 - A y0)/(e rho); y_{k+1} = (2/(e rho))(c y_k - A y_k) - y_{k-1}/rho^2
 // (rho > 1: scaled by rho^-k, so the result is T_p(.)/rho^p and high degrees cannot overflow).  Steps run one per
-// launch (sell_op_block) or two per launch (pf_twostep.hip) through four rotating temporaries; the caller's src is
-// never overwritten and the last step lands in dst.
+// launch (sell_op_block) through rotating temporaries; the caller's src is never overwritten and the last step
+// lands in dst.
 struct ChebRun {
     pf_graph* g;
     const double* vals;
-    const double* ghvals;  // ghost-row values of the same operator, or nullptr: one step per launch only
     const double* src;
     double* dst;
     int32_t degree;
@@ -642,7 +641,6 @@ struct ChebRun {
     int32_t done = 0;
 
     int32_t left() const { return degree - done; }
-    bool can_double() const { return ghvals != nullptr && done >= 1 && left() >= 2; }
     double* free_tmp(int which) const {  // the which-th temporary that holds neither y_{done-1} nor y_done
         for (int t = 0; t < PF_WS_TMPS; ++t) {
             double* b = pf_tmp(g, t);
@@ -662,35 +660,7 @@ struct ChebRun {
         yp = yc, yc = target, done += 1;
         return a;
     }
-    pf_ts_args twin() {  // two steps k, k+1 > 1
-        double* z1 = free_tmp(0);
-        double* z2 = left() == 2 ? dst : free_tmp(1);
-        const pf_ts_args a{g, vals, ghvals, yp, yc, z1, z2, 2.0 / (e * rho), c, 1.0 / (rho * rho)};
-        yp = z1, yc = z2, done += 2;
-        return a;
-    }
 };
-
-// Two steps per launch is OFF by default: measured slower than two one-step launches on MI355X (10.3 vs 9.0 us at
-// 250k rows, 39.5 vs 33 us at 1M; see pf_twostep.hip).  -1: not decided (environment PF_TWO_STEP=1 enables), 0 off,
-// 1 on; pf_two_step_enable overrides.
-int g_two_step = -1;
-
-bool two_step_enabled() {
-    if (g_two_step < 0) {
-        const char* v = getenv("PF_TWO_STEP");
-        g_two_step = (v && v[0] == '1') ? 1 : 0;
-    }
-    return g_two_step == 1;
-}
-
-// ghost-row values matching `vals` if the two-step structures of g exist (built on first use), else nullptr
-const double* two_step_values(pf_graph* g, const double* vals, int32_t degree) {
-    if (!two_step_enabled() || degree < 3) return nullptr;
-    if (g->two_step < 0 && pf_twostep_prepare(g) != PF_OK) return nullptr;
-    if (g->two_step != 1) return nullptr;
-    return vals == g->sval_sym ? g->ts_gh_sym : g->ts_gh_rw;
-}
 
 struct OpTimer {
     pf_ctx* c;
@@ -857,11 +827,6 @@ int pf_spmv(pf_graph* g, int32_t op, int32_t src, int32_t dst) {
     return t.finish();
 }
 
-int pf_two_step_enable(int on) {
-    g_two_step = on ? 1 : 0;
-    return PF_OK;
-}
-
 int pf_cheb(pf_graph* g, int32_t op, int32_t src, int32_t dst, int32_t degree, double c, double e, double rho) {
     PF_TRY(check_slots(g, src, 1, "pf_cheb"));
     PF_TRY(check_slots(g, dst, 1, "pf_cheb"));
@@ -874,25 +839,20 @@ int pf_cheb(pf_graph* g, int32_t op, int32_t src, int32_t dst, int32_t degree, d
         int done = 0;
         PF_TRY(pf_persist_cheb(&pa, nullptr, &done));
         if (done) {
-            t.launches = (degree + 253) / 254;  // at most 254 steps per launch (pf_persist.hip)
+            t.launches = 1;
             t.persist_steps = degree;
             return t.finish();
         }
     }
-    ChebRun r{g, vals, two_step_values(g, vals, degree), pf_slot(g, src), pf_slot(g, dst), degree, c, e, rho};
+    ChebRun r{g, vals, pf_slot(g, src), pf_slot(g, dst), degree, c, e, rho};
     int64_t launches = 1;
     {
         const OpArgs a = r.first();
         PF_TRY(launch_op(g, a.sval, a.x, a.prev, a.out, a.alpha, a.shift, a.beta));
     }
     while (r.left() > 0) {
-        if (r.can_double()) {
-            const pf_ts_args a = r.twin();
-            PF_TRY(pf_twostep_launch(&a, nullptr));
-        } else {
-            const OpArgs a = r.single();
-            PF_TRY(launch_op(g, a.sval, a.x, a.prev, a.out, a.alpha, a.shift, a.beta));
-        }
+        const OpArgs a = r.single();
+        PF_TRY(launch_op(g, a.sval, a.x, a.prev, a.out, a.alpha, a.shift, a.beta));
         ++launches;
     }
     t.launches = launches;
@@ -918,34 +878,26 @@ int pf_cheb2(pf_graph* ga, int32_t op_a, int32_t src_a, int32_t dst_a, int32_t d
         int done = 0;
         PF_TRY(pf_persist_cheb(&pa, &pb, &done));
         if (done) {
-            t.launches = (std::max(degree_a, degree_b) + 253) / 254;
+            t.launches = 1;
             t.persist_steps = std::max(degree_a, degree_b);
             return t.finish();
         }
     }
-    ChebRun ra{ga, va, two_step_values(ga, va, degree_a), pf_slot(ga, src_a), pf_slot(ga, dst_a), degree_a, c_a, e_a, rho_a};
-    ChebRun rb{gb, vb, two_step_values(gb, vb, degree_b), pf_slot(gb, src_b), pf_slot(gb, dst_b), degree_b, c_b, e_b, rho_b};
+    ChebRun ra{ga, va, pf_slot(ga, src_a), pf_slot(ga, dst_a), degree_a, c_a, e_a, rho_a};
+    ChebRun rb{gb, vb, pf_slot(gb, src_b), pf_slot(gb, dst_b), degree_b, c_b, e_b, rho_b};
     int64_t launches = 1;
     {
         const OpArgs a = ra.first(), b = rb.first();
         PF_TRY(launch_op2(ga, a, b, false));
     }
     while (ra.left() > 0 || rb.left() > 0) {
-        if (ra.can_double() && rb.can_double()) {  // both graphs: two steps in one launch
-            const pf_ts_args a = ra.twin(), b = rb.twin();
-            PF_TRY(pf_twostep_launch(&a, &b));
-        } else if (ra.left() > 0 && rb.left() > 0) {
+        if (ra.left() > 0 && rb.left() > 0) {
             const OpArgs a = ra.single(), b = rb.single();
             PF_TRY(launch_op2(ga, a, b, true));
         } else {  // the longer recurrence finishes alone
             ChebRun& r = ra.left() > 0 ? ra : rb;
-            if (r.can_double()) {
-                const pf_ts_args a = r.twin();
-                PF_TRY(pf_twostep_launch(&a, nullptr));
-            } else {
-                const OpArgs a = r.single();
-                PF_TRY(launch_op(r.g, a.sval, a.x, a.prev, a.out, a.alpha, a.shift, a.beta));
-            }
+            const OpArgs a = r.single();
+            PF_TRY(launch_op(r.g, a.sval, a.x, a.prev, a.out, a.alpha, a.shift, a.beta));
         }
         ++launches;
     }

@@ -1,564 +1,397 @@
-// A whole Chebyshev recurrence in ONE kernel: the operator stays in LDS, only the vectors travel.
+// A whole Chebyshev recurrence in ONE kernel: the operator stays in registers, x in LDS, only boundary values travel.
 //
-// One step per launch (pf_operator.hip) streams the SELL-64 matrix of the graph(s) through the chip on every step:
-// 26 MB per 250k-vertex mesh, ~5 us, and the L2s do not keep it from one launch to the next (PMC: the fetched bytes
-// per launch equal the algorithmic bytes).  But 1/256 of that matrix is ~74 KB - less than the 160 KB of LDS a CU
-// has.  So: 256 blocks (one per CU, 1024 threads), each copies its contiguous run of SELL slices of both graphs into
-// LDS once, then the steps of  y_{k+1} = (2/(e rho)) (c y_k - A y_k) - y_{k-1}/rho^2  run inside the kernel with a
-// grid-wide barrier between steps.  Per step only x (gathered through L2), y_{k-1}, the diagonal and the output cross
-// the fabric: 8 MB instead of 26 MB per graph.  The arithmetic per row is the one of sell_op_block, operation for
-// operation: results are bit-identical to the one-step-per-launch path (tests/test_gpu_parity.py).
+// One step per launch (pf_operator.hip) streams the SELL-64 matrix of the graph(s) through the chip on every step
+// (26 MB per 250k-vertex mesh, ~5 us) behind a ~1.5 us kernel boundary, and a filter application is ~145 dependent
+// steps.  But 1/256 of that matrix is ~60 KB - and a CU has 512 KB of vector registers.  So: one block of 1024 threads
+// per CU owns a WINDOW of NW x 1024 consecutive solver-order rows of each graph (a compact patch of the surface, Morton
+// order, pf_reorder.hip), every thread keeps the entries of its NW rows in registers (values + 16-bit window-local
+// column slots, pf_windows.hip; rows wider than JR entries keep the rest in LDS), the window's x and the ~220 outside
+// values its rows read live in LDS (double buffered: one block barrier per step), and all steps of
+//   y_{k+1} = (2/(e rho)) (c y_k - A y_k) - y_{k-1}/rho^2
+// run inside the kernel.  Every gather of a step is an LDS read; y_{k-1} of a row is the x the same thread used one
+// step earlier (a register).  The arithmetic per row is the one of sell_op_block, operation for operation (contraction
+// off, explicit fma): results are bit-identical to the one-step-per-launch path (tests/test_gpu_parity.py).
 //
-// Coherence.  The 8 XCDs have private L2s and every CU a private L1; neither snoops the others.  Measured on MI355X
-// (250k rows, per step): compute 2.3 us; a barrier of atomics 1.5 us; but an agent-scope release (L2 write-back) and
-// acquire (L2 + L1 invalidate) by every block 5.8 + 3.7 us, and `buffer_inv sc0` does not drop the L1.  Two measures
-// remove all invalidation and all write-backs:
-//   * every step writes its result to a buffer NOBODY HAS READ OR WRITTEN in this kernel (a ring of PS_RING vectors per
-//     graph, at most PS_RING - 2 steps per launch): no cache can hold a stale copy of a line that was never touched,
-//     so readers need no invalidate; kernel boundaries (which do invalidate) recycle the ring;
-//   * writers store their results with agent scope (`global_store ... sc1`: written through the XCD's L2 to memory)
-//     and every wave waits for the acknowledgement before its block arrives at the barrier, so no L2 write-back is
-//     needed either (one `buffer_wbl2` per XCD and step by the last block to arrive was 0.4 us slower).
-// The barrier itself: blocks arrive on the counter of their XCD (32 arrivals each; same-address atomics serialise at
-// ~10 ns), the last arrival of an XCD bumps the device-wide counter, which everybody polls.  6.5 us per step of a
-// 250k-vertex pair, of which ~4 us are the x gathers (bound by the L1's line rate, not by latency: issuing both
-// graphs' gathers together changed nothing) and ~2.5 us the chain store-acknowledge -> arrive -> count -> poll.
-// Two kernels follow.  k_sell_persist is the scheme above as described (any partition of the slices over the blocks,
-// x gathered through L1/L2, grid barrier).  k_sell_persist_x, preferred when the graph's 1024-row windows fit, also
-// keeps x in LDS and replaces the barrier by point-to-point flags between neighbouring windows (4.3 us per step of the
-// pair); its own comment explains the differences.  Both write results to fresh ring buffers with write-through stores.
-// Tried and dropped: one kernel per graph (512 threads, half the LDS, two blocks per CU) on two streams, hoping one
-// graph's barrier chain would hide behind the other graph's gathers: 6.9 us per step of the pair against 6.5 us for
-// both graphs in one kernel (bit-identical results either way).
-// Every wait is bounded: a block that waits longer than a few seconds raises the abort flag, every other block sees
-// it in its own wait loop, and the kernel drains; the host reports PF_E_HIP at its next synchronisation.  One block
-// per CU (grid <= CU count, checked against the occupancy query) makes all blocks resident on an idle device.
+// Hand-off between windows.  The 8 XCDs have private L2s and every CU a private L1; neither snoops the others.  What
+// crosses windows per step is small: the rows of a window that other windows read (its BOUNDARY rows, ~25 %, sorted to
+// the front of the window by pf_reorder.hip).  Per graph a ring of 4 vectors carries them: step k of a launch lives in
+// slot (k + phase) & 3.
+//   * producer: boundary rows are computed FIRST (their waves run at raised priority) and stored with agent scope
+//     (`global_store ... sc1`: written through the XCD's L2 to memory); interior rows - which nobody else reads - are
+//     computed while those values travel, and never leave the CU;
+//   * consumer: one lane per outside row polls that row's slot in the ring with agent-scope loads (`sc1`: always served
+//     from memory side, never from a stale L1/L2 line) until the value is no longer the EMPTY sentinel (a NaN payload no
+//     arithmetic produces); the value itself is the message - no flag, no fence, no second round trip.  8-byte
+//     naturally aligned accesses are single-copy atomic, so there is no tearing to guard against;
+//   * recycling: at step k a window writes EMPTY over its own step k-2 values.  Safe: it could only start step k after
+//     receiving step k-1 from every window it reads; those windows are exactly the windows that read it
+//     (pf_windows.hip makes the relation symmetric), and each of them sent step k-1 after it had consumed step k-2.
+//     Every wave drains its stores (s_waitcnt vmcnt(0)) before the step's barrier, so the EMPTY of step k is in memory
+//     before the same thread's step k+1 value is even issued: a reader that sees step k+1 can never afterwards see the
+//     stale step k-2 value in the slot it polls for step k+2;
+//   * across launches: the only slot left non-empty is the one of step degree-1; the next launch of the graph starts at
+//     phase' = (phase + degree) & 3, which makes that slot "step 3" of the new launch - emptied by every window in its
+//     step 1, two hand-offs before anybody polls it.
+// Measured on MI355X (250k-vertex pair): see DESIGN.md section 4 - the step is bound by one memory-side hand-off
+// (~1 us) plus the boundary rows' LDS gathers, not by HBM or LDS bandwidth.
+//
+// Every wait is bounded: a lane that polls longer than a few seconds raises the abort flag, every other block sees it
+// in its own wait loop, the kernel drains, and the host reports PF_E_PERSIST_TIMEOUT at its next synchronising call
+// (pf_persist_check), with the stream drained and the path switched off, so the caller can simply repeat the solve.
+// A plain launch with grid <= CU count and one block per CU (checked against the occupancy query): all blocks are
+// resident on an idle device.  hipLaunchCooperativeKernel would add only the same size check at +15-19 us of host time
+// per launch (MI355X_MICROARCH.md, "coop-launch": identical residency), and cannot protect against another tenant either.
 #include <stdlib.h>
 
 #include <algorithm>
 #include <atomic>
+#include <mutex>
 #include <vector>
 
 #include "pf_internal.h"
 
 namespace {
 
-// Two persistent kernels in flight on different streams could each be given part of the CUs and wait for the rest
-// forever (until the bounded waits give up): only one ctx of the process uses this path at a time.
+// Two resident kernels in flight on different streams could each be given part of the CUs and wait for the rest until
+// the bounded waits give up: only one ctx of the process uses this path at a time.
 std::atomic<pf_ctx*> g_owner{nullptr};
+std::atomic<int> g_persist{-1};            // -1 undecided (environment PF_PERSIST=0 disables), 0 off, 1 on
+std::atomic<uint64_t> g_abort_epoch{1};    // bumped when a launch aborted: every graph's ring is refilled before reuse
+std::atomic<int> g_test_aborts{0};         // pf_persist_test_hook: launches that start with the abort flag raised
 
-constexpr int PS_THREADS = 1024;
-constexpr int PS_SYNC_STRIDE = 32;       // uint32 words between counters (128 B: one cache line each)
-constexpr int PS_SYNC_WORDS = 10 * PS_SYNC_STRIDE;  // 8 XCD counters, device counter, abort flag
-constexpr int PS_MAX_WINDOWS = 256;       // blocks of the x-in-LDS kernel (one window of 1024 rows each)
-constexpr int PS_RING = 256;             // result buffers per graph; a launch runs at most PS_RING - 2 steps
-constexpr unsigned PS_SPIN_LIMIT = 4000000u;
-constexpr size_t PS_LDS_LIMIT = 160 * 1024 - 2048;  // static __shared__ of the kernels (neighbour list, state) lives in the remainder
+constexpr int RX_THREADS = PF_WIN_THREADS;
+constexpr unsigned long long RX_EMPTY = 0xFFFFDEADFFFFDEADull;  // quiet NaN with a payload arithmetic never produces
+constexpr unsigned RX_EMPTY32 = 0xFFFFDEADu;
+constexpr unsigned RX_SPIN_LIMIT = 4000000u;
+constexpr size_t RX_LDS_LIMIT = 160 * 1024 - 512;  // the kernels' static __shared__ lives in the remainder
+constexpr int RX_JR = 8;                           // entries of a row kept in registers
 
-struct PsGraph {
+struct RxGraph {
     const int64_t* slice_ptr;
-    const int32_t* scol;
+    const int32_t* slot;     // [sell_entries] window-local slots
+    const int32_t* gh_cnt;   // [windows]
+    const int32_t* gh_row;   // [windows][PF_WIN_GHOSTS]
+    const int32_t* need;     // [windows] leading rows other windows read
     const double* sval;
     const double* diag;
-    const double* y_prev;  // y_{k_begin-2} (unused when k_begin == 1)
-    const double* y_cur;   // y_{k_begin-1}
-    double* dst;           // y_degree
-    double* ring;          // [PS_RING][n_pad]: y_k lives in ring[(k-1) % PS_RING] for k < degree
+    const double* src;       // y_0
+    double* dst;             // y_degree
+    double* ring;            // [4][n_pad]
     int64_t n_pad;
-    int64_t n_slices;
-    int32_t k_begin, k_end;  // steps of this launch (1-based, inclusive); k_end < k_begin: nothing left for this graph
+    int32_t n_windows;
     int32_t degree;
+    int32_t phase;
     double a1, a2, shift, beta;  // step 1: a1 (c x - A x); later: a2 (c x - A x) - beta prev
 };
 
-struct PsArgs {
-    PsGraph g[2];
-    uint32_t* sync;
-    int32_t* host_abort;  // pinned: set to 1 when a barrier wait ran out
+struct RxArgs {
+    RxGraph g[2];
+    uint32_t* abort_flag;  // device word: some wait ran out (or the test hook raised it)
+    int32_t* host_abort;   // pinned: set to 1 when this launch gave up
 };
 
-// Bounded wait for *word >= target; false (and the abort flag raised) if it ran out or another block gave up.
-__device__ __forceinline__ bool wait_for(uint32_t* word, unsigned target, uint32_t* abort_flag) {
-    unsigned spins = 0;
-    while (__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-        if (++spins > PS_SPIN_LIMIT || __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
-            __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            return false;
-        }
-        __builtin_amdgcn_s_sleep(2);
-    }
-    return true;
+template <int NG, int NW>
+constexpr int rx_table_bytes() {
+    return ((NG * NW * 16 + 1) * 4 + 15) & ~15;
 }
 
-// Grid barrier (results were stored write-through; this wave has waited for their acknowledgement).
-__device__ __forceinline__ bool grid_barrier(uint32_t* sync, unsigned xcd, unsigned per_xcd, unsigned epoch, int* s_state) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's results have been acknowledged by the L2
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t* xc = sync + xcd * PS_SYNC_STRIDE;
-        uint32_t* dc = sync + 8 * PS_SYNC_STRIDE;
-        uint32_t* ab = sync + 9 * PS_SYNC_STRIDE;
-        if (atomicAdd(xc, 1u) + 1u == per_xcd * epoch) atomicAdd(dc, 1u);
-        *s_state = wait_for(dc, 8u * epoch, ab) ? 0 : 1;
-    }
-    __syncthreads();
-    return *s_state == 0;
-}
-
-template <int NG>
-__global__ __launch_bounds__(PS_THREADS) void k_sell_persist(PsArgs a) {
+template <int NG, int NW, int JR>
+__global__ __launch_bounds__(RX_THREADS) void k_cheb_resident(RxArgs a) {
     // The floating-point operations are spelled out (and contraction is off) so that they are the ones the compiler
     // forms for sell_op_block: acc = d x; acc = fma(v, x, acc)...; t = fma(c, x, -acc); r = fma(alpha, t, -(beta prev)).
 #pragma clang fp contract(off)
     extern __shared__ __align__(16) unsigned char lds[];
     __shared__ int s_state;
+    constexpr int RB = NW * RX_THREADS;
     const unsigned G = gridDim.x, per_xcd = G >> 3;
     const unsigned xcd = blockIdx.x & 7u;
-    const unsigned blk = xcd * per_xcd + (blockIdx.x >> 3);  // every XCD owns one contiguous run of (Morton-ordered) rows
+    const int32_t win = (int32_t)(xcd * per_xcd + (blockIdx.x >> 3));  // every XCD owns one contiguous run of windows
     const int tid = threadIdx.x;
     const int lane = tid & (PF_WAVE - 1);
-
-    // ---- stage this block's slices: values, then columns, then slice offsets
-    int64_t s_lo[2] = {0, 0};
-    int32_t n_sl[2] = {0, 0};
-    double* lval[2] = {nullptr, nullptr};
-    int32_t* lcol[2] = {nullptr, nullptr};
-    int32_t* lbase[2] = {nullptr, nullptr};
-    size_t off = 0;
-#pragma unroll
-    for (int q = 0; q < NG; ++q) {
-        const PsGraph& g = a.g[q];
-        s_lo[q] = (int64_t)blk * g.n_slices / G;
-        n_sl[q] = (int32_t)((int64_t)(blk + 1) * g.n_slices / G - s_lo[q]);
-        const int64_t e_lo = g.slice_ptr[s_lo[q]];
-        const int64_t cnt = g.slice_ptr[s_lo[q] + n_sl[q]] - e_lo;
-        lval[q] = reinterpret_cast<double*>(lds + off);
-        off += (size_t)cnt * sizeof(double);
-        for (int64_t i = tid; i < cnt; i += PS_THREADS) lval[q][i] = g.sval[e_lo + i];
-    }
-#pragma unroll
-    for (int q = 0; q < NG; ++q) {
-        const PsGraph& g = a.g[q];
-        const int64_t e_lo = g.slice_ptr[s_lo[q]];
-        const int64_t cnt = g.slice_ptr[s_lo[q] + n_sl[q]] - e_lo;
-        lcol[q] = reinterpret_cast<int32_t*>(lds + off);
-        off += (size_t)cnt * sizeof(int32_t);
-        for (int64_t i = tid; i < cnt; i += PS_THREADS) lcol[q][i] = g.scol[e_lo + i];
-    }
-#pragma unroll
-    for (int q = 0; q < NG; ++q) {
-        const PsGraph& g = a.g[q];
-        const int64_t e_lo = g.slice_ptr[s_lo[q]];
-        lbase[q] = reinterpret_cast<int32_t*>(lds + off);
-        off += (size_t)(n_sl[q] + 1) * sizeof(int32_t);
-        for (int i = tid; i <= n_sl[q]; i += PS_THREADS) lbase[q][i] = (int32_t)(g.slice_ptr[s_lo[q] + i] - e_lo);
-    }
-    __syncthreads();
-
-    int32_t n_steps = a.g[0].k_end - a.g[0].k_begin + 1;
-    if (NG > 1 && a.g[1].k_end - a.g[1].k_begin + 1 > n_steps) n_steps = a.g[1].k_end - a.g[1].k_begin + 1;
-
-    constexpr int JP = 4;  // pairs of entries gathered up front per row (widths up to 9); wider rows finish in a loop
-    for (int32_t t = 0; t < n_steps; ++t) {
-        // per-graph vectors of this step
-        const double* xq[NG];
-        const double* pq[NG];
-        double* oq[NG];
-        double alq[NG];
-        int32_t rows[NG];
-        int32_t most_rows = 0;
-#pragma unroll
-        for (int q = 0; q < NG; ++q) {
-            const PsGraph& g = a.g[q];
-            const int32_t k = g.k_begin + t;
-            xq[q] = t == 0 ? g.y_cur : g.ring + (int64_t)((k - 2) % PS_RING) * g.n_pad;
-            pq[q] = k == 1 ? nullptr : (t == 0 ? g.y_prev : (t == 1 ? g.y_cur : g.ring + (int64_t)((k - 3) % PS_RING) * g.n_pad));
-            oq[q] = k == g.degree ? g.dst : g.ring + (int64_t)((k - 1) % PS_RING) * g.n_pad;
-            alq[q] = k == 1 ? g.a1 : g.a2;
-            rows[q] = k <= g.k_end ? n_sl[q] * PF_WAVE : 0;  // a graph whose recurrence is over sits the step out
-            most_rows = rows[q] > most_rows ? rows[q] : most_rows;
-        }
-        // The rows of BOTH graphs a thread owns are gathered before any of them is summed: the step is bound by the
-        // latency of the x gathers, and this keeps twice as many in flight.  Per row the operations and their order
-        // are those of sell_op_block.
-        for (int32_t r = tid; r < most_rows; r += PS_THREADS) {
-            bool act[NG];
-            int64_t row[NG];
-            int32_t base[NG];
-            int width[NG], pairs[NG];
-            double xi[NG], dg[NG], pv[NG];
-            double2 vv[NG][JP];
-            double xa[NG][JP], xb[NG][JP];
-            double vt[NG], xt[NG];
-#pragma unroll
-            for (int q = 0; q < NG; ++q) {
-                act[q] = r < rows[q];
-                const int32_t rr = act[q] ? r : lane;  // an idle lane reads (and discards) a row of the first slice
-                const int32_t sl = rr >> 6;
-                row[q] = (s_lo[q] << 6) + rr;
-                base[q] = lbase[q][sl];
-                width[q] = act[q] ? (lbase[q][sl + 1] - base[q]) >> 6 : 0;
-                pairs[q] = width[q] >> 1;
-                xi[q] = xq[q][row[q]];
-                dg[q] = a.g[q].diag[row[q]];
-                pv[q] = pq[q] ? pq[q][row[q]] : 0.0;
-#pragma unroll
-                for (int j = 0; j < JP; ++j) {
-                    const bool on = j < pairs[q];
-                    const int32_t e = on ? base[q] + j * (2 * PF_WAVE) + 2 * lane : 0;
-                    const int2 c0 = *reinterpret_cast<const int2*>(lcol[q] + e);
-                    vv[q][j] = *reinterpret_cast<const double2*>(lval[q] + e);
-                    xa[q][j] = xq[q][on ? c0.x : (int32_t)row[q]];
-                    xb[q][j] = xq[q][on ? c0.y : (int32_t)row[q]];
-                }
-                const bool odd = (width[q] & 1) && pairs[q] <= JP;
-                const int32_t e = odd ? base[q] + pairs[q] * (2 * PF_WAVE) + lane : 0;
-                vt[q] = lval[q][e];
-                xt[q] = xq[q][odd ? lcol[q][e] : (int32_t)row[q]];
-            }
-#pragma unroll
-            for (int q = 0; q < NG; ++q) {
-                double acc = dg[q] * xi[q];
-#pragma unroll
-                for (int j = 0; j < JP; ++j) {
-                    const double s0 = __builtin_fma(vv[q][j].x, xa[q][j], acc);
-                    const double s1 = __builtin_fma(vv[q][j].y, xb[q][j], s0);
-                    acc = j < pairs[q] ? s1 : acc;
-                }
-                if (pairs[q] > JP) {  // wide rows: the remaining pairs (and the odd entry) in order
-                    const double2* vp2 = reinterpret_cast<const double2*>(lval[q] + base[q]) + lane;
-                    const int2* cp2 = reinterpret_cast<const int2*>(lcol[q] + base[q]) + lane;
-                    for (int j = JP; j < pairs[q]; ++j) {
-                        const int2 c0 = cp2[j * PF_WAVE];
-                        const double2 v0 = vp2[j * PF_WAVE];
-                        acc = __builtin_fma(v0.x, xq[q][c0.x], acc);
-                        acc = __builtin_fma(v0.y, xq[q][c0.y], acc);
-                    }
-                    if (width[q] & 1) {
-                        const int32_t e = base[q] + pairs[q] * (2 * PF_WAVE) + lane;
-                        acc = __builtin_fma(lval[q][e], xq[q][lcol[q][e]], acc);
-                    }
-                } else if (width[q] & 1) {
-                    acc = __builtin_fma(vt[q], xt[q], acc);
-                }
-                const double u = __builtin_fma(a.g[q].shift, xi[q], -acc);
-                double res;
-                if (pq[q]) {
-                    const double w = a.g[q].beta * pv[q];
-                    res = __builtin_fma(alq[q], u, -w);
-                } else {
-                    res = alq[q] * u;
-                }
-                // agent-scope store: written through the XCD's L2 to memory, so the barrier needs no L2 write-back
-                if (act[q]) __hip_atomic_store(&oq[q][row[q]], res, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-        if (t + 1 < n_steps && !grid_barrier(a.sync, xcd, per_xcd, (unsigned)(t + 1), &s_state)) {
-            if (tid == 0) *a.host_abort = 1;
-            return;
-        }
-    }
-}
-
-// ---- variant with x in LDS as well ------------------------------------------------------------------------------
-// A block owns a WINDOW of 1024 consecutive rows (one row per thread and graph).  Besides the window's SELL entries
-// (columns as 16-bit window-local slots: own row, or 1024 + index into the window's sorted list of outside rows,
-// pf_window_slots_prepare) LDS holds the x values of the window's own rows - updated in place from the results, after
-// the barrier's first __syncthreads - and of its outside rows, fetched from global memory at the start of a step
-// (~220 values per window).  All gathers of a step are LDS reads; y_{k-1} of a row is the x the same thread used one
-// step earlier (a register); the diagonal is a register.  Per step a block reads only its outside rows from memory.
-// Same operations in the same order as sell_op_block: bit-identical results.
-struct PxGraph {
-    const int64_t* slice_ptr;
-    const int32_t* slot;     // [sell_entries] window-local slots
-    const int32_t* gh_cnt;   // [windows]
-    const int32_t* gh_row;   // [windows][PF_TS_GHOSTS]
-    const double* sval;
-    const double* diag;
-    const double* y_prev;
-    const double* y_cur;
-    double* dst;
-    double* ring;
-    int64_t n_pad;
-    int32_t n_windows;
-    int32_t k_begin, k_end, degree;
-    double a1, a2, shift, beta;
-};
-
-struct PxArgs {
-    PxGraph g[2];
-    uint32_t* sync;
-    int32_t* host_abort;
-};
-
-template <int NG>
-__global__ __launch_bounds__(PS_THREADS) void k_sell_persist_x(PxArgs a) {
-#pragma clang fp contract(off)
-    extern __shared__ __align__(16) unsigned char lds[];
-    __shared__ int s_state;
-    const unsigned G = gridDim.x, per_xcd = G >> 3;
-    const unsigned xcd = blockIdx.x & 7u;
-    const int32_t win = (int32_t)(xcd * per_xcd + (blockIdx.x >> 3));
-    const int tid = threadIdx.x;
-    const int lane = tid & (PF_WAVE - 1);
-    const int sl = tid >> 6;
+    const int wave = tid >> 6;
 
     bool have[NG];
-    int32_t ghosts[NG];
-    double* lval[NG];
-    double* xl[NG];
-    int32_t* lbase[NG];
-    unsigned short* lslot[NG];
-    const int32_t* ghr[NG];
-    int64_t row[NG];
-    double dg[NG], pv[NG];
-    size_t off = 0;
+    int32_t ghosts[NG], need_r[NG], xlen[NG], ghrow[NG];
+    int64_t row0[NG];
+    double* xb[NG];
+    double v[NG][NW][JR];
+    unsigned slp[NG][NW][JR / 2];
+    double dg[NG][NW], pv[NG][NW];
+    int32_t width[NG][NW], ovoff[NG][NW];
+    int64_t sbase[NG][NW];
+
+    int32_t* ovtab = reinterpret_cast<int32_t*>(lds);
+    size_t off = rx_table_bytes<NG, NW>();
 #pragma unroll
     for (int q = 0; q < NG; ++q) {
-        const PxGraph& g = a.g[q];
+        const RxGraph& g = a.g[q];
         have[q] = win < g.n_windows;
-        const int64_t s0 = (int64_t)(have[q] ? win : 0) * (PF_TS_ROWS / PF_WAVE);
-        const int64_t e_lo = g.slice_ptr[s0];
-        const int64_t cnt = have[q] ? g.slice_ptr[s0 + PF_TS_ROWS / PF_WAVE] - e_lo : 0;
-        ghosts[q] = have[q] ? g.gh_cnt[win] : 0;
-        ghr[q] = g.gh_row + (int64_t)(have[q] ? win : 0) * PF_TS_GHOSTS;
-        row[q] = (int64_t)(have[q] ? win : 0) * PF_TS_ROWS + tid;
-        lval[q] = reinterpret_cast<double*>(lds + off);
-        off += (size_t)cnt * sizeof(double);
-        xl[q] = reinterpret_cast<double*>(lds + off);
-        off += (size_t)(have[q] ? PF_TS_ROWS + ghosts[q] : 0) * sizeof(double);
-        lbase[q] = reinterpret_cast<int32_t*>(lds + off);
-        off += (size_t)(PF_TS_ROWS / PF_WAVE + 2) * sizeof(int32_t);  // 18 words: keeps the 8-byte alignment
-        lslot[q] = reinterpret_cast<unsigned short*>(lds + off);
-        off = (off + (size_t)cnt * sizeof(unsigned short) + 15) & ~(size_t)15;  // the next graph's values: 16-byte aligned
-        for (int64_t i = tid; i < cnt; i += PS_THREADS) {
-            lval[q][i] = g.sval[e_lo + i];
-            lslot[q][i] = (unsigned short)g.slot[e_lo + i];
+        const int32_t wq = have[q] ? win : 0;
+        ghosts[q] = have[q] ? g.gh_cnt[wq] : 0;
+        need_r[q] = have[q] ? ((g.need[wq] + PF_WAVE - 1) & ~(PF_WAVE - 1)) : 0;
+        row0[q] = (int64_t)wq * RB;
+        ghrow[q] = tid < ghosts[q] ? g.gh_row[(int64_t)wq * PF_WIN_GHOSTS + tid] : 0;
+        xlen[q] = have[q] ? RB + ((ghosts[q] + 1) & ~1) : 0;
+        xb[q] = reinterpret_cast<double*>(lds + off);
+        off += (size_t)2 * xlen[q] * sizeof(double);
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            const int64_t row = row0[q] + w * RX_THREADS + tid;
+            const int64_t s = row >> 6;
+            sbase[q][w] = g.slice_ptr[s];
+            width[q][w] = have[q] ? (int32_t)((g.slice_ptr[s + 1] - sbase[q][w]) >> 6) : 0;
+            dg[q][w] = have[q] ? g.diag[row] : 0.0;
+            pv[q][w] = 0.0;
+            if (lane == 0) ovtab[(q * NW + w) * 16 + wave] = width[q][w] > JR ? (width[q][w] - JR) * PF_WAVE : 0;
         }
-        if (tid <= PF_TS_ROWS / PF_WAVE) lbase[q][tid] = have[q] ? (int32_t)(g.slice_ptr[s0 + tid] - e_lo) : 0;
-        dg[q] = have[q] ? g.diag[row[q]] : 0.0;
-        pv[q] = (have[q] && g.y_prev) ? g.y_prev[row[q]] : 0.0;
-        if (have[q]) xl[q][tid] = g.y_cur[row[q]];
     }
-    // the windows whose results this one reads (owners of its outside rows, either graph): the only blocks it has to
-    // wait for - no grid-wide barrier
-    __shared__ uint32_t nb_bits[PS_MAX_WINDOWS / 32];
-    __shared__ int32_t nb_list[PS_MAX_WINDOWS];
-    __shared__ int32_t nb_count;
-    if (tid < PS_MAX_WINDOWS / 32) nb_bits[tid] = 0u;
-    if (tid == 0) {
-        nb_count = 0;
-        s_state = 0;
+    if (tid == 0) s_state = (int)__hip_atomic_load(a.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (tid == 0) {  // exclusive prefix of the waves' overflow counts (<= 128 entries)
+        int32_t run = 0;
+        for (int i = 0; i < NG * NW * 16; ++i) {
+            const int32_t c = ovtab[i];
+            ovtab[i] = run;
+            run += c;
+        }
+        ovtab[NG * NW * 16] = run;
     }
     __syncthreads();
+    if (s_state != 0) {  // aborted before it began (test hook, or an earlier launch that is still being drained)
+        if (tid == 0) *a.host_abort = 1;
+        return;
+    }
+    double* ov_val = reinterpret_cast<double*>(lds + off);
+    unsigned short* ov_slot = reinterpret_cast<unsigned short*>(lds + off + (size_t)ovtab[NG * NW * 16] * sizeof(double));
+
+    // ---- this thread's rows: entries into registers (and, beyond JR per row, into LDS), x_0 into LDS
 #pragma unroll
-    for (int q = 0; q < NG; ++q)
-        for (int h = tid; h < ghosts[q]; h += PS_THREADS) {
-            const int32_t w = ghr[q][h] / PF_TS_ROWS;
-            atomicOr(&nb_bits[w >> 5], 1u << (w & 31));
+    for (int q = 0; q < NG; ++q) {
+        const RxGraph& g = a.g[q];
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            const int32_t wd = width[q][w];
+            const int32_t pairs = wd >> 1;
+            const int64_t base = sbase[q][w];
+            ovoff[q][w] = ovtab[(q * NW + w) * 16 + wave];
+#pragma unroll
+            for (int p = 0; p < JR / 2; ++p) {
+                double2 vv = make_double2(0.0, 0.0);
+                int2 ss = make_int2(0, 0);
+                if (p < pairs) {
+                    vv = *reinterpret_cast<const double2*>(g.sval + base + (int64_t)p * (2 * PF_WAVE) + 2 * lane);
+                    ss = *reinterpret_cast<const int2*>(g.slot + base + (int64_t)p * (2 * PF_WAVE) + 2 * lane);
+                }
+                v[q][w][2 * p] = vv.x;
+                v[q][w][2 * p + 1] = vv.y;
+                slp[q][w][p] = (unsigned)ss.x | ((unsigned)ss.y << 16);
+            }
+            if (wd & 1) {  // the odd last entry sits behind the pairs, one per lane
+                const int64_t idx = base + (int64_t)pairs * (2 * PF_WAVE) + lane;
+                const double tv = g.sval[idx];
+                const unsigned ts = (unsigned)g.slot[idx];
+                if (wd - 1 < JR) {
+#pragma unroll
+                    for (int p = 0; p < JR / 2; ++p)
+                        if (2 * p == wd - 1) {
+                            v[q][w][2 * p] = tv;
+                            slp[q][w][p] = ts;
+                        }
+                } else {
+                    const int32_t o = ovoff[q][w] + (wd - 1 - JR) * PF_WAVE + lane;
+                    ov_val[o] = tv;
+                    ov_slot[o] = (unsigned short)ts;
+                }
+            }
+            for (int p = JR / 2; p < pairs; ++p) {  // wide rows: the remaining pairs, entry-major in LDS
+                const int64_t idx = base + (int64_t)p * (2 * PF_WAVE) + 2 * lane;
+                const double2 vv = *reinterpret_cast<const double2*>(g.sval + idx);
+                const int2 ss = *reinterpret_cast<const int2*>(g.slot + idx);
+                const int32_t o = ovoff[q][w] + (2 * p - JR) * PF_WAVE + lane;
+                ov_val[o] = vv.x;
+                ov_slot[o] = (unsigned short)ss.x;
+                ov_val[o + PF_WAVE] = vv.y;
+                ov_slot[o + PF_WAVE] = (unsigned short)ss.y;
+            }
+            if (have[q]) xb[q][w * RX_THREADS + tid] = g.src[row0[q] + w * RX_THREADS + tid];
         }
+        if (tid < ghosts[q]) xb[q][RB + tid] = g.src[ghrow[q]];
+    }
     __syncthreads();
-    if (tid < PS_MAX_WINDOWS && ((nb_bits[tid >> 5] >> (tid & 31)) & 1u)) nb_list[atomicAdd(&nb_count, 1)] = tid;
-    __syncthreads();
-    const int32_t n_nb = nb_count;
-    uint32_t* flags = a.sync + PS_SYNC_WORDS;            // [PS_MAX_WINDOWS] one 128-byte line each: steps finished
-    uint32_t* ab = a.sync + 9 * PS_SYNC_STRIDE;
 
-    int32_t n_steps = a.g[0].k_end - a.g[0].k_begin + 1;
-    if (NG > 1 && a.g[1].k_end - a.g[1].k_begin + 1 > n_steps) n_steps = a.g[1].k_end - a.g[1].k_begin + 1;
-    constexpr int JP = 4;
+    int32_t n_steps = a.g[0].degree;
+    if (NG > 1 && a.g[1].degree > n_steps) n_steps = a.g[1].degree;
+    int32_t need_max = need_r[0];
+    if (NG > 1 && need_r[1] > need_max) need_max = need_r[1];
+    const bool early = (tid & ~(PF_WAVE - 1)) < need_max;  // this wave owns boundary rows (its w = 0 rows)
+    int cur = 0;
 
-    for (int32_t t = 0; t < n_steps; ++t) {
-        bool step[NG];
-        double res[NG], xi[NG];
-        // outside rows of this step: y_{k-1} of other windows, written (write-through) before the last barrier
+    for (int32_t k = 1; k <= n_steps; ++k) {
+        if (early) __builtin_amdgcn_s_setprio(3);
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+#pragma unroll
+            for (int q = 0; q < NG; ++q) {
+                const RxGraph& g = a.g[q];
+                if (!have[q] || k > g.degree) continue;  // (block-uniform) a graph whose recurrence is over sits the step out
+                const double* x = xb[q] + (size_t)cur * xlen[q];
+                double* xn = xb[q] + (size_t)(cur ^ 1) * xlen[q];
+                const int32_t lr = w * RX_THREADS + tid;
+                const int32_t wd = width[q][w];
+                const double xi = x[lr];
+                double acc = dg[q][w] * xi;
+#pragma unroll
+                for (int j = 0; j < JR; ++j) {
+                    if (j < wd) {
+                        const unsigned s = (j & 1) ? (slp[q][w][j >> 1] >> 16) : (slp[q][w][j >> 1] & 0xffffu);
+                        acc = __builtin_fma(v[q][w][j], x[s], acc);
+                    }
+                }
+                for (int j = JR; j < wd; ++j) {
+                    const int32_t o = ovoff[q][w] + (j - JR) * PF_WAVE + lane;
+                    acc = __builtin_fma(ov_val[o], x[ov_slot[o]], acc);
+                }
+                const double u = __builtin_fma(g.shift, xi, -acc);
+                double res;
+                if (k == 1) {
+                    res = g.a1 * u;
+                } else {
+                    const double wp = g.beta * pv[q][w];
+                    res = __builtin_fma(g.a2, u, -wp);
+                }
+                pv[q][w] = xi;
+                xn[lr] = res;
+                const int64_t row = row0[q] + lr;
+                if (k == g.degree) g.dst[row] = res;
+                if (lr < need_r[q]) {  // (wave-uniform) a boundary row: hand it over, and recycle the slot of step k-2
+                    unsigned long long* ring = reinterpret_cast<unsigned long long*>(g.ring);
+                    if (k < g.degree)
+                        __hip_atomic_store(ring + (int64_t)((k + g.phase) & 3) * g.n_pad + row,
+                                           (unsigned long long)__double_as_longlong(res), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(ring + (int64_t)((k + 2 + g.phase) & 3) * g.n_pad + row, RX_EMPTY, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            if (w == 0 && early) __builtin_amdgcn_s_setprio(0);
+        }
+        if (k == n_steps) break;
+        // ---- the outside values of step k, straight from their owners' stores
 #pragma unroll
         for (int q = 0; q < NG; ++q) {
-            const PxGraph& g = a.g[q];
-            const int32_t k = g.k_begin + t;
-            step[q] = have[q] && k <= g.k_end;
-            const double* xg = t == 0 ? g.y_cur : g.ring + (int64_t)((k - 2) % PS_RING) * g.n_pad;
-            if (step[q])
-                for (int h = tid; h < ghosts[q]; h += PS_THREADS) xl[q][PF_TS_ROWS + h] = xg[ghr[q][h]];
+            const RxGraph& g = a.g[q];
+            if (have[q] && k < g.degree && tid < ghosts[q]) {
+                const unsigned long long* p =
+                    reinterpret_cast<const unsigned long long*>(g.ring) + (int64_t)((k + g.phase) & 3) * g.n_pad + ghrow[q];
+                unsigned long long bits;
+                unsigned spins = 0;
+                while ((bits = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == RX_EMPTY) {
+                    ++spins;
+                    if (spins > RX_SPIN_LIMIT ||
+                        ((spins & 63u) == 0u && __hip_atomic_load(a.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+                        __hip_atomic_store(a.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        s_state = 1;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                xb[q][(size_t)(cur ^ 1) * xlen[q] + RB + tid] = __longlong_as_double((long long)bits);
+            }
         }
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < NG; ++q) {
-            const PxGraph& g = a.g[q];
-            const int32_t k = g.k_begin + t;
-            const int32_t base = lbase[q][sl];
-            const int width = step[q] ? (lbase[q][sl + 1] - base) >> 6 : 0;
-            const int pairs = width >> 1;
-            xi[q] = step[q] ? xl[q][tid] : 0.0;
-            double acc = dg[q] * xi[q];
-#pragma unroll
-            for (int j = 0; j < JP; ++j) {
-                const bool on = j < pairs;
-                const int32_t e = on ? base + j * (2 * PF_WAVE) + 2 * lane : 0;
-                const unsigned int two = *reinterpret_cast<const unsigned int*>(lslot[q] + e);
-                const double2 v = *reinterpret_cast<const double2*>(lval[q] + e);
-                const double x0 = xl[q][on ? (two & 0xffffu) : 0], x1 = xl[q][on ? (two >> 16) : 0];
-                const double s0 = __builtin_fma(v.x, x0, acc);
-                const double s1 = __builtin_fma(v.y, x1, s0);
-                acc = on ? s1 : acc;
-            }
-            for (int j = JP; j < pairs; ++j) {  // wide rows
-                const int32_t e = base + j * (2 * PF_WAVE) + 2 * lane;
-                const unsigned int two = *reinterpret_cast<const unsigned int*>(lslot[q] + e);
-                const double2 v = *reinterpret_cast<const double2*>(lval[q] + e);
-                acc = __builtin_fma(v.x, xl[q][two & 0xffffu], acc);
-                acc = __builtin_fma(v.y, xl[q][two >> 16], acc);
-            }
-            if (width & 1) {
-                const int32_t e = base + pairs * (2 * PF_WAVE) + lane;
-                acc = __builtin_fma(lval[q][e], xl[q][lslot[q][e]], acc);
-            }
-            const double u = __builtin_fma(g.shift, xi[q], -acc);
-            if (k == 1) {
-                res[q] = g.a1 * u;
-            } else {
-                const double w = g.beta * pv[q];
-                res[q] = __builtin_fma(g.a2, u, -w);
-            }
-            double* out = k == g.degree ? g.dst : g.ring + (int64_t)((k - 1) % PS_RING) * g.n_pad;
-            if (step[q]) __hip_atomic_store(&out[row[q]], res[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        if (t + 1 == n_steps) break;
-        // ---- publish "step t done" and wait for the neighbours' (point to point: a window only ever reads the windows
-        // of its outside rows); the window's own x is replaced by the results in between.  Results are in buffers
-        // nobody touched before, so a window running a step ahead of a distant one harms nobody.
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's results have been acknowledged
-        __syncthreads();  // ... every wave's; and every thread has finished reading xl for this step
-#pragma unroll
-        for (int q = 0; q < NG; ++q)
-            if (step[q]) {
-                xl[q][tid] = res[q];
-                pv[q] = xi[q];
-            }
-        if (tid == 0) __hip_atomic_store(flags + (int64_t)win * PS_SYNC_STRIDE, (uint32_t)(t + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        for (int i = tid; i < n_nb; i += PS_THREADS)
-            if (!wait_for(flags + (int64_t)nb_list[i] * PS_SYNC_STRIDE, (uint32_t)(t + 1), ab)) s_state = 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's hand-offs and EMPTY stores are in memory (see header)
         __syncthreads();
         if (s_state != 0) {
             if (tid == 0) *a.host_abort = 1;
             return;
         }
+        cur ^= 1;
     }
 }
 
-// -1 undecided (environment PF_PERSIST=0 disables), 0 off, 1 on
-int g_persist = -1;
-
 bool persist_enabled() {
-    if (g_persist < 0) {
-        const char* v = getenv("PF_PERSIST");
-        g_persist = (v && v[0] == '0') ? 0 : ((v && v[0] == '2') ? 2 : 1);
+    int v = g_persist.load();
+    if (v < 0) {
+        const char* e = getenv("PF_PERSIST");
+        v = (e && e[0] == '0') ? 0 : 1;
+        g_persist.store(v);
     }
-    return g_persist >= 1;
+    return v >= 1;
+}
+
+using RxKernel = void (*)(RxArgs);
+RxKernel rx_kernel(int ng, int nw) {
+    if (ng == 1 && nw == 1) return k_cheb_resident<1, 1, RX_JR>;
+    if (ng == 2 && nw == 1) return k_cheb_resident<2, 1, RX_JR>;
+    if (ng == 1 && nw == 2) return k_cheb_resident<1, 2, RX_JR>;
+    if (ng == 2 && nw == 2) return k_cheb_resident<2, 2, RX_JR>;
+    if (ng == 1 && nw == 4) return k_cheb_resident<1, 4, RX_JR>;
+    return nullptr;
 }
 
 struct DeviceFacts {
-    int grid = 0;  // 0: persistent path unavailable on this device
-    bool ready = false;
+    std::once_flag once;
+    int grid = 0;  // 0: resident path unavailable on this device
 };
 DeviceFacts g_facts[64];
 
 int device_grid(int device) {
     if (device < 0 || device >= 64) return 0;
     DeviceFacts& f = g_facts[device];
-    if (!f.ready) {
-        f.ready = true;
+    std::call_once(f.once, [&] {
         hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, device) != hipSuccess) return 0;
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_sell_persist<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)PS_LDS_LIMIT) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(k_sell_persist<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)PS_LDS_LIMIT) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(k_sell_persist_x<1>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)PS_LDS_LIMIT) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(k_sell_persist_x<2>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)PS_LDS_LIMIT) != hipSuccess) {
-            (void)hipGetLastError();
-            return 0;
-        }
-        int per_cu = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_sell_persist<2>, PS_THREADS, PS_LDS_LIMIT) != hipSuccess || per_cu < 1) {
-            (void)hipGetLastError();
-            return 0;
+        if (hipGetDeviceProperties(&prop, device) != hipSuccess) return;
+        const int shapes[5][2] = {{1, 1}, {2, 1}, {1, 2}, {2, 2}, {1, 4}};
+        for (const auto& s : shapes) {
+            const void* fn = reinterpret_cast<const void*>(rx_kernel(s[0], s[1]));
+            int per_cu = 0;
+            if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RX_LDS_LIMIT) != hipSuccess ||
+                hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, RX_THREADS, RX_LDS_LIMIT) != hipSuccess || per_cu < 1) {
+                (void)hipGetLastError();
+                return;
+            }
         }
         f.grid = std::min(prop.multiProcessorCount, 256) & ~7;  // one block per CU, a multiple of the 8 XCDs
-    }
+    });
     return f.grid;
 }
 
-// -1 undecided (environment PF_PERSIST_X=0 disables the variant with x in LDS), 0 off, 1 on
-int g_x_state = -1;
-bool x_enabled() {
-    if (g_x_state < 0) {
-        const char* v = getenv("PF_PERSIST_X");
-        g_x_state = (v && v[0] == '0') ? 0 : 1;
-    }
-    return g_x_state == 1;
-}
-
-// LDS bytes of the fullest window for the x-in-LDS kernel (layout as in k_sell_persist_x), both graphs together
-int64_t lds_need_x(pf_graph* ga, pf_graph* gb) {
+// LDS bytes of the fullest window (layout as in k_cheb_resident); -1 if the graph(s) cannot use the kernel
+int64_t lds_need(pf_graph* ga, pf_graph* gb, int nw) {
     pf_graph* gs[2] = {ga, gb};
-    const int64_t wa = ga->n_pad / PF_TS_ROWS, wb = gb ? gb->n_pad / PF_TS_ROWS : 0;
+    const int ng = gb ? 2 : 1;
+    const int64_t RB = (int64_t)nw * RX_THREADS;
+    const int64_t wa = ga->n_pad / RB, wb = gb ? gb->n_pad / RB : 0;
     int64_t worst = 0;
     for (int64_t w = 0; w < std::max(wa, wb); ++w) {
-        int64_t need = 0;
-        for (int q = 0; q < 2; ++q) {
+        int64_t need = ((ng * nw * 16 + 1) * 4 + 15) & ~15, ov = 0;
+        for (int q = 0; q < ng; ++q) {
             pf_graph* g = gs[q];
-            if (!g) continue;
-            if (g->h_slice_ptr.empty() || (int64_t)g->h_px_gh_cnt.size() * PF_TS_ROWS != g->n_pad) return -1;
-            need += (PF_TS_ROWS / PF_WAVE + 2) * 4;
-            if (w < g->n_pad / PF_TS_ROWS) {
-                const int64_t s0 = w * (PF_TS_ROWS / PF_WAVE);
-                const int64_t cnt = g->h_slice_ptr[(size_t)(s0 + PF_TS_ROWS / PF_WAVE)] - g->h_slice_ptr[(size_t)s0];
-                need += cnt * 8 + (PF_TS_ROWS + g->h_px_gh_cnt[(size_t)w]) * 8 + cnt * 2;
+            if (g->h_slice_ptr.empty() || (int64_t)g->h_px_gh_cnt.size() * RB != g->n_pad) return -1;
+            if (w >= g->n_pad / RB) continue;
+            need += 2 * (RB + ((g->h_px_gh_cnt[(size_t)w] + 1) & ~1)) * 8;
+            for (int64_t s = w * (RB / PF_WAVE); s < (w + 1) * (RB / PF_WAVE); ++s) {
+                const int64_t width = (g->h_slice_ptr[(size_t)s + 1] - g->h_slice_ptr[(size_t)s]) / PF_WAVE;
+                if (width > RX_JR) ov += (width - RX_JR) * PF_WAVE;
             }
-            need = (need + 15) & ~(int64_t)15;
         }
+        need += ov * 10 + 16;
         worst = std::max(worst, need);
     }
     return worst;
 }
 
-// LDS bytes the fullest block needs for g when the slices are split over `grid` blocks
-int64_t lds_need(pf_graph* g, int grid) {
-    if (g->h_slice_ptr.empty()) {
-        g->h_slice_ptr.resize((size_t)g->n_slices + 1);
-        if (hipMemcpyAsync(g->h_slice_ptr.data(), g->slice_ptr, sizeof(int64_t) * (g->n_slices + 1), hipMemcpyDeviceToHost,
-                           g->ctx->stream) != hipSuccess ||
-            hipStreamSynchronize(g->ctx->stream) != hipSuccess) {
-            (void)hipGetLastError();
-            g->h_slice_ptr.clear();
-            return -1;
-        }
-        g->persist_grid = 0;
-    }
-    if (g->persist_grid != grid) {
-        int64_t worst = 0;
-        for (int b = 0; b < grid; ++b) {
-            const int64_t lo = (int64_t)b * g->n_slices / grid, hi = (int64_t)(b + 1) * g->n_slices / grid;
-            const int64_t cnt = g->h_slice_ptr[(size_t)hi] - g->h_slice_ptr[(size_t)lo];
-            worst = std::max(worst, cnt * 12 + (hi - lo + 1) * 4);
-        }
-        g->persist_lds = worst;
-        g->persist_grid = grid;
-    }
-    return g->persist_lds;
-}
-
 }  // namespace
 
 int pf_persist_set(int on) {
-    g_persist = on == 2 ? 2 : (on ? 1 : 0);
+    g_persist.store(on ? 1 : 0);
     return PF_OK;
 }
 
 extern "C" int pf_persist_enable(int on) { return pf_persist_set(on); }
+
+extern "C" int pf_persist_test_hook(int n_launches) {
+    g_test_aborts.store(n_launches > 0 ? n_launches : 0);
+    return PF_OK;
+}
 
 // Runs the recurrence(s) in one kernel if the device, the sizes and the switch allow it.  *done = 1 when it was
 // launched; 0 means "use the one-step-per-launch path" (never an error by itself).
@@ -566,140 +399,84 @@ int pf_persist_cheb(const pf_persist_args* a, const pf_persist_args* b, int* don
     *done = 0;
     if (!persist_enabled()) return PF_OK;
     pf_graph* ga = a->g;
+    pf_graph* gb = b ? b->g : nullptr;
     pf_ctx* ctx = ga->ctx;
     const int32_t longest = std::max(a->degree, b ? b->degree : 0);
-    if (longest < 8) return PF_OK;  // staging the matrix must pay for itself
+    if (longest < 8) return PF_OK;  // loading the matrix must pay for itself
+    if (gb && gb->win_rows != ga->win_rows) return PF_OK;
+    const int nw = ga->win_rows / RX_THREADS, ng = gb ? 2 : 1;
+    RxKernel kernel = rx_kernel(ng, nw);
+    if (!kernel) return PF_OK;
     PF_HIP(hipSetDevice(ctx->device));  // function attributes, occupancy queries and launches below are per device
-    int grid = device_grid(ctx->device);
-    if (grid < 8) return PF_OK;
-    // Preferred: x in LDS as well (windows of 1024 rows; needs the window-local slots of the graph(s), built once)
-    int64_t need = 0;
-    bool use_x = false;
-    if (x_enabled()) {
-        const int64_t wa = ga->n_pad / PF_TS_ROWS, wb = b ? b->g->n_pad / PF_TS_ROWS : 0;
-        const int64_t gx = (std::max(wa, wb) + 7) & ~(int64_t)7;
-        const bool in_range = gx >= 8 && gx <= grid;  // (do not build window slots for graphs that cannot use them)
-        if (in_range) {
-            PF_TRY(pf_window_slots_prepare(ga));
-            if (b) PF_TRY(pf_window_slots_prepare(b->g));
-        }
-        if (in_range && ga->px_state == 1 && (!b || b->g->px_state == 1)) {
-            {
-                const int64_t nx = lds_need_x(ga, b ? b->g : nullptr);
-                if (nx > 0 && (size_t)nx + 64 <= PS_LDS_LIMIT) {
-                    use_x = true;
-                    need = nx;
-                    grid = (int)gx;
-                }
-            }
-        }
-    }
-    if (!use_x) {
-        // Without x in LDS one graph alone gains nothing (250k rows: 5.0 us per step here, 4.7 us per launch there: the
-        // barrier costs what the matrix traffic saves; with x in LDS it is 3.0 us); two graphs share every barrier
-        // (6.5 vs 10.1 us).  pf_persist_enable(2) forces it.
-        if (!b && g_persist != 2) return PF_OK;
-        if (ga->n_slices < grid || (b && b->g->n_slices < grid)) return PF_OK;
-        need = lds_need(ga, grid);
-        if (need < 0) return PF_OK;
-        if (b) {
-            const int64_t nb = lds_need(b->g, grid);
-            if (nb < 0) return PF_OK;
-            need += nb;
-        }
-        if ((size_t)need + 64 > PS_LDS_LIMIT) return PF_OK;
-    }
+    const int dev_grid = device_grid(ctx->device);
+    if (dev_grid < 8) return PF_OK;
+    const int64_t wa = ga->n_pad / ga->win_rows, wb = gb ? gb->n_pad / gb->win_rows : 0;
+    const int64_t grid = (std::max(wa, wb) + 7) & ~(int64_t)7;
+    if (grid > dev_grid) return PF_OK;
+    PF_TRY(pf_window_slots_prepare(ga));
+    if (gb) PF_TRY(pf_window_slots_prepare(gb));
+    if (ga->px_state != 1 || (gb && gb->px_state != 1)) return PF_OK;
+    const int64_t need = lds_need(ga, gb, nw);
+    if (need < 0 || (size_t)need > RX_LDS_LIMIT) return PF_OK;
     {
         pf_ctx* expected = nullptr;
         if (!g_owner.compare_exchange_strong(expected, ctx) && expected != ctx) return PF_OK;  // another ctx owns the path
     }
     hipStream_t st = ctx->stream;
     if (!ctx->persist_sync) {
-        PF_HIP(pf_malloc(st, (void**)&ctx->persist_sync, sizeof(uint32_t) * (PS_SYNC_WORDS + PS_MAX_WINDOWS * PS_SYNC_STRIDE)));
+        PF_HIP(pf_malloc(st, (void**)&ctx->persist_sync, sizeof(uint32_t) * 32));
+        PF_HIP(hipMemsetAsync(ctx->persist_sync, 0, sizeof(uint32_t) * 32, st));
         PF_HIP(hipHostMalloc((void**)&ctx->persist_abort, sizeof(int32_t), hipHostMallocDefault));
         *ctx->persist_abort = 0;
     }
+    const uint64_t epoch = g_abort_epoch.load();
     const pf_persist_args* in[2] = {a, b};
-    const int ng = b ? 2 : 1;
+    RxArgs args{};
     for (int q = 0; q < ng; ++q) {
         pf_graph* g = in[q]->g;
-        if (!g->persist_ring) PF_HIP(pf_malloc(st, (void**)&g->persist_ring, sizeof(double) * (size_t)PS_RING * (size_t)g->n_pad));
-    }
-    int32_t finished[2] = {0, 0};
-    bool launched = false;
-    while (finished[0] < a->degree || (b && finished[1] < b->degree)) {
-        PsArgs args{};
-        PxArgs xargs{};
-        for (int q = 0; q < ng; ++q) {
-            pf_graph* g = in[q]->g;
-            PsGraph& p = args.g[q];
-            auto where = [&](int32_t k) -> const double* {  // y_k: the caller's src, or its ring slot
-                return k == 0 ? in[q]->src : g->persist_ring + (int64_t)((k - 1) % PS_RING) * g->n_pad;
-            };
-            p.slice_ptr = g->slice_ptr;
-            p.scol = g->scol;
-            p.sval = in[q]->vals;
-            p.diag = g->diag;
-            p.k_begin = finished[q] + 1;
-            p.k_end = std::min(in[q]->degree, finished[q] + PS_RING - 2);
-            p.y_cur = where(p.k_begin - 1);
-            p.y_prev = p.k_begin >= 2 ? where(p.k_begin - 2) : nullptr;
-            p.dst = in[q]->dst;
-            p.ring = g->persist_ring;
-            p.n_pad = g->n_pad;
-            p.n_slices = g->n_slices;
-            p.degree = in[q]->degree;
-            p.a1 = 1.0 / (in[q]->e * in[q]->rho);
-            p.a2 = 2.0 / (in[q]->e * in[q]->rho);
-            p.shift = in[q]->c;
-            p.beta = 1.0 / (in[q]->rho * in[q]->rho);
-            finished[q] = std::max(finished[q], p.k_end);
-            PxGraph& x = xargs.g[q];
-            x.slice_ptr = g->slice_ptr;
-            x.slot = g->px_slot;
-            x.gh_cnt = g->px_gh_cnt;
-            x.gh_row = g->px_gh_row;
-            x.sval = p.sval;
-            x.diag = p.diag;
-            x.y_prev = p.y_prev;
-            x.y_cur = p.y_cur;
-            x.dst = p.dst;
-            x.ring = p.ring;
-            x.n_pad = p.n_pad;
-            x.n_windows = (int32_t)(g->n_pad / PF_TS_ROWS);
-            x.k_begin = p.k_begin;
-            x.k_end = p.k_end;
-            x.degree = p.degree;
-            x.a1 = p.a1;
-            x.a2 = p.a2;
-            x.shift = p.shift;
-            x.beta = p.beta;
+        if (!g->persist_ring) {
+            PF_HIP(pf_malloc(st, (void**)&g->persist_ring, sizeof(double) * 4 * (size_t)g->n_pad));
+            g->persist_epoch = 0;
         }
-        args.sync = xargs.sync = ctx->persist_sync;
-        args.host_abort = xargs.host_abort = ctx->persist_abort;
-        PF_HIP(hipMemsetAsync(ctx->persist_sync, 0, sizeof(uint32_t) * (PS_SYNC_WORDS + (use_x ? PS_MAX_WINDOWS * PS_SYNC_STRIDE : 0)), st));
-        if (getenv("PF_PERSIST_TEST_ABORT"))  // test hook: the first barrier finds the abort flag raised (tests/test_gpu_parity.py)
-            PF_HIP(hipMemsetAsync(ctx->persist_sync + 9 * PS_SYNC_STRIDE, 1, sizeof(uint32_t), st));
-        // A plain launch, not hipLaunchCooperativeKernel: one block per CU is resident-able by construction (grid <=
-        // CU count, the occupancy query above says one block fits a CU), a block that has to wait for a CU another
-        // stream is using starts as soon as that kernel ends, and every barrier wait is bounded anyway.  (The
-        // cooperative entry point runs on a separate queue whose teardown crashes rocprofv3 at process exit.)
-        if (use_x && b)
-            k_sell_persist_x<2><<<dim3((unsigned)grid), dim3(PS_THREADS), (size_t)(need + 64), st>>>(xargs);
-        else if (use_x)
-            k_sell_persist_x<1><<<dim3((unsigned)grid), dim3(PS_THREADS), (size_t)(need + 64), st>>>(xargs);
-        else if (b)
-            k_sell_persist<2><<<dim3((unsigned)grid), dim3(PS_THREADS), (size_t)(need + 64), st>>>(args);
-        else
-            k_sell_persist<1><<<dim3((unsigned)grid), dim3(PS_THREADS), (size_t)(need + 64), st>>>(args);
-        const hipError_t err = hipGetLastError();
-        if (err != hipSuccess) {
-            g_facts[ctx->device].grid = 0;  // the classic path from now on
-            PF_CHECK(!launched, PF_E_HIP, "persistent Chebyshev kernel: launch of a later segment failed: %s", hipGetErrorString(err));
-            return PF_OK;
+        if (g->persist_epoch != epoch) {  // new, or left in an unknown state by an aborted launch: all slots empty
+            PF_HIP(hipMemsetD32Async((hipDeviceptr_t)g->persist_ring, (int)RX_EMPTY32, (size_t)8 * (size_t)g->n_pad, st));
+            g->persist_epoch = epoch;
+            g->persist_phase = 0;
         }
-        launched = true;
+        RxGraph& p = args.g[q];
+        p.slice_ptr = g->slice_ptr;
+        p.slot = g->px_slot;
+        p.gh_cnt = g->px_gh_cnt;
+        p.gh_row = g->px_gh_row;
+        p.need = g->px_need;
+        p.sval = in[q]->vals;
+        p.diag = g->diag;
+        p.src = in[q]->src;
+        p.dst = in[q]->dst;
+        p.ring = g->persist_ring;
+        p.n_pad = g->n_pad;
+        p.n_windows = (int32_t)(g->n_pad / g->win_rows);
+        p.degree = in[q]->degree;
+        p.phase = g->persist_phase;
+        p.a1 = 1.0 / (in[q]->e * in[q]->rho);
+        p.a2 = 2.0 / (in[q]->e * in[q]->rho);
+        p.shift = in[q]->c;
+        p.beta = 1.0 / (in[q]->rho * in[q]->rho);
     }
+    args.abort_flag = ctx->persist_sync;
+    args.host_abort = ctx->persist_abort;
+    if (g_test_aborts.load() > 0) {  // pf_persist_test_hook: this launch finds the abort flag raised
+        g_test_aborts.fetch_sub(1);
+        PF_HIP(hipMemsetAsync(ctx->persist_sync, 1, sizeof(uint32_t), st));
+    }
+    kernel<<<dim3((unsigned)grid), dim3(RX_THREADS), (size_t)need, st>>>(args);
+    const hipError_t err = hipGetLastError();
+    if (err != hipSuccess) {
+        g_persist.store(0);  // the classic path from now on
+        (void)hipGetLastError();
+        return PF_OK;
+    }
+    for (int q = 0; q < ng; ++q) in[q]->g->persist_phase = (in[q]->g->persist_phase + in[q]->degree) & 3;
     *done = 1;
     return PF_OK;
 }
@@ -709,12 +486,23 @@ void pf_persist_release(pf_ctx* ctx) {
     g_owner.compare_exchange_strong(expected, nullptr);
 }
 
+// Called wherever the library has just synchronised with the stream.  If a resident launch gave up: drain the stream
+// (launches queued behind the failed one give up at once: the flag is still raised), lower the flags, declare every
+// ring unknown, switch the path off for the process and report it - the results of the filter applications since the
+// last clean check are invalid, and repeating the solve (now one step per launch) is all the caller has to do.
 int pf_persist_check(pf_ctx* ctx) {
     if (ctx->persist_abort && *ctx->persist_abort) {
+        (void)hipStreamSynchronize(ctx->stream);
         *ctx->persist_abort = 0;
-        g_persist = 0;  // whatever kept the blocks apart, do not try again in this process
-        PF_CHECK(false, PF_E_HIP, "persistent Chebyshev kernel: a grid barrier timed out (the results of that filter "
-                                  "application are invalid); the one-step-per-launch path is used from now on");
+        (void)hipMemsetAsync(ctx->persist_sync, 0, sizeof(uint32_t) * 32, ctx->stream);
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipGetLastError();
+        g_persist.store(0);
+        g_abort_epoch.fetch_add(1);
+        PF_CHECK(false, PF_E_PERSIST_TIMEOUT,
+                 "resident Chebyshev kernel: a wait for a neighbouring window ran out (device shared with another tenant?); "
+                 "the filter applications since the last synchronisation are invalid, the stream is drained and the "
+                 "one-step-per-launch path is used from now on: repeat the solve");
     }
     return PF_OK;
 }

@@ -8,16 +8,18 @@
 //   1. Morton (Z-order) code of each vertex position, 10 bits per axis -> radix sort: vertices
 //      that are close on the surface become close in index, a wave's 64 rows gather from a
 //      handful of lines;
-//   2. inside windows of PF_SIGMA consecutive rows, a stable sort by descending degree: the 64
-//      rows of a SELL slice then share one width and the padding disappears.
+//   2. inside windows of g->win_rows (1024, 2048 or 4096) consecutive rows, a stable sort by
+//      (boundary first, descending degree): the 64 rows of a SELL slice then share one width and the
+//      padding disappears; and the rows of a window that other windows touch - or that touch other
+//      windows - are its FIRST rows, so that the resident Chebyshev kernel (pf_persist.hip), whose
+//      blocks own one window each, can compute and publish exactly those rows first and do the
+//      interior rows while the published values travel.
 // perm[new] = old (-1 on padding rows), iperm[old] = new.  The radix sorts are hipCUB's.
 #include <hipcub/hipcub.hpp>
 
 #include "pf_internal.h"
 
 namespace {
-
-constexpr int PF_SIGMA = 1024;
 
 inline unsigned nblk(int64_t n) { return (unsigned)((n + PF_BLOCK - 1) / PF_BLOCK); }
 
@@ -99,15 +101,41 @@ __global__ __launch_bounds__(PF_BLOCK) void k_morton_keys(const double* __restri
     vals[i] = (int32_t)i;
 }
 
-// second key: window of PF_SIGMA Morton-consecutive rows, then descending degree
+__global__ __launch_bounds__(PF_BLOCK) void k_scatter_pos(const int32_t* __restrict__ order, int64_t n, int32_t* __restrict__ pos) {
+    const int64_t r = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
+    if (r < n) pos[order[r]] = (int32_t)r;
+}
+
+// flag[r] = 1 for the Morton positions whose row has an entry in another window, and for the positions such an
+// entry points at (W may be asymmetric: a row can be read from outside without reading outside itself)
+__global__ __launch_bounds__(PF_BLOCK) void k_boundary_flags(const int32_t* __restrict__ order, const int32_t* __restrict__ rowptr,
+                                                             const int32_t* __restrict__ col, const int32_t* __restrict__ pos,
+                                                             int64_t n, int32_t win_rows, unsigned* __restrict__ flag) {
+    const int64_t r = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
+    if (r >= n) return;
+    const int32_t old = order[r];
+    const int32_t w = (int32_t)(r / win_rows);
+    bool mine = false;
+    for (int32_t a = rowptr[old]; a < rowptr[old + 1]; ++a) {
+        const int32_t rj = pos[col[a]];
+        if (rj / win_rows != w) {
+            mine = true;
+            flag[rj] = 1u;  // (plain stores of the same value: a benign race)
+        }
+    }
+    if (mine) flag[r] = 1u;
+}
+
+// second key: window of win_rows Morton-consecutive rows, then boundary rows first, then descending degree
 __global__ __launch_bounds__(PF_BLOCK) void k_degree_keys(const int32_t* __restrict__ order, const int32_t* __restrict__ rowptr,
-                                                          int64_t n, unsigned* __restrict__ keys) {
+                                                          const unsigned* __restrict__ flag, int64_t n, int32_t win_rows,
+                                                          unsigned* __restrict__ keys) {
     const int64_t r = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
     if (r >= n) return;
     const int32_t old = order[r];
     int32_t d = rowptr[old + 1] - rowptr[old];
     d = d > 1023 ? 1023 : d;
-    keys[r] = ((unsigned)(r / PF_SIGMA) << 10) | (unsigned)(1023 - d);
+    keys[r] = ((unsigned)(r / win_rows) << 11) | (flag[r] ? 0u : 1024u) | (unsigned)(1023 - d);
 }
 
 __global__ __launch_bounds__(PF_BLOCK) void k_iota(int32_t* __restrict__ v, int64_t n) {
@@ -183,14 +211,19 @@ int pf_compute_order(pf_graph* g, const double* d_pts) {
         if (fail(hipGetLastError())) break;
         if (fail(hipcub::DeviceRadixSort::SortPairs(nullptr, need, k0, k1, v0, v1, in, 0, 30, st))) break;
         tmp_bytes = need;
-        int bits2 = 10;
-        for (int64_t w = (n + PF_SIGMA - 1) / PF_SIGMA; w > 0; w >>= 1) ++bits2;
+        const int32_t win_rows = g->win_rows;
+        int bits2 = 11;
+        for (int64_t w = (n + win_rows - 1) / win_rows; w > 0; w >>= 1) ++bits2;
         if (fail(hipcub::DeviceRadixSort::SortPairs(nullptr, need, k0, k1, v0, v1, in, 0, bits2, st))) break;
         tmp_bytes = need > tmp_bytes ? need : tmp_bytes;
         if (fail(pf_malloc(st, &tmp, tmp_bytes))) break;
         need = tmp_bytes;
         if (fail(hipcub::DeviceRadixSort::SortPairs(tmp, need, k0, k1, v0, v1, in, 0, 30, st))) break;  // v1 = Morton order
-        k_degree_keys<<<nblk(n), PF_BLOCK, 0, st>>>(v1, g->rowptr, n, k0);
+        // v0 <- Morton position of every vertex, k1 <- boundary flags (both are scratch until the second sort)
+        k_scatter_pos<<<nblk(n), PF_BLOCK, 0, st>>>(v1, n, v0);
+        if (fail(hipMemsetAsync(k1, 0, sizeof(unsigned) * n, st))) break;
+        k_boundary_flags<<<nblk(n), PF_BLOCK, 0, st>>>(v1, g->rowptr, g->col, v0, n, win_rows, k1);
+        k_degree_keys<<<nblk(n), PF_BLOCK, 0, st>>>(v1, g->rowptr, k1, n, win_rows, k0);
         if (fail(hipGetLastError())) break;
         need = tmp_bytes;
         if (fail(hipcub::DeviceRadixSort::SortPairs(tmp, need, k0, k1, v1, g->perm, in, 0, bits2, st))) break;

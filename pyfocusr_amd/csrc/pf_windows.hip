@@ -1,0 +1,204 @@
+// Window structures of the resident Chebyshev kernel (pf_persist.hip), built once per graph on first use.
+//
+// A window is a run of g->win_rows (1024, 2048 or 4096) consecutive solver-order rows - a compact patch of the surface
+// (Morton order) with its boundary rows first (pf_reorder.hip) - owned by one block of the resident kernel.  Per window:
+//   * the sorted list of OUTSIDE rows its rows read (px_gh_row, at most PF_WIN_GHOSTS);
+//   * for every SELL entry of its rows, the window-local slot of the entry's column: the row's index inside the
+//     window, or win_rows + index into that list (px_slot) - 16 bits are enough, and every gather of a step becomes an
+//     LDS read;
+//   * how many of its leading rows some other window reads (px_need): only those are published every step.
+// The hand-off protocol of the kernel recycles a slot of a window's published rows once every reader is known to be a
+// step further, and it knows that from the values it receives itself; so "A reads B" has to imply "B reads A".  On
+// meshes whose W is symmetric it does.  One-way edges (graph.py:178 on open or non-manifold meshes) can break it at
+// window level; then B gets row 0 of A as an extra outside row (read every step, never used).
+#include <algorithm>
+#include <climits>
+
+#include "pf_internal.h"
+
+namespace {
+
+constexpr int WB_CAP = 4096;  // outside-column candidates of a window before deduplication
+constexpr int WB_ADJ_WORDS = PF_WIN_MAX / 32;
+
+// pass 1: which windows read which (bit matrix), and the extent of each window's externally read rows
+__global__ __launch_bounds__(PF_WIN_THREADS) void k_win_scan(const int64_t* __restrict__ slice_ptr, const int32_t* __restrict__ scol,
+                                                             int32_t win_rows, uint32_t* __restrict__ adj, int32_t* __restrict__ need) {
+    const int tid = threadIdx.x;
+    const int lane = tid & (PF_WAVE - 1);
+    const int32_t A = (int32_t)blockIdx.x;
+    const int64_t r0 = (int64_t)A * win_rows;
+    if (tid == 0) atomicMax(&need[A], 1);  // row 0 of every window is always published (extra outside rows point at it)
+    for (int32_t lr = tid; lr < win_rows; lr += PF_WIN_THREADS) {
+        const int64_t s = (r0 + lr) >> 6;
+        const int64_t base = slice_ptr[s];
+        const int32_t width = (int32_t)((slice_ptr[s + 1] - base) >> 6);
+        for (int32_t j = 0; j < width; ++j) {
+            const int32_t c = scol[pf_sell_index(base, width, j, lane)];
+            const int32_t B = c / win_rows;
+            if (B != A) {
+                atomicOr(&adj[(int64_t)A * WB_ADJ_WORDS + (B >> 5)], 1u << (B & 31));
+                atomicMax(&need[B], c - B * win_rows + 1);
+            }
+        }
+    }
+}
+
+// pass 2: one block per window: sorted unique outside rows (+ row 0 of the windows that read this one without being
+// read by it), then the window-local slot of every entry
+__global__ __launch_bounds__(PF_WIN_THREADS) void k_win_build(const int64_t* __restrict__ slice_ptr, const int32_t* __restrict__ scol,
+                                                              int32_t win_rows, int32_t n_windows, const uint32_t* __restrict__ adj,
+                                                              int32_t* __restrict__ slot_out, int32_t* __restrict__ gh_cnt,
+                                                              int32_t* __restrict__ gh_row, int32_t* __restrict__ flags) {
+    __shared__ int32_t cand[WB_CAP];
+    __shared__ int32_t ghost[PF_WIN_GHOSTS];
+    __shared__ int32_t cnt, hcount;
+    const int tid = threadIdx.x;
+    const int lane = tid & (PF_WAVE - 1);
+    const int32_t A = (int32_t)blockIdx.x;
+    const int64_t r0 = (int64_t)A * win_rows;
+    if (tid == 0) cnt = 0, hcount = 0;
+    for (int k = tid; k < WB_CAP; k += PF_WIN_THREADS) cand[k] = INT_MAX;
+    __syncthreads();
+    for (int32_t lr = tid; lr < win_rows; lr += PF_WIN_THREADS) {
+        const int64_t s = (r0 + lr) >> 6;
+        const int64_t base = slice_ptr[s];
+        const int32_t width = (int32_t)((slice_ptr[s + 1] - base) >> 6);
+        for (int32_t j = 0; j < width; ++j) {
+            const int32_t c = scol[pf_sell_index(base, width, j, lane)];
+            if (c < r0 || c >= r0 + win_rows) {
+                const int p = atomicAdd(&cnt, 1);
+                if (p < WB_CAP) cand[p] = c;
+            }
+        }
+    }
+    for (int32_t B = tid; B < n_windows; B += PF_WIN_THREADS) {
+        if (B == A) continue;
+        const bool b_reads_a = (adj[(int64_t)B * WB_ADJ_WORDS + (A >> 5)] >> (A & 31)) & 1u;
+        const bool a_reads_b = (adj[(int64_t)A * WB_ADJ_WORDS + (B >> 5)] >> (B & 31)) & 1u;
+        if (b_reads_a && !a_reads_b) {
+            const int p = atomicAdd(&cnt, 1);
+            if (p < WB_CAP) cand[p] = B * win_rows;
+        }
+    }
+    __syncthreads();
+    if (cnt > WB_CAP) {  // block-uniform
+        if (tid == 0) atomicOr(flags, 1);
+        return;
+    }
+    // bitonic sort of cand[0, WB_CAP) ascending (INT_MAX padding sorts to the end)
+    for (int k = 2; k <= WB_CAP; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < WB_CAP; i += PF_WIN_THREADS) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const int32_t a = cand[i], b = cand[ixj];
+                    const bool up = (i & k) == 0;
+                    if ((a > b) == up) {
+                        cand[i] = b;
+                        cand[ixj] = a;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (tid == 0) {  // unique, serial: <= 4096 steps once per window
+        int h = 0;
+        int32_t last = -1;
+        for (int i = 0; i < WB_CAP; ++i) {
+            const int32_t c = cand[i];
+            if (c == INT_MAX) break;
+            if (c != last) {
+                if (h < PF_WIN_GHOSTS) ghost[h] = c;
+                ++h;
+                last = c;
+            }
+        }
+        hcount = h;
+    }
+    __syncthreads();
+    const int h = hcount;
+    if (h > PF_WIN_GHOSTS) {
+        if (tid == 0) atomicOr(flags, 1);
+        return;
+    }
+    if (tid == 0) gh_cnt[A] = h;
+    for (int i = tid; i < PF_WIN_GHOSTS; i += PF_WIN_THREADS) gh_row[(int64_t)A * PF_WIN_GHOSTS + i] = i < h ? ghost[i] : 0;
+    for (int32_t lr = tid; lr < win_rows; lr += PF_WIN_THREADS) {
+        const int64_t s = (r0 + lr) >> 6;
+        const int64_t base = slice_ptr[s];
+        const int32_t width = (int32_t)((slice_ptr[s + 1] - base) >> 6);
+        for (int32_t j = 0; j < width; ++j) {
+            const int64_t idx = pf_sell_index(base, width, j, lane);
+            const int32_t c = scol[idx];
+            int32_t slot;
+            if (c >= r0 && c < r0 + win_rows) {
+                slot = (int32_t)(c - r0);
+            } else {
+                int lo = 0, hi = h;  // lower bound in the sorted list (c is in it)
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (ghost[mid] < c) lo = mid + 1;
+                    else hi = mid;
+                }
+                slot = win_rows + lo;
+            }
+            slot_out[idx] = slot;
+        }
+    }
+}
+
+}  // namespace
+
+// g->px_state: -1 not tried, 0 this graph is not covered (the callers have other paths), 1 ready
+int pf_window_slots_prepare(pf_graph* g) {
+    if (g->px_state >= 0) return PF_OK;
+    g->px_state = 0;
+    if (g->win_rows <= 0 || g->n_pad % g->win_rows != 0 || g->sell_entries <= 0) return PF_OK;
+    const int64_t nw = g->n_pad / g->win_rows;
+    if (nw > 256) return PF_OK;  // one window per block, one block per CU
+    hipStream_t st = g->ctx->stream;
+    int32_t* flags = nullptr;
+    uint32_t* adj = nullptr;
+    hipError_t e = pf_malloc(st, (void**)&flags, sizeof(int32_t));
+    if (e == hipSuccess) e = pf_malloc(st, (void**)&adj, sizeof(uint32_t) * (size_t)nw * WB_ADJ_WORDS);
+    if (e == hipSuccess) e = pf_malloc(st, (void**)&g->px_slot, sizeof(int32_t) * (size_t)g->sell_entries);
+    if (e == hipSuccess) e = pf_malloc(st, (void**)&g->px_gh_cnt, sizeof(int32_t) * nw);
+    if (e == hipSuccess) e = pf_malloc(st, (void**)&g->px_need, sizeof(int32_t) * nw);
+    if (e == hipSuccess) e = pf_malloc(st, (void**)&g->px_gh_row, sizeof(int32_t) * nw * PF_WIN_GHOSTS);
+    if (e == hipSuccess) e = hipMemsetAsync(flags, 0, sizeof(int32_t), st);
+    if (e == hipSuccess) e = hipMemsetAsync(adj, 0, sizeof(uint32_t) * (size_t)nw * WB_ADJ_WORDS, st);
+    if (e == hipSuccess) e = hipMemsetAsync(g->px_gh_cnt, 0, sizeof(int32_t) * nw, st);
+    if (e == hipSuccess) e = hipMemsetAsync(g->px_need, 0, sizeof(int32_t) * nw, st);
+    int32_t h_flag = 1;
+    g->h_px_gh_cnt.assign((size_t)nw, 0);
+    if (e == hipSuccess) {
+        k_win_scan<<<(unsigned)nw, PF_WIN_THREADS, 0, st>>>(g->slice_ptr, g->scol, g->win_rows, adj, g->px_need);
+        k_win_build<<<(unsigned)nw, PF_WIN_THREADS, 0, st>>>(g->slice_ptr, g->scol, g->win_rows, (int32_t)nw, adj, g->px_slot,
+                                                             g->px_gh_cnt, g->px_gh_row, flags);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(&h_flag, flags, sizeof(int32_t), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(g->h_px_gh_cnt.data(), g->px_gh_cnt, sizeof(int32_t) * nw, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    pf_free(st, flags);
+    pf_free(st, adj);
+    if (e != hipSuccess || h_flag) {
+        (void)hipGetLastError();
+        pf_window_slots_free(g);
+        return PF_OK;
+    }
+    g->px_state = 1;
+    return PF_OK;
+}
+
+void pf_window_slots_free(pf_graph* g) {
+    hipStream_t st = g->ctx->stream;
+    pf_free(st, g->px_slot);
+    pf_free(st, g->px_gh_cnt);
+    pf_free(st, g->px_gh_row);
+    pf_free(st, g->px_need);
+    g->px_slot = g->px_gh_cnt = g->px_gh_row = g->px_need = nullptr;
+    g->h_px_gh_cnt.clear();
+}

@@ -319,31 +319,15 @@ def _paired_spectra(ga, gb):
     """Both spectra on ONE stream with the two Chebyshev recurrences advancing in shared kernel
     launches (`pf_cheb2`): a 250k-vertex filter step alone is a ~5 us kernel of which ~3 us is
     launch/ramp latency, so two graphs per launch cost ~1.5x one."""
-    gens = []
     for g in (ga, gb):
         if g.verbose:
             print("Beginning Eigen Decomposition")
-        gens.append(_device_eigs_gen(g.device, k=g.n_spectral_features + 1, n_k_needed=g.n_spectral_features,
-                                     k_buffer=1, minmax=g.norm_eig_vecs is True, verbose=g.verbose))
-    try:
-        ra, rb = drive_pair(gens[0], ga.device, gens[1], gb.device)
-    except _hip.PfError as exc:
-        # A grid barrier of the persistent filter kernel timed out (another tenant on the device?): the library has
-        # switched that path off and said so; the eigenpairs are computed again, one step per launch.
-        if "persistent Chebyshev kernel" not in str(exc):
-            raise
-        for g in (ga, gb):
-            g.device.orth_abandon()
-        for _ in range(8):  # launches queued ahead of the report (speculative filter applications) may raise it again
-            try:
-                ga.device.ctx.sync()
-                break
-            except _hip.PfError as again:
-                if "persistent Chebyshev kernel" not in str(again):
-                    raise
-        gens = [_device_eigs_gen(g.device, k=g.n_spectral_features + 1, n_k_needed=g.n_spectral_features, k_buffer=1,
-                                 minmax=g.norm_eig_vecs is True, verbose=g.verbose) for g in (ga, gb)]
-        ra, rb = drive_pair(gens[0], ga.device, gens[1], gb.device)
+
+    def solver(g):  # a factory: `drive_pair` repeats both solves if the resident filter kernel had to give up
+        return lambda: _device_eigs_gen(g.device, k=g.n_spectral_features + 1, n_k_needed=g.n_spectral_features,
+                                        k_buffer=1, minmax=g.norm_eig_vecs is True, verbose=g.verbose)
+
+    ra, rb = drive_pair(solver(ga), ga.device, solver(gb), gb.device)
     for g, (vals, vecs, stats) in ((ga, ra), (gb, rb)):
         g.eig_vals, g.eig_vecs, g.eigs_stats = vals, vecs, stats
         if g.verbose:
@@ -390,7 +374,7 @@ def _device_eigs_gen(dev, k, n_k_needed, k_buffer=1, minmax=False, verbose=False
 
 
 def _device_eigs(dev, k, n_k_needed, k_buffer=1, minmax=False, verbose=False, **solver_kw):
-    return drive(_device_eigs_gen(dev, k, n_k_needed, k_buffer, minmax, verbose, **solver_kw), dev)
+    return drive(lambda: _device_eigs_gen(dev, k, n_k_needed, k_buffer, minmax, verbose, **solver_kw), dev)
 
 
 def _device_from_matrix(matrix, ctx=None):

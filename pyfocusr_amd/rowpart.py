@@ -324,6 +324,11 @@ class RowPartitionedOps(object):
         out, self._pending = self._pending, None
         return out
 
+    def sync(self):
+        fn = getattr(self.local, "sync", None)
+        if fn is not None:
+            fn()
+
     def resnorm(self, ax, x, lam):
         r = self.local.resnorm(ax, x, lam)
         return float(np.sqrt(self.comm.allreduce_sum(np.array([r * r]))[0]))

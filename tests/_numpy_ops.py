@@ -117,6 +117,9 @@ class NumpyOps(object):
         Y = np.asarray(Y, dtype=np.float64)
         self.ws[:, dst_first : dst_first + Y.shape[1]] = self.ws[:, src_first : src_first + m] @ Y
 
+    def sync(self):
+        pass
+
     def resnorm(self, ax, x, lam):
         return float(np.linalg.norm(self.ws[:, ax] - lam * self.ws[:, x]))
 

@@ -912,80 +912,50 @@ def test_hungarian_correspondence_small(golden, ctx):
         Focusr(a, b, icp_register_first=False, initial_correspondence_type="nearest", ctx=ctx)
 
 
-def test_two_step_kernel_bit_identical(golden, hip, ctx):
-    """Two recurrence steps per launch (windows + ghost rows, pf_twostep.hip) against one step per launch: the
-    filter output must be the same bits, for both operators, single and paired, even and odd degrees."""
-    from pyfocusr_amd.meshgen import blob_mesh
-
-    rng = np.random.default_rng(3)
-    m = blob_mesh(30000, seed=8)
-    graphs = [hip.DeviceLaplacian(golden("target_mesh")["points"], golden("target_mesh")["faces"], ctx=ctx),
-              hip.DeviceLaplacian(golden("source_mesh_15k")["points"], golden("source_mesh_15k")["faces"], ctx=ctx),  # RW operator
-              hip.DeviceLaplacian(m.points, m.faces, ctx=ctx)]
-    try:
-        for g in graphs:
-            g.ws_ensure(4)
-            g.upload(0, rng.standard_normal(g.n))
-
-        hip.persist_enable(False)  # compare the two multi-launch paths with each other
-
-        def run(on):
-            hip.two_step_enable(on)
-            out = []
-            for g in graphs:
-                for p, rho in ((1, 1.0), (2, 1.0), (3, 1.0), (4, 1.0), (7, 1.0), (40, 1.0), (145, 1.02)):
-                    g.cheb(0, 1, p, 1.03, 0.98, rho)
-                    out.append(g.download_slots(1, 1).copy())
-            for pa, pb in ((6, 6), (9, 4), (1, 5), (33, 40)):
-                graphs[0].cheb2((0, 2, pa, 1.0, 1.0, 1.0), graphs[2], (0, 2, pb, 1.01, 0.99, 1.0))
-                out.append(graphs[0].download_slots(2, 1).copy())
-                out.append(graphs[2].download_slots(2, 1).copy())
-            return out
-
-        a, b = run(False), run(True)
-        assert len(a) == len(b)
-        for i, (x, y) in enumerate(zip(a, b)):
-            assert np.all(np.isfinite(x)) and np.array_equal(x, y), i
-    finally:
-        hip.two_step_enable(False)  # the defaults
-        hip.persist_enable(True)
-        for g in graphs:
-            g.close()
-
-
-def test_persistent_kernel_bit_identical(golden, hip, ctx):
-    """The whole recurrence in one cooperative kernel (operator in LDS, grid barrier between steps, pf_persist.hip)
-    against one step per launch: same bits for both operators, single and paired, equal and unequal degrees, from
-    graphs with one slice per block (15k) to the bench size (250k pair: the fullest LDS)."""
+def test_resident_kernel_bit_identical(golden, hip, ctx):
+    """The whole recurrence in one resident kernel (operator in registers, x in LDS, boundary rows handed over through
+    memory, pf_persist.hip) against one step per launch: same bits for both operators, single and paired, equal and
+    unequal degrees (short, odd, > 256 steps: the 4-slot ring wraps many times), repeated launches on one graph (the
+    ring phase carries over), graphs from 15k rows (asymmetric W: window relations symmetrised) to the bench size
+    (250k pair, 1024-row windows), a 400k mesh (2048-row windows) and a 700k mesh (4096-row windows)."""
     from pyfocusr_amd.meshgen import blob_mesh
 
     rng = np.random.default_rng(4)
     big = [blob_mesh(250000, seed=s) for s in (0, 1)]
     m = blob_mesh(60000, seed=8)
+    m2, m4 = blob_mesh(400000, seed=9), blob_mesh(700000, seed=10)
     graphs = [hip.DeviceLaplacian(golden("source_mesh_15k")["points"], golden("source_mesh_15k")["faces"], ctx=ctx),  # RW
               hip.DeviceLaplacian(golden("target_mesh_15k")["points"], golden("target_mesh_15k")["faces"], ctx=ctx),
               hip.DeviceLaplacian(m.points, m.faces, ctx=ctx),
               hip.DeviceLaplacian(big[0].points, big[0].faces, ctx=ctx),
-              hip.DeviceLaplacian(big[1].points, big[1].faces, ctx=ctx)]
+              hip.DeviceLaplacian(big[1].points, big[1].faces, ctx=ctx),
+              hip.DeviceLaplacian(m2.points, m2.faces, ctx=ctx),
+              hip.DeviceLaplacian(m4.points, m4.faces, ctx=ctx)]
     try:
         for g in graphs:
             g.ws_ensure(4)
             g.upload(0, rng.standard_normal(g.n))
 
         def run(on):
-            hip.persist_enable(2 if on else 0)  # 2: single-graph applications too
+            hip.persist_enable(on)
+            ctx.timing_enable(True)
+            ctx.timing(reset=True)
             out = []
             for g in graphs:
-                for p, rho in ((8, 1.0), (9, 1.0), (10, 1.0), (41, 1.0), (145, 1.02), (255, 1.02), (600, 1.03)):  # > 254 steps: several launches
+                for p, rho in ((8, 1.0), (9, 1.0), (10, 1.0), (11, 1.0), (41, 1.0), (145, 1.02), (255, 1.02), (600, 1.03)):
                     g.cheb(0, 1, p, 1.03, 0.98, rho)
                     out.append(g.download_slots(1, 1).copy())
-            for ia, ib, pa, pb in ((2, 1, 12, 12), (2, 0, 9, 30), (3, 4, 145, 145), (3, 4, 150, 139), (4, 2, 20, 64), (3, 4, 300, 520)):
+            for ia, ib, pa, pb in ((2, 1, 12, 12), (2, 0, 9, 30), (3, 4, 145, 145), (3, 4, 150, 139), (4, 2, 20, 64),
+                                   (3, 4, 300, 520), (0, 1, 1, 40), (1, 0, 2, 9), (5, 3, 33, 34)):
                 graphs[ia].cheb2((0, 2, pa, 1.0, 1.0, 1.0), graphs[ib], (0, 2, pb, 1.01, 0.99, 1.0))
                 out.append(graphs[ia].download_slots(2, 1).copy())
                 out.append(graphs[ib].download_slots(2, 1).copy())
-            return out
+            tm = ctx.timing(reset=True)
+            ctx.timing_enable(False)
+            return out, tm
 
-        a, b = run(False), run(True)
+        (a, tm_a), (b, tm_b) = run(False), run(True)
+        assert tm_a["persist_launches"] == 0 and tm_b["persist_launches"] >= 8 * len(graphs) + 6  # the path really ran
         assert len(a) == len(b)
         for i, (x, y) in enumerate(zip(a, b)):
             assert np.all(np.isfinite(x)) and np.array_equal(x, y), i
@@ -995,17 +965,18 @@ def test_persistent_kernel_bit_identical(golden, hip, ctx):
             g.close()
 
 
-def test_persistent_kernel_timeout_is_survived(hip, ctx, monkeypatch):
-    """A barrier of the persistent kernel that gives up (forced here through the library's test hook) must not cost the
-    caller the result: the library reports it and switches the path off, and the pair is solved again one step per
-    launch."""
-    from pyfocusr_amd import Graph
+def test_resident_kernel_timeout_is_survived(hip, ctx):
+    """A wait of the resident kernel that gives up (forced through the library's test hook) must not cost any caller
+    the result: the library reports PF_E_PERSIST_TIMEOUT once, with its stream drained and the path switched off, and
+    every driver repeats the solve one step per launch - the paired Python driver, the single-graph driver
+    (`Graph.get_graph_spectrum`), `recursive_eig` on a plain matrix, and the C entry `pf_eigs_smallest`."""
+    from pyfocusr_amd import Graph, recursive_eig
     from pyfocusr_amd.graph import compute_spectra
     from pyfocusr_amd.meshgen import blob_mesh
 
     meshes = [blob_mesh(60000, seed=s) for s in (3, 4)]
 
-    def spectra():
+    def pair():
         graphs = [Graph(m, n_spectral_features=4, n_rand_samples=10**9, ctx=ctx, verbose=False) for m in meshes]
         compute_spectra(graphs)
         vals = [g.eig_vals.copy() for g in graphs]
@@ -1013,29 +984,75 @@ def test_persistent_kernel_timeout_is_survived(hip, ctx, monkeypatch):
             g.device.close()
         return vals
 
+    def single():
+        g = Graph(meshes[0], n_spectral_features=4, n_rand_samples=10**9, ctx=ctx, verbose=False)
+        g.get_graph_spectrum()
+        vals = g.eig_vals.copy()
+        g.device.close()
+        return [vals]
+
+    def spread(v):  # 10 bits -> every third bit
+        v = v.astype(np.uint64) & 0x3FF
+        v = (v | (v << 16)) & 0x030000FF
+        v = (v | (v << 8)) & 0x0300F00F
+        v = (v | (v << 4)) & 0x030C30C3
+        return (v | (v << 2)) & 0x09249249
+
+    # a matrix carries no geometry to renumber by: the resident kernel covers it when its own order is local (Morton here)
+    pts = meshes[1].points
+    q = ((pts - pts.min(axis=0)) / np.ptp(pts, axis=0) * 1023.0).astype(np.uint64)
+    order = np.argsort(spread(q[:, 0]) | (spread(q[:, 1]) << 1) | (spread(q[:, 2]) << 2), kind="stable")
+    inv = np.empty(len(order), dtype=np.int64)
+    inv[order] = np.arange(len(order))
+    L_local = sparse.csr_matrix(orc.graph_matrices(pts[order], inv[meshes[1].faces])[3])
+
+    def plain_matrix():
+        return [recursive_eig(L_local, k=5, n_k_needed=4)[0]]
+
+    def c_call():
+        dev = hip.DeviceLaplacian(meshes[0].points, meshes[0].faces, ctx=ctx)
+        vals = dev.eigs_smallest(4)[0]
+        dev.close()
+        return [vals]
+
+    def resident_launches(fn):
+        ctx.timing_enable(True)
+        ctx.timing(reset=True)
+        out = fn()
+        n = ctx.timing(reset=True)["persist_launches"]
+        ctx.timing_enable(False)
+        return out, n
+
     try:
+        for fn in (pair, single, plain_matrix, c_call):
+            hip.persist_enable(True)
+            good, n_good = resident_launches(fn)
+            assert n_good > 0, fn.__name__  # the resident kernel is what normally runs here
+            hip.persist_enable(True)
+            hip.persist_test_hook(1)  # the next resident launch gives up at once
+            survived, n_after = resident_launches(fn)
+            assert 1 <= n_after <= 4 and n_after < n_good, (fn.__name__, n_after, n_good)  # aborted launch(es queued before the report), then the path is off
+            for x, y in zip(good, survived):
+                np.testing.assert_allclose(x, y, rtol=1e-9, err_msg=fn.__name__)
+        # a raw filter application surfaces the distinct status code at the next synchronising call, once
         hip.persist_enable(True)
-        good = spectra()
-        monkeypatch.setenv("PF_PERSIST_TEST_ABORT", "1")
-        survived = spectra()  # first filter application aborts -> PfError inside -> solved again without the kernel
-        monkeypatch.delenv("PF_PERSIST_TEST_ABORT")
-        for a, b in zip(good, survived):
-            np.testing.assert_allclose(a, b, rtol=1e-9)
         dev = hip.DeviceLaplacian(meshes[0].points, meshes[0].faces, ctx=ctx)
         dev.ws_ensure(4)
         dev.upload(0, np.ones(dev.n))
-        before = ctx.timing(reset=True)
-        dev2 = hip.DeviceLaplacian(meshes[1].points, meshes[1].faces, ctx=ctx)
-        dev2.ws_ensure(4)
-        dev2.upload(0, np.ones(dev2.n))
-        ctx.timing_enable(True)
-        dev.cheb2((0, 1, 20, 1.0, 1.0, 1.0), dev2, (0, 1, 20, 1.0, 1.0, 1.0))
-        assert ctx.timing(reset=True)["persist_launches"] == 0  # switched off by the timeout
-        ctx.timing_enable(False)
+        hip.persist_test_hook(1)
+        dev.cheb(0, 1, 20, 1.0, 1.0, 1.0)
+        with pytest.raises(hip.PfError) as err:
+            ctx.sync()
+        assert err.value.code == hip.PF_E_PERSIST_TIMEOUT
+        ctx.sync()  # drained and cleared: no second report
+        dev.cheb(0, 1, 20, 1.0, 1.0, 1.0)  # one step per launch now
+        ref = dev.download_slots(1, 1).copy()
+        hip.persist_enable(True)
+        dev.cheb(0, 2, 20, 1.0, 1.0, 1.0)  # resident again (ring refilled after the abort): same bits
+        assert np.array_equal(dev.download_slots(2, 1), ref)
         dev.close()
-        dev2.close()
-        del before
     finally:
+        hip.persist_test_hook(0)
         hip.persist_enable(True)
 
 
