@@ -64,7 +64,6 @@ constexpr unsigned long long RX_EMPTY = 0xFFFFDEADFFFFDEADull;  // quiet NaN wit
 constexpr unsigned RX_EMPTY32 = 0xFFFFDEADu;
 constexpr unsigned RX_SPIN_LIMIT = 4000000u;
 constexpr size_t RX_LDS_LIMIT = 160 * 1024 - 512;  // the kernels' static __shared__ lives in the remainder
-constexpr int RX_JR = 8;                           // entries of a row kept in registers
 
 struct RxGraph {
     const int64_t* slice_ptr;
@@ -93,6 +92,39 @@ struct RxArgs {
 template <int NG, int NW>
 constexpr int rx_table_bytes() {
     return ((NG * NW * 16 + 1) * 4 + 15) & ~15;
+}
+
+// d x_i + sum_{j < W} v[j] x[slot j], entries in order; all W + 1 LDS reads are issued before the first fma waits for one
+// (a loop with a per-lane bound makes the compiler wait for every LDS read separately: 9 round trips per row)
+template <int W, int JR>
+__device__ __forceinline__ double rx_row(const double* x, int lr, double dg, double& xi, const double (&v)[JR],
+                                         const unsigned (&slp)[JR / 2]) {
+#pragma clang fp contract(off)
+    double xs[W > 0 ? W : 1];
+    xi = x[lr];
+#pragma unroll
+    for (int j = 0; j < W; ++j) xs[j] = x[(j & 1) ? (slp[j >> 1] >> 16) : (slp[j >> 1] & 0xffffu)];
+    double acc = dg * xi;
+#pragma unroll
+    for (int j = 0; j < W; ++j) acc = __builtin_fma(v[j], xs[j], acc);
+    return acc;
+}
+
+template <int JR>
+__device__ __forceinline__ double rx_row_dispatch(int w_uniform, const double* x, int lr, double dg, double& xi,
+                                                  const double (&v)[JR], const unsigned (&slp)[JR / 2]) {
+    static_assert(JR == 4 || JR == 6 || JR == 8, "register entries per row");
+    switch (w_uniform) {  // a slice (= wave) has one width; at most JR of its entries are in registers
+        case 0: return rx_row<0, JR>(x, lr, dg, xi, v, slp);
+        case 1: return rx_row<1, JR>(x, lr, dg, xi, v, slp);
+        case 2: return rx_row<2, JR>(x, lr, dg, xi, v, slp);
+        case 3: return rx_row<3, JR>(x, lr, dg, xi, v, slp);
+        case 4: return rx_row<4, JR>(x, lr, dg, xi, v, slp);
+        case 5: return rx_row<(JR > 5 ? 5 : JR), JR>(x, lr, dg, xi, v, slp);
+        case 6: return rx_row<(JR > 6 ? 6 : JR), JR>(x, lr, dg, xi, v, slp);
+        case 7: return rx_row<(JR > 7 ? 7 : JR), JR>(x, lr, dg, xi, v, slp);
+        default: return rx_row<JR, JR>(x, lr, dg, xi, v, slp);
+    }
 }
 
 template <int NG, int NW, int JR>
@@ -238,15 +270,9 @@ __global__ __launch_bounds__(RX_THREADS) void k_cheb_resident(RxArgs a) {
                 double* xn = xb[q] + (size_t)(cur ^ 1) * xlen[q];
                 const int32_t lr = w * RX_THREADS + tid;
                 const int32_t wd = width[q][w];
-                const double xi = x[lr];
-                double acc = dg[q][w] * xi;
-#pragma unroll
-                for (int j = 0; j < JR; ++j) {
-                    if (j < wd) {
-                        const unsigned s = (j & 1) ? (slp[q][w][j >> 1] >> 16) : (slp[q][w][j >> 1] & 0xffffu);
-                        acc = __builtin_fma(v[q][w][j], x[s], acc);
-                    }
-                }
+                double xi;
+                double acc = rx_row_dispatch<JR>(__builtin_amdgcn_readfirstlane(wd < JR ? wd : JR), x, lr, dg[q][w], xi, v[q][w],
+                                                 slp[q][w]);
                 for (int j = JR; j < wd; ++j) {
                     const int32_t o = ovoff[q][w] + (j - JR) * PF_WAVE + lane;
                     acc = __builtin_fma(ov_val[o], x[ov_slot[o]], acc);
@@ -275,11 +301,19 @@ __global__ __launch_bounds__(RX_THREADS) void k_cheb_resident(RxArgs a) {
             if (w == 0 && early) __builtin_amdgcn_s_setprio(0);
         }
         if (k == n_steps) break;
-        // ---- the outside values of step k, straight from their owners' stores
+        // ---- the outside values of step k, straight from their owners' stores.  The owners stored them about when this
+        // block stored its own, and an agent-scope store takes ~0.5 us to land: a poll issued at once would just miss it
+        // and cost a second round trip, so the first poll is held back by about that long - the interior rows of the
+        // other waves are being computed meanwhile.
+        // (measured at 250k rows, s_sleep units of 64 cycles: one graph 2.22 us per step polling at once, 1.42 held back by
+        // 16; a pair, whose second graph's poll follows the first one's round trip anyway, 1.92 -> 1.84 held back by 4)
+        bool slept = false;
 #pragma unroll
         for (int q = 0; q < NG; ++q) {
             const RxGraph& g = a.g[q];
             if (have[q] && k < g.degree && tid < ghosts[q]) {
+                if (!slept) __builtin_amdgcn_s_sleep(NG == 1 ? 16 : 4);
+                slept = true;
                 const unsigned long long* p =
                     reinterpret_cast<const unsigned long long*>(g.ring) + (int64_t)((k + g.phase) & 3) * g.n_pad + ghrow[q];
                 unsigned long long bits;
@@ -318,12 +352,14 @@ bool persist_enabled() {
 }
 
 using RxKernel = void (*)(RxArgs);
+// entries of a row kept in registers, by kernel shape: 8 where the register file allows it (a thread holds NG x NW rows)
+constexpr int rx_jr(int ng, int nw) { return ng * nw <= 2 ? 8 : 4; }
 RxKernel rx_kernel(int ng, int nw) {
-    if (ng == 1 && nw == 1) return k_cheb_resident<1, 1, RX_JR>;
-    if (ng == 2 && nw == 1) return k_cheb_resident<2, 1, RX_JR>;
-    if (ng == 1 && nw == 2) return k_cheb_resident<1, 2, RX_JR>;
-    if (ng == 2 && nw == 2) return k_cheb_resident<2, 2, RX_JR>;
-    if (ng == 1 && nw == 4) return k_cheb_resident<1, 4, RX_JR>;
+    if (ng == 1 && nw == 1) return k_cheb_resident<1, 1, rx_jr(1, 1)>;
+    if (ng == 2 && nw == 1) return k_cheb_resident<2, 1, rx_jr(2, 1)>;
+    if (ng == 1 && nw == 2) return k_cheb_resident<1, 2, rx_jr(1, 2)>;
+    if (ng == 2 && nw == 2) return k_cheb_resident<2, 2, rx_jr(2, 2)>;
+    if (ng == 1 && nw == 4) return k_cheb_resident<1, 4, rx_jr(1, 4)>;
     return nullptr;
 }
 
@@ -356,6 +392,7 @@ int device_grid(int device) {
 
 // LDS bytes of the fullest window (layout as in k_cheb_resident); -1 if the graph(s) cannot use the kernel
 int64_t lds_need(pf_graph* ga, pf_graph* gb, int nw) {
+    const int jr = rx_jr(gb ? 2 : 1, nw);
     pf_graph* gs[2] = {ga, gb};
     const int ng = gb ? 2 : 1;
     const int64_t RB = (int64_t)nw * RX_THREADS;
@@ -370,7 +407,7 @@ int64_t lds_need(pf_graph* ga, pf_graph* gb, int nw) {
             need += 2 * (RB + ((g->h_px_gh_cnt[(size_t)w] + 1) & ~1)) * 8;
             for (int64_t s = w * (RB / PF_WAVE); s < (w + 1) * (RB / PF_WAVE); ++s) {
                 const int64_t width = (g->h_slice_ptr[(size_t)s + 1] - g->h_slice_ptr[(size_t)s]) / PF_WAVE;
-                if (width > RX_JR) ov += (width - RX_JR) * PF_WAVE;
+                if (width > jr) ov += (width - jr) * PF_WAVE;
             }
         }
         need += ov * 10 + 16;
