@@ -26,7 +26,10 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 METRIC = "lowest-k eigenpairs/sec + KNN-correspondence wall-clock, 250k-vertex mesh pair k=5"
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md, HBM)
+# LDS peak (MI355X_MICROARCH.md, LDS table): ds_read_b64 conflict-free = 256 B per clock and CU; 256 CUs; 2.4 GHz
+LDS_PEAK_GBS = 256.0 * 256 * 2.4
+PMC_SUMMARY = os.path.join("profiles", "r02_pmc_summary.json")
 
 
 def spmv_algorithmic_bytes(n, nnz_l):
@@ -38,7 +41,7 @@ def spmv_algorithmic_bytes(n, nnz_l):
 def hot_path_step(ctxs, mesh_t, mesh_s, k, n_samples, timers, keep_graphs=False):
     """Same calls as Focusr.__init__ + align_maps (focusr.py:134-170, 514-545) without ICP/CPD."""
     from pyfocusr_amd import Graph, eigsort
-    from pyfocusr_amd.graph import compute_spectra
+    from pyfocusr_amd.graph import compute_spectra, spectral_knn
 
     ctx = ctxs[0]
     t0 = time.perf_counter()
@@ -58,9 +61,12 @@ def hot_path_step(ctxs, mesh_t, mesh_s, k, n_samples, timers, keep_graphs=False)
     Q = eigsort(gt, gs, k, target_as_reference=True).sort_eigenmaps()
     w = Q[:k] * np.max((gs.eig_vals[:k], gt.eig_vals[:k]), axis=0)  # focusr.py:481-490
     w = np.exp(-(w**2) / (2 * np.mean(w) ** 2))
-    src, tgt = gs.eig_vecs[:, :k] * w[None, :], gt.eig_vecs[:, :k] * w[None, :]
     t1 = time.perf_counter()
-    idx = ctx.knn1(tgt, src)  # focusr.py:351-353
+    # focusr.py:351-353 on eig_vecs[:, :k] * w of both meshes, read where the eigensolves left them (HBM); what
+    # Focusr.get_initial_correspondences does.  (Two contexts, --streams 2: the host arrays, as before.)
+    idx = spectral_knn(gt, gs, k, w)
+    if idx is None:
+        idx = ctx.knn1(gt.eig_vecs[:, :k] * w[None, :], gs.eig_vecs[:, :k] * w[None, :])
     t2 = time.perf_counter()
     timers["eigsort"] += t1 - t0
     timers["knn"] += t2 - t1
@@ -70,32 +76,42 @@ def hot_path_step(ctxs, mesh_t, mesh_s, k, n_samples, timers, keep_graphs=False)
         g.device.close()
     if keep_graphs:
         return graphs
-    return idx, res, (gt.device.nnz_l, gs.device.nnz_l), (tgt, src)
+    return idx, res, (gt.device.nnz_l, gs.device.nnz_l), (gt.eig_vecs, gs.eig_vecs, w, gt.eig_vals, gs.eig_vals)
 
 
-def cpu_baseline(mesh_t, k, coords, knn_sample):
+def cpu_baseline(mesh_t, k, coords, knn_sample, gpu_vals, gpu_idx, eigs_runs=2):
     """The oracle (reference calls restated: scipy eigs shift-invert + KDTree, 1 thread, exactly as
     the reference issues them) on a bounded sample of the same workload: ONE of the two
-    eigensolves, and the KDTree correspondence of `knn_sample` of the n source rows against the
-    full target set — on the very coordinate arrays the GPU KNN of the last step consumed."""
+    eigensolves (`eigs_runs` timed runs, the median), and the KDTree correspondence of `knn_sample` of the n
+    source rows against the full target set — on the very coordinate arrays the GPU KNN of the last step
+    consumed.  The pair figure is EXTRAPOLATED from that sample (2 x eigensolve + KDTree build + query scaled to n
+    rows).  Because the same arrays are in hand, the sample doubles as the parity check at full size: relative
+    eigenvalue error of the device solve against scipy's, and KNN indices against the KDTree's."""
     from oracle import reference_port as orc
     from scipy.spatial import KDTree
 
     t0 = time.perf_counter()
     W, deg, d_inv, L = orc.graph_matrices(mesh_t.points, mesh_t.faces)
     t_asm = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    vals, vecs = orc.recursive_eig(L, k + 1, k)
-    t_eigs = time.perf_counter() - t0
+    t_runs = []
+    for _ in range(max(1, eigs_runs)):
+        t0 = time.perf_counter()
+        vals, vecs = orc.recursive_eig(L, k + 1, k)
+        t_runs.append(time.perf_counter() - t0)
+    t_eigs = float(np.median(t_runs))
+    vals = np.sort(vals)[:k]
+    eig_err = float(np.max(np.abs(np.asarray(gpu_vals)[:k] / vals - 1.0)))
     tgt, src = coords
     rng = np.random.default_rng(0)
-    q = src[np.sort(rng.choice(len(src), knn_sample, replace=False))]
+    rows = np.sort(rng.choice(len(src), knn_sample, replace=False))
+    q = src[rows]
     t0 = time.perf_counter()
     tree = KDTree(tgt)
     t_tree = time.perf_counter() - t0
     t0 = time.perf_counter()
-    tree.query(q)
+    _, kd_idx = tree.query(q)
     t_query = time.perf_counter() - t0
+    knn_mismatches = int(np.sum(kd_idx != np.asarray(gpu_idx)[rows]))
     n = len(src)
     t_pair = 2 * (t_asm + t_eigs) + t_tree + t_query * (n / knn_sample)
     # SURVEY 8d "best-effort CPU" row: the same calls with KDTree.query(workers=-1) on every host core
@@ -104,13 +120,19 @@ def cpu_baseline(mesh_t, k, coords, knn_sample):
     tree.query(q, workers=-1)
     t_query_mt = time.perf_counter() - t0
     t_pair_mt = 2 * (t_asm + t_eigs) + t_tree + t_query_mt * (n / knn_sample)
-    best_effort = dict(value=2 * k / t_pair_mt, unit="eigenpairs/s", cores=os.cpu_count(), pair_seconds=t_pair_mt,
+    best_effort = dict(value=2 * k / t_pair_mt, unit="eigenpairs/s", cores=os.cpu_count(), pair_seconds_extrapolated=t_pair_mt,
                        sample="as above with KDTree.query(workers=-1): %.3fs for the sample" % t_query_mt)
-    return dict(best_effort_all_cores=best_effort, value=2 * k / t_pair, unit="eigenpairs/s", cores=1, kind="port",
-                sample="1 of 2 meshes: vectorised assembly %.2fs + scipy eigs(sigma=1e-10, ncv=4(k+1)) %.2fs; KDTree build "
-                       "%.2fs + query of %d/%d source points %.2fs (scaled x%.0f); pair estimate %.1fs"
-                       % (t_asm, t_eigs, t_tree, knn_sample, n, t_query, n / knn_sample, t_pair),
-                pair_seconds=t_pair)
+    base = dict(best_effort_all_cores=best_effort, value=2 * k / t_pair, unit="eigenpairs/s", cores=1, kind="port",
+                sample="1 of 2 meshes: vectorised assembly %.2fs + scipy eigs(sigma=1e-10, ncv=4(k+1)) %s s (median of %d runs); "
+                       "KDTree build %.2fs + query of %d/%d source points %.2fs (scaled x%.0f); pair figure extrapolated: %.1fs"
+                       % (t_asm, "/".join("%.2f" % t for t in t_runs), len(t_runs), t_tree, knn_sample, n, t_query,
+                          n / knn_sample, t_pair),
+                pair_seconds_extrapolated=t_pair)
+    parity = dict(max_rel_eigenvalue_error_vs_cpu=eig_err, knn_index_mismatches_vs_kdtree=knn_mismatches,
+                  knn_rows_checked=int(knn_sample),
+                  note="device eigenvalues of the target mesh of the last timed step against scipy eigs on the oracle's L; "
+                       "device 1-NN indices of the last timed step against KDTree on the sampled source rows")
+    return base, parity
 
 
 def device_copy_gbs(torch, dev, n_bytes=1 << 30, reps=10):
@@ -307,8 +329,26 @@ def main():
         elapsed = float(t.item())
     tms = [c.timing() for c in set(ctxs)]
     tm = dict(knn_ms=tms[0]["knn_ms"])
-    for key in ("op_ms", "op_launches", "op_bytes", "persist_ms", "persist_launches", "persist_steps", "persist_bytes"):
+    for key in ("op_ms", "op_launches", "op_bytes", "persist_ms", "persist_launches", "persist_steps", "persist_bytes",
+                "persist_lds_bytes"):
         tm[key] = sum(t[key] for t in tms)
+
+    # The kernel that DOES stream the operators through HBM (one step per launch, k_sell_op2): the path of graphs the
+    # resident kernel does not cover.  One untimed extra step with the resident kernel switched off gives its HBM
+    # roofline entry in the same run.
+    stream_tm = None
+    if rank == 0 and not args.no_extras:
+        _hip.persist_enable(False)
+        try:
+            extra = dict(assembly=0.0, eigensolve=0.0, eigsort=0.0, knn=0.0, matvecs=0)
+            for c in set(ctxs):
+                c.timing(reset=True)
+            hot_path_step(ctxs, mesh_t, mesh_s, args.k, args.samples, extra)
+            sts = [c.timing(reset=True) for c in set(ctxs)]
+            stream_tm = {key: sum(t[key] for t in sts) for key in ("op_ms", "op_launches", "op_bytes", "persist_launches")}
+            stream_tm["eigensolve_ms"] = 1e3 * extra["eigensolve"]
+        finally:
+            _hip.persist_enable(True)
 
     split = None
     if world == 2:
@@ -358,33 +398,72 @@ def main():
 
     if rank == 0:
         n = args.n
-        # The dominant kernel: the persistent Chebyshev kernel (a whole recurrence of both graphs per launch, operators
-        # resident in LDS) when the library used it, else the one-step-per-launch operator kernel.  Algorithmic bytes
-        # per launch: the library sums 12 nnz + 20 n + 4 over the graphs and steps each launch advances.
-        persistent = tm.get("persist_launches", 0) > 0 and tm["persist_ms"] > 0.5 * tm["op_ms"]
-        if persistent:
-            launches, kernel_ms, kernel_bytes = tm["persist_launches"], tm["persist_ms"], tm["persist_bytes"]
-            kernel_name = ("k_sell_persist_x<2> (the whole Chebyshev recurrence of both graphs of the pair in one launch: SELL-64 "
-                           "operators and the x of each 1024-row window resident in LDS, neighbouring windows synchronise point to "
-                           "point between steps, f64)")
+        pmc = {}
+        if os.path.exists(os.path.join(REPO, PMC_SUMMARY)):
+            with open(os.path.join(REPO, PMC_SUMMARY)) as fh:
+                pmc = json.load(fh).get("kernels", {})  # separate --pmc passes of this command (tools/pmc_make_summary.py)
+        # The dominant kernel.  With the resident kernel (the default for this workload) the operators live in registers
+        # and x in LDS: its bytes are LDS bytes, its step time is set by one memory-side hand-off between neighbouring
+        # windows plus the LDS gathers of the boundary rows, and what it moves through HBM is two orders of magnitude
+        # below the algorithmic bytes of one step per launch.  So: `bound` "lds", `achieved` = LDS bytes per launch / launch
+        # time against the LDS peak; `hbm_frac` from PMC traffic; the algorithmic figure stays as an EFFECTIVE rate,
+        # never divided by a peak.  Otherwise (resident path off / not applicable): the streaming kernel, HBM roofline.
+        resident = tm.get("persist_launches", 0) > 0 and tm["persist_ms"] > 0.5 * tm["op_ms"]
+        if resident:
+            launches, kernel_ms = tm["persist_launches"], tm["persist_ms"]
+            kernel_us = 1e3 * kernel_ms / max(launches, 1)
+            lds_per_launch = tm["persist_lds_bytes"] / max(launches, 1)
+            achieved = lds_per_launch / (kernel_us * 1e-6) / 1e9
+            steps_per_launch = tm["persist_steps"] / max(launches, 1)
+            entry = pmc.get("k_cheb_resident<2, 1, 8>", {})
+            traffic = entry.get("hbm_bytes_per_step", None)
+            traffic = None if traffic is None else traffic * steps_per_launch + entry.get("hbm_bytes_per_launch_fixed", 0.0)
+            roofline = {
+                "bound": "lds",
+                "kernel": "k_cheb_resident<2, 1, 8> (a whole Chebyshev recurrence of both graphs of the pair per launch: one block "
+                          "per CU owns a 1024-row window of each graph, SELL-64 entries in registers, the window's x double-buffered "
+                          "in LDS, boundary rows handed to neighbouring windows through memory, value = message; f64)",
+                "achieved": achieved, "peak": LDS_PEAK_GBS, "unit": "GB/s", "frac": achieved / LDS_PEAK_GBS,
+                "traffic": traffic,
+                "traffic_source": (PMC_SUMMARY + " (rocprofv3 --pmc passes of this command, committed; not measured in this run)")
+                if traffic is not None else None,
+                "hbm_frac": None if traffic is None else traffic / (kernel_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                "lds_bytes_per_launch": lds_per_launch,
+                "avg_launch_us_hip_events": kernel_us, "launches": launches, "steps_per_launch": steps_per_launch,
+                "us_per_step_of_the_pair": 1e3 * kernel_ms / max(tm["persist_steps"], 1),
+                "effective_algorithmic_GBps": tm["persist_bytes"] / max(launches, 1) / (kernel_us * 1e-6) / 1e9,
+                "note": "frac is LDS bytes (8 B per gathered x + 16 B per row + 8 B per outside row, counted by the library) "
+                        "against the conflict-free ds_read_b64 peak; random 8-byte gathers conflict ~3-4x, and each step waits "
+                        "for one memory-side hand-off (~1 us): the kernel is latency-bound, neither LDS- nor HBM-bandwidth-bound "
+                        "(DESIGN.md section 4).  effective_algorithmic_GBps = SURVEY 8d bytes (12 nnz + 20 n + 4 per graph and step, "
+                        "what one step per launch streams) over the same time: an effective rate, not a roofline fraction.",
+            }
         else:
             launches, kernel_ms, kernel_bytes = tm["op_launches"], tm["op_ms"], tm["op_bytes"]
-            kernel_name = ("k_sell_op2/k_sell_op (fused SpMV + Chebyshev recurrence, SELL-64, f64; both graphs of the pair "
-                           "per launch)")
-        kernel_us = 1e3 * kernel_ms / max(launches, 1)
-        alg_bytes = kernel_bytes / max(launches, 1)
-        achieved = alg_bytes / (kernel_us * 1e-6) / 1e9
-        traffic = None
-        pmc = os.path.join(REPO, "profiles", "pmc_summary.json")
-        if os.path.exists(pmc):
-            with open(pmc) as fh:
-                summary = json.load(fh)  # PMC passes of this command (profiles/)
-            if persistent:
-                per_step = summary.get("persistent_kernel", {}).get("hbm_bytes_per_pair_step")
-                if per_step is not None:
-                    traffic = per_step * tm["persist_steps"] / max(launches, 1)
-            elif summary.get("hbm_bytes_per_graph_step") is not None:
-                traffic = summary["hbm_bytes_per_graph_step"] * alg_bytes / spmv_algorithmic_bytes(n, nnz[0])
+            kernel_us = 1e3 * kernel_ms / max(launches, 1)
+            alg_bytes = kernel_bytes / max(launches, 1)
+            achieved = alg_bytes / (kernel_us * 1e-6) / 1e9
+            entry = pmc.get("k_sell_op2<true>", {})
+            traffic = entry.get("hbm_bytes_per_launch")
+            roofline = {"bound": "hbm", "kernel": "k_sell_op2/k_sell_op (fused SpMV + Chebyshev recurrence, SELL-64, f64; both graphs "
+                                                  "of the pair per launch)",
+                        "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                        "traffic": traffic, "traffic_source": PMC_SUMMARY if traffic is not None else None,
+                        "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us_hip_events": kernel_us, "launches": launches}
+        roofline_stream = None
+        if stream_tm is not None and stream_tm["op_launches"] > 0 and stream_tm["persist_launches"] == 0:
+            us = 1e3 * stream_tm["op_ms"] / stream_tm["op_launches"]
+            alg = stream_tm["op_bytes"] / stream_tm["op_launches"]
+            entry = pmc.get("k_sell_op2<true>", {})
+            roofline_stream = {
+                "bound": "hbm", "kernel": "k_sell_op2 (one Chebyshev step of both graphs per launch, SELL-64 streamed from HBM / "
+                                          "Infinity Cache; the path of graphs the resident kernel does not cover; measured in ONE extra, "
+                                          "untimed step of this run with the resident kernel switched off)",
+                "achieved": alg / (us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": entry.get("hbm_bytes_per_launch"),
+                "traffic_source": PMC_SUMMARY if entry.get("hbm_bytes_per_launch") is not None else None,
+                "algorithmic_bytes_per_launch": alg, "avg_launch_us_hip_events": us, "launches": stream_tm["op_launches"],
+                "eigensolve_ms_of_that_step": stream_tm["eigensolve_ms"]}
         out = {
             "metric": METRIC,
             "value": world * 2 * args.k * args.steps / elapsed,
@@ -410,22 +489,12 @@ def main():
             "operator_algorithmic_bytes_per_step": tm["op_bytes"] / args.steps,
             "knn_kernel_ms": tm["knn_ms"],
             "max_eig_residual": float(max_res),
-            "roofline": {"bound": "hbm", "kernel": kernel_name,
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
-                         "graph_steps_per_launch": alg_bytes / spmv_algorithmic_bytes(n, nnz[0]),
-                         "avg_launch_us_hip_events": kernel_us, "launches": launches},
+            "roofline": roofline,
         }
-        if persistent:
-            out["roofline"]["steps_per_launch"] = tm["persist_steps"] / max(launches, 1)
-            out["roofline"]["us_per_step_of_the_pair"] = 1e3 * kernel_ms / max(tm["persist_steps"], 1)
-            out["roofline"]["note"] = ("algorithmic bytes are what one step per launch would stream (12 nnz + 20 n + 4 per graph "
-                                       "and step); the operators and x stay in LDS here, so `traffic` (PMC) is far below them and "
-                                       "`achieved` is an effective rate that can exceed the HBM peak, not HBM traffic")
+        if roofline_stream is not None:
+            out["roofline_streaming_kernel"] = roofline_stream
         if not args.no_extras:
-            copy_gbs = device_copy_gbs(torch, torch.device("cuda", local))
-            out["roofline"]["achievable_copy"] = copy_gbs
-            out["roofline"]["frac_of_achievable_copy"] = achieved / copy_gbs
+            out["roofline"]["achievable_hbm_copy_GBps"] = device_copy_gbs(torch, torch.device("cuda", local))
         if split is not None:
             out["split_pair"] = split
         if rowp is not None:
@@ -435,8 +504,11 @@ def main():
             if c2 is not None:
                 out["bundled_15k_pair"] = c2
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(mesh_t, args.k, coords, min(args.cpu_knn_sample, n))
-            out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+            vt, vs, w, vals_t, vals_s = coords  # last timed step; the coordinate arrays are built here, outside the timed region
+            coords = (vt[:, :args.k] * w[None, :], vs[:, :args.k] * w[None, :])
+            out["cpu_baseline"], out["parity_at_full_size"] = cpu_baseline(mesh_t, args.k, coords, min(args.cpu_knn_sample, n),
+                                                                         vals_t, idx)
+            out["speedup_vs_cpu_baseline_extrapolated"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

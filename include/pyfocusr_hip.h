@@ -67,11 +67,13 @@ typedef struct pf_timing {
     double op_bytes;     /* algorithmic bytes they moved: sum of 12 nnz + 20 n + 4 per graph and step */
     double knn_ms;       /* device time of the last pf_knn_run                                    */
     double build_ms;     /* device time of the last pf_graph_build (kernels only)                 */
-    /* the part of the above done by the persistent kernel (pf_persist_enable): one launch = a whole recurrence */
+    /* the part of the above done by the resident kernel (pf_persist_enable): one launch = a whole recurrence */
     double persist_ms;
     int64_t persist_launches;
     int64_t persist_steps; /* recurrence steps those launches ran (the longer of the two graphs per launch) */
     double persist_bytes;  /* algorithmic bytes, counted as for op_bytes                                   */
+    double persist_lds_bytes; /* LDS bytes the resident launches moved: per graph and step 8 B per stored SELL entry
+                                 (the gathered x) + 16 B per row (own x read, result written) + 8 B per outside row */
 } pf_timing;
 
 /* ---- context -------------------------------------------------------------------------- */
@@ -169,6 +171,13 @@ int pf_resnorm(pf_graph* g, int32_t ax, int32_t x, double lam, double* out);    
  * out: host n x count row-major (numpy (n, count) C-order). */
 int pf_finalize_vectors(pf_graph* g, int32_t first, int32_t count, int32_t from_sym, int32_t minmax,
                         double* out);
+/* The block written by the last pf_finalize_vectors stays resident in HBM.  out[t][c] = that block's row rows[t]
+ * (n_rows x count, row-major): the sampled eigenvector rows of Graph.get_rand_eig_vecs (graph.py:266-267) without
+ * touching the host copy. */
+int pf_final_rows(pf_graph* g, const int64_t* rows, int64_t n_rows, double* out);
+/* the same for the mesh's points (graphs built from a mesh keep them): out[t] = pts[rows[t]] (n_rows x 3), the gather
+ * inside Graph.get_rand_normalized_points (graph.py:269-272) */
+int pf_point_rows(pf_graph* g, const int64_t* rows, int64_t n_rows, double* out);
 /* y = A x on host vectors (tests / roofline probes) */
 int pf_spmv_host(pf_graph* g, int32_t op, const double* x, double* y);
 /* Repeated mean filter out = (D+I)^-1 (W+I) applied `iterations` times to values[n][ncols]
@@ -187,6 +196,12 @@ int pf_knn1(pf_ctx* ctx, const double* ref, int64_t n_ref, const double* qry, in
  * Focusr.get_weighted_final_node_locations (focusr.py:409-412).  idx_out / d2_out: n_qry x k row-major. */
 int pf_knn(pf_ctx* ctx, const double* ref, int64_t n_ref, const double* qry, int64_t n_qry, int32_t d, int32_t k,
            int64_t* idx_out, double* d2_out);
+/* focusr.py:351-353 with the coordinates taken from the two graphs' resident pf_finalize_vectors blocks instead of
+ * host arrays: ref[i][c] = final_ref[i][col_ref[c]] * scale_ref[c], qry likewise (c < d) - the column selection, sign
+ * flips and permutation of eigsort (eigsort.py:108-122) and the spectral weights (focusr.py:481-501) are folded into
+ * col / scale, so the n x k coordinates never cross PCIe.  Same search, same arithmetic as pf_knn1. */
+int pf_knn1_graphs(pf_graph* ref_g, pf_graph* qry_g, int32_t d, const int32_t* col_ref, const double* scale_ref,
+                   const int32_t* col_qry, const double* scale_qry, int64_t* idx_out, double* d2_out);
 /* split form (inputs resident in HBM across the timed region) */
 int pf_knn_upload(pf_ctx* ctx, const double* ref, int64_t n_ref, const double* qry, int64_t n_qry, int32_t d);
 int pf_knn_run(pf_ctx* ctx);

@@ -47,7 +47,7 @@ class EigsStats(C.Structure):
 class Timing(C.Structure):
     _fields_ = [("op_ms", C.c_double), ("op_launches", C.c_int64), ("op_bytes", C.c_double), ("knn_ms", C.c_double),
                 ("build_ms", C.c_double), ("persist_ms", C.c_double), ("persist_launches", C.c_int64),
-                ("persist_steps", C.c_int64), ("persist_bytes", C.c_double)]
+                ("persist_steps", C.c_int64), ("persist_bytes", C.c_double), ("persist_lds_bytes", C.c_double)]
 
 
 # name -> (restype, argtypes): every symbol include/pyfocusr_hip.h declares.
@@ -90,10 +90,13 @@ SIGNATURES = {
     "pf_combine": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _f64p, C.c_int32, C.c_int32]),
     "pf_resnorm": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_double, _f64p]),
     "pf_finalize_vectors": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _f64p]),
+    "pf_final_rows": (C.c_int, [C.c_void_p, _i64p, C.c_int64, _f64p]),
+    "pf_point_rows": (C.c_int, [C.c_void_p, _i64p, C.c_int64, _f64p]),
     "pf_spmv_host": (C.c_int, [C.c_void_p, C.c_int32, _f64p, _f64p]),
     "pf_mean_filter": (C.c_int, [C.c_void_p, _f64p, C.c_int32, C.c_int32, _f64p]),
     "pf_knn1": (C.c_int, [C.c_void_p, _f64p, C.c_int64, _f64p, C.c_int64, C.c_int32, _i64p, _f64p]),
     "pf_knn": (C.c_int, [C.c_void_p, _f64p, C.c_int64, _f64p, C.c_int64, C.c_int32, C.c_int32, _i64p, _f64p]),
+    "pf_knn1_graphs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, _i32p, _f64p, _i32p, _f64p, _i64p, _f64p]),
     "pf_knn_upload": (C.c_int, [C.c_void_p, _f64p, C.c_int64, _f64p, C.c_int64, C.c_int32]),
     "pf_knn_run": (C.c_int, [C.c_void_p]),
     "pf_knn_download": (C.c_int, [C.c_void_p, _i64p, _f64p]),
@@ -238,7 +241,7 @@ class Context(object):
         _check(self._lib.pf_timing_get(self._h, C.byref(t), int(bool(reset))))
         return dict(op_ms=t.op_ms, op_launches=int(t.op_launches), op_bytes=t.op_bytes, knn_ms=t.knn_ms,
                     build_ms=t.build_ms, persist_ms=t.persist_ms, persist_launches=int(t.persist_launches),
-                    persist_steps=int(t.persist_steps), persist_bytes=t.persist_bytes)
+                    persist_steps=int(t.persist_steps), persist_bytes=t.persist_bytes, persist_lds_bytes=t.persist_lds_bytes)
 
     # ---- nearest neighbour -------------------------------------------------------------
     def knn1(self, ref, qry, return_d2=False):
@@ -262,6 +265,22 @@ class Context(object):
         _check(self._lib.pf_knn(self._h, _f64(ref), ref.shape[0], _f64(qry), qry.shape[0], ref.shape[1], int(k),
                                 idx.ctypes.data_as(_i64p), _f64(d2)))
         return idx, d2
+
+    def knn1_graphs(self, dev_ref, dev_qry, col_ref, scale_ref, col_qry, scale_qry, return_d2=False):
+        """`knn1` on coordinates built on the device from the two graphs' resident eigenvector blocks:
+        ref[:, c] = final_ref[:, col_ref[c]] * scale_ref[c], qry likewise."""
+        col_ref = np.ascontiguousarray(col_ref, dtype=np.int32)
+        col_qry = np.ascontiguousarray(col_qry, dtype=np.int32)
+        scale_ref, scale_qry = _c_f64(scale_ref), _c_f64(scale_qry)
+        d = len(col_ref)
+        if not (len(col_qry) == len(scale_ref) == len(scale_qry) == d):
+            raise ValueError("col / scale arrays must share one length d")
+        idx = np.empty(dev_qry.n, dtype=np.int64)
+        d2 = np.empty(dev_qry.n, dtype=np.float64) if return_d2 else None
+        _check(self._lib.pf_knn1_graphs(dev_ref._h, dev_qry._h, d, col_ref.ctypes.data_as(_i32p), _f64(scale_ref),
+                                        col_qry.ctypes.data_as(_i32p), _f64(scale_qry), idx.ctypes.data_as(_i64p),
+                                        _f64(d2) if return_d2 else None))
+        return (idx, d2) if return_d2 else idx
 
     def knn_upload(self, ref, qry):
         ref, qry = _c_f64(ref), _c_f64(qry)
@@ -518,6 +537,7 @@ class DeviceLaplacian(object):
         self.max_degree = int(info.max_degree)
         self.n_oneway = int(info.n_oneway)
         self.op = PF_OP_SYM if self.symmetric else PF_OP_RW
+        self.has_points = matrix is None
         self._rows = []
 
     def close(self):
@@ -633,6 +653,21 @@ class DeviceLaplacian(object):
         out = np.empty((self.n, int(count)), dtype=np.float64)
         _check(self._lib.pf_finalize_vectors(self._h, int(first), int(count), int(self.op == PF_OP_SYM), int(bool(minmax)),
                                              _f64(out)))
+        self._final_count = int(count)  # the same block stays resident on the device (final_rows, Context.knn1_graphs)
+        return out
+
+    def final_rows(self, rows):
+        """Rows of the block the last `finalize_vectors` left on the device -> (len(rows), count) array."""
+        rows = np.ascontiguousarray(rows, dtype=np.int64)
+        out = np.empty((len(rows), self._final_count), dtype=np.float64)
+        _check(self._lib.pf_final_rows(self._h, rows.ctypes.data_as(_i64p), len(rows), _f64(out)))
+        return out
+
+    def point_rows(self, rows):
+        """Rows of the mesh's points as they sit on the device -> (len(rows), 3) array (mesh-built graphs only)."""
+        rows = np.ascontiguousarray(rows, dtype=np.int64)
+        out = np.empty((len(rows), 3), dtype=np.float64)
+        _check(self._lib.pf_point_rows(self._h, rows.ctypes.data_as(_i64p), len(rows), _f64(out)))
         return out
 
     def spmv_host(self, x, op=None):

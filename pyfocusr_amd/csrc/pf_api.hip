@@ -74,6 +74,7 @@ int pf_timing_collect(pf_ctx* c) {
             c->persist_launches += sp.launches;
             c->persist_steps += sp.persist_steps;
             c->persist_bytes += sp.bytes;
+            c->persist_lds_bytes += sp.lds_bytes;
         }
         c->spans_free.emplace_back(sp.e0, sp.e1);
     }
@@ -172,8 +173,9 @@ int pf_timing_get(pf_ctx* c, pf_timing* out, int reset) {
     out->persist_launches = c->persist_launches;
     out->persist_steps = c->persist_steps;
     out->persist_bytes = c->persist_bytes;
+    out->persist_lds_bytes = c->persist_lds_bytes;
     if (reset) {
-        c->persist_ms = c->persist_bytes = 0.0;
+        c->persist_ms = c->persist_bytes = c->persist_lds_bytes = 0.0;
         c->persist_launches = c->persist_steps = 0;
         c->op_ms = 0.0;
         c->op_launches = 0;

@@ -454,6 +454,8 @@ void pf_graph_free(pf_graph* g) {
     hipSetDevice(g->ctx->device);
     hipStream_t st = g->ctx->stream;
     pf_free(st, g->persist_ring);
+    pf_free(st, g->final_vecs);
+    pf_free(st, g->pts);
     pf_window_slots_free(g);
     pf_free(st, g->rowptr);
     pf_free(st, g->col);
@@ -639,6 +641,8 @@ int pf_graph_build_device(pf_mesh* mesh, pf_graph** out) {
     k_compact_rows<<<nblk(n), PF_BLOCK, 0, st>>>(start, g->rowptr, n, rcol, rw, g->col, g->w, g->deg, g->g, g->sg);
     PF_HIP(hipGetLastError());
     PF_TRY(finish_graph(g, d_pts, false));
+    PF_TRY(dev_alloc(st, &g->pts, 3 * n));  // kept for pf_point_rows (the mesh object may go away before the graph)
+    PF_HIP(hipMemcpyAsync(g->pts, d_pts, sizeof(double) * 3 * n, hipMemcpyDeviceToDevice, st));
     PF_HIP(hipEventRecord(ctx->ev1, st));
     PF_HIP(hipStreamSynchronize(st));
     float ms = 0.f;

@@ -53,7 +53,7 @@ struct pf_ctx {
     double op_ms = 0.0;
     int64_t op_launches = 0;
     double op_bytes = 0.0;
-    double persist_ms = 0.0, persist_bytes = 0.0;
+    double persist_ms = 0.0, persist_bytes = 0.0, persist_lds_bytes = 0.0;
     int64_t persist_launches = 0, persist_steps = 0;
     double knn_ms = 0.0;
     double build_ms = 0.0;
@@ -85,7 +85,8 @@ struct pf_ctx {
         hipEvent_t e0, e1;
         int64_t launches;
         double bytes;
-        int64_t persist_steps;  // > 0: one launch of the persistent kernel that ran this many steps
+        int64_t persist_steps;  // > 0: resident launch(es) that ran this many steps
+        double lds_bytes;       // LDS bytes those steps moved (pf_persist.hip)
     };
     std::vector<TimedSpan> spans_pending;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> spans_free;
@@ -136,6 +137,7 @@ struct pf_graph {
     int32_t* px_gh_row = nullptr;  // [windows][PF_WIN_GHOSTS]
     int32_t* px_need = nullptr;    // [windows] leading rows of the window that other windows read (>= 1)
     std::vector<int32_t> h_px_gh_cnt;
+    int64_t px_gh_total = 0;       // sum of h_px_gh_cnt
     double* persist_ring = nullptr;  // [4][n_pad] hand-off buffers of the windows' boundary rows (sentinel when empty)
     int32_t persist_phase = 0;       // ring slot of step k of the next launch = (k + phase) & 3
     uint64_t persist_epoch = 0;      // ring known good for this value of the library's abort epoch
@@ -156,6 +158,11 @@ struct pf_graph {
     int32_t orth_host_cap = 0;
     int32_t orth_pending = -1;   // count of the orth in flight, -1 if none
     hipEvent_t orth_ev = nullptr;
+    // the last pf_finalize_vectors result stays in HBM (mesh order, [n][final_count] row-major) for pf_final_rows and
+    // pf_knn1_graphs: the spectral coordinates never have to come back from the host
+    double* final_vecs = nullptr;
+    int32_t final_count = 0;
+    double* pts = nullptr;  // [n][3] the mesh's points (graphs built from a mesh): pf_point_rows
 };
 
 // Caching device allocator, one cache per ctx (pf_api.hip).  Every use of a block is enqueued on
@@ -203,7 +210,7 @@ struct pf_persist_args {
     int32_t degree;
     double c, e, rho;
 };
-int pf_persist_cheb(const pf_persist_args* a, const pf_persist_args* b /* nullable */, int* done);
+int pf_persist_cheb(const pf_persist_args* a, const pf_persist_args* b /* nullable */, int* done, double* lds_bytes /* += */);
 int pf_persist_check(pf_ctx* ctx);  // PF_E_PERSIST_TIMEOUT (stream drained, path switched off) if a wait of an earlier launch ran out
 int pf_persist_set(int on);
 void pf_persist_release(pf_ctx* ctx);  // pf_destroy: another ctx may take the resident path over

@@ -441,11 +441,11 @@ int sort_points(pf_ctx* c, const double* pts, int64_t n, int d, int morton, int 
 
 extern "C" {
 
-int pf_knn_upload(pf_ctx* c, const double* ref, int64_t n_ref, const double* qry, int64_t n_qry, int32_t d) {
+// device buffers and grid parameters of a (n_ref, n_qry, d) problem; the coordinates are filled in by the caller
+static int knn_prepare(pf_ctx* c, int64_t n_ref, int64_t n_qry, int32_t d) {
     PF_CHECK(c != nullptr, PF_E_ARG, "pf_knn_upload: ctx is NULL");
     const int32_t k = c->knn_k_next;
     c->knn_k_next = 1;
-    PF_CHECK(c && ref && qry, PF_E_ARG, "pf_knn_upload: NULL argument");
     PF_CHECK(k >= 1 && k <= 4 && k <= n_ref, PF_E_ARG, "pf_knn: k = %d out of range (1..4, <= n_ref)", k);
     PF_CHECK(n_ref > 0 && n_ref < ((int64_t)1 << 31) && n_qry > 0 && n_qry < ((int64_t)1 << 31) && d >= 1 && d <= 16, PF_E_ARG,
              "pf_knn_upload: n_ref %lld, n_qry %lld, d %d out of range (1 <= d <= 16)", (long long)n_ref, (long long)n_qry, d);
@@ -473,6 +473,24 @@ int pf_knn_upload(pf_ctx* c, const double* ref, int64_t n_ref, const double* qry
     c->knn_nref = n_ref;
     c->knn_nqry = n_qry;
     c->knn_d = d;
+    return PF_OK;
+}
+
+// coord[i][c] = fin[i][col[c]] * scale[c]
+__global__ __launch_bounds__(PF_BLOCK) void k_coords_from_final(const double* __restrict__ fin, int64_t n, int32_t fc, int32_t d,
+                                                                const int32_t* __restrict__ col, const double* __restrict__ scale,
+                                                                double* __restrict__ out) {
+    const int64_t e = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
+    if (e >= n * d) return;
+    const int64_t i = e / d;
+    const int32_t c = (int32_t)(e - i * d);
+    out[e] = fin[i * fc + col[c]] * scale[c];
+}
+
+int pf_knn_upload(pf_ctx* c, const double* ref, int64_t n_ref, const double* qry, int64_t n_qry, int32_t d) {
+    PF_CHECK(c && ref && qry, PF_E_ARG, "pf_knn_upload: NULL argument");
+    PF_TRY(knn_prepare(c, n_ref, n_qry, d));
+    hipStream_t st = c->stream;
     PF_HIP(hipMemcpyAsync(c->knn_ref, ref, sizeof(double) * n_ref * d, hipMemcpyHostToDevice, st));
     PF_HIP(hipMemcpyAsync(c->knn_qry, qry, sizeof(double) * n_qry * d, hipMemcpyHostToDevice, st));
     PF_HIP(hipStreamSynchronize(st));
@@ -553,6 +571,43 @@ int pf_knn(pf_ctx* c, const double* ref, int64_t n_ref, const double* qry, int64
 int pf_knn1(pf_ctx* c, const double* ref, int64_t n_ref, const double* qry, int64_t n_qry, int32_t d, int64_t* idx_out,
             double* d2_out) {
     PF_TRY(pf_knn_upload(c, ref, n_ref, qry, n_qry, d));
+    PF_TRY(pf_knn_run(c));
+    return pf_knn_download(c, idx_out, d2_out);
+}
+
+int pf_knn1_graphs(pf_graph* ref_g, pf_graph* qry_g, int32_t d, const int32_t* col_ref, const double* scale_ref,
+                   const int32_t* col_qry, const double* scale_qry, int64_t* idx_out, double* d2_out) {
+    PF_CHECK(ref_g && qry_g && col_ref && scale_ref && col_qry && scale_qry && idx_out, PF_E_ARG, "pf_knn1_graphs: NULL argument");
+    PF_CHECK(ref_g->ctx == qry_g->ctx, PF_E_ARG, "pf_knn1_graphs: the two graphs must share one ctx");
+    PF_CHECK(ref_g->final_vecs && qry_g->final_vecs, PF_E_STATE, "pf_knn1_graphs: no pf_finalize_vectors result is resident");
+    PF_CHECK(d >= 1 && d <= 16, PF_E_ARG, "pf_knn1_graphs: d = %d out of range", d);
+    for (int32_t c = 0; c < d; ++c)
+        PF_CHECK(col_ref[c] >= 0 && col_ref[c] < ref_g->final_count && col_qry[c] >= 0 && col_qry[c] < qry_g->final_count, PF_E_ARG,
+                 "pf_knn1_graphs: column %d out of range", c);
+    pf_ctx* c = ref_g->ctx;
+    PF_TRY(knn_prepare(c, ref_g->n, qry_g->n, d));
+    hipStream_t st = c->stream;
+    int32_t* d_col = nullptr;
+    double* d_scale = nullptr;
+    PF_HIP(pf_malloc(st, (void**)&d_col, sizeof(int32_t) * 32));
+    hipError_t e = pf_malloc(st, (void**)&d_scale, sizeof(double) * 32);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_col, col_ref, sizeof(int32_t) * d, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_col + 16, col_qry, sizeof(int32_t) * d, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_scale, scale_ref, sizeof(double) * d, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_scale + 16, scale_qry, sizeof(double) * d, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) {
+        k_coords_from_final<<<nblk(ref_g->n * d), PF_BLOCK, 0, st>>>(ref_g->final_vecs, ref_g->n, ref_g->final_count, d, d_col, d_scale,
+                                                                    c->knn_ref);
+        k_coords_from_final<<<nblk(qry_g->n * d), PF_BLOCK, 0, st>>>(qry_g->final_vecs, qry_g->n, qry_g->final_count, d, d_col + 16,
+                                                                    d_scale + 16, c->knn_qry);
+        e = hipGetLastError();
+    }
+    hipError_t e2 = hipStreamSynchronize(st);  // (the host arrays col/scale may be temporaries of the caller)
+    pf_free(st, d_col);
+    pf_free(st, d_scale);
+    PF_HIP(e);
+    PF_HIP(e2);
+    c->knn_ready = true;
     PF_TRY(pf_knn_run(c));
     return pf_knn_download(c, idx_out, d2_out);
 }

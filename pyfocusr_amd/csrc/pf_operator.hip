@@ -425,6 +425,15 @@ __global__ __launch_bounds__(PF_BLOCK) void k_vec_apply(const double* __restrict
     }
 }
 
+// out[t][c] = final[rows[t]][c]: sampled rows of the resident eigenvector block (graph.py:266-267 on the device)
+__global__ __launch_bounds__(PF_BLOCK) void k_final_rows(const double* __restrict__ fin, const int64_t* __restrict__ rows, int64_t n_rows,
+                                                         int32_t fc, double* __restrict__ out) {
+    const int64_t e = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
+    if (e >= n_rows * fc) return;
+    const int64_t t = e / fc;
+    out[e] = fin[rows[t] * fc + (e - t * fc)];
+}
+
 // Mean filter (graph.py:349-353): out = ((D+I)^-1 (W+I)) in, applied `iterations` times to an n x ncols array.
 // scipy forms average_mat = D_inv @ (W + I) as a sparse-sparse product whose rows come out in DESCENDING column
 // order (SMMP linked list), and average_mat @ v then sums in that order with the products (dinv*w)*v.  The same
@@ -668,6 +677,7 @@ struct OpTimer {
     double bytes;
     bool on;
     int64_t persist_steps = 0;
+    double lds_bytes = 0.0;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     OpTimer(pf_ctx* ctx, int64_t n, double b) : c(ctx), launches(n), bytes(b), on(ctx->timing) {
         if (!on) return;
@@ -685,7 +695,7 @@ struct OpTimer {
     int finish() {  // never blocks: the span is resolved in pf_timing_get
         if (!on) return PF_OK;
         PF_HIP(hipEventRecord(e1, c->stream));
-        c->spans_pending.push_back({e0, e1, launches, bytes, persist_steps});
+        c->spans_pending.push_back({e0, e1, launches, bytes, persist_steps, lds_bytes});
         return PF_OK;
     }
 };
@@ -837,7 +847,7 @@ int pf_cheb(pf_graph* g, int32_t op, int32_t src, int32_t dst, int32_t degree, d
     {  // the whole recurrence in one kernel with the operator in LDS, when it fits (pf_persist.hip)
         const pf_persist_args pa{g, vals, pf_slot(g, src), pf_slot(g, dst), degree, c, e, rho};
         int done = 0;
-        PF_TRY(pf_persist_cheb(&pa, nullptr, &done));
+        PF_TRY(pf_persist_cheb(&pa, nullptr, &done, &t.lds_bytes));
         if (done) {
             t.launches = 1;
             t.persist_steps = degree;
@@ -876,7 +886,7 @@ int pf_cheb2(pf_graph* ga, int32_t op_a, int32_t src_a, int32_t dst_a, int32_t d
         const pf_persist_args pa{ga, va, pf_slot(ga, src_a), pf_slot(ga, dst_a), degree_a, c_a, e_a, rho_a};
         const pf_persist_args pb{gb, vb, pf_slot(gb, src_b), pf_slot(gb, dst_b), degree_b, c_b, e_b, rho_b};
         int done = 0;
-        PF_TRY(pf_persist_cheb(&pa, &pb, &done));
+        PF_TRY(pf_persist_cheb(&pa, &pb, &done, &t.lds_bytes));
         if (done) {
             t.launches = 1;
             t.persist_steps = std::max(degree_a, degree_b);
@@ -885,8 +895,8 @@ int pf_cheb2(pf_graph* ga, int32_t op_a, int32_t src_a, int32_t dst_a, int32_t d
         // The pair does not fit one resident launch (windows of 2048+ rows: registers / LDS): each graph in its own
         // resident launch still beats one step per launch by far (1M rows: 2 x 4 us per step against 30 us shared).
         int done_a = 0, done_b = 0;
-        PF_TRY(pf_persist_cheb(&pa, nullptr, &done_a));
-        PF_TRY(pf_persist_cheb(&pb, nullptr, &done_b));
+        PF_TRY(pf_persist_cheb(&pa, nullptr, &done_a, &t.lds_bytes));
+        PF_TRY(pf_persist_cheb(&pb, nullptr, &done_b, &t.lds_bytes));
         if (done_a || done_b) {
             t.launches = done_a + done_b;
             t.persist_steps = (done_a ? degree_a : 0) + (done_b ? degree_b : 0);
@@ -1092,6 +1102,9 @@ int pf_finalize_vectors(pf_graph* g, int32_t first, int32_t count, int32_t from_
         params[4 * c + 3] = minmax ? 0.5 : 0.0;
     }
     double *d_params = nullptr, *d_out = nullptr;
+    pf_free(st, g->final_vecs);  // the result stays resident (pf_final_rows, pf_knn1_graphs) until the next call
+    g->final_vecs = nullptr;
+    g->final_count = 0;
     PF_HIP(pf_malloc(st, (void**)&d_params, sizeof(double) * params.size()));
     hipError_t e = pf_malloc(st, (void**)&d_out, sizeof(double) * (size_t)g->n * count);
     if (e == hipSuccess) e = hipMemcpyAsync(d_params, params.data(), sizeof(double) * params.size(), hipMemcpyHostToDevice, st);
@@ -1102,10 +1115,53 @@ int pf_finalize_vectors(pf_graph* g, int32_t first, int32_t count, int32_t from_
     if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, sizeof(double) * (size_t)g->n * count, hipMemcpyDeviceToHost, st);
     hipError_t e2 = hipStreamSynchronize(st);
     pf_free(st, d_params);
+    if (e == hipSuccess && e2 == hipSuccess) {
+        g->final_vecs = d_out;
+        g->final_count = count;
+    } else {
+        pf_free(st, d_out);
+    }
+    PF_HIP(e);
+    PF_HIP(e2);
+    return PF_OK;
+}
+
+// out[t][c] = src[rows[t]][c] for a resident [n][width] block of the graph
+static int rows_to_host(pf_graph* g, const double* src, int32_t width, const int64_t* rows, int64_t n_rows, double* out,
+                        const char* who) {
+    if (n_rows == 0) return PF_OK;
+    PF_HIP(hipSetDevice(g->ctx->device));
+    hipStream_t st = g->ctx->stream;
+    for (int64_t i = 0; i < n_rows; ++i)
+        PF_CHECK(rows[i] >= 0 && rows[i] < g->n, PF_E_ARG, "%s: row %lld out of range", who, (long long)rows[i]);
+    int64_t* d_rows = nullptr;
+    double* d_out = nullptr;
+    PF_HIP(pf_malloc(st, (void**)&d_rows, sizeof(int64_t) * n_rows));
+    hipError_t e = pf_malloc(st, (void**)&d_out, sizeof(double) * (size_t)n_rows * width);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_rows, rows, sizeof(int64_t) * n_rows, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) {
+        k_final_rows<<<nblk(n_rows * width), PF_BLOCK, 0, st>>>(src, d_rows, n_rows, width, d_out);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, sizeof(double) * (size_t)n_rows * width, hipMemcpyDeviceToHost, st);
+    hipError_t e2 = hipStreamSynchronize(st);
+    pf_free(st, d_rows);
     pf_free(st, d_out);
     PF_HIP(e);
     PF_HIP(e2);
     return PF_OK;
+}
+
+int pf_final_rows(pf_graph* g, const int64_t* rows, int64_t n_rows, double* out) {
+    PF_CHECK(g != nullptr && rows != nullptr && out != nullptr && n_rows >= 0, PF_E_ARG, "pf_final_rows: bad argument");
+    PF_CHECK(g->final_vecs != nullptr, PF_E_STATE, "pf_final_rows: no pf_finalize_vectors result is resident");
+    return rows_to_host(g, g->final_vecs, g->final_count, rows, n_rows, out, "pf_final_rows");
+}
+
+int pf_point_rows(pf_graph* g, const int64_t* rows, int64_t n_rows, double* out) {
+    PF_CHECK(g != nullptr && rows != nullptr && out != nullptr && n_rows >= 0, PF_E_ARG, "pf_point_rows: bad argument");
+    PF_CHECK(g->pts != nullptr, PF_E_STATE, "pf_point_rows: this graph was not built from a mesh");
+    return rows_to_host(g, g->pts, 3, rows, n_rows, out, "pf_point_rows");
 }
 
 int pf_spmv_host(pf_graph* g, int32_t op, const double* x, double* y) {

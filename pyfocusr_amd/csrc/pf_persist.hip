@@ -432,7 +432,7 @@ extern "C" int pf_persist_test_hook(int n_launches) {
 
 // Runs the recurrence(s) in one kernel if the device, the sizes and the switch allow it.  *done = 1 when it was
 // launched; 0 means "use the one-step-per-launch path" (never an error by itself).
-int pf_persist_cheb(const pf_persist_args* a, const pf_persist_args* b, int* done) {
+int pf_persist_cheb(const pf_persist_args* a, const pf_persist_args* b, int* done, double* lds_bytes) {
     *done = 0;
     if (!persist_enabled()) return PF_OK;
     pf_graph* ga = a->g;
@@ -513,7 +513,13 @@ int pf_persist_cheb(const pf_persist_args* a, const pf_persist_args* b, int* don
         (void)hipGetLastError();
         return PF_OK;
     }
-    for (int q = 0; q < ng; ++q) in[q]->g->persist_phase = (in[q]->g->persist_phase + in[q]->degree) & 3;
+    for (int q = 0; q < ng; ++q) {
+        pf_graph* g = in[q]->g;
+        g->persist_phase = (g->persist_phase + in[q]->degree) & 3;
+        // LDS bytes of this launch: per step and row the own x (8) and the result (8), per stored entry the gathered x
+        // (8), per outside row its value written once (8); the entries themselves live in registers
+        if (lds_bytes) *lds_bytes += (double)in[q]->degree * (8.0 * (double)g->sell_entries + 16.0 * (double)g->n_pad + 8.0 * (double)g->px_gh_total);
+    }
     *done = 1;
     return PF_OK;
 }

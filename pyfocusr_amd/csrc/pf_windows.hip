@@ -189,6 +189,8 @@ int pf_window_slots_prepare(pf_graph* g) {
         pf_window_slots_free(g);
         return PF_OK;
     }
+    g->px_gh_total = 0;
+    for (int32_t c : g->h_px_gh_cnt) g->px_gh_total += c;
     g->px_state = 1;
     return PF_OK;
 }

@@ -95,10 +95,20 @@ class eigsort(object):
         else:
             vecs, flip_cols = self.graph_target.eig_vecs, [m0 for m0, _ in flipped_pairs]
             dst, src = np.asarray(source_matches), np.asarray(target_matches)
+        mutated = self.graph_source if self.target_as_reference is True else self.graph_target
+        fmap = getattr(mutated, "_final_map", None)  # the same flips / permutation for the graph's device-resident block
         for col in flip_cols:
             vecs[:, col] = vecs[:, col] * -1
+            if fmap is not None:
+                fmap[1][col] = -fmap[1][col]
         if not np.array_equal(dst, src):
             vecs[:, dst] = vecs[:, src]
+            if fmap is not None:
+                cols, signs = fmap[0].copy(), fmap[1].copy()
+                cols[dst], signs[dst] = fmap[0][src], fmap[1][src]
+                fmap = (cols, signs)
+        if fmap is not None:
+            mutated._final_map = fmap
         self.target_matches, self.source_matches = np.asarray(target_matches), np.asarray(source_matches)
         self.flipped_pairs = flipped_pairs
 

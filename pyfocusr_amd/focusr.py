@@ -24,7 +24,7 @@ import numpy as np
 
 from . import _hip
 from .eigsort import eigsort
-from .graph import Graph, compute_spectra
+from .graph import Graph, compute_spectra, spectral_knn
 from .main import print_header
 from .vtk_functions import PolyMesh, apply_transform, icp_transform, set_mesh_scalars, vtk_deep_copy
 
@@ -166,8 +166,9 @@ class Focusr(object):
         self.Q = None
         self.spec_weights = None
         self.spectral_weights = None
-        self.source_spectral_coords = None
-        self.target_spectral_coords = None
+        self._coords = {"source": None, "target": None}  # explicit arrays; None: derived on demand from `_coords_recipe`
+        self._coords_recipe = None                       # (n_coords, weights or None) of calc_spectral_coords
+        self._coords_derived = {"source": False, "target": False}
         self.source_extra_features = None
         self.target_extra_features = None
         self.use_features_as_coords = use_features_as_coords
@@ -183,6 +184,32 @@ class Focusr(object):
         self.nearest_neighbor_transformed_points = None
         self.weighted_avg_transformed_points = None
         self.average_mesh = None
+
+    # ------------------------------------------------------------------ spectral coordinates (focusr.py:459-508)
+    # The reference stores two (n, k) arrays.  Here they are derived on first access from the graphs' eigenvectors
+    # and the weights, so that a pipeline which only needs the correspondences (KNN on the device-resident
+    # eigenvectors, `spectral_knn`) never builds them; assigning an array (CPD registration, appended point
+    # coordinates) makes it an ordinary attribute again.
+    def _get_coords(self, which):
+        state = self.__dict__.setdefault("_coords", {"source": None, "target": None})
+        derived = self.__dict__.setdefault("_coords_derived", {"source": False, "target": False})
+        if state[which] is None and derived[which] and getattr(self, "_coords_recipe", None) is not None:
+            n_coords, weights = self._coords_recipe
+            vecs = (self.graph_source if which == "source" else self.graph_target).eig_vecs[:, :n_coords]
+            state[which] = vecs if weights is None else vecs * weights[None, :]
+        return state[which]
+
+    def _set_coords(self, which, value):
+        self.__dict__.setdefault("_coords", {"source": None, "target": None})[which] = value
+        self.__dict__.setdefault("_coords_derived", {"source": False, "target": False})[which] = False
+
+    source_spectral_coords = property(lambda self: self._get_coords("source"), lambda self, v: self._set_coords("source", v))
+    target_spectral_coords = property(lambda self: self._get_coords("target"), lambda self, v: self._set_coords("target", v))
+
+    def _derive_coords(self, n_coords, weights):
+        self._coords_recipe = (n_coords, weights)
+        self._coords = {"source": None, "target": None}
+        self._coords_derived = {"source": True, "target": True}
 
     # ------------------------------------------------------------------ point sets
     def append_pts_to_spectral_coords(self):
@@ -235,11 +262,20 @@ class Focusr(object):
         self.corresponding_target_idx_for_each_source_pt = target_idx
 
     def get_initial_correspondences(self):
-        """focusr.py:355-366."""
+        """focusr.py:355-366.  While both coordinate sets are still what `calc_spectral_coords` defined (no
+        registration moved them), the nearest-neighbour search reads the eigenvectors where the eigensolve left
+        them, in HBM (`spectral_knn`); otherwise, and always for "hungarian", the arrays are used."""
         if self.initial_correspondence_type == "hungarian":
             self.get_hungarian_correspondence(self.target_spectral_coords, self.source_spectral_coords)
-        else:
-            self.get_kd_correspondence(self.target_spectral_coords, self.source_spectral_coords)
+            return
+        derived = self.__dict__.get("_coords_derived", {})
+        if derived.get("source") and derived.get("target") and self.__dict__.get("_coords_recipe") is not None:
+            n_coords, weights = self._coords_recipe
+            idx = spectral_knn(self.graph_target, self.graph_source, n_coords, weights)
+            if idx is not None:
+                self.corresponding_target_idx_for_each_source_pt = idx
+                return
+        self.get_kd_correspondence(self.target_spectral_coords, self.source_spectral_coords)
 
     def get_smoothed_correspondences(self):
         """focusr.py:368-396 (mean filters and the second NN query on the device)."""
@@ -348,17 +384,13 @@ class Focusr(object):
 
     def calc_weighted_spectral_coords(self):
         self.calc_c_weighting_spectral()
-        self.source_spectral_coords = (
-            self.graph_source.eig_vecs[:, : self.n_spectral_features] * self.spectral_weights[None, :])
-        self.target_spectral_coords = (
-            self.graph_target.eig_vecs[:, : self.n_spectral_features] * self.spectral_weights[None, :])
+        self._derive_coords(self.n_spectral_features, self.spectral_weights)  # eig_vecs[:, :ns] * weights, on demand
 
     def calc_spectral_coords(self):
         if self.get_weighted_spectral_coords is True:
             self.calc_weighted_spectral_coords()
         elif self.get_weighted_spectral_coords is False:
-            self.source_spectral_coords = self.graph_source.eig_vecs[:, : self.n_spectral_features]
-            self.target_spectral_coords = self.graph_target.eig_vecs[:, : self.n_spectral_features]
+            self._derive_coords(self.n_spectral_features, None)  # eig_vecs[:, :ns], on demand
 
     # ------------------------------------------------------------------ align_maps (focusr.py:514-568)
     def align_maps(self):

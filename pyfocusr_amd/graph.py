@@ -31,7 +31,7 @@ from . import _hip
 from ._krylov import MIN_EIG_VAL, drive, drive_pair, filtered_eigs_gen
 from .vtk_functions import mesh_arrays, vtk_deep_copy  # noqa: F401
 
-__all__ = ["Graph", "recursive_eig", "compute_spectra"]
+__all__ = ["Graph", "recursive_eig", "compute_spectra", "spectral_knn"]
 
 
 class _DeviceBackedCSR(sparse.csr_matrix):
@@ -110,10 +110,29 @@ class Graph(object):
         self.G = None
 
         self.eig_vals = None
-        self.eig_vecs = None
+        self._eig_vecs = None
+        self._final_map = None  # (cols, signs): eig_vecs[:, c] == signs[c] * (device-resident block)[:, cols[c]], or None
         self.eig_val_gap = None
         self.eigs_stats = None
         self.rand_idxs = self.get_list_rand_idxs(n_rand_samples)
+
+    # ------------------------------------------------------------------ eigenvectors: host array + device-resident twin
+    @property
+    def eig_vecs(self):
+        return self._eig_vecs
+
+    @eig_vecs.setter
+    def eig_vecs(self, value):
+        """Assigning eigenvectors from outside disconnects the host array from the block the solver left on the
+        device (`_set_spectrum` is the one place that keeps them connected)."""
+        self._eig_vecs = value
+        self._final_map = None
+
+    def _set_spectrum(self, vals, vecs, stats):
+        self.eig_vals, self._eig_vecs, self.eigs_stats = vals, vecs, stats
+        m = 0 if vecs is None else vecs.shape[1]
+        on_device = self._device is not None and getattr(self._device, "_final_count", 0) == m and m > 0
+        self._final_map = (np.arange(m), np.ones(m)) if on_device else None
 
     # ------------------------------------------------------------------ device graph
     @property
@@ -222,14 +241,14 @@ class Graph(object):
         dev = self.device
         if self.verbose:
             print("Beginning Eigen Decomposition")
-        self.eig_vals, self.eig_vecs, self.eigs_stats = _device_eigs(
+        self._set_spectrum(*_device_eigs(
             dev,
             k=self.n_spectral_features + 1,
             n_k_needed=self.n_spectral_features,
             k_buffer=1,
             minmax=self.norm_eig_vecs is True,
             verbose=self.verbose,
-        )
+        ))
         if self.verbose:
             print("All final eigenvalues are: \n{}".format(self.eig_vals))
             print("-" * 72)
@@ -240,10 +259,23 @@ class Graph(object):
         self.eig_val_gap = np.mean(np.diff(self.eig_vals))
 
     def get_rand_eig_vecs(self):
+        fm = self._final_map
+        if fm is not None and self._device is not None and getattr(self._device, "_h", None):
+            # the sampled rows straight from the block the solver left in HBM: a random gather of rows of the
+            # freshly downloaded (cache-cold) host array costs more than the whole device round trip
+            rows = self._device.final_rows(self.rand_idxs)
+            cols, signs = fm
+            if np.array_equal(cols, np.arange(len(cols))) and np.all(signs == 1.0):
+                return rows
+            return rows[:, cols] * signs
         return self.eig_vecs[self.rand_idxs, :]
 
     def get_rand_normalized_points(self):
-        sample = self.points[self.rand_idxs, :]  # gathered once (the reference gathers the same rows three times)
+        dev = self._device
+        if dev is not None and getattr(dev, "_h", None) and getattr(dev, "has_points", False) and len(self.rand_idxs) < self.n_points:
+            sample = dev.point_rows(self.rand_idxs)  # the same rows from the copy in HBM: cheaper than a cache-cold host gather
+        else:
+            sample = self.points[self.rand_idxs, :]  # gathered once (the reference gathers the same rows three times)
         return (sample - np.min(sample, axis=0)) / np.ptp(sample, axis=0)
 
     def get_list_rand_idxs(self, n_rand_samples, replace=False, force_randomization=False):
@@ -329,11 +361,39 @@ def _paired_spectra(ga, gb):
 
     ra, rb = drive_pair(solver(ga), ga.device, solver(gb), gb.device)
     for g, (vals, vecs, stats) in ((ga, ra), (gb, rb)):
-        g.eig_vals, g.eig_vecs, g.eigs_stats = vals, vecs, stats
+        g._set_spectrum(vals, vecs, stats)
         if g.verbose:
             print("All final eigenvalues are: \n{}".format(g.eig_vals))
             print("-" * 72)
             print("Final eigenvalues of interest are: \n{}".format(g.eig_vals))
+
+
+def spectral_knn(graph_target, graph_source, n_coords, weights=None):
+    """focusr.py:351-353 on the spectral coordinates `eig_vecs[:, :n_coords] * weights` of two graphs WITHOUT the
+    n x k coordinate arrays crossing PCIe: both graphs still hold the block their eigensolve left in HBM, and the
+    column permutation / sign flips `eigsort` applied to the host arrays (eigsort.py:108-122) are folded, with the
+    weights, into per-column scale factors of `pf_knn1_graphs`.  Bit-identical to `ctx.knn1(target_coords,
+    source_coords)` on the host arrays ((-v) w = v (-w) exactly).  Returns the target index of every source vertex,
+    or None when a graph's host eigenvectors are no longer the device block's (assigned from outside, device
+    closed, graphs on different contexts): the caller then takes the host-array path."""
+    devs = []
+    for g in (graph_target, graph_source):
+        fm, dev = getattr(g, "_final_map", None), getattr(g, "_device", None)
+        if fm is None or dev is None or not getattr(dev, "_h", None) or n_coords > len(fm[0]):
+            return None
+        devs.append(dev)
+    if devs[0].ctx is not devs[1].ctx:
+        return None
+    for g, dev in zip((graph_target, graph_source), devs):
+        # guard against in-place edits of the host array nobody told us about: 64 rows must agree exactly
+        rows = np.linspace(0, g.n_points - 1, num=min(64, g.n_points)).astype(np.int64)
+        cols, signs = g._final_map
+        if not np.array_equal(dev.final_rows(rows)[:, cols] * signs, g.eig_vecs[rows][:, :len(cols)]):
+            g._final_map = None
+            return None
+    w = np.ones(n_coords) if weights is None else np.asarray(weights, dtype=np.float64)
+    (ct, st), (cs, ss) = graph_target._final_map, graph_source._final_map
+    return devs[0].ctx.knn1_graphs(devs[0], devs[1], ct[:n_coords], st[:n_coords] * w, cs[:n_coords], ss[:n_coords] * w)
 
 
 def _device_eigs_gen(dev, k, n_k_needed, k_buffer=1, minmax=False, verbose=False, **solver_kw):

@@ -745,6 +745,68 @@ def test_focusr_default_tail_of_align_maps(golden, ctx):
     assert reg.average_mesh.faces.shape == gs_["faces"].shape
 
 
+def test_spectral_knn_on_device_resident_eigenvectors(golden, ctx):
+    """focusr.py:351-353 with the coordinates taken from the blocks the eigensolves left in HBM (`spectral_knn` ->
+    `pf_knn1_graphs`): indices and distances bit-identical to the host-array path, with eigsort's flips and column
+    permutation (eigsort.py:108-122) folded into the call, weighted and un-weighted; sampled rows (`pf_final_rows`,
+    graph.py:266-267) equal to fancy indexing of the host array; falls back when the host array was replaced."""
+    from pyfocusr_amd import Focusr, Graph, eigsort
+    from pyfocusr_amd.graph import compute_spectra, spectral_knn
+
+    p, gt_, gs_ = golden("pair_15k"), golden("target_mesh_15k"), golden("source_mesh_15k")
+    for ref_is_target in (True, False):
+        gt = Graph(mesh_of(gt_), n_spectral_features=5, n_rand_samples=3000, ctx=ctx, verbose=False)
+        gs = Graph(mesh_of(gs_), n_spectral_features=5, n_rand_samples=3000, ctx=ctx, verbose=False)
+        compute_spectra([gt, gs])
+        assert gs._final_map is not None and gs.eig_vecs.shape[1] == 9  # widened: 9 columns resident
+        assert np.array_equal(gs.get_rand_eig_vecs(), gs.eig_vecs[gs.rand_idxs, :])
+        assert np.array_equal(gt.get_rand_eig_vecs(), gt.eig_vecs[gt.rand_idxs, :])
+        sorter = eigsort(gt, gs, 5, target_as_reference=ref_is_target)
+        # make the assignment a genuine permutation + flips so that the folding is exercised
+        sorter.sort_eigenmaps()
+        moved = gs if ref_is_target else gt
+        moved.eig_vecs[:, [0, 2]] = moved.eig_vecs[:, [2, 0]]  # an edit eigsort did not make ...
+        assert spectral_knn(gt, gs, 5) is None and moved._final_map is None  # ... is noticed: host path
+        moved._final_map = None
+    gt = Graph(mesh_of(gt_), n_spectral_features=5, n_rand_samples=20000, ctx=ctx, verbose=False)
+    gs = Graph(mesh_of(gs_), n_spectral_features=5, n_rand_samples=20000, ctx=ctx, verbose=False)
+    compute_spectra([gt, gs])
+    gs._final_map = None
+    gs.eig_vecs = gs.eig_vecs[:, ::-1].copy()  # column order reversed before eigsort: it has to permute
+    gs._final_map = (np.arange(9)[::-1].copy(), np.ones(9))
+    sorter = eigsort(gt, gs, 5, target_as_reference=True)
+    Q = sorter.sort_eigenmaps()
+    assert not np.array_equal(sorter.source_matches, sorter.target_matches)  # a real permutation
+    assert len(sorter.flipped_pairs) > 0
+    w = np.array([0.9, 0.8, 0.1, 0.5, 0.7])
+    for weights in (None, w):
+        ct = gt.eig_vecs[:, :5] if weights is None else gt.eig_vecs[:, :5] * weights[None, :]
+        cs = gs.eig_vecs[:, :5] if weights is None else gs.eig_vecs[:, :5] * weights[None, :]
+        idx_host, d2_host = ctx.knn1(ct, cs, return_d2=True)
+        idx_dev = spectral_knn(gt, gs, 5, weights)
+        assert idx_dev is not None and np.array_equal(idx_dev, idx_host)
+        (c_t, s_t), (c_s, s_s) = gt._final_map, gs._final_map
+        ww = np.ones(5) if weights is None else weights
+        idx2, d2_dev = ctx.knn1_graphs(gt.device, gs.device, c_t[:5], s_t[:5] * ww, c_s[:5], s_s[:5] * ww, return_d2=True)
+        assert np.array_equal(idx2, idx_host) and np.array_equal(d2_dev, d2_host)
+    # through Focusr: derived coordinates take the device path, assigned ones the host path; same indices
+    reg = object.__new__(Focusr)
+    reg._ctx = ctx
+    reg.initial_correspondence_type = "kd"
+    reg.graph_target, reg.graph_source, reg.Q, reg.n_spectral_features = gt, gs, Q, 5
+    for weighted in (False, True):
+        reg.get_weighted_spectral_coords = weighted
+        reg.calc_spectral_coords()
+        reg.get_initial_correspondences()
+        a = reg.corresponding_target_idx_for_each_source_pt.copy()
+        reg.target_spectral_coords = reg.target_spectral_coords.copy()  # now an ordinary attribute: host path
+        reg.get_initial_correspondences()
+        assert np.array_equal(a, reg.corresponding_target_idx_for_each_source_pt)
+        assert np.array_equal(a, orc.knn1(reg.target_spectral_coords, reg.source_spectral_coords))
+    with pytest.raises(Exception):
+        ctx.knn1_graphs(gt.device, gs.device, [0, 99], [1.0, 1.0], [0, 1], [1.0, 1.0])
+
+
 def test_tail_vs_reference_fixture(golden, ctx):
     """SURVEY f1/f2 against outputs of the REFERENCE's own methods (tests/golden/tail_5k.npz, written by
     tools/make_golden.py: tail_fixture): `Graph.mean_filter_graph` (graph.py:320-354, n x 3 and n x 1, 25 and 300

@@ -1,0 +1,90 @@
+#!/usr/bin/env python3
+"""profiles/r02_pmc_summary.json from rocprofv3 output directories (run on the GPU box, see profiles/README.md):
+
+    python tools/pmc_make_summary.py --fetch DIR --write DIR [--fetch-stream DIR --write-stream DIR] \\
+        --stats KERNEL_STATS_CSV --bench BENCH_JSON_OF_THE_PROFILED_RUN --out profiles/r02_pmc_summary.json
+
+FETCH_SIZE / WRITE_SIZE come from SEPARATE --pmc passes (MI355X_MICROARCH.md: they do not fit one pass) and are in KB;
+on gfx950 FETCH_SIZE tallies 128-byte requests at 64 bytes, so read bytes = 2 x FETCH_SIZE (same guide, HBM section;
+calibrated there for wide streaming loads - the 8-byte agent-scope hand-off accesses of the resident kernel are outside
+that calibration, which the summary says)."""
+import argparse
+import csv
+import glob
+import json
+import os
+from collections import defaultdict
+
+
+def counter_avg(directory, counter):
+    acc = defaultdict(lambda: [0, 0.0])
+    for f in glob.glob(os.path.join(directory, "**", "*counter_collection.csv"), recursive=True):
+        with open(f) as fh:
+            for row in csv.DictReader(fh):
+                if row.get("Counter_Name") != counter:
+                    continue
+                a = acc[row.get("Kernel_Name", "")]
+                a[0] += 1
+                a[1] += float(row["Counter_Value"])
+    return {k: (v[0], v[1] / max(v[0], 1)) for k, v in acc.items()}
+
+
+def pick(table, needle):
+    hits = [(k, v) for k, v in table.items() if needle in k]
+    if not hits:
+        return None, (0, 0.0)
+    return max(hits, key=lambda kv: kv[1][0])
+
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--fetch", required=True)
+ap.add_argument("--write", required=True)
+ap.add_argument("--fetch-stream")
+ap.add_argument("--write-stream")
+ap.add_argument("--stats")
+ap.add_argument("--bench")
+ap.add_argument("--out", required=True)
+args = ap.parse_args()
+
+stats = {}
+if args.stats and os.path.exists(args.stats):
+    with open(args.stats) as fh:
+        for row in csv.DictReader(fh):
+            stats[row["Name"]] = dict(calls=int(row["Calls"]), avg_ns=float(row["AverageNs"]), pct=float(row["Percentage"]))
+bench = {}
+if args.bench and os.path.exists(args.bench):
+    with open(args.bench) as fh:
+        for line in fh:
+            if line.startswith("{"):
+                bench = json.loads(line)
+kernels = {}
+for label, needle, fdir, wdir in (("k_cheb_resident<2, 1, 8>", "k_cheb_resident<2, 1, 8>", args.fetch, args.write),
+                                  ("k_sell_op2<true>", "k_sell_op2<true>", args.fetch_stream, args.write_stream)):
+    if not fdir or not wdir:
+        continue
+    fname, (fcalls, fkb) = pick(counter_avg(fdir, "FETCH_SIZE"), needle)
+    wname, (wcalls, wkb) = pick(counter_avg(wdir, "WRITE_SIZE"), needle)
+    if fname is None or wname is None:
+        continue
+    entry = dict(dispatches_counted_fetch=fcalls, dispatches_counted_write=wcalls, FETCH_SIZE_avg_KB=fkb, WRITE_SIZE_avg_KB=wkb,
+                 hbm_read_bytes_per_launch=2.0 * fkb * 1024.0, hbm_write_bytes_per_launch=wkb * 1024.0,
+                 hbm_bytes_per_launch=2.0 * fkb * 1024.0 + wkb * 1024.0,
+                 correction="read bytes = 2 x FETCH_SIZE x 1024 (gfx950: 128-B requests tallied at 64 B), WRITE_SIZE exact "
+                            "(MI355X_MICROARCH.md, HBM)")
+    st = next((v for k, v in stats.items() if needle in k), None)
+    if st:
+        entry.update(kernel_trace_calls=st["calls"], kernel_trace_avg_ns=st["avg_ns"], kernel_trace_pct_of_device_time=st["pct"])
+    if label.startswith("k_cheb_resident") and bench.get("roofline", {}).get("steps_per_launch"):
+        spl = bench["roofline"]["steps_per_launch"]
+        entry.update(steps_per_launch_avg=spl, hbm_bytes_per_step=entry["hbm_bytes_per_launch"] / spl,
+                     hbm_bytes_per_launch_fixed=0.0,
+                     note="per step of the pair; includes the once-per-launch load of the operators into registers spread over "
+                          "the launch's steps; hand-off accesses are 8-byte agent-scope loads / stores (outside the guide's "
+                          "calibration of FETCH_SIZE, which is for wide streaming reads)")
+    kernels[label] = entry
+out = dict(source="rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) -- python3 bench.py --steps 2 --warmup 1 "
+                  "--no-extras --no-cpu-baseline (250k-vertex pair, k=5); streaming kernel: the same with PF_PERSIST=0",
+           kernels=kernels)
+with open(args.out, "w") as fh:
+    json.dump(out, fh, indent=1)
+print(json.dumps(out, indent=1))
