@@ -208,20 +208,28 @@ def row_partition_step(ctx, dist, torch, mesh, k, s):
 
 
 def split_pair_step(ctx, dist, torch, tdev, rank, mesh, k, n_samples):
-    """BASELINE config C4: rank 0 = target, rank 1 = source; all-gather of the normalised
-    eigenvectors (n x k f64) over RCCL/xGMI; eigsort replicated (k x k work); KNN sharded by
-    source rows; indices gathered on rank 0."""
-    from pyfocusr_amd import Graph, eigsort
-    from pyfocusr_amd.parallel import all_gather_rows, gather_spectral, shard_rows
+    """BASELINE config C4: rank 0 = target, rank 1 = source; one all-gather of the eigenvector blocks as they sit in
+    HBM (RCCL over xGMI, enqueued on the library's stream; nothing but 5000-row samples reaches a host); eigsort
+    replicated (k x k work); KNN sharded by source rows, read from the gathered device buffer; int64 indices gathered."""
+    from pyfocusr_amd import Graph
+    from pyfocusr_amd.parallel import all_gather_rows, gather_spectral, shard_rows, split_pair_correspondence
 
     g = Graph(mesh, n_spectral_features=k, n_rand_samples=n_samples, ctx=ctx, verbose=False)
     g.get_graph_spectrum()
+    if tdev == "cuda":
+        stream = torch.cuda.ExternalStream(ctx.stream_ptr, device=torch.device("cuda", ctx.device))
+        idx, _, _ = split_pair_correspondence(dist, torch, g, k, n_samples, seed=1234, stream=stream)
+        g.device.close()
+        return idx
+    # rehearsal over gloo (CPU tensors): the host-staged form
+    from pyfocusr_amd import eigsort
+
     vals, vecs, pts = gather_spectral(dist, torch, g.eig_vals, g.eig_vecs, g.points)
     graphs = []
     for r in range(2):
         h = Graph.__new__(Graph)
         h.points, h.n_points, h.eig_vals, h.eig_vecs = pts[r], len(pts[r]), vals[r], vecs[r].copy()
-        h.eig_val_gap, h.verbose, h._ctx = None, False, ctx
+        h.eig_val_gap, h.verbose, h._ctx, h._device = None, False, ctx, None
         np.random.seed(1234)  # identical sample on both ranks
         h.rand_idxs = h.get_list_rand_idxs(n_samples)
         graphs.append(h)
@@ -232,7 +240,7 @@ def split_pair_step(ctx, dist, torch, tdev, rank, mesh, k, n_samples):
     src, tgt = gs.eig_vecs[:, :k] * w[None, :], gt.eig_vecs[:, :k] * w[None, :]
     lo, hi = shard_rows(len(src), 2, rank)
     part = ctx.knn1(tgt, src[lo:hi])
-    parts = all_gather_rows(dist, torch, part.astype(np.float64))  # ragged shards (float64 carries int32 exactly)
+    parts = all_gather_rows(dist, torch, part.astype(np.float64))
     g.device.close()
     return np.concatenate([p[:, 0] for p in parts]).astype(np.int64)
 
@@ -277,6 +285,7 @@ def main():
 
     if args.share_gpu:
         local = 0
+        os.environ["PF_PERSIST"] = "0"  # several processes on one GPU cannot all keep a resident kernel's blocks on it
     torch.cuda.set_device(local)
     dist = None
     tdev = "cuda" if args.backend == "nccl" else "cpu"  # where the collectives' tensors live

@@ -202,6 +202,16 @@ int pf_knn(pf_ctx* ctx, const double* ref, int64_t n_ref, const double* qry, int
  * col / scale, so the n x k coordinates never cross PCIe.  Same search, same arithmetic as pf_knn1. */
 int pf_knn1_graphs(pf_graph* ref_g, pf_graph* qry_g, int32_t d, const int32_t* col_ref, const double* scale_ref,
                    const int32_t* col_qry, const double* scale_qry, int64_t* idx_out, double* d2_out);
+/* The same on any two row-major blocks in device memory (row strides in doubles): what the ranks of a split pair hold
+ * after the RCCL all-gather of their resident blocks - qry_block may point at a row range of a block, the
+ * query shard of this rank.  The pointers must be valid on ctx's device; work is enqueued on ctx's stream. */
+int pf_knn1_blocks(pf_ctx* ctx, const double* ref_block, int64_t n_ref, int32_t ref_stride, const double* qry_block,
+                   int64_t n_qry, int32_t qry_stride, int32_t d, const int32_t* col_ref, const double* scale_ref,
+                   const int32_t* col_qry, const double* scale_qry, int64_t* idx_out, double* d2_out);
+/* Device address and shape of the resident block ([n_rows][n_cols] row-major float64, owned by the graph, valid until
+ * the next pf_finalize_vectors on it or pf_graph_free): lets a peer library (RCCL through torch) send it without a
+ * host round trip. */
+int pf_final_device(pf_graph* g, double** block, int64_t* n_rows, int32_t* n_cols);
 /* split form (inputs resident in HBM across the timed region) */
 int pf_knn_upload(pf_ctx* ctx, const double* ref, int64_t n_ref, const double* qry, int64_t n_qry, int32_t d);
 int pf_knn_run(pf_ctx* ctx);

@@ -97,6 +97,9 @@ SIGNATURES = {
     "pf_knn1": (C.c_int, [C.c_void_p, _f64p, C.c_int64, _f64p, C.c_int64, C.c_int32, _i64p, _f64p]),
     "pf_knn": (C.c_int, [C.c_void_p, _f64p, C.c_int64, _f64p, C.c_int64, C.c_int32, C.c_int32, _i64p, _f64p]),
     "pf_knn1_graphs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, _i32p, _f64p, _i32p, _f64p, _i64p, _f64p]),
+    "pf_knn1_blocks": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
+                                 _i32p, _f64p, _i32p, _f64p, _i64p, _f64p]),
+    "pf_final_device": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), _i64p, _i32p]),
     "pf_knn_upload": (C.c_int, [C.c_void_p, _f64p, C.c_int64, _f64p, C.c_int64, C.c_int32]),
     "pf_knn_run": (C.c_int, [C.c_void_p]),
     "pf_knn_download": (C.c_int, [C.c_void_p, _i64p, _f64p]),
@@ -278,6 +281,24 @@ class Context(object):
         idx = np.empty(dev_qry.n, dtype=np.int64)
         d2 = np.empty(dev_qry.n, dtype=np.float64) if return_d2 else None
         _check(self._lib.pf_knn1_graphs(dev_ref._h, dev_qry._h, d, col_ref.ctypes.data_as(_i32p), _f64(scale_ref),
+                                        col_qry.ctypes.data_as(_i32p), _f64(scale_qry), idx.ctypes.data_as(_i64p),
+                                        _f64(d2) if return_d2 else None))
+        return (idx, d2) if return_d2 else idx
+
+    def knn1_blocks(self, ref_ptr, n_ref, ref_stride, qry_ptr, n_qry, qry_stride, col_ref, scale_ref, col_qry, scale_qry,
+                    return_d2=False):
+        """`knn1` on coordinates built from two row-major float64 blocks already in this device's memory (integer
+        addresses, row strides in doubles): block[:, col[c]] * scale[c] for c < d."""
+        col_ref = np.ascontiguousarray(col_ref, dtype=np.int32)
+        col_qry = np.ascontiguousarray(col_qry, dtype=np.int32)
+        scale_ref, scale_qry = _c_f64(scale_ref), _c_f64(scale_qry)
+        d = len(col_ref)
+        if not (len(col_qry) == len(scale_ref) == len(scale_qry) == d):
+            raise ValueError("col / scale arrays must share one length d")
+        idx = np.empty(int(n_qry), dtype=np.int64)
+        d2 = np.empty(int(n_qry), dtype=np.float64) if return_d2 else None
+        _check(self._lib.pf_knn1_blocks(self._h, C.c_void_p(int(ref_ptr)), int(n_ref), int(ref_stride), C.c_void_p(int(qry_ptr)),
+                                        int(n_qry), int(qry_stride), d, col_ref.ctypes.data_as(_i32p), _f64(scale_ref),
                                         col_qry.ctypes.data_as(_i32p), _f64(scale_qry), idx.ctypes.data_as(_i64p),
                                         _f64(d2) if return_d2 else None))
         return (idx, d2) if return_d2 else idx
@@ -662,6 +683,12 @@ class DeviceLaplacian(object):
         out = np.empty((len(rows), self._final_count), dtype=np.float64)
         _check(self._lib.pf_final_rows(self._h, rows.ctypes.data_as(_i64p), len(rows), _f64(out)))
         return out
+
+    def final_device(self):
+        """(device address, n_rows, n_cols) of the block the last `finalize_vectors` left in HBM (row-major float64)."""
+        ptr, n_rows, n_cols = C.c_void_p(), C.c_int64(), C.c_int32()
+        _check(self._lib.pf_final_device(self._h, C.byref(ptr), C.byref(n_rows), C.byref(n_cols)))
+        return int(ptr.value), int(n_rows.value), int(n_cols.value)
 
     def point_rows(self, rows):
         """Rows of the mesh's points as they sit on the device -> (len(rows), 3) array (mesh-built graphs only)."""

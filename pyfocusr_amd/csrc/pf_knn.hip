@@ -575,17 +575,16 @@ int pf_knn1(pf_ctx* c, const double* ref, int64_t n_ref, const double* qry, int6
     return pf_knn_download(c, idx_out, d2_out);
 }
 
-int pf_knn1_graphs(pf_graph* ref_g, pf_graph* qry_g, int32_t d, const int32_t* col_ref, const double* scale_ref,
-                   const int32_t* col_qry, const double* scale_qry, int64_t* idx_out, double* d2_out) {
-    PF_CHECK(ref_g && qry_g && col_ref && scale_ref && col_qry && scale_qry && idx_out, PF_E_ARG, "pf_knn1_graphs: NULL argument");
-    PF_CHECK(ref_g->ctx == qry_g->ctx, PF_E_ARG, "pf_knn1_graphs: the two graphs must share one ctx");
-    PF_CHECK(ref_g->final_vecs && qry_g->final_vecs, PF_E_STATE, "pf_knn1_graphs: no pf_finalize_vectors result is resident");
-    PF_CHECK(d >= 1 && d <= 16, PF_E_ARG, "pf_knn1_graphs: d = %d out of range", d);
-    for (int32_t c = 0; c < d; ++c)
-        PF_CHECK(col_ref[c] >= 0 && col_ref[c] < ref_g->final_count && col_qry[c] >= 0 && col_qry[c] < qry_g->final_count, PF_E_ARG,
-                 "pf_knn1_graphs: column %d out of range", c);
-    pf_ctx* c = ref_g->ctx;
-    PF_TRY(knn_prepare(c, ref_g->n, qry_g->n, d));
+int pf_knn1_blocks(pf_ctx* c, const double* ref_block, int64_t n_ref, int32_t ref_stride, const double* qry_block, int64_t n_qry,
+                   int32_t qry_stride, int32_t d, const int32_t* col_ref, const double* scale_ref, const int32_t* col_qry,
+                   const double* scale_qry, int64_t* idx_out, double* d2_out) {
+    PF_CHECK(c && ref_block && qry_block && col_ref && scale_ref && col_qry && scale_qry && idx_out, PF_E_ARG,
+             "pf_knn1_blocks: NULL argument");
+    PF_CHECK(d >= 1 && d <= 16 && ref_stride >= 1 && qry_stride >= 1, PF_E_ARG, "pf_knn1_blocks: d = %d / strides out of range", d);
+    for (int32_t k = 0; k < d; ++k)
+        PF_CHECK(col_ref[k] >= 0 && col_ref[k] < ref_stride && col_qry[k] >= 0 && col_qry[k] < qry_stride, PF_E_ARG,
+                 "pf_knn1_blocks: column %d out of range", k);
+    PF_TRY(knn_prepare(c, n_ref, n_qry, d));
     hipStream_t st = c->stream;
     int32_t* d_col = nullptr;
     double* d_scale = nullptr;
@@ -596,10 +595,8 @@ int pf_knn1_graphs(pf_graph* ref_g, pf_graph* qry_g, int32_t d, const int32_t* c
     if (e == hipSuccess) e = hipMemcpyAsync(d_scale, scale_ref, sizeof(double) * d, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipMemcpyAsync(d_scale + 16, scale_qry, sizeof(double) * d, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) {
-        k_coords_from_final<<<nblk(ref_g->n * d), PF_BLOCK, 0, st>>>(ref_g->final_vecs, ref_g->n, ref_g->final_count, d, d_col, d_scale,
-                                                                    c->knn_ref);
-        k_coords_from_final<<<nblk(qry_g->n * d), PF_BLOCK, 0, st>>>(qry_g->final_vecs, qry_g->n, qry_g->final_count, d, d_col + 16,
-                                                                    d_scale + 16, c->knn_qry);
+        k_coords_from_final<<<nblk(n_ref * d), PF_BLOCK, 0, st>>>(ref_block, n_ref, ref_stride, d, d_col, d_scale, c->knn_ref);
+        k_coords_from_final<<<nblk(n_qry * d), PF_BLOCK, 0, st>>>(qry_block, n_qry, qry_stride, d, d_col + 16, d_scale + 16, c->knn_qry);
         e = hipGetLastError();
     }
     hipError_t e2 = hipStreamSynchronize(st);  // (the host arrays col/scale may be temporaries of the caller)
@@ -610,6 +607,24 @@ int pf_knn1_graphs(pf_graph* ref_g, pf_graph* qry_g, int32_t d, const int32_t* c
     c->knn_ready = true;
     PF_TRY(pf_knn_run(c));
     return pf_knn_download(c, idx_out, d2_out);
+}
+
+int pf_knn1_graphs(pf_graph* ref_g, pf_graph* qry_g, int32_t d, const int32_t* col_ref, const double* scale_ref,
+                   const int32_t* col_qry, const double* scale_qry, int64_t* idx_out, double* d2_out) {
+    PF_CHECK(ref_g && qry_g, PF_E_ARG, "pf_knn1_graphs: NULL argument");
+    PF_CHECK(ref_g->ctx == qry_g->ctx, PF_E_ARG, "pf_knn1_graphs: the two graphs must share one ctx");
+    PF_CHECK(ref_g->final_vecs && qry_g->final_vecs, PF_E_STATE, "pf_knn1_graphs: no pf_finalize_vectors result is resident");
+    return pf_knn1_blocks(ref_g->ctx, ref_g->final_vecs, ref_g->n, ref_g->final_count, qry_g->final_vecs, qry_g->n, qry_g->final_count, d,
+                          col_ref, scale_ref, col_qry, scale_qry, idx_out, d2_out);
+}
+
+int pf_final_device(pf_graph* g, double** block, int64_t* n_rows, int32_t* n_cols) {
+    PF_CHECK(g && block && n_rows && n_cols, PF_E_ARG, "pf_final_device: NULL argument");
+    PF_CHECK(g->final_vecs != nullptr, PF_E_STATE, "pf_final_device: no pf_finalize_vectors result is resident");
+    *block = g->final_vecs;
+    *n_rows = g->n;
+    *n_cols = g->final_count;
+    return PF_OK;
 }
 
 }  // extern "C"

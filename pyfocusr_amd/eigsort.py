@@ -98,11 +98,13 @@ class eigsort(object):
         mutated = self.graph_source if self.target_as_reference is True else self.graph_target
         fmap = getattr(mutated, "_final_map", None)  # the same flips / permutation for the graph's device-resident block
         for col in flip_cols:
-            vecs[:, col] = vecs[:, col] * -1
+            if vecs is not None:  # (None: a graph held on another rank / on the device only, see parallel.py)
+                vecs[:, col] = vecs[:, col] * -1
             if fmap is not None:
                 fmap[1][col] = -fmap[1][col]
         if not np.array_equal(dst, src):
-            vecs[:, dst] = vecs[:, src]
+            if vecs is not None:
+                vecs[:, dst] = vecs[:, src]
             if fmap is not None:
                 cols, signs = fmap[0].copy(), fmap[1].copy()
                 cols[dst], signs[dst] = fmap[0][src], fmap[1][src]

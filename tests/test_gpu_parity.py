@@ -807,6 +807,77 @@ def test_spectral_knn_on_device_resident_eigenvectors(golden, ctx):
         ctx.knn1_graphs(gt.device, gs.device, [0, 99], [1.0, 1.0], [0, 1], [1.0, 1.0])
 
 
+def test_split_pair_device_to_device(golden, ctx):
+    """BASELINE config C4 on one GPU: the two ranks of `parallel.split_pair_correspondence` as threads of this process,
+    device-to-device copies standing in for RCCL's all-gather (everything else is the shipped path: the resident
+    blocks wrapped zero-copy as torch tensors, samples taken from the gathered device buffer, the query-sharded KNN
+    reading that buffer through `pf_knn1_blocks`, int64 index shards).  On the bundled 15k pair with every vertex
+    sampled the result must be the reference's: Q and all 14 996 weighted correspondence indices of pair_15k.npz."""
+    import threading
+
+    import torch
+
+    from pyfocusr_amd import Graph
+    from pyfocusr_amd.graph import compute_spectra
+    from pyfocusr_amd.parallel import split_pair_correspondence
+
+    p, gt_, gs_ = golden("pair_15k"), golden("target_mesh_15k"), golden("source_mesh_15k")
+    graphs = [Graph(mesh_of(g), n_spectral_features=5, n_rand_samples=10**9, ctx=ctx, verbose=False) for g in (gt_, gs_)]
+    compute_spectra(graphs)
+    lock, barrier, shared, results, errors = threading.Lock(), threading.Barrier(2), {}, {}, []
+
+    class ThreadDist(object):
+        def __init__(self, rank):
+            self.rank = rank
+
+        def get_world_size(self):
+            return 2
+
+        def get_rank(self):
+            return self.rank
+
+        def all_gather_into_tensor(self, out, inp):
+            shared[self.rank] = inp
+            barrier.wait()
+            n = inp.numel()
+            for r in range(2):
+                out[r * n:(r + 1) * n].copy_(shared[r].reshape(-1))  # device-to-device
+            torch.cuda.synchronize()
+            barrier.wait()
+
+    class Locked(object):  # calls on one ctx must not overlap in time
+        def knn1(self, ref, qry):
+            with lock:
+                return ctx.knn1(ref, qry)
+
+    def knn_blocks(ref, n_ref, qry, n_qry, stride, ct, st, cs, ss):
+        with lock:
+            return ctx.knn1_blocks(ref.data_ptr(), n_ref, stride, qry.data_ptr(), n_qry, stride, ct, st, cs, ss)
+
+    def run(rank):
+        try:
+            results[rank] = split_pair_correspondence(ThreadDist(rank), torch, graphs[rank], 5, 10**9, seed=3,
+                                                      knn_blocks=knn_blocks, knn_ctx=Locked())
+        except BaseException as exc:  # noqa: BLE001
+            errors.append(exc)
+            barrier.abort()
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if errors:
+        raise errors[0]
+    for rank in range(2):
+        idx, Q, w = results[rank]
+        np.testing.assert_allclose(Q, p["Q"], rtol=1e-5)
+        np.testing.assert_allclose(w, p["spectral_weights"], rtol=1e-5)
+        assert idx.dtype == np.int64 and len(idx) == 14996
+        assert int(np.sum(idx != p["knn_idx_w"])) == 0
+    assert np.array_equal(results[0][0], results[1][0])
+
+
 def test_tail_vs_reference_fixture(golden, ctx):
     """SURVEY f1/f2 against outputs of the REFERENCE's own methods (tests/golden/tail_5k.npz, written by
     tools/make_golden.py: tail_fixture): `Graph.mean_filter_graph` (graph.py:320-354, n x 3 and n x 1, 25 and 300
