@@ -165,6 +165,10 @@ int pf_scale(pf_graph* g, int32_t slot, double alpha);
 /* slots [dst_first, dst_first+k) = slots [src_first, src_first+m) * Y, Y row-major m x k; ranges must not overlap */
 int pf_combine(pf_graph* g, int32_t src_first, int32_t m, const double* Y, int32_t k, int32_t dst_first);
 int pf_resnorm(pf_graph* g, int32_t ax, int32_t x, double lam, double* out);     /* ||ax - lam x||_2 */
+/* the batched forms the Rayleigh-Ritz step uses (one copy and one synchronisation instead of one per vector):
+ * out[i][j] = <slot first_a+i, slot first_b+j> (count_a x count_b, row-major); out[i] = ||slot ax_first+i - lam[i] slot x_first+i||_2 */
+int pf_gram(pf_graph* g, int32_t first_a, int32_t count_a, int32_t first_b, int32_t count_b, double* out);
+int pf_resnorms(pf_graph* g, int32_t ax_first, int32_t x_first, const double* lam, int32_t count, double* out);
 /* Eigenvector post-processing (graph.py:254-257 + the sign/scale convention): for each of
  * `count` slots from `first`: x <- sqrt(g) .* x if from_sym; scale to unit 2-norm; flip so the
  * largest-|entry| (lowest index on ties) is positive; if minmax: (v - min)/(max - min) - 0.5.

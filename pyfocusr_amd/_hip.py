@@ -89,6 +89,8 @@ SIGNATURES = {
     "pf_scale": (C.c_int, [C.c_void_p, C.c_int32, C.c_double]),
     "pf_combine": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _f64p, C.c_int32, C.c_int32]),
     "pf_resnorm": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_double, _f64p]),
+    "pf_gram": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _f64p]),
+    "pf_resnorms": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _f64p, C.c_int32, _f64p]),
     "pf_finalize_vectors": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _f64p]),
     "pf_final_rows": (C.c_int, [C.c_void_p, _i64p, C.c_int64, _f64p]),
     "pf_point_rows": (C.c_int, [C.c_void_p, _i64p, C.c_int64, _f64p]),
@@ -669,6 +671,19 @@ class DeviceLaplacian(object):
         out = C.c_double()
         _check(self._lib.pf_resnorm(self._h, int(ax), int(x), float(lam), C.byref(out)))
         return float(out.value)
+
+    def gram(self, first_a, count_a, first_b, count_b):
+        """(count_a, count_b) matrix of inner products <slot first_a+i, slot first_b+j>, one synchronisation."""
+        out = np.empty((int(count_a), int(count_b)), dtype=np.float64)
+        _check(self._lib.pf_gram(self._h, int(first_a), int(count_a), int(first_b), int(count_b), _f64(out)))
+        return out
+
+    def resnorms(self, ax_first, x_first, lams):
+        """||slot(ax_first+i) - lams[i] slot(x_first+i)||_2 for every i, one synchronisation."""
+        lams = _c_f64(lams)
+        out = np.empty(len(lams), dtype=np.float64)
+        _check(self._lib.pf_resnorms(self._h, int(ax_first), int(x_first), _f64(lams), len(lams), _f64(out)))
+        return out
 
     def finalize_vectors(self, first, count, minmax):
         out = np.empty((self.n, int(count)), dtype=np.float64)

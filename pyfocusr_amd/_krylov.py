@@ -476,8 +476,11 @@ def _solve_gen(ops, n_wanted, symmetric, null_slots=0, cut=None, tol=1e-12, m_ma
     for i in range(q):
         ops.spmv(B0 + i, A0 + i)  # A z_i -> region A (Krylov basis no longer needed)
         stats.matvecs += 1
-    for i in range(q):
-        HA[:, i] = ops.dots(A0 + i, B0, q)
+    if hasattr(ops, "gram"):  # all q^2 inner products behind one synchronisation
+        HA[:, :] = ops.gram(A0, q, B0, q).T
+    else:
+        for i in range(q):
+            HA[:, i] = ops.dots(A0 + i, B0, q)
     if symmetric:
         lam, R = np.linalg.eigh(0.5 * (HA + HA.T))
     else:
@@ -525,6 +528,9 @@ def _solve_gen(ops, n_wanted, symmetric, null_slots=0, cut=None, tol=1e-12, m_ma
     ops.combine(B0, q, R, X0)  # X = Z R
     ops.combine(A0, q, R, AX0)  # A X = (A Z) R
     # (for a complex pair the real part alone is not an eigenvector: its "residual" is |Im lambda| * |Im x|)
-    stats.residuals = np.array([ops.resnorm(AX0 + i, X0 + i, lam[i]) for i in range(nk)])
+    if hasattr(ops, "resnorms"):
+        stats.residuals = np.asarray(ops.resnorms(AX0, X0, lam[:nk]))
+    else:
+        stats.residuals = np.array([ops.resnorm(AX0 + i, X0 + i, lam[i]) for i in range(nk)])
     ops.sync()  # nothing of this solve is left in flight (a speculative filter application that failed surfaces here)
     return lam, X0, stats

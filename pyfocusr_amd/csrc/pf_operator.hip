@@ -1072,6 +1072,38 @@ int pf_resnorm(pf_graph* g, int32_t ax, int32_t x, double lam, double* out) {
     return PF_OK;
 }
 
+int pf_gram(pf_graph* g, int32_t first_a, int32_t count_a, int32_t first_b, int32_t count_b, double* out) {
+    PF_TRY(check_slots(g, first_a, count_a, "pf_gram"));
+    PF_TRY(check_slots(g, first_b, count_b, "pf_gram"));
+    PF_CHECK(out != nullptr && count_a > 0 && count_b > 0, PF_E_ARG, "pf_gram: bad argument");
+    PF_TRY(pf_reduce_ensure(g, std::max(count_b, (count_a * count_b + 7) / 8)));  // coef holds 8 x coef_cap doubles
+    hipStream_t st = g->ctx->stream;
+    for (int32_t i = 0; i < count_a; ++i)
+        PF_TRY(dots_device(g, first_a + i, first_b, count_b, g->coef + (size_t)i * count_b, nullptr, 0));
+    PF_HIP(hipMemcpyAsync(out, g->coef, sizeof(double) * (size_t)count_a * count_b, hipMemcpyDeviceToHost, st));
+    PF_HIP(hipStreamSynchronize(st));
+    return PF_OK;
+}
+
+int pf_resnorms(pf_graph* g, int32_t ax_first, int32_t x_first, const double* lam, int32_t count, double* out) {
+    PF_TRY(check_slots(g, ax_first, count, "pf_resnorms"));
+    PF_TRY(check_slots(g, x_first, count, "pf_resnorms"));
+    PF_CHECK(out != nullptr && lam != nullptr && count > 0, PF_E_ARG, "pf_resnorms: bad argument");
+    hipStream_t st = g->ctx->stream;
+    PF_TRY(pf_reduce_ensure(g, count));
+    for (int32_t i = 0; i < count; ++i) {
+        k_resnorm_partial<<<(unsigned)g->n_chunks, PF_BLOCK, 0, st>>>(pf_slot(g, ax_first + i), pf_slot(g, x_first + i), lam[i], g->n_pad,
+                                                                      g->n_chunks, g->partials);
+        PF_HIP(hipGetLastError());
+        k_dot_finish<<<1, PF_WAVE, 0, st>>>(g->partials, g->n_chunks, g->coef + i, nullptr, 0);
+        PF_HIP(hipGetLastError());
+    }
+    PF_HIP(hipMemcpyAsync(out, g->coef, sizeof(double) * count, hipMemcpyDeviceToHost, st));
+    PF_HIP(hipStreamSynchronize(st));
+    for (int32_t i = 0; i < count; ++i) out[i] = sqrt(out[i] > 0.0 ? out[i] : 0.0);
+    return PF_OK;
+}
+
 int pf_finalize_vectors(pf_graph* g, int32_t first, int32_t count, int32_t from_sym, int32_t minmax, double* out) {
     PF_TRY(check_slots(g, first, count, "pf_finalize_vectors"));
     PF_CHECK(out != nullptr && count > 0, PF_E_ARG, "pf_finalize_vectors: bad argument");
