@@ -423,7 +423,7 @@ def main():
             kernel_us = 1e3 * kernel_ms / max(launches, 1)
             lds_per_launch = tm["persist_lds_bytes"] / max(launches, 1)
             achieved = lds_per_launch / (kernel_us * 1e-6) / 1e9
-            steps_per_launch = tm["persist_steps"] / max(launches, 1)
+            steps_per_launch = tm["persist_steps"] / 2.0 / max(launches, 1)  # the library counts graph-steps: two per pair-step
             entry = pmc.get("k_cheb_resident<2, 1, 8>", {})
             traffic = entry.get("hbm_bytes_per_step", None)
             traffic = None if traffic is None else traffic * steps_per_launch + entry.get("hbm_bytes_per_launch_fixed", 0.0)
@@ -439,7 +439,7 @@ def main():
                 "hbm_frac": None if traffic is None else traffic / (kernel_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                 "lds_bytes_per_launch": lds_per_launch,
                 "avg_launch_us_hip_events": kernel_us, "launches": launches, "steps_per_launch": steps_per_launch,
-                "us_per_step_of_the_pair": 1e3 * kernel_ms / max(tm["persist_steps"], 1),
+                "us_per_step_of_the_pair": 2e3 * kernel_ms / max(tm["persist_steps"], 1),
                 "effective_algorithmic_GBps": tm["persist_bytes"] / max(launches, 1) / (kernel_us * 1e-6) / 1e9,
                 "note": "frac is LDS bytes (8 B per gathered x + 16 B per row + 8 B per outside row, counted by the library) "
                         "against the conflict-free ds_read_b64 peak; random 8-byte gathers conflict ~3-4x, and each step waits "

@@ -70,7 +70,7 @@ typedef struct pf_timing {
     /* the part of the above done by the resident kernel (pf_persist_enable): one launch = a whole recurrence */
     double persist_ms;
     int64_t persist_launches;
-    int64_t persist_steps; /* recurrence steps those launches ran (the longer of the two graphs per launch) */
+    int64_t persist_steps; /* recurrence steps those launches ran, summed over the graphs of a launch (graph-steps) */
     double persist_bytes;  /* algorithmic bytes, counted as for op_bytes                                   */
     double persist_lds_bytes; /* LDS bytes the resident launches moved: per graph and step 8 B per stored SELL entry
                                  (the gathered x) + 16 B per row (own x read, result written) + 8 B per outside row */

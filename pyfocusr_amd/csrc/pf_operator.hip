@@ -889,7 +889,7 @@ int pf_cheb2(pf_graph* ga, int32_t op_a, int32_t src_a, int32_t dst_a, int32_t d
         PF_TRY(pf_persist_cheb(&pa, &pb, &done, &t.lds_bytes));
         if (done) {
             t.launches = 1;
-            t.persist_steps = std::max(degree_a, degree_b);
+            t.persist_steps = degree_a + degree_b;
             return t.finish();
         }
         // The pair does not fit one resident launch (windows of 2048+ rows: registers / LDS): each graph in its own
