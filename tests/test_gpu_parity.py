@@ -1,5 +1,7 @@
 """GPU parity tests: the HIP path, called through the C-ABI (ctypes), against the
 oracle and the reference-generated golden fixtures.  Run with `-m gpu` on an MI355X."""
+import os
+
 import numpy as np
 import pytest
 from scipy import sparse
@@ -876,6 +878,45 @@ def test_split_pair_device_to_device(golden, ctx):
         assert idx.dtype == np.int64 and len(idx) == 14996
         assert int(np.sum(idx != p["knn_idx_w"])) == 0
     assert np.array_equal(results[0][0], results[1][0])
+
+
+def test_rccl_all_gather_of_resident_block(golden, ctx):
+    """The RCCL leg of the split pair on the hardware at hand (ONE GPU, so a world of one rank): the resident eigenvector
+    block wrapped zero-copy as a torch tensor, `all_gather_into_tensor` (backend "nccl" = RCCL) enqueued on the library's
+    own stream through `torch.cuda.ExternalStream`, and `pf_knn1_blocks` reading the gathered buffer.  The two-rank
+    control flow is covered by `test_split_pair_device_to_device` and tests/test_parallel_gloo.py."""
+    import socket
+
+    import torch
+    import torch.distributed as dist
+
+    from pyfocusr_amd import Graph
+    from pyfocusr_amd.parallel import _all_gather_stack, resident_block_tensor
+
+    g_ = golden("target_mesh")
+    gr = Graph(mesh_of(g_), n_spectral_features=3, n_rand_samples=10**9, ctx=ctx, verbose=False)
+    gr.get_graph_spectrum()
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", ctx.device))
+    try:
+        block = resident_block_tensor(torch, gr.device, ctx.device)
+        assert block.data_ptr() == gr.device.final_device()[0] and tuple(block.shape) == gr.eig_vecs.shape  # zero-copy
+        assert np.array_equal(block.cpu().numpy(), gr.eig_vecs)
+        stream = torch.cuda.ExternalStream(ctx.stream_ptr, device=torch.device("cuda", ctx.device))
+        with torch.cuda.stream(stream):
+            both = _all_gather_stack(dist, torch, block)
+        stream.synchronize()
+        assert tuple(both.shape) == (1,) + gr.eig_vecs.shape and np.array_equal(both[0].cpu().numpy(), gr.eig_vecs)
+        n, m = gr.eig_vecs.shape
+        idx, d2 = ctx.knn1_blocks(both[0].data_ptr(), n, m, both[0].data_ptr() + 8 * 100 * m, n - 100, m, np.arange(3), np.ones(3),
+                                  np.arange(3), np.ones(3), return_d2=True)
+        assert np.array_equal(idx, np.arange(100, n)) and np.all(d2 == 0)  # every row finds itself
+    finally:
+        dist.destroy_process_group()
 
 
 def test_tail_vs_reference_fixture(golden, ctx):
