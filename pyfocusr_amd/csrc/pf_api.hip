@@ -139,6 +139,8 @@ void pf_destroy(pf_ctx* c) {
         hipEventDestroy(pr.first);
         hipEventDestroy(pr.second);
     }
+    for (auto& pb : c->pinned_pool) hipHostFree(pb.second);
+    for (hipEvent_t ev : c->event_pool) hipEventDestroy(ev);
     pf_persist_release(c);
     if (c->persist_abort) hipHostFree(c->persist_abort);
     hipEventDestroy(c->ev0);

@@ -478,11 +478,9 @@ void pf_graph_free(pf_graph* g) {
     pf_free(st, g->ws);
     pf_free(st, g->partials);
     pf_free(st, g->coef);
-    if (g->orth_host) {
-        hipStreamSynchronize(st);
-        hipHostFree(g->orth_host);
-    }
-    if (g->orth_ev) hipEventDestroy(g->orth_ev);
+    if (g->orth_pending >= 0) hipStreamSynchronize(st);  // an orthogonalisation nobody collected still writes the pinned buffer
+    if (g->orth_host) g->ctx->pinned_pool.emplace_back(g->orth_host_cap, g->orth_host);
+    if (g->orth_ev) g->ctx->event_pool.push_back(g->orth_ev);
     delete g;
 }
 

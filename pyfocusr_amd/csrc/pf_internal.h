@@ -90,6 +90,10 @@ struct pf_ctx {
     };
     std::vector<TimedSpan> spans_pending;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> spans_free;
+    // pinned host buffers and events of freed graphs, handed to the next graph (hipHostMalloc / hipHostFree and event
+    // creation cost 0.1-0.2 ms each: more than a 250k-vertex assembly kernel)
+    std::vector<std::pair<int32_t, double*>> pinned_pool;  // (capacity in doubles - 1, buffer)
+    std::vector<hipEvent_t> event_pool;                    // created with hipEventDisableTiming
     // allocator state
     std::multimap<size_t, void*> free_blocks;   // size -> block
     std::unordered_map<void*, size_t> live_blocks;

@@ -958,16 +958,34 @@ int pf_orth_begin(pf_graph* g, int32_t w, int32_t first, int32_t count, int32_t 
     hipStream_t st = g->ctx->stream;
     PF_TRY(pf_reduce_ensure(g, std::max(count, 1)));
     if (count > g->orth_host_cap || !g->orth_host) {
+        pf_ctx* c = g->ctx;
         if (g->orth_host) {
             PF_HIP(hipStreamSynchronize(st));
-            PF_HIP(hipHostFree(g->orth_host));
+            c->pinned_pool.emplace_back(g->orth_host_cap, g->orth_host);
             g->orth_host = nullptr;
         }
         const int32_t cap = std::max(count, 64);
-        PF_HIP(hipHostMalloc((void**)&g->orth_host, sizeof(double) * (size_t)(cap + 1), hipHostMallocDefault));
-        g->orth_host_cap = cap;
+        for (size_t i = 0; i < c->pinned_pool.size(); ++i)
+            if (c->pinned_pool[i].first >= cap) {  // a buffer a freed graph left behind
+                g->orth_host_cap = c->pinned_pool[i].first;
+                g->orth_host = c->pinned_pool[i].second;
+                c->pinned_pool.erase(c->pinned_pool.begin() + (long)i);
+                break;
+            }
+        if (!g->orth_host) {
+            PF_HIP(hipHostMalloc((void**)&g->orth_host, sizeof(double) * (size_t)(cap + 1), hipHostMallocDefault));
+            g->orth_host_cap = cap;
+        }
     }
-    if (!g->orth_ev) PF_HIP(hipEventCreateWithFlags(&g->orth_ev, hipEventDisableTiming));
+    if (!g->orth_ev) {
+        pf_ctx* c = g->ctx;
+        if (!c->event_pool.empty()) {
+            g->orth_ev = c->event_pool.back();
+            c->event_pool.pop_back();
+        } else {
+            PF_HIP(hipEventCreateWithFlags(&g->orth_ev, hipEventDisableTiming));
+        }
+    }
     const int32_t cap = g->coef_cap;
     double* hpass = g->coef;           // coefficients of the current pass
     double* hsum = g->coef + cap;      // h1 + h2

@@ -21,14 +21,20 @@ namespace {
 constexpr int WB_CAP = 4096;  // outside-column candidates of a window before deduplication
 constexpr int WB_ADJ_WORDS = PF_WIN_MAX / 32;
 
-// pass 1: which windows read which (bit matrix), and the extent of each window's externally read rows
+// pass 1: which windows read which (bit matrix), and the extent of each window's externally read rows.  A window's
+// outside entries hit a handful of neighbours: merged in LDS first (same-address atomics in memory serialise at ~10 ns)
 __global__ __launch_bounds__(PF_WIN_THREADS) void k_win_scan(const int64_t* __restrict__ slice_ptr, const int32_t* __restrict__ scol,
-                                                             int32_t win_rows, uint32_t* __restrict__ adj, int32_t* __restrict__ need) {
+                                                             int32_t win_rows, int32_t n_windows, uint32_t* __restrict__ adj,
+                                                             int32_t* __restrict__ need) {
+    __shared__ uint32_t l_adj[WB_ADJ_WORDS];
+    __shared__ int32_t l_need[PF_WIN_MAX];
     const int tid = threadIdx.x;
     const int lane = tid & (PF_WAVE - 1);
     const int32_t A = (int32_t)blockIdx.x;
     const int64_t r0 = (int64_t)A * win_rows;
-    if (tid == 0) atomicMax(&need[A], 1);  // row 0 of every window is always published (extra outside rows point at it)
+    for (int i = tid; i < WB_ADJ_WORDS; i += PF_WIN_THREADS) l_adj[i] = 0u;
+    for (int i = tid; i < PF_WIN_MAX; i += PF_WIN_THREADS) l_need[i] = 0;
+    __syncthreads();
     for (int32_t lr = tid; lr < win_rows; lr += PF_WIN_THREADS) {
         const int64_t s = (r0 + lr) >> 6;
         const int64_t base = slice_ptr[s];
@@ -37,11 +43,17 @@ __global__ __launch_bounds__(PF_WIN_THREADS) void k_win_scan(const int64_t* __re
             const int32_t c = scol[pf_sell_index(base, width, j, lane)];
             const int32_t B = c / win_rows;
             if (B != A) {
-                atomicOr(&adj[(int64_t)A * WB_ADJ_WORDS + (B >> 5)], 1u << (B & 31));
-                atomicMax(&need[B], c - B * win_rows + 1);
+                atomicOr(&l_adj[B >> 5], 1u << (B & 31));
+                atomicMax(&l_need[B], c - B * win_rows + 1);
             }
         }
     }
+    __syncthreads();
+    for (int i = tid; i < WB_ADJ_WORDS; i += PF_WIN_THREADS)
+        if (l_adj[i]) adj[(int64_t)A * WB_ADJ_WORDS + i] = l_adj[i];  // row A of the matrix is this block's alone
+    for (int32_t B = tid; B < n_windows; B += PF_WIN_THREADS)
+        if (l_need[B] > 0) atomicMax(&need[B], l_need[B]);
+    if (tid == 0) atomicMax(&need[A], 1);  // row 0 of every window is always published (extra outside rows point at it)
 }
 
 // pass 2: one block per window: sorted unique outside rows (+ row 0 of the windows that read this one without being
@@ -86,10 +98,13 @@ __global__ __launch_bounds__(PF_WIN_THREADS) void k_win_build(const int64_t* __r
         if (tid == 0) atomicOr(flags, 1);
         return;
     }
-    // bitonic sort of cand[0, WB_CAP) ascending (INT_MAX padding sorts to the end)
-    for (int k = 2; k <= WB_CAP; k <<= 1) {
+    // bitonic sort of cand[0, cap) ascending, cap = the power of two that holds the candidates (INT_MAX padding sorts to
+    // the end; a window has ~500 of them, not WB_CAP)
+    int cap = 64;
+    while (cap < cnt) cap <<= 1;  // block-uniform
+    for (int k = 2; k <= cap; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < WB_CAP; i += PF_WIN_THREADS) {
+            for (int i = tid; i < cap; i += PF_WIN_THREADS) {
                 const int ixj = i ^ j;
                 if (ixj > i) {
                     const int32_t a = cand[i], b = cand[ixj];
@@ -106,7 +121,7 @@ __global__ __launch_bounds__(PF_WIN_THREADS) void k_win_build(const int64_t* __r
     if (tid == 0) {  // unique, serial: <= 4096 steps once per window
         int h = 0;
         int32_t last = -1;
-        for (int i = 0; i < WB_CAP; ++i) {
+        for (int i = 0; i < cap; ++i) {
             const int32_t c = cand[i];
             if (c == INT_MAX) break;
             if (c != last) {
@@ -174,7 +189,7 @@ int pf_window_slots_prepare(pf_graph* g) {
     int32_t h_flag = 1;
     g->h_px_gh_cnt.assign((size_t)nw, 0);
     if (e == hipSuccess) {
-        k_win_scan<<<(unsigned)nw, PF_WIN_THREADS, 0, st>>>(g->slice_ptr, g->scol, g->win_rows, adj, g->px_need);
+        k_win_scan<<<(unsigned)nw, PF_WIN_THREADS, 0, st>>>(g->slice_ptr, g->scol, g->win_rows, (int32_t)nw, adj, g->px_need);
         k_win_build<<<(unsigned)nw, PF_WIN_THREADS, 0, st>>>(g->slice_ptr, g->scol, g->win_rows, (int32_t)nw, adj, g->px_slot,
                                                              g->px_gh_cnt, g->px_gh_row, flags);
         e = hipGetLastError();
