@@ -143,7 +143,7 @@ __global__ __launch_bounds__(RX_THREADS) void k_cheb_resident(RxArgs a) {
     const int wave = tid >> 6;
 
     bool have[NG];
-    int32_t ghosts[NG], need_r[NG], xlen[NG], ghrow[NG];
+    int32_t ghosts[NG], need_r[NG], xlen[NG], ghrow[NG], gh_lane[NG];
     int64_t row0[NG];
     double* xb[NG];
     double v[NG][NW][JR];
@@ -162,7 +162,16 @@ __global__ __launch_bounds__(RX_THREADS) void k_cheb_resident(RxArgs a) {
         ghosts[q] = have[q] ? g.gh_cnt[wq] : 0;
         need_r[q] = have[q] ? ((g.need[wq] + PF_WAVE - 1) & ~(PF_WAVE - 1)) : 0;
         row0[q] = (int64_t)wq * RB;
-        ghrow[q] = tid < ghosts[q] ? g.gh_row[(int64_t)wq * PF_WIN_GHOSTS + tid] : 0;
+        // Which thread fetches which outside row.  One graph: thread t fetches row t.  Two graphs: the second graph's
+        // rows are fetched by the waves of the block's upper half (thread 512 + t fetches row t) when both lists fit a
+        // half, so that the two graphs' polls are in flight TOGETHER instead of one round trip after the other
+        gh_lane[q] = tid;
+        if (NG == 2) {
+            const int32_t g0 = win < a.g[0].n_windows ? a.g[0].gh_cnt[win] : 0;
+            const int32_t g1 = win < a.g[1].n_windows ? a.g[1].gh_cnt[win] : 0;
+            if (q == 1 && g0 <= RX_THREADS / 2 && g1 <= RX_THREADS / 2) gh_lane[q] = tid - RX_THREADS / 2;
+        }
+        ghrow[q] = (gh_lane[q] >= 0 && gh_lane[q] < ghosts[q]) ? g.gh_row[(int64_t)wq * PF_WIN_GHOSTS + gh_lane[q]] : 0;
         xlen[q] = have[q] ? RB + ((ghosts[q] + 1) & ~1) : 0;
         xb[q] = reinterpret_cast<double*>(lds + off);
         off += (size_t)2 * xlen[q] * sizeof(double);
@@ -247,7 +256,7 @@ __global__ __launch_bounds__(RX_THREADS) void k_cheb_resident(RxArgs a) {
             }
             if (have[q]) xb[q][w * RX_THREADS + tid] = g.src[row0[q] + w * RX_THREADS + tid];
         }
-        if (tid < ghosts[q]) xb[q][RB + tid] = g.src[ghrow[q]];
+        if (gh_lane[q] >= 0 && gh_lane[q] < ghosts[q]) xb[q][RB + gh_lane[q]] = g.src[ghrow[q]];
     }
     __syncthreads();
 
@@ -306,13 +315,14 @@ __global__ __launch_bounds__(RX_THREADS) void k_cheb_resident(RxArgs a) {
         // and cost a second round trip, so the first poll is held back by about that long - the interior rows of the
         // other waves are being computed meanwhile.
         // (measured at 250k rows, s_sleep units of 64 cycles: one graph 2.22 us per step polling at once, 1.42 held back by
-        // 16; a pair, whose second graph's poll follows the first one's round trip anyway, 1.92 -> 1.84 held back by 4)
+        // 16; a pair with the two graphs' polls on the two halves of the block: 2.46 / 2.25 / 2.04 / 1.93 / 2.03 / 2.14
+        // held back by 4 / 8 / 12 / 16 / 20 / 24)
         bool slept = false;
 #pragma unroll
         for (int q = 0; q < NG; ++q) {
             const RxGraph& g = a.g[q];
-            if (have[q] && k < g.degree && tid < ghosts[q]) {
-                if (!slept) __builtin_amdgcn_s_sleep(NG == 1 ? 16 : 4);
+            if (have[q] && k < g.degree && gh_lane[q] >= 0 && gh_lane[q] < ghosts[q]) {
+                if (!slept && gh_lane[q] == tid) __builtin_amdgcn_s_sleep(16);  // (the upper half's waves arrive late anyway)
                 slept = true;
                 const unsigned long long* p =
                     reinterpret_cast<const unsigned long long*>(g.ring) + (int64_t)((k + g.phase) & 3) * g.n_pad + ghrow[q];
@@ -328,7 +338,7 @@ __global__ __launch_bounds__(RX_THREADS) void k_cheb_resident(RxArgs a) {
                     }
                     __builtin_amdgcn_s_sleep(1);
                 }
-                xb[q][(size_t)(cur ^ 1) * xlen[q] + RB + tid] = __longlong_as_double((long long)bits);
+                xb[q][(size_t)(cur ^ 1) * xlen[q] + RB + gh_lane[q]] = __longlong_as_double((long long)bits);
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's hand-offs and EMPTY stores are in memory (see header)
