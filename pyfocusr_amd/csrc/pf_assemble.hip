@@ -414,7 +414,7 @@ int finish_graph(pf_graph* g, const double* d_pts, bool numeric_symmetry) {
     PF_TRY(pf_exclusive_scan_i64(st, width64, g->slice_ptr, g->n_slices + 1));
     int32_t h_stats[6];
     PF_HIP(hipMemcpyAsync(h_stats, stats, sizeof(int32_t) * 5, hipMemcpyDeviceToHost, st));
-    g->h_slice_ptr.resize((size_t)g->n_slices + 1);  // the persistent Chebyshev kernel sizes its LDS from this
+    g->h_slice_ptr.resize((size_t)g->n_slices + 1);  // the resident Chebyshev kernel sizes its LDS from this
     PF_HIP(hipMemcpyAsync(g->h_slice_ptr.data(), g->slice_ptr, sizeof(int64_t) * (g->n_slices + 1), hipMemcpyDeviceToHost, st));
     PF_HIP(hipMemcpyAsync(&g->sell_entries, g->slice_ptr + g->n_slices, sizeof(int64_t), hipMemcpyDeviceToHost, st));
     PF_HIP(hipStreamSynchronize(st));

@@ -48,7 +48,7 @@ struct pf_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timing = false;
-    uint32_t* persist_sync = nullptr;  // barrier counters of the persistent Chebyshev kernel (pf_persist.hip)
+    uint32_t* persist_sync = nullptr;  // device word(s) of the resident Chebyshev kernel: its abort flag (pf_persist.hip)
     int32_t* persist_abort = nullptr;  // pinned host word: a barrier wait ran out
     double op_ms = 0.0;
     int64_t op_launches = 0;
