@@ -20,7 +20,13 @@ import os
 import sys
 import time
 
-import numpy as np
+# One process per GPU: the host side of a step is small dense algebra (<= 49 x 49) and numpy element-wise work; BLAS /
+# OpenMP thread pools would only spin against the other ranks' on a shared host (torchrun sets OMP_NUM_THREADS=1 itself
+# for N > 1; the same here for N = 1 keeps the per-rank figure comparable).
+for _var in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+    os.environ.setdefault(_var, "1")
+
+import numpy as np  # noqa: E402
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)

@@ -1098,13 +1098,23 @@ def test_resident_kernel_bit_identical(golden, hip, ctx):
     big = [blob_mesh(250000, seed=s) for s in (0, 1)]
     m = blob_mesh(60000, seed=8)
     m2, m4 = blob_mesh(400000, seed=9), blob_mesh(700000, seed=10)
+    # rows wider than the 8 entries a thread keeps in registers (the rest of such a row lives in LDS): a 30k blob with
+    # extra faces between every fifth vertex and pairs of its nearest neighbours
+    from scipy.spatial import cKDTree
+
+    mw = blob_mesh(30000, seed=12)
+    _, nn = cKDTree(mw.points).query(mw.points[::5], k=9)
+    extra = np.concatenate([np.stack([nn[:, 0], nn[:, a], nn[:, b]], axis=1) for a, b in ((1, 2), (3, 4), (5, 6), (7, 8), (2, 5))])
+    wide_faces = np.concatenate([mw.faces, extra.astype(mw.faces.dtype)])
     graphs = [hip.DeviceLaplacian(golden("source_mesh_15k")["points"], golden("source_mesh_15k")["faces"], ctx=ctx),  # RW
               hip.DeviceLaplacian(golden("target_mesh_15k")["points"], golden("target_mesh_15k")["faces"], ctx=ctx),
               hip.DeviceLaplacian(m.points, m.faces, ctx=ctx),
               hip.DeviceLaplacian(big[0].points, big[0].faces, ctx=ctx),
               hip.DeviceLaplacian(big[1].points, big[1].faces, ctx=ctx),
               hip.DeviceLaplacian(m2.points, m2.faces, ctx=ctx),
-              hip.DeviceLaplacian(m4.points, m4.faces, ctx=ctx)]
+              hip.DeviceLaplacian(m4.points, m4.faces, ctx=ctx),
+              hip.DeviceLaplacian(mw.points, wide_faces, ctx=ctx)]
+    assert graphs[-1].max_degree > 10  # (its widest SELL slices overflow the register entries)
     try:
         for g in graphs:
             g.ws_ensure(4)
@@ -1120,7 +1130,7 @@ def test_resident_kernel_bit_identical(golden, hip, ctx):
                     g.cheb(0, 1, p, 1.03, 0.98, rho)
                     out.append(g.download_slots(1, 1).copy())
             for ia, ib, pa, pb in ((2, 1, 12, 12), (2, 0, 9, 30), (3, 4, 145, 145), (3, 4, 150, 139), (4, 2, 20, 64),
-                                   (3, 4, 300, 520), (0, 1, 1, 40), (1, 0, 2, 9), (5, 3, 33, 34)):
+                                   (3, 4, 300, 520), (0, 1, 1, 40), (1, 0, 2, 9), (5, 3, 33, 34), (7, 2, 25, 31)):
                 graphs[ia].cheb2((0, 2, pa, 1.0, 1.0, 1.0), graphs[ib], (0, 2, pb, 1.01, 0.99, 1.0))
                 out.append(graphs[ia].download_slots(2, 1).copy())
                 out.append(graphs[ib].download_slots(2, 1).copy())
