@@ -229,19 +229,19 @@ __device__ __forceinline__ void topk_insert(double (&best)[K], int32_t (&bidx)[K
     }
 }
 
-template <int D, int K>
-__global__ __launch_bounds__(PF_BLOCK) void k_knn_grid(const double* __restrict__ ref_s /* rows sorted by cell */,
+template <int D, int K, int BS, int LANE_CELLS>
+__global__ __launch_bounds__(BS) void k_knn_grid(const double* __restrict__ ref_s /* rows sorted by cell */,
                                                        const int32_t* __restrict__ ref_orig,
                                                        const int32_t* __restrict__ cell_start, int64_t n_ref,
                                                        const double* __restrict__ qry_s, const int32_t* __restrict__ qry_orig,
                                                        int64_t n_qry, const KnnGrid* __restrict__ gp,
                                                        int64_t* __restrict__ idx_out, double* __restrict__ d2_out) {
-    constexpr int KNN_TILE = KNN_LDS_DOUBLES / (D <= 8 ? 8 : 16);
+    constexpr int KNN_TILE = (BS >= 256 ? KNN_LDS_DOUBLES : KNN_LDS_DOUBLES / 4) / (D <= 8 ? 8 : 16);
     __shared__ double tile[KNN_TILE * D];
     __shared__ int32_t tile_idx[KNN_TILE];
-    __shared__ int box[PF_BLOCK / PF_WAVE][4];
+    __shared__ int box[BS / PF_WAVE][4];
     const KnnGrid g = *gp;
-    const int64_t qi = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
+    const int64_t qi = (int64_t)blockIdx.x * BS + threadIdx.x;
     const int64_t qq = qi < n_qry ? qi : n_qry - 1;  // tail lanes replay the last query, result discarded
     double q[D];
 #pragma unroll
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(PF_BLOCK) void k_knn_grid(const double* __restrict_
         }
         __syncthreads();
 #pragma unroll
-        for (int w = 0; w < PF_BLOCK / PF_WAVE; ++w) {
+        for (int w = 0; w < BS / PF_WAVE; ++w) {
             bx0 = min(bx0, box[w][0]);
             bx1 = max(bx1, box[w][1]);
             by0 = min(by0, box[w][2]);
@@ -336,7 +336,6 @@ __global__ __launch_bounds__(PF_BLOCK) void k_knn_grid(const double* __restrict_
         int ly0 = cell_of(yl, g.lo1, g.s1, g.r1), ly1 = cell_of(yh, g.lo1, g.s1, g.r1);
         const bool bounded = best < INFINITY;
         const int cells = bounded ? (lx1 - lx0 + 1) * (ly1 - ly0 + 1) : 0x7fffffff;
-        constexpr int LANE_CELLS = 512;
         if (!__syncthreads_or(cells > LANE_CELLS)) {  // block-uniform
             if (!(lx0 >= rx0 && lx1 <= rx1 && ly0 >= ry0 && ly1 <= ry1)) {  // something outside the scanned ring
                 for (int y = ly0; y <= ly1; ++y) {
@@ -379,8 +378,8 @@ __global__ __launch_bounds__(PF_BLOCK) void k_knn_grid(const double* __restrict_
         for (int32_t t0 = run_b; t0 < run_e; t0 += KNN_TILE) {
             const int cnt = (run_e - t0) < KNN_TILE ? (run_e - t0) : KNN_TILE;
             __syncthreads();
-            for (int k = threadIdx.x; k < cnt * D; k += PF_BLOCK) tile[k] = ref_s[(int64_t)t0 * D + k];
-            for (int k = threadIdx.x; k < cnt; k += PF_BLOCK) tile_idx[k] = ref_orig[t0 + k];
+            for (int k = threadIdx.x; k < cnt * D; k += BS) tile[k] = ref_s[(int64_t)t0 * D + k];
+            for (int k = threadIdx.x; k < cnt; k += BS) tile_idx[k] = ref_orig[t0 + k];
             __syncthreads();
             for (int r = 0; r < cnt; ++r) {
                 double s;
@@ -424,9 +423,14 @@ __global__ __launch_bounds__(PF_BLOCK) void k_knn_grid(const double* __restrict_
 
 template <int D, int K>
 int launch_knn_k(pf_ctx* c) {
-    k_knn_grid<D, K><<<nblk(c->knn_nqry), PF_BLOCK, 0, c->stream>>>(c->knn_ref_s, c->knn_ref_orig, c->knn_cell_start, c->knn_nref,
-                                                                 c->knn_qry_s, c->knn_qry_orig, c->knn_nqry,
-                                                                 (const KnnGrid*)c->knn_grid, c->knn_idx, c->knn_d2);
+    // Block size: one wave per block for shallow coordinates (d <= 6: the usual spectral embeddings; whether the lane-
+    // private scan applies is then decided per wave, and a stray lane with a large square drags only 63 others into the
+    // shared scan: 1.60 -> 1.39 ms at 250k x 250k, d = 5), four waves for deep ones, whose large squares make the shared
+    // LDS tiles the common case (1M x 1M, d = 10: 161 ms with 256 threads, 172 with 64).
+    constexpr int BS = D <= 6 ? PF_WAVE : PF_BLOCK;
+    k_knn_grid<D, K, BS, 512><<<(unsigned)((c->knn_nqry + BS - 1) / BS), BS, 0, c->stream>>>(
+        c->knn_ref_s, c->knn_ref_orig, c->knn_cell_start, c->knn_nref, c->knn_qry_s, c->knn_qry_orig, c->knn_nqry,
+        (const KnnGrid*)c->knn_grid, c->knn_idx, c->knn_d2);
     PF_HIP(hipGetLastError());
     return PF_OK;
 }
