@@ -540,3 +540,21 @@ def test_header_is_plain_c_and_links_from_c(tmp_path):
                     "-l:" + os.path.basename(_hip.LIB_PATH), "-Wl,-rpath," + libdir], check=True)
     out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()
     assert int(out[0]) >= 1 and out[1] == "1"
+
+
+@pytest.mark.parametrize("n,m", [(1, 1), (1, 7), (5, 3), (64, 64), (1000, 999), (14998, 14996), (4000, 5000)])
+def test_w1_quantile_form_equals_scipy(n, m):
+    """eigsort.calc_c_hist's W1 for samples of different size (the 14 998 / 14 996-vertex pair) against
+    scipy.stats.wasserstein_distance, the function eigsort.py:176-187 calls; ties included."""
+    from scipy.stats import wasserstein_distance
+
+    from pyfocusr_amd.eigsort import _w1_quantile_plan
+
+    rng = np.random.default_rng(n * 31 + m)
+    u, v = np.sort(rng.normal(size=n)), np.sort(rng.normal(size=m) * 0.7 + 0.2)
+    if n > 4:
+        u[1], v[:2] = u[2], u[2]  # ties within and across the samples
+        u.sort(), v.sort()
+    lens, iu, iv = _w1_quantile_plan(n, m)
+    assert abs(lens.sum() - 1.0) < 1e-12 and iu.max() == n - 1 and iv.max() == m - 1
+    np.testing.assert_allclose((np.abs(u[iu] - v[iv]) * lens).sum(), wasserstein_distance(u, v), rtol=1e-12, atol=1e-15)
