@@ -153,14 +153,19 @@ int pf_cheb(pf_graph* g, int32_t op, int32_t src, int32_t dst, int32_t degree, d
 int pf_cheb2(pf_graph* ga, int32_t op_a, int32_t src_a, int32_t dst_a, int32_t degree_a, double c_a, double e_a, double rho_a,
              pf_graph* gb, int32_t op_b, int32_t src_b, int32_t dst_b, int32_t degree_b, double c_b, double e_b, double rho_b);
 int pf_dots(pf_graph* g, int32_t w, int32_t first, int32_t count, double* out);  /* out[b] = <slot first+b, slot w> */
-/* classical Gram-Schmidt twice of slot w against slots [first, first+count): h[count] = summed
- * coefficients, *nrm = ||w|| afterwards (w is left un-normalised). */
+/* classical Gram-Schmidt of slot w against slots [first, first+count), a second pass when the first one cancelled
+ * digits: h[count] = summed coefficients, *nrm = ||w|| afterwards (w is left un-normalised). */
 int pf_orth(pf_graph* g, int32_t w, int32_t first, int32_t count, double* h, double* nrm);
 /* The same in two phases, so that the host can queue the next filter application before it reads the
  * coefficients: begin enqueues the kernels (and, if `normalize`, w <- w/||w|| with the norm taken on the
  * device) plus an asynchronous copy of the results; end waits for them.  One orth in flight per graph. */
 int pf_orth_begin(pf_graph* g, int32_t w, int32_t first, int32_t count, int32_t normalize);
 int pf_orth_end(pf_graph* g, double* h, double* nrm);
+/* 1 if the last pf_orth_end found that the first Gram-Schmidt pass had cancelled digits (|w'| < 0.3 |w|) and ran the
+ * second pass itself, after everything queued behind pf_orth_begin: work queued in between that READ slot w (the next
+ * filter application of a pipelined driver) saw the un-refined, un-normalised vector and has to be repeated.  Rare:
+ * never on the 250k blobs, a few times per solve right after a restart on small graphs. */
+int pf_orth_redone(pf_graph* g);
 int pf_scale(pf_graph* g, int32_t slot, double alpha);
 /* slots [dst_first, dst_first+k) = slots [src_first, src_first+m) * Y, Y row-major m x k; ranges must not overlap */
 int pf_combine(pf_graph* g, int32_t src_first, int32_t m, const double* Y, int32_t k, int32_t dst_first);

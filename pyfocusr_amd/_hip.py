@@ -86,6 +86,7 @@ SIGNATURES = {
     "pf_orth": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, _f64p, _f64p]),
     "pf_orth_begin": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "pf_orth_end": (C.c_int, [C.c_void_p, _f64p, _f64p]),
+    "pf_orth_redone": (C.c_int, [C.c_void_p]),
     "pf_scale": (C.c_int, [C.c_void_p, C.c_int32, C.c_double]),
     "pf_combine": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _f64p, C.c_int32, C.c_int32]),
     "pf_resnorm": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_double, _f64p]),
@@ -649,6 +650,8 @@ class DeviceLaplacian(object):
         h = np.empty(max(self._orth_count, 1), dtype=np.float64)
         nrm = C.c_double()
         _check(self._lib.pf_orth_end(self._h, _f64(h), C.byref(nrm)))
+        # the step needed its second Gram-Schmidt pass, run only now: anything queued since orth_begin that read w is stale
+        self.orth_redone = self._lib.pf_orth_redone(self._h) == 1
         return h[: self._orth_count], float(nrm.value)
 
     def orth_abandon(self):

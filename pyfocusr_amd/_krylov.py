@@ -41,6 +41,7 @@ class EigsStats(object):
         self.cut = 0.0
         self.residuals = None  # ||A x - lambda x||_2 of the returned pairs (operator actually iterated)
         self.n_null = 0
+        self.second_passes = 0  # outer steps whose Gram-Schmidt projection cancelled digits (second pass run by orth_end)
 
     def as_dict(self):
         return dict(self.__dict__)
@@ -387,6 +388,9 @@ def _solve_gen(ops, n_wanted, symmetric, null_slots=0, cut=None, tol=1e-12, m_ma
                     yield (A0 + j + 1, A0 + j + 2, p, c, e, rho)
                     stats.matvecs += p
                 h, beta = ops.orth_end()
+                if getattr(ops, "orth_redone", False):
+                    stats.second_passes += 1
+                    spec = False  # w was refined after the speculative application had read it: apply the filter again
                 if not (np.isfinite(beta) and np.all(np.isfinite(h))):
                     # eigenvalues outside the damped set grow like ratio^p: at high degree (small cut: k = 1 on a
                     # large open mesh) even a modest outlier overflows before any Ritz value could expose it

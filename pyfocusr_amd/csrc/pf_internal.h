@@ -158,10 +158,12 @@ struct pf_graph {
     int32_t coef_cap = 0;
     int64_t n_chunks = 0;
     // split-phase orthogonalisation (pf_orth_begin / pf_orth_end): results land in pinned host memory
-    double* orth_host = nullptr; // [orth_host_cap + 1] pinned
+    double* orth_host = nullptr; // [orth_host_cap + 2] pinned: h, |w'|^2, verdict
     int32_t orth_host_cap = 0;
     int32_t orth_pending = -1;   // count of the orth in flight, -1 if none
     hipEvent_t orth_ev = nullptr;
+    int32_t orth_w = 0, orth_first = 0, orth_normalize = 0;  // arguments of the orth in flight (pf_orth_end's second pass)
+    int32_t orth_redone = 0;     // the last pf_orth_end ran the second Gram-Schmidt pass itself
     // the last pf_finalize_vectors result stays in HBM (mesh order, [n][final_count] row-major) for pf_final_rows and
     // pf_knn1_graphs: the spectral coordinates never have to come back from the host
     double* final_vecs = nullptr;

@@ -111,12 +111,11 @@ __global__ __launch_bounds__(PF_OP_BLOCK) void k_sell_op2(OpArgs a, OpArgs b) {
 
 // partial[b][chunk] = sum over the chunk's rows of V_b[i] * w[i]   (fixed order -> deterministic)
 // partial[b][chunk] = <slot first+b, slot wslot> over the chunk; with self_col >= 0 column b == self_col is w itself
-// (|w|^2 rides along); with `gate` the launch does nothing unless *gate != 0 (the conditional second Gram-Schmidt pass)
+// (|w|^2 rides along)
 __global__ __launch_bounds__(PF_BLOCK) void k_dot_partial(const double* __restrict__ ws, int64_t n_pad, int32_t first,
                                                           int32_t wslot, int64_t n_chunks, double* __restrict__ partial,
-                                                          int32_t self_col = -1, const double* __restrict__ gate = nullptr) {
+                                                          int32_t self_col = -1) {
     __shared__ double red[PF_BLOCK / PF_WAVE];
-    if (gate && *gate == 0.0) return;
     const int b = blockIdx.y;
     const int64_t chunk = blockIdx.x;
     const double* v = ws + (int64_t)(b == self_col ? wslot : first + b) * n_pad;
@@ -166,26 +165,17 @@ __global__ __launch_bounds__(PF_BLOCK) void k_multi_axpy(double* __restrict__ ws
     *reinterpret_cast<double2*>(ws + (int64_t)wslot * n_pad + i) = acc;
 }
 
-// Fused forms for pf_orth_begin (one Gram-Schmidt pass = k_dot_partial + this; no separate finish launch):
+// Fused forms for pf_orth_begin (one Gram-Schmidt pass = k_dot_partial + one of these; no separate finish launch):
 // every block finishes the per-chunk partial sums itself - in k_dot_finish's order, so all blocks (and the host) see
-// the same bits - then subtracts.  Block 0 also publishes the coefficients: hsum[b] (+)= h[b].
+// the same bits - then subtracts.  Block 0 also publishes the coefficients.
 constexpr int PF_ORTH_MAX = 256;
-// pass 0 (decide != nullptr): partial holds count + 1 columns, the last one |w|^2.  After the projection
-// |w'|^2 = |w|^2 - sum h^2 (Pythagoras; exact enough for a threshold): if |w'| < 0.3 |w| the projection cancelled
-// digits and the second pass runs ("twice is enough", Daniel-Gragg-Kaufman-Stewart; ARPACK's criterion with a looser
-// constant) - *decide = 1 - else it is skipped: the basis then stays orthogonal to ~eps / 0.3, far inside what
-// Lanczos needs (semi-orthogonality sqrt(eps) already preserves the Ritz values).  Measured on the 250k blobs: the ratio
-// is 0.35-0.78 in every step, so the second pass (40 % of the Gram-Schmidt traffic) almost never runs.
-// pass 1 (gate != nullptr): nothing happens unless *gate != 0.
+// k_axpy_finishing: a plain pass, hsum[b] (+)= h[b] (the second pass of the rare case below).
 __global__ __launch_bounds__(PF_BLOCK) void k_axpy_finishing(double* __restrict__ ws, int64_t n_pad, int32_t first, int32_t count,
                                                              int32_t wslot, const double* __restrict__ partial, int64_t n_chunks,
-                                                             double* __restrict__ hsum, int accumulate, double* __restrict__ decide,
-                                                             const double* __restrict__ gate) {
-    __shared__ double hs[PF_ORTH_MAX + 1];
-    if (gate && *gate == 0.0) return;
+                                                             double* __restrict__ hsum, int accumulate) {
+    __shared__ double hs[PF_ORTH_MAX];
     const int lane = threadIdx.x & (PF_WAVE - 1);
-    const int cols = decide ? count + 1 : count;
-    for (int b = threadIdx.x / PF_WAVE; b < cols; b += PF_BLOCK / PF_WAVE) {
+    for (int b = threadIdx.x / PF_WAVE; b < count; b += PF_BLOCK / PF_WAVE) {
         double s = 0.0;
         for (int64_t k = lane; k < n_chunks; k += PF_WAVE) s += partial[(int64_t)b * n_chunks + k];
 #pragma unroll
@@ -193,13 +183,63 @@ __global__ __launch_bounds__(PF_BLOCK) void k_axpy_finishing(double* __restrict_
         if (lane == 0) hs[b] = s;
     }
     __syncthreads();
-    if (blockIdx.x == 0) {
+    if (blockIdx.x == 0)
         for (int b = threadIdx.x; b < count; b += PF_BLOCK) hsum[b] = accumulate ? hsum[b] + hs[b] : hs[b];
-        if (decide && threadIdx.x == 0) {
-            double sum = 0.0;
-            for (int b = 0; b < count; ++b) sum += hs[b] * hs[b];
-            const double before = hs[count], after = before - sum;
-            *decide = (after >= 0.09 * before) ? 0.0 : 1.0;  // (NaN or a vanished vector: take the second pass)
+    const int64_t i = 2 * ((int64_t)blockIdx.x * PF_BLOCK + threadIdx.x);
+    if (i >= n_pad) return;
+    double2 acc = *reinterpret_cast<double2*>(ws + (int64_t)wslot * n_pad + i);
+    for (int b = 0; b < count; ++b) {
+        const double hb = hs[b];
+        const double2 v = *reinterpret_cast<const double2*>(ws + (int64_t)(first + b) * n_pad + i);
+        acc.x -= hb * v.x;
+        acc.y -= hb * v.y;
+    }
+    *reinterpret_cast<double2*>(ws + (int64_t)wslot * n_pad + i) = acc;
+}
+// k_project_normalize: the whole orthogonalisation step behind ONE k_dot_partial (whose last column is |w|^2):
+//   w' = w - V h,  h = V^T w;   |w'|^2 = |w|^2 - sum h^2  (Pythagoras);   w' /= |w'| if `normalize`
+// and h, |w'|^2 and a verdict go straight to the host's pinned buffer: host_out = [h (count), |w'|^2, redo].
+// If |w'| < 0.3 |w| the projection cancelled digits - the second Gram-Schmidt pass is due ("twice is enough", Daniel,
+// Gragg, Kaufman, Stewart; ARPACK's criterion with a looser constant) and Pythagoras is no longer a fair norm: redo = 1,
+// w' stays un-normalised and pf_orth_end runs the second pass itself.  Otherwise the basis stays orthogonal to ~eps / 0.3
+// and |w'| carries a relative error <= ~eps / 0.09: far inside what Lanczos needs (semi-orthogonality sqrt(eps) already
+// preserves the Ritz values; the eigenvalues handed out come from a Rayleigh-Ritz step on the operator itself).
+// Measured on the 250k blobs: the ratio is 0.35-0.78 in every step - the second pass almost never runs, and a step
+// costs 2 launches where it took 6 (the two gated passes and the separate norm were ~4.4 us of launch floor each).
+__global__ __launch_bounds__(PF_BLOCK) void k_project_normalize(double* __restrict__ ws, int64_t n_pad, int32_t first, int32_t count,
+                                                                int32_t wslot, const double* __restrict__ partial, int64_t n_chunks,
+                                                                double* __restrict__ hsum, double* __restrict__ nrm2,
+                                                                double* __restrict__ host_out, int normalize) {
+    __shared__ double hs[PF_ORTH_MAX + 1];
+    __shared__ double s_scale, s_after, s_redo;
+    const int lane = threadIdx.x & (PF_WAVE - 1);
+    for (int b = threadIdx.x / PF_WAVE; b < count + 1; b += PF_BLOCK / PF_WAVE) {
+        double s = 0.0;
+        for (int64_t k = lane; k < n_chunks; k += PF_WAVE) s += partial[(int64_t)b * n_chunks + k];
+#pragma unroll
+        for (int off = PF_WAVE / 2; off > 0; off >>= 1) s += __shfl_down(s, off, PF_WAVE);
+        if (lane == 0) hs[b] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {  // the same sequence in every block: the same bits
+        double sum = 0.0;
+        for (int b = 0; b < count; ++b) sum += hs[b] * hs[b];
+        const double before = hs[count], after = before - sum;
+        const bool fine = after >= 0.09 * before;  // (false for NaN and for a vanished vector: take the second pass)
+        s_redo = fine ? 0.0 : 1.0;
+        s_after = after;
+        s_scale = (fine && normalize && after > 1e-280) ? 1.0 / sqrt(after) : 1.0;
+    }
+    __syncthreads();
+    if (blockIdx.x == 0) {
+        for (int b = threadIdx.x; b < count; b += PF_BLOCK) {
+            hsum[b] = hs[b];
+            host_out[b] = hs[b];
+        }
+        if (threadIdx.x == 0) {
+            *nrm2 = s_after;
+            host_out[count] = s_after;
+            host_out[count + 1] = s_redo;
         }
     }
     const int64_t i = 2 * ((int64_t)blockIdx.x * PF_BLOCK + threadIdx.x);
@@ -211,6 +251,9 @@ __global__ __launch_bounds__(PF_BLOCK) void k_axpy_finishing(double* __restrict_
         acc.x -= hb * v.x;
         acc.y -= hb * v.y;
     }
+    const double sc = s_scale;
+    acc.x *= sc;
+    acc.y *= sc;
     *reinterpret_cast<double2*>(ws + (int64_t)wslot * n_pad + i) = acc;
 }
 __global__ __launch_bounds__(PF_BLOCK) void k_scale_finishing(double* __restrict__ x, int64_t n_pad, const double* __restrict__ partial,
@@ -231,6 +274,7 @@ __global__ __launch_bounds__(PF_BLOCK) void k_scale_finishing(double* __restrict
         if (threadIdx.x == 0) {
             *nrm2 = v;
             host_out[count] = v;
+            host_out[count + 1] = 0.0;  // (the verdict slot of k_project_normalize: nothing left to redo)
         }
     }
     const int64_t i = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
@@ -991,7 +1035,7 @@ int pf_orth_begin(pf_graph* g, int32_t w, int32_t first, int32_t count, int32_t 
                 break;
             }
         if (!g->orth_host) {
-            PF_HIP(hipHostMalloc((void**)&g->orth_host, sizeof(double) * (size_t)(cap + 1), hipHostMallocDefault));
+            PF_HIP(hipHostMalloc((void**)&g->orth_host, sizeof(double) * (size_t)(cap + 2), hipHostMallocDefault));
             g->orth_host_cap = cap;
         }
     }
@@ -1008,19 +1052,18 @@ int pf_orth_begin(pf_graph* g, int32_t w, int32_t first, int32_t count, int32_t 
     double* hpass = g->coef;           // coefficients of the current pass
     double* hsum = g->coef + cap;      // h1 + h2
     double* nrm2 = g->coef + 2 * cap;  // ||w||^2
-    if (count < PF_ORTH_MAX) {
-        // 6 launches and no copies instead of 9 + 2: the finishing of every reduction rides in its consumer.  The second
-        // pass is conditional (k_axpy_finishing): its two launches return at once when the first pass kept |w| above 0.3
-        double* need2 = g->coef + 3 * cap;
-        for (int pass = 0; pass < 2 && count > 0; ++pass) {
-            dim3 grid((unsigned)g->n_chunks, (unsigned)(pass == 0 ? count + 1 : count));
-            k_dot_partial<<<grid, PF_BLOCK, 0, st>>>(g->ws, g->n_pad, first, w, g->n_chunks, g->partials, pass == 0 ? count : -1,
-                                                    pass == 0 ? nullptr : need2);
-            PF_HIP(hipGetLastError());
-            k_axpy_finishing<<<nblk(g->n_pad / 2), PF_BLOCK, 0, st>>>(g->ws, g->n_pad, first, count, w, g->partials, g->n_chunks,
-                                                                     hsum, pass, pass == 0 ? need2 : nullptr, pass == 0 ? nullptr : need2);
-            PF_HIP(hipGetLastError());
-        }
+    g->orth_host[count + 1] = 0.0;     // the verdict slot; only k_project_normalize ever raises it
+    g->orth_w = w, g->orth_first = first, g->orth_normalize = normalize ? 1 : 0;
+    if (count > 0 && count < PF_ORTH_MAX) {
+        // 2 launches and no copies: the projection, its norm (Pythagoras) and the normalisation ride behind one batch of
+        // dot products; the second Gram-Schmidt pass is pf_orth_end's business in the rare step that needs it
+        k_dot_partial<<<dim3((unsigned)g->n_chunks, (unsigned)(count + 1)), PF_BLOCK, 0, st>>>(g->ws, g->n_pad, first, w, g->n_chunks,
+                                                                                               g->partials, count);
+        PF_HIP(hipGetLastError());
+        k_project_normalize<<<nblk(g->n_pad / 2), PF_BLOCK, 0, st>>>(g->ws, g->n_pad, first, count, w, g->partials, g->n_chunks, hsum,
+                                                                    nrm2, g->orth_host, normalize ? 1 : 0);
+        PF_HIP(hipGetLastError());
+    } else if (count == 0) {
         k_dot_partial<<<dim3((unsigned)g->n_chunks, 1u), PF_BLOCK, 0, st>>>(g->ws, g->n_pad, w, w, g->n_chunks, g->partials);
         PF_HIP(hipGetLastError());
         k_scale_finishing<<<nblk(g->n_pad), PF_BLOCK, 0, st>>>(pf_slot(g, w), g->n_pad, g->partials, g->n_chunks, normalize ? 1 : 0,
@@ -1053,11 +1096,37 @@ int pf_orth_end(pf_graph* g, double* h, double* nrm) {
     PF_HIP(hipSetDevice(g->ctx->device));
     PF_HIP(hipEventSynchronize(g->orth_ev));
     g->orth_pending = -1;
+    g->orth_redone = 0;
     PF_TRY(pf_persist_check(g->ctx));
+    if (g->orth_host[count + 1] != 0.0) {
+        // the first pass cancelled digits (or w vanished): second pass, exact norm, normalisation - synchronously.
+        // Whatever was queued behind pf_orth_begin read a w that is only now final: pf_orth_redone tells the caller.
+        hipStream_t st = g->ctx->stream;
+        double* hsum = g->coef + g->coef_cap;
+        double* nrm2 = g->coef + 2 * g->coef_cap;
+        const int32_t w = g->orth_w, first = g->orth_first;
+        k_dot_partial<<<dim3((unsigned)g->n_chunks, (unsigned)count), PF_BLOCK, 0, st>>>(g->ws, g->n_pad, first, w, g->n_chunks, g->partials);
+        PF_HIP(hipGetLastError());
+        k_axpy_finishing<<<nblk(g->n_pad / 2), PF_BLOCK, 0, st>>>(g->ws, g->n_pad, first, count, w, g->partials, g->n_chunks, hsum, 1);
+        PF_HIP(hipGetLastError());
+        k_dot_partial<<<dim3((unsigned)g->n_chunks, 1u), PF_BLOCK, 0, st>>>(g->ws, g->n_pad, w, w, g->n_chunks, g->partials);
+        PF_HIP(hipGetLastError());
+        k_scale_finishing<<<nblk(g->n_pad), PF_BLOCK, 0, st>>>(pf_slot(g, w), g->n_pad, g->partials, g->n_chunks, g->orth_normalize,
+                                                              hsum, count, nrm2, g->orth_host);
+        PF_HIP(hipGetLastError());
+        PF_HIP(hipStreamSynchronize(st));
+        PF_TRY(pf_persist_check(g->ctx));
+        g->orth_redone = 1;
+    }
     for (int32_t b = 0; b < count; ++b) h[b] = g->orth_host[b];
     const double v = g->orth_host[count];
     *nrm = sqrt(v > 0.0 ? v : 0.0);
     return PF_OK;
+}
+
+int pf_orth_redone(pf_graph* g) {
+    PF_CHECK(g != nullptr, PF_E_ARG, "pf_orth_redone: NULL graph");
+    return g->orth_redone;
 }
 
 int pf_orth(pf_graph* g, int32_t w, int32_t first, int32_t count, double* h, double* nrm) {

@@ -268,6 +268,50 @@ def test_vector_kernels(golden, devices):
     assert np.array_equal(z == 0, deg == 0) and dev.n_isolated == 2
 
 
+def test_orth_one_pass_with_second_pass_on_demand(golden, devices):
+    """pf_orth_begin / pf_orth_end: projection, Pythagorean norm and normalisation behind one batch of dot products; when
+    the projection cancels digits (|w'| < 0.3 |w|) pf_orth_end runs the second Gram-Schmidt pass itself and says so
+    (`pf_orth_redone`: a pipelined driver then repeats what it queued on the un-refined vector)."""
+    dev = devices("source_mesh_15k")
+    n = dev.n
+    rng = np.random.default_rng(11)
+    Qb, _ = np.linalg.qr(rng.standard_normal((n, 6)))
+    dev.ws_ensure(12)
+    for b in range(6):
+        dev.upload(b, Qb[:, b])
+    noise = rng.standard_normal(n)
+    for label, w, expect_redo in (("random", rng.standard_normal(n), False),
+                                  ("mild", Qb @ np.array([0.5, -0.3, 0.2, 0.1, 0.0, 0.4]) + 2.0 * noise / np.linalg.norm(noise), False),
+                                  ("cancelling", 3.0 * Qb[:, 0] - 2.0 * Qb[:, 4] + 1e-7 * noise, True),
+                                  ("inside the span", Qb @ np.arange(1.0, 7.0), True)):
+        for normalize in (True, False):
+            dev.upload(8, w)
+            dev.orth_begin(8, 0, 6, normalize=normalize)
+            h, nrm = dev.orth_end()
+            assert dev.orth_redone == expect_redo, label
+            r = w - Qb @ (Qb.T @ w)
+            r = r - Qb @ (Qb.T @ r)
+            np.testing.assert_allclose(h, Qb.T @ w, rtol=1e-12, atol=1e-12, err_msg=label)
+            got = dev.download_slots(8, 1)[:, 0]
+            if label == "inside the span":
+                assert nrm < 1e-13 * np.linalg.norm(w)  # nothing left; the vector is not normalised (the driver stops)
+                continue
+            np.testing.assert_allclose(nrm, np.linalg.norm(r), rtol=1e-13 if not expect_redo else 1e-8, err_msg=label)
+            scale = 1.0 / nrm if normalize else 1.0
+            # orthogonal to the basis: ~eps |w| / |w'| after one pass, ~eps after two
+            assert np.max(np.abs(Qb.T @ got)) < 1e-13 * np.linalg.norm(got) * (np.linalg.norm(w) / nrm if not expect_redo else 1.0)
+            np.testing.assert_allclose(got, r * scale, rtol=0, atol=(1e-13 if not expect_redo else 1e-8) * np.linalg.norm(r * scale), err_msg=label)
+            if normalize:
+                np.testing.assert_allclose(np.linalg.norm(got), 1.0, rtol=1e-13)
+    # an empty basis: just the norm
+    dev.upload(8, noise)
+    dev.orth_begin(8, 0, 0, normalize=True)
+    h, nrm = dev.orth_end()
+    assert len(h) == 0 and not dev.orth_redone
+    np.testing.assert_allclose(nrm, np.linalg.norm(noise), rtol=1e-14)
+    np.testing.assert_allclose(dev.download_slots(8, 1)[:, 0], noise / np.linalg.norm(noise), rtol=1e-14)
+
+
 def test_null_vectors_and_finalize(golden, devices):
     for name in ("target_mesh", "source_mesh_15k"):
         g, dev = golden(name), devices(name)

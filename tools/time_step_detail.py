@@ -16,6 +16,7 @@ from pyfocusr_amd.meshgen import blob_mesh  # noqa: E402
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 250000
 k = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 ctx = _hip.default_context()
+ctx.timing_enable(True)
 meshes = [blob_mesh(n, s) for s in (0, 1)]
 for m in meshes:
     m._pf_device_mesh = _hip.DeviceMesh(m.points, m.faces, ctx=ctx)
@@ -36,6 +37,10 @@ for name in ("orth_end", "orth_begin", "cheb2", "cheb", "finalize_vectors", "com
                 calls[name] += time.perf_counter() - t0
         return wrapped
     setattr(_hip.DeviceLaplacian, name, make(fn, name))
+for name in ("final_rows",):
+    setattr(_hip.DeviceLaplacian, name, make(getattr(_hip.DeviceLaplacian, name), name))
+for name in ("knn1_graphs", "knn1"):
+    setattr(_hip.Context, name, make(getattr(_hip.Context, name), name))
 
 
 def step():
@@ -67,9 +72,12 @@ def step():
     w = Q[:k] * np.max((gs.eig_vals[:k], gt.eig_vals[:k]), axis=0)
     w = np.exp(-(w**2) / (2 * np.mean(w) ** 2))
     mark("weights")
+    calls.clear()
     idx = spectral_knn(gt, gs, k, w)
     assert idx is not None
     mark("knn (device-resident coordinates)")
+    knn_calls = dict(calls)
+    knn_calls["library's events around pf_knn_run"] = 1e-3 * ctx.timing()["knn_ms"]
     for g in graphs:
         g.device.close()
     mark("close")
@@ -77,6 +85,8 @@ def step():
         acc[b].append(tb - ta)
     for name, v in spectra_calls.items():
         acc["  spectra: " + name].append(v)
+    for name, v in knn_calls.items():
+        acc["  knn: " + name].append(v)
     acc["TOTAL"].append(T[-1][1] - T[0][1])
 
 
