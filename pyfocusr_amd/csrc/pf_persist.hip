@@ -94,14 +94,13 @@ constexpr int rx_table_bytes() {
     return ((NG * NW * 16 + 1) * 4 + 15) & ~15;
 }
 
-// d x_i + sum_{j < W} v[j] x[slot j], entries in order; all W + 1 LDS reads are issued before the first fma waits for one
+// d x_i + sum_{j < W} v[j] x[slot j], entries in order (x_i: the caller's register); all W LDS reads are issued before the first fma waits for one
 // (a loop with a per-lane bound makes the compiler wait for every LDS read separately: 9 round trips per row)
 template <int W, int JR>
-__device__ __forceinline__ double rx_row(const double* x, int lr, double dg, double& xi, const double (&v)[JR],
+__device__ __forceinline__ double rx_row(const double* x, double dg, double xi, const double (&v)[JR],
                                          const unsigned (&slp)[JR / 2]) {
 #pragma clang fp contract(off)
     double xs[W > 0 ? W : 1];
-    xi = x[lr];
 #pragma unroll
     for (int j = 0; j < W; ++j) xs[j] = x[(j & 1) ? (slp[j >> 1] >> 16) : (slp[j >> 1] & 0xffffu)];
     double acc = dg * xi;
@@ -111,19 +110,19 @@ __device__ __forceinline__ double rx_row(const double* x, int lr, double dg, dou
 }
 
 template <int JR>
-__device__ __forceinline__ double rx_row_dispatch(int w_uniform, const double* x, int lr, double dg, double& xi,
+__device__ __forceinline__ double rx_row_dispatch(int w_uniform, const double* x, double dg, double xi,
                                                   const double (&v)[JR], const unsigned (&slp)[JR / 2]) {
     static_assert(JR == 4 || JR == 6 || JR == 8, "register entries per row");
     switch (w_uniform) {  // a slice (= wave) has one width; at most JR of its entries are in registers
-        case 0: return rx_row<0, JR>(x, lr, dg, xi, v, slp);
-        case 1: return rx_row<1, JR>(x, lr, dg, xi, v, slp);
-        case 2: return rx_row<2, JR>(x, lr, dg, xi, v, slp);
-        case 3: return rx_row<3, JR>(x, lr, dg, xi, v, slp);
-        case 4: return rx_row<4, JR>(x, lr, dg, xi, v, slp);
-        case 5: return rx_row<(JR > 5 ? 5 : JR), JR>(x, lr, dg, xi, v, slp);
-        case 6: return rx_row<(JR > 6 ? 6 : JR), JR>(x, lr, dg, xi, v, slp);
-        case 7: return rx_row<(JR > 7 ? 7 : JR), JR>(x, lr, dg, xi, v, slp);
-        default: return rx_row<JR, JR>(x, lr, dg, xi, v, slp);
+        case 0: return rx_row<0, JR>(x, dg, xi, v, slp);
+        case 1: return rx_row<1, JR>(x, dg, xi, v, slp);
+        case 2: return rx_row<2, JR>(x, dg, xi, v, slp);
+        case 3: return rx_row<3, JR>(x, dg, xi, v, slp);
+        case 4: return rx_row<4, JR>(x, dg, xi, v, slp);
+        case 5: return rx_row<(JR > 5 ? 5 : JR), JR>(x, dg, xi, v, slp);
+        case 6: return rx_row<(JR > 6 ? 6 : JR), JR>(x, dg, xi, v, slp);
+        case 7: return rx_row<(JR > 7 ? 7 : JR), JR>(x, dg, xi, v, slp);
+        default: return rx_row<JR, JR>(x, dg, xi, v, slp);
     }
 }
 
@@ -148,7 +147,7 @@ __global__ __launch_bounds__(RX_THREADS) void k_cheb_resident(RxArgs a) {
     double* xb[NG];
     double v[NG][NW][JR];
     unsigned slp[NG][NW][JR / 2];
-    double dg[NG][NW], pv[NG][NW];
+    double dg[NG][NW], pv[NG][NW], xc[NG][NW];
     int32_t width[NG][NW], ovoff[NG][NW];
     int64_t sbase[NG][NW];
 
@@ -254,7 +253,8 @@ __global__ __launch_bounds__(RX_THREADS) void k_cheb_resident(RxArgs a) {
                 ov_val[o + PF_WAVE] = vv.y;
                 ov_slot[o + PF_WAVE] = (unsigned short)ss.y;
             }
-            if (have[q]) xb[q][w * RX_THREADS + tid] = g.src[row0[q] + w * RX_THREADS + tid];
+            xc[q][w] = have[q] ? g.src[row0[q] + w * RX_THREADS + tid] : 0.0;
+            if (have[q]) xb[q][w * RX_THREADS + tid] = xc[q][w];
         }
         if (gh_lane[q] >= 0 && gh_lane[q] < ghosts[q]) xb[q][RB + gh_lane[q]] = g.src[ghrow[q]];
     }
@@ -279,9 +279,8 @@ __global__ __launch_bounds__(RX_THREADS) void k_cheb_resident(RxArgs a) {
                 double* xn = xb[q] + (size_t)(cur ^ 1) * xlen[q];
                 const int32_t lr = w * RX_THREADS + tid;
                 const int32_t wd = width[q][w];
-                double xi;
-                double acc = rx_row_dispatch<JR>(__builtin_amdgcn_readfirstlane(wd < JR ? wd : JR), x, lr, dg[q][w], xi, v[q][w],
-                                                 slp[q][w]);
+                const double xi = xc[q][w];  // the row's own x: last step's result, still in its register
+                double acc = rx_row_dispatch<JR>(__builtin_amdgcn_readfirstlane(wd < JR ? wd : JR), x, dg[q][w], xi, v[q][w], slp[q][w]);
                 for (int j = JR; j < wd; ++j) {
                     const int32_t o = ovoff[q][w] + (j - JR) * PF_WAVE + lane;
                     acc = __builtin_fma(ov_val[o], x[ov_slot[o]], acc);
@@ -295,6 +294,7 @@ __global__ __launch_bounds__(RX_THREADS) void k_cheb_resident(RxArgs a) {
                     res = __builtin_fma(g.a2, u, -wp);
                 }
                 pv[q][w] = xi;
+                xc[q][w] = res;
                 xn[lr] = res;
                 const int64_t row = row0[q] + lr;
                 if (k == g.degree) g.dst[row] = res;
