@@ -61,6 +61,8 @@ struct pf_ctx {
     double* knn_ref = nullptr;   // [n_ref][d] as uploaded
     double* knn_qry = nullptr;   // [n_qry][d]
     double* knn_ref_s = nullptr; // rows sorted along the search axis
+    double* knn_ref_soa = nullptr;  // the same rows coordinate-major, [d][knn_ref_ld] (k_knn_coop)
+    int64_t knn_cap_ref_soa = 0, knn_ref_ld = 0;
     double* knn_qry_s = nullptr;
     unsigned* knn_ref_key = nullptr; // sorted grid-cell ids (references: row-major; queries: Morton)
     unsigned* knn_qry_key = nullptr;

@@ -242,7 +242,8 @@ __global__ __launch_bounds__(BS) void k_knn_grid(const double* __restrict__ ref_
     __shared__ int box[BS / PF_WAVE][4];
     const KnnGrid g = *gp;
     const int64_t qi = (int64_t)blockIdx.x * BS + threadIdx.x;
-    const int64_t qq = qi < n_qry ? qi : n_qry - 1;  // tail lanes replay the last query, result discarded
+    const bool mine = qi < n_qry;
+    const int64_t qq = mine ? qi : n_qry - 1;  // tail lanes replay the last query, result discarded
     double q[D];
 #pragma unroll
     for (int c = 0; c < D; ++c) q[c] = qry_s[qq * D + c];
@@ -352,7 +353,7 @@ __global__ __launch_bounds__(BS) void k_knn_grid(const double* __restrict__ ref_
                     }
                 }
             }
-            if (qi < n_qry) {
+            if (mine) {
                 const int64_t dst = qry_orig[qi];
 #pragma unroll
                 for (int j = 0; j < K; ++j) {
@@ -411,7 +412,7 @@ __global__ __launch_bounds__(BS) void k_knn_grid(const double* __restrict__ ref_
             by1 = min(by1, ny1);
         }
     }
-    if (qi < n_qry) {
+    if (mine) {
         const int64_t dst = qry_orig[qi];
 #pragma unroll
         for (int j = 0; j < K; ++j) {
@@ -421,6 +422,172 @@ __global__ __launch_bounds__(BS) void k_knn_grid(const double* __restrict__ ref_
     }
 }
 
+// ---- 1-NN, a GROUP of queries per wave (the default for k = 1) -----------------------------------------------------
+// k_knn_grid gives every lane a query; a wave then runs as long as its lane with the largest square, and the launch as
+// long as its slowest wave: on the 250k x 250k bench pair (d = 5) a lane scans 760 candidates on average, the worst lane
+// of a wave 2300, and the slowest wave ran 5x longer than the average one - 2.4 ms of which ~0.6 were work.  Here a wave
+// owns knn_group(d) Morton-consecutive queries (neighbours in the grid plane: their squares nearly coincide) and its 64
+// lanes scan the candidates of the squares' bounding rectangle, one candidate per lane and step, against all queries
+// of the group: the coordinate-major copy of the sorted references makes each load 512 contiguous bytes, a candidate
+// is fetched once per group instead of once per query, and the work of a wave is a sum over a rectangle instead of a
+// maximum over 64 lanes.  Per query the lanes' (distance, original index) pairs are reduced lexicographically across
+// the wave - the minimum of that pair is unique, so the result does not depend on who found it or on how many extra
+// candidates were looked at: bit-identical to k_knn_grid and to a brute force.
+// Clouds that are far apart make the rectangle the whole grid: the scan is then a brute force whose loads are shared by
+// the group only - per 64 queries no more arithmetic than k_knn_grid's shared LDS tiles.  k_knn_grid serves k > 1.
+// queries per wave: their coordinates stay in registers (G x d doubles, wave-uniform)
+constexpr int knn_group(int d) { return d <= 4 ? 8 : (d <= 8 ? 4 : 2); }
+
+__device__ __forceinline__ void wave_argmin(double& s, int32_t& o) {
+#pragma unroll
+    for (int off = PF_WAVE / 2; off > 0; off >>= 1) {
+        const double s2 = __shfl_xor(s, off, PF_WAVE);
+        const int32_t o2 = __shfl_xor(o, off, PF_WAVE);
+        const bool take = s2 < s || (s2 == s && o2 < o);
+        s = take ? s2 : s;
+        o = take ? o2 : o;
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(PF_BLOCK) void k_knn_coop(const double* __restrict__ soa, int64_t ld, const int32_t* __restrict__ ref_orig,
+                                                       const int32_t* __restrict__ cell_start, const double* __restrict__ qry_s,
+                                                       const int32_t* __restrict__ qry_orig, int64_t n_qry,
+                                                       const KnnGrid* __restrict__ gp, int64_t* __restrict__ idx_out,
+                                                       double* __restrict__ d2_out) {
+    constexpr int G = knn_group(D);
+    const KnnGrid g = *gp;
+    const int lane = threadIdx.x & (PF_WAVE - 1);
+    const int64_t group = (int64_t)blockIdx.x * (PF_BLOCK / PF_WAVE) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x / PF_WAVE));
+    const int64_t q0 = group * G;
+    if (q0 >= n_qry) return;  // (wave-uniform)
+    const int nq = n_qry - q0 < G ? (int)(n_qry - q0) : G;
+    double q[G][D];  // wave-uniform (a short group replays its last query)
+    double best[G];
+    int32_t bidx[G];
+    int ux0 = 0x7fffffff, ux1 = -1, uy0 = 0x7fffffff, uy1 = -1;  // the cells of the group's queries
+#pragma unroll
+    for (int i = 0; i < G; ++i) {
+        const int64_t qi = q0 + (i < nq ? i : nq - 1);
+#pragma unroll
+        for (int c = 0; c < D; ++c) q[i][c] = qry_s[qi * D + c];
+        const int cx = cell_of(pick<D>(q[i], g.a0), g.lo0, g.s0, g.r0), cy = cell_of(pick<D>(q[i], g.a1), g.lo1, g.s1, g.r1);
+        ux0 = min(ux0, cx), ux1 = max(ux1, cx);
+        uy0 = min(uy0, cy), uy1 = max(uy1, cy);
+        best[i] = INFINITY;
+        bidx[i] = 0x7fffffff;
+    }
+    // One scan serves every stage.  The references of the cells [x0, x1] of up to 64 grid rows - lane l names its row in
+    // `row_of` (-1: none) - are per row one contiguous run of the sorted array: lane l fetches the run of its row (one
+    // round trip for all rows), the runs are cut into chunks of 64 candidates, numbered through the rows, and the wave
+    // takes one chunk per step (other waves cover the latency of its loads).
+    auto scan_rows = [&](int row_of, int x0, int x1) {
+        int32_t b_l = 0, e_l = 0;
+        if (row_of >= 0) {
+            b_l = cell_start[row_of * g.r0 + x0];
+            e_l = cell_start[row_of * g.r0 + x1 + 1];
+        }
+        int32_t inc = (e_l - b_l + PF_WAVE - 1) >> 6;  // chunks of this lane's row; below: inclusive prefix over the lanes
+#pragma unroll
+        for (int off = 1; off < PF_WAVE; off <<= 1) {
+            const int32_t up = __shfl_up(inc, off, PF_WAVE);
+            if (lane >= off) inc += up;
+        }
+        const int32_t total = __builtin_amdgcn_readlane(inc, PF_WAVE - 1);
+        for (int32_t j = 0; j < total; ++j) {
+            const int row = (int)__popcll(__ballot(inc <= j));  // lanes whose rows end before chunk j
+            const int32_t first = row > 0 ? __builtin_amdgcn_readlane(inc, row - 1) : 0;
+            const int32_t r = __builtin_amdgcn_readlane(b_l, row) + (j - first) * PF_WAVE + lane;
+            if (r < __builtin_amdgcn_readlane(e_l, row)) {
+                double x[D];
+#pragma unroll
+                for (int c = 0; c < D; ++c) x[c] = soa[(int64_t)c * ld + r];
+                const int32_t o = ref_orig[r];
+#pragma unroll
+                for (int i = 0; i < G; ++i) {
+                    double s = 0.0;
+#pragma unroll
+                    for (int c = 0; c < D; ++c) {  // dist2's operations, in its order
+                        const double df = q[i][c] - x[c];
+                        const double sq = df * df;
+                        s = (c == 0) ? sq : s + sq;
+                    }
+                    if (s < best[i] || (s == best[i] && o < bidx[i])) {  // (a candidate met twice changes nothing)
+                        best[i] = s;
+                        bidx[i] = o;
+                    }
+                }
+            }
+        }
+    };
+    // every lane <- the wave's best per query (a valid starting point for whatever is scanned next); the rectangle that
+    // can still hold a winner or a tie: within sqrt(best) of a query on both grid axes, the whole grid without a bound
+    auto bounds = [&](int& bx0, int& bx1, int& by0, int& by1) -> bool {
+        bool all = true;
+        bx0 = 0x7fffffff, bx1 = -1, by0 = 0x7fffffff, by1 = -1;
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            wave_argmin(best[i], bidx[i]);
+            all = all && best[i] < INFINITY;
+            const double qx = pick<D>(q[i], g.a0), qy = pick<D>(q[i], g.a1);
+            const double rad = sqrt(best[i]) * (1.0 + 1e-9) + 1e-300;  // inflated against the rounding of sqrt / the subtractions
+            double xl = qx - rad, xh = qx + rad, yl = qy - rad, yh = qy + rad;
+            xl -= fabs(xl) * 1e-15;
+            xh += fabs(xh) * 1e-15;
+            yl -= fabs(yl) * 1e-15;
+            yh += fabs(yh) * 1e-15;
+            bx0 = min(bx0, cell_of(xl, g.lo0, g.s0, g.r0)), bx1 = max(bx1, cell_of(xh, g.lo0, g.s0, g.r0));
+            by0 = min(by0, cell_of(yl, g.lo1, g.s1, g.r1)), by1 = max(by1, cell_of(yh, g.lo1, g.s1, g.r1));
+        }
+        if (!all) bx0 = 0, by0 = 0, bx1 = g.r0 - 1, by1 = g.r1 - 1;
+        return all;
+    };
+    // phase 1: the ring of cells around the group's queries, grown until every query has an upper bound (4 rings at most)
+    int x0 = 0, x1 = -1, y0 = 0, y1 = -1;
+    int rx0 = 0, rx1 = -1, ry0 = 0, ry1 = -1;
+    for (int ring = 1; ring <= 4; ++ring) {
+        rx0 = max(ux0 - ring, 0), rx1 = min(ux1 + ring, g.r0 - 1);
+        ry0 = max(uy0 - ring, 0), ry1 = min(uy1 + ring, g.r1 - 1);
+        for (int yb = ry0; yb <= ry1; yb += PF_WAVE) scan_rows(yb + lane <= ry1 ? yb + lane : -1, rx0, rx1);
+        if (bounds(x0, x1, y0, y1)) break;
+    }
+    // phase 2: the rows of the rectangle from the group's own row outwards, a few at a time (4 + 4, 8 + 8, ... 32 + 32), and
+    // after each batch the rectangle is re-derived from what has been found: bounds only shrink, and when the first one
+    // is loose (clouds that are poorly aligned) the outer rows and columns drop out before they are read
+    if (!(x0 >= rx0 && x1 <= rx1 && y0 >= ry0 && y1 <= ry1)) {  // (else the ring already held every candidate)
+        const int mid = min(max((uy0 + uy1) / 2, y0), y1);
+        int lo = mid, hi = mid - 1;  // rows [lo, hi] are done
+        int w = 4;
+        while (lo > y0 || hi < y1) {
+            const int na = max(min(w, y1 - hi), 0), nb = max(min(w, lo - y0), 0);  // (a side that is finished may be past its bound)
+            scan_rows(lane < na ? hi + 1 + lane : (lane < na + nb ? lo - 1 - (lane - na) : -1), x0, x1);
+            hi += na;
+            lo -= nb;
+            w = min(2 * w, PF_WAVE / 2);
+            int nx0, nx1, ny0, ny1;
+            bounds(nx0, nx1, ny0, ny1);
+            x0 = max(x0, nx0), x1 = min(x1, nx1);
+            y0 = max(y0, ny0), y1 = min(y1, ny1);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < G; ++i) {
+        if (lane == i && i < nq) {
+            const int64_t dst = qry_orig[q0 + i];
+            idx_out[dst] = bidx[i];
+            d2_out[dst] = best[i];
+        }
+    }
+}
+
+__global__ __launch_bounds__(PF_BLOCK) void k_gather_rows_soa(const double* __restrict__ pts, const int32_t* __restrict__ order,
+                                                              int64_t n, int d, int64_t ld, double* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const int64_t src = order[i];
+    for (int c = 0; c < d; ++c) out[(int64_t)c * ld + i] = pts[src * d + c];
+}
+
 template <int D, int K>
 int launch_knn_k(pf_ctx* c) {
     // Block size: one wave per block for shallow coordinates (d <= 6: the usual spectral embeddings; whether the lane-
@@ -428,9 +595,16 @@ int launch_knn_k(pf_ctx* c) {
     // shared scan: 1.60 -> 1.39 ms at 250k x 250k, d = 5), four waves for deep ones, whose large squares make the shared
     // LDS tiles the common case (1M x 1M, d = 10: 161 ms with 256 threads, 172 with 64).
     constexpr int BS = D <= 6 ? PF_WAVE : PF_BLOCK;
-    k_knn_grid<D, K, BS, 512><<<(unsigned)((c->knn_nqry + BS - 1) / BS), BS, 0, c->stream>>>(
-        c->knn_ref_s, c->knn_ref_orig, c->knn_cell_start, c->knn_nref, c->knn_qry_s, c->knn_qry_orig, c->knn_nqry,
-        (const KnnGrid*)c->knn_grid, c->knn_idx, c->knn_d2);
+    if constexpr (K == 1) {
+        const int64_t waves = (c->knn_nqry + knn_group(D) - 1) / knn_group(D);
+        k_knn_coop<D><<<(unsigned)((waves + PF_BLOCK / PF_WAVE - 1) / (PF_BLOCK / PF_WAVE)), PF_BLOCK, 0, c->stream>>>(
+            c->knn_ref_soa, c->knn_ref_ld, c->knn_ref_orig, c->knn_cell_start, c->knn_qry_s, c->knn_qry_orig, c->knn_nqry,
+            (const KnnGrid*)c->knn_grid, c->knn_idx, c->knn_d2);
+    } else {
+        k_knn_grid<D, K, BS, 512><<<(unsigned)((c->knn_nqry + BS - 1) / BS), BS, 0, c->stream>>>(
+            c->knn_ref_s, c->knn_ref_orig, c->knn_cell_start, c->knn_nref, c->knn_qry_s, c->knn_qry_orig, c->knn_nqry,
+            (const KnnGrid*)c->knn_grid, c->knn_idx, c->knn_d2);
+    }
     PF_HIP(hipGetLastError());
     return PF_OK;
 }
@@ -508,6 +682,8 @@ static int knn_prepare(pf_ctx* c, int64_t n_ref, int64_t n_qry, int32_t d) {
     PF_TRY(grow(st, &c->knn_ref, &c->knn_cap_ref, n_ref * 16));
     PF_TRY(grow(st, &c->knn_ref_s, &c->knn_cap_ref_s, n_ref * 16));
     PF_TRY(grow(st, &c->knn_ref_key, &c->knn_cap_ref_key, n_ref));
+    c->knn_ref_ld = (n_ref + PF_WAVE - 1) & ~(int64_t)(PF_WAVE - 1);
+    PF_TRY(grow(st, &c->knn_ref_soa, &c->knn_cap_ref_soa, c->knn_ref_ld * d));
     // grid resolution: ~4 references per cell if they were spread over the plane
     int res = (int)sqrt((double)n_ref / 4.0);
     res = res < 4 ? 4 : (res > 2048 ? 2048 : res);
@@ -570,6 +746,10 @@ int pf_knn_run(pf_ctx* c) {
     PF_TRY(sort_points(c, c->knn_ref, c->knn_nref, d, 0, cell_bits, c->knn_ref_key, c->knn_ref_orig, c->knn_ref_s));
     k_cell_start<<<nblk(n_cells + 1), PF_BLOCK, 0, st>>>(c->knn_ref_key, c->knn_nref, n_cells, c->knn_cell_start);
     PF_HIP(hipGetLastError());
+    if (c->knn_k == 1) {
+        k_gather_rows_soa<<<nblk(c->knn_nref), PF_BLOCK, 0, st>>>(c->knn_ref, c->knn_ref_orig, c->knn_nref, d, c->knn_ref_ld, c->knn_ref_soa);
+        PF_HIP(hipGetLastError());
+    }
     PF_TRY(sort_points(c, c->knn_qry, c->knn_nqry, d, 1, 32, c->knn_qry_key, c->knn_qry_orig, c->knn_qry_s));
     int r = PF_E_ARG;
     switch (d) {

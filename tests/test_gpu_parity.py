@@ -623,6 +623,35 @@ def test_knn_window_edge_cases(ctx):
     check(grid[rng.permutation(len(grid))], grid + 0.5)
 
 
+def test_knn_grids_of_many_rows_and_shrinking_rectangles(ctx):
+    """The 1-NN kernel's group scan where its rectangle logic is stressed: grids of more than 64 rows (row batches),
+    first bounds as wide as the grid (the rectangle shrinks while it is scanned), groups of queries that are far apart
+    (Morton jumps, few queries), clouds that do not overlap, every group size (d <= 4: 8, d <= 8: 4, else 2)."""
+    rng = np.random.default_rng(21)
+
+    def check(ref, qry):
+        idx, d2 = ctx.knn1(ref, qry, return_d2=True)
+        bidx, bd2 = orc.knn1_bruteforce(ref, qry, chunk=256)
+        assert np.array_equal(idx, bidx) and np.array_equal(d2, bd2)
+
+    for d in (2, 4, 5, 8, 9, 13):
+        check(rng.uniform(-0.5, 0.5, (40000, d)), rng.uniform(-0.5, 0.5, (1500, d)))  # unrelated clouds, 100 x 100 cells
+    check(rng.uniform(0, 1, (30000, 4)), rng.uniform(3, 4, (900, 4)))  # disjoint: every rectangle is the grid (86 rows)
+    check(rng.uniform(0, 1, (30000, 6)) * np.array([1000.0, 1.0, 1e-3, 1.0, 50.0, 1.0]), rng.uniform(0, 1, (700, 6)) * np.array([1000.0, 1.0, 1e-3, 1.0, 50.0, 1.0]))
+    check(rng.uniform(0, 1, (50000, 3)), rng.uniform(0, 1, (37, 3)))  # 37 queries spread over 111 x 111 cells: groups span the grid
+    ref = np.concatenate([rng.uniform(0, 0.05, (20000, 5)), rng.uniform(0.95, 1.0, (20000, 5))])  # two corners, empty middle
+    check(ref, rng.uniform(0, 1, (1200, 5)))
+    ref = rng.uniform(0, 1, (25000, 5))
+    check(ref, ref[rng.permutation(25000)[:4000]] + 1e-4 * rng.standard_normal((4000, 5)))  # registered: the ring holds everything
+    qry = rng.uniform(0, 1, (600, 5))
+    qry[::7] = np.nan  # queries nothing compares with: index 0x7fffffff and an infinite distance, as before
+    idx, d2 = ctx.knn1(ref, qry, return_d2=True)
+    ok = ~np.isnan(qry[:, 0])
+    bidx, bd2 = orc.knn1_bruteforce(ref, qry[ok], chunk=256)
+    assert np.array_equal(idx[ok], bidx) and np.array_equal(d2[ok], bd2)
+    assert np.all(idx[~ok] == 0x7FFFFFFF) and np.all(np.isinf(d2[~ok]))
+
+
 def test_knn_property_random_shapes(ctx):
     """Property test (hypothesis): any point sets, any d <= 16 — device result == brute force, bit for bit."""
     from hypothesis import given, settings
