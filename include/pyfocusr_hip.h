@@ -161,6 +161,10 @@ int pf_orth(pf_graph* g, int32_t w, int32_t first, int32_t count, double* h, dou
  * device) plus an asynchronous copy of the results; end waits for them.  One orth in flight per graph. */
 int pf_orth_begin(pf_graph* g, int32_t w, int32_t first, int32_t count, int32_t normalize);
 int pf_orth_end(pf_graph* g, double* h, double* nrm);
+/* pf_orth_begin for the two graphs of a pair (one ctx) in shared launches, as pf_cheb2 does for the filter; each
+ * graph's coefficients are collected with its own pf_orth_end. */
+int pf_orth_begin2(pf_graph* ga, int32_t w_a, int32_t first_a, int32_t count_a, int32_t normalize_a, pf_graph* gb, int32_t w_b,
+                   int32_t first_b, int32_t count_b, int32_t normalize_b);
 /* 1 if the last pf_orth_end found that the first Gram-Schmidt pass had cancelled digits (|w'| < 0.3 |w|) and ran the
  * second pass itself, after everything queued behind pf_orth_begin: work queued in between that READ slot w (the next
  * filter application of a pipelined driver) saw the un-refined, un-normalised vector and has to be repeated.  Rare:

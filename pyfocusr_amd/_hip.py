@@ -86,6 +86,8 @@ SIGNATURES = {
     "pf_orth": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, _f64p, _f64p]),
     "pf_orth_begin": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "pf_orth_end": (C.c_int, [C.c_void_p, _f64p, _f64p]),
+    "pf_orth_begin2": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                 C.c_int32]),
     "pf_orth_redone": (C.c_int, [C.c_void_p]),
     "pf_scale": (C.c_int, [C.c_void_p, C.c_int32, C.c_double]),
     "pf_combine": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _f64p, C.c_int32, C.c_int32]),
@@ -645,6 +647,13 @@ class DeviceLaplacian(object):
     def orth_begin(self, w, first, count, normalize=True):
         _check(self._lib.pf_orth_begin(self._h, int(w), int(first), int(count), int(bool(normalize))))
         self._orth_count = int(count)
+
+    def orth_begin2(self, req, other, req_other):
+        """`orth_begin(*req)` of this graph and `other.orth_begin(*req_other)` in shared launches (requests:
+        (w, first, count, normalize)); each graph collects with its own `orth_end`."""
+        _check(self._lib.pf_orth_begin2(self._h, int(req[0]), int(req[1]), int(req[2]), int(bool(req[3])), other._h, int(req_other[0]),
+                                        int(req_other[1]), int(req_other[2]), int(bool(req_other[3]))))
+        self._orth_count, other._orth_count = int(req[2]), int(req_other[2])
 
     def orth_end(self):
         h = np.empty(max(self._orth_count, 1), dtype=np.float64)

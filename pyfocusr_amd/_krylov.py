@@ -196,7 +196,10 @@ def drive(gen, ops):
         try:
             req = next(g)
             while True:
-                ops.cheb(*req)
+                if req[0] == "orth":
+                    ops.orth_begin(*req[1:])
+                else:
+                    ops.cheb(*req)
                 req = g.send(None)
         except StopIteration as stop:
             return stop.value
@@ -239,8 +242,20 @@ def _drive_pair_once(gens, ops):
 
     advance(0, True)
     advance(1, True)
+    def is_orth(i):
+        return gens[i] is not None and reqs[i][0] == "orth"
+
+    pair_orth = hasattr(ops[0], "orth_begin2")
     while gens[0] is not None or gens[1] is not None:
-        if gens[0] is not None and gens[1] is not None:
+        if is_orth(0) and is_orth(1) and pair_orth:  # both Gram-Schmidt steps behind the same two launches
+            ops[0].orth_begin2(reqs[0][1:], ops[1], reqs[1][1:])
+            advance(0)
+            advance(1)
+        elif is_orth(0) or is_orth(1):
+            i = 0 if is_orth(0) else 1
+            ops[i].orth_begin(*reqs[i][1:])
+            advance(i)
+        elif gens[0] is not None and gens[1] is not None:
             ops[0].cheb2(reqs[0], ops[1], reqs[1])
             advance(0)
             advance(1)
@@ -286,9 +301,10 @@ def filtered_eigs_gen(ops, n_wanted, symmetric, ellipse=None, **kw):
 def _solve_gen(ops, n_wanted, symmetric, null_slots=0, cut=None, tol=1e-12, m_max=None,
                max_restarts=60, max_filter_resets=8, seed=0, strength=2.0, hi=2.0,
                nonsym_degree_cap=128, half_height=None, verbose=False, adapt_cut=False):
-    """Generator form of the solver: yields `(src, dst, degree, c, e)` whenever the Chebyshev
-    filter has to be applied (the only expensive device operation) and receives nothing back;
-    `drive` / `drive_pair` execute the requests (`(src, dst, degree, c, e, rho)`).  Its return value is the solver result.
+    """Generator form of the solver: yields `(src, dst, degree, c, e, rho)` whenever the Chebyshev filter has to be
+    applied (the only expensive device operation) and `("orth", w, first, count, normalize)` whenever a Gram-Schmidt
+    step has to be started (`ops.orth_begin`); it receives nothing back.  `drive` / `drive_pair` execute the requests -
+    the pair driver in launches that two graphs share.  Its return value is the solver result.
 
     Smallest `n_wanted` non-null eigenpairs of the Laplacian held by `ops`.
 
@@ -382,7 +398,7 @@ def _solve_gen(ops, n_wanted, symmetric, null_slots=0, cut=None, tol=1e-12, m_ma
                     stats.matvecs += p
                 stats.outer_steps += 1
                 # CGS2 + normalisation entirely on the device; the coefficients come back asynchronously
-                ops.orth_begin(A0 + j + 1, A0, j + 1, normalize=True)
+                yield ("orth", A0 + j + 1, A0, j + 1, True)  # ops.orth_begin(...), which a pair driver shares between two graphs
                 spec = j + 1 < m_max and not near  # (a speculative application after the last step would be wasted)
                 if spec:  # keep the device busy: queue the next filter application before reading this step's result
                     yield (A0 + j + 1, A0 + j + 2, p, c, e, rho)

@@ -196,26 +196,67 @@ __global__ __launch_bounds__(PF_BLOCK) void k_axpy_finishing(double* __restrict_
     }
     *reinterpret_cast<double2*>(ws + (int64_t)wslot * n_pad + i) = acc;
 }
-// k_project_normalize: the whole orthogonalisation step behind ONE k_dot_partial (whose last column is |w|^2):
-//   w' = w - V h,  h = V^T w;   |w'|^2 = |w|^2 - sum h^2  (Pythagoras);   w' /= |w'| if `normalize`
+// The orthogonalisation step of one graph - or of the two graphs of a pair in the same two launches (blockIdx.z) - is
+// k_orth_dots + k_orth_project:
+//   h = V^T w and |w|^2 (partial sums per chunk);   w' = w - V h;   |w'|^2 = |w|^2 - sum h^2  (Pythagoras);
+//   w' /= |w'| if `normalize`
 // and h, |w'|^2 and a verdict go straight to the host's pinned buffer: host_out = [h (count), |w'|^2, redo].
 // If |w'| < 0.3 |w| the projection cancelled digits - the second Gram-Schmidt pass is due ("twice is enough", Daniel,
 // Gragg, Kaufman, Stewart; ARPACK's criterion with a looser constant) and Pythagoras is no longer a fair norm: redo = 1,
 // w' stays un-normalised and pf_orth_end runs the second pass itself.  Otherwise the basis stays orthogonal to ~eps / 0.3
 // and |w'| carries a relative error <= ~eps / 0.09: far inside what Lanczos needs (semi-orthogonality sqrt(eps) already
 // preserves the Ritz values; the eigenvalues handed out come from a Rayleigh-Ritz step on the operator itself).
-// Measured on the 250k blobs: the ratio is 0.35-0.78 in every step - the second pass almost never runs, and a step
-// costs 2 launches where it took 6 (the two gated passes and the separate norm were ~4.4 us of launch floor each).
-__global__ __launch_bounds__(PF_BLOCK) void k_project_normalize(double* __restrict__ ws, int64_t n_pad, int32_t first, int32_t count,
-                                                                int32_t wslot, const double* __restrict__ partial, int64_t n_chunks,
-                                                                double* __restrict__ hsum, double* __restrict__ nrm2,
-                                                                double* __restrict__ host_out, int normalize) {
+// Measured on the 250k blobs: the ratio is 0.35-0.78 in all steps but one or two per solve, and a step costs 2 launches
+// where it took 6 (the two gated passes and the separate norm were ~4.4 us of launch floor each).
+struct OrthArgs {
+    double* ws;
+    int64_t n_pad, n_chunks;
+    int32_t first, count, wslot, normalize;
+    double* partial;   // [count + 1][n_chunks]
+    double* hsum;      // device copy of h
+    double* nrm2;      // device copy of |w'|^2
+    double* host_out;  // pinned: h, |w'|^2, redo
+};
+struct OrthArgs2 {
+    OrthArgs g[2];
+};
+
+// partial[b][chunk] = <slot first+b, slot wslot> over the chunk, b < count; partial[count][chunk] = |w|^2 over the chunk
+// (k_dot_partial's sums, in its order)
+__global__ __launch_bounds__(PF_BLOCK) void k_orth_dots(OrthArgs2 a2) {
+    __shared__ double red[PF_BLOCK / PF_WAVE];
+    const OrthArgs& a = a2.g[blockIdx.z];
+    const int b = blockIdx.y;
+    const int64_t chunk = blockIdx.x;
+    if (b > a.count || chunk >= a.n_chunks) return;  // (block-uniform: the grid is sized for the larger graph of a pair)
+    const double* v = a.ws + (int64_t)(b == a.count ? a.wslot : a.first + b) * a.n_pad;
+    const double* w = a.ws + (int64_t)a.wslot * a.n_pad;
+    const int64_t lo = chunk * PF_DOT_CHUNK;
+    const int64_t hi = lo + PF_DOT_CHUNK < a.n_pad ? lo + PF_DOT_CHUNK : a.n_pad;
+    double s = 0.0;
+    for (int64_t i = lo + 2 * threadIdx.x; i < hi; i += 2 * PF_BLOCK) {
+        const double2 x = *reinterpret_cast<const double2*>(v + i);
+        const double2 c = *reinterpret_cast<const double2*>(w + i);
+        s += x.x * c.x;
+        s += x.y * c.y;
+    }
+#pragma unroll
+    for (int off = PF_WAVE / 2; off > 0; off >>= 1) s += __shfl_down(s, off, PF_WAVE);
+    if ((threadIdx.x & (PF_WAVE - 1)) == 0) red[threadIdx.x / PF_WAVE] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) a.partial[(int64_t)b * a.n_chunks + chunk] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(PF_BLOCK) void k_orth_project(OrthArgs2 a2) {
     __shared__ double hs[PF_ORTH_MAX + 1];
     __shared__ double s_scale, s_after, s_redo;
+    const OrthArgs& a = a2.g[blockIdx.z];
+    if (2 * (int64_t)blockIdx.x * PF_BLOCK >= a.n_pad) return;  // (block-uniform)
     const int lane = threadIdx.x & (PF_WAVE - 1);
+    const int32_t count = a.count;
     for (int b = threadIdx.x / PF_WAVE; b < count + 1; b += PF_BLOCK / PF_WAVE) {
         double s = 0.0;
-        for (int64_t k = lane; k < n_chunks; k += PF_WAVE) s += partial[(int64_t)b * n_chunks + k];
+        for (int64_t k = lane; k < a.n_chunks; k += PF_WAVE) s += a.partial[(int64_t)b * a.n_chunks + k];
 #pragma unroll
         for (int off = PF_WAVE / 2; off > 0; off >>= 1) s += __shfl_down(s, off, PF_WAVE);
         if (lane == 0) hs[b] = s;
@@ -228,33 +269,33 @@ __global__ __launch_bounds__(PF_BLOCK) void k_project_normalize(double* __restri
         const bool fine = after >= 0.09 * before;  // (false for NaN and for a vanished vector: take the second pass)
         s_redo = fine ? 0.0 : 1.0;
         s_after = after;
-        s_scale = (fine && normalize && after > 1e-280) ? 1.0 / sqrt(after) : 1.0;
+        s_scale = (fine && a.normalize && after > 1e-280) ? 1.0 / sqrt(after) : 1.0;
     }
     __syncthreads();
     if (blockIdx.x == 0) {
         for (int b = threadIdx.x; b < count; b += PF_BLOCK) {
-            hsum[b] = hs[b];
-            host_out[b] = hs[b];
+            a.hsum[b] = hs[b];
+            a.host_out[b] = hs[b];
         }
         if (threadIdx.x == 0) {
-            *nrm2 = s_after;
-            host_out[count] = s_after;
-            host_out[count + 1] = s_redo;
+            *a.nrm2 = s_after;
+            a.host_out[count] = s_after;
+            a.host_out[count + 1] = s_redo;
         }
     }
     const int64_t i = 2 * ((int64_t)blockIdx.x * PF_BLOCK + threadIdx.x);
-    if (i >= n_pad) return;
-    double2 acc = *reinterpret_cast<double2*>(ws + (int64_t)wslot * n_pad + i);
+    if (i >= a.n_pad) return;
+    double2 acc = *reinterpret_cast<double2*>(a.ws + (int64_t)a.wslot * a.n_pad + i);
     for (int b = 0; b < count; ++b) {
         const double hb = hs[b];
-        const double2 v = *reinterpret_cast<const double2*>(ws + (int64_t)(first + b) * n_pad + i);
+        const double2 v = *reinterpret_cast<const double2*>(a.ws + (int64_t)(a.first + b) * a.n_pad + i);
         acc.x -= hb * v.x;
         acc.y -= hb * v.y;
     }
     const double sc = s_scale;
     acc.x *= sc;
     acc.y *= sc;
-    *reinterpret_cast<double2*>(ws + (int64_t)wslot * n_pad + i) = acc;
+    *reinterpret_cast<double2*>(a.ws + (int64_t)a.wslot * a.n_pad + i) = acc;
 }
 __global__ __launch_bounds__(PF_BLOCK) void k_scale_finishing(double* __restrict__ x, int64_t n_pad, const double* __restrict__ partial,
                                                               int64_t n_chunks, int normalize, const double* __restrict__ hsum,
@@ -274,7 +315,7 @@ __global__ __launch_bounds__(PF_BLOCK) void k_scale_finishing(double* __restrict
         if (threadIdx.x == 0) {
             *nrm2 = v;
             host_out[count] = v;
-            host_out[count + 1] = 0.0;  // (the verdict slot of k_project_normalize: nothing left to redo)
+            host_out[count + 1] = 0.0;  // (the verdict slot of k_orth_project: nothing left to redo)
         }
     }
     const int64_t i = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
@@ -1012,13 +1053,14 @@ int pf_dots(pf_graph* g, int32_t w, int32_t first, int32_t count, double* out) {
     return PF_OK;
 }
 
-int pf_orth_begin(pf_graph* g, int32_t w, int32_t first, int32_t count, int32_t normalize) {
+// checks, pinned result buffer, event: everything of pf_orth_begin that comes before the launches
+static int orth_prepare(pf_graph* g, int32_t w, int32_t first, int32_t count, int32_t normalize) {
     PF_TRY(check_slots(g, w, 1, "pf_orth_begin"));
     PF_TRY(check_slots(g, first, count, "pf_orth_begin"));
     PF_CHECK(w < first || w >= first + count, PF_E_ARG, "pf_orth_begin: w inside the basis range");
     PF_CHECK(g->orth_pending < 0, PF_E_STATE, "pf_orth_begin: a previous pf_orth_begin has not been collected");
     hipStream_t st = g->ctx->stream;
-    PF_TRY(pf_reduce_ensure(g, count + 1));  // (+ the |w|^2 column of the first pass)
+    PF_TRY(pf_reduce_ensure(g, count + 1));  // (+ the |w|^2 column)
     if (count > g->orth_host_cap || !g->orth_host) {
         pf_ctx* c = g->ctx;
         if (g->orth_host) {
@@ -1048,20 +1090,39 @@ int pf_orth_begin(pf_graph* g, int32_t w, int32_t first, int32_t count, int32_t 
             PF_HIP(hipEventCreateWithFlags(&g->orth_ev, hipEventDisableTiming));
         }
     }
+    g->orth_host[count + 1] = 0.0;     // the verdict slot; only k_orth_project ever raises it
+    g->orth_w = w, g->orth_first = first, g->orth_normalize = normalize ? 1 : 0;
+    return PF_OK;
+}
+
+static OrthArgs orth_args(pf_graph* g, int32_t w, int32_t first, int32_t count, int32_t normalize) {
+    OrthArgs a{};
+    a.ws = g->ws;
+    a.n_pad = g->n_pad;
+    a.n_chunks = g->n_chunks;
+    a.first = first, a.count = count, a.wslot = w, a.normalize = normalize ? 1 : 0;
+    a.partial = g->partials;
+    a.hsum = g->coef + g->coef_cap;
+    a.nrm2 = g->coef + 2 * g->coef_cap;
+    a.host_out = g->orth_host;
+    return a;
+}
+
+int pf_orth_begin(pf_graph* g, int32_t w, int32_t first, int32_t count, int32_t normalize) {
+    PF_TRY(orth_prepare(g, w, first, count, normalize));
+    hipStream_t st = g->ctx->stream;
     const int32_t cap = g->coef_cap;
     double* hpass = g->coef;           // coefficients of the current pass
     double* hsum = g->coef + cap;      // h1 + h2
     double* nrm2 = g->coef + 2 * cap;  // ||w||^2
-    g->orth_host[count + 1] = 0.0;     // the verdict slot; only k_project_normalize ever raises it
-    g->orth_w = w, g->orth_first = first, g->orth_normalize = normalize ? 1 : 0;
     if (count > 0 && count < PF_ORTH_MAX) {
         // 2 launches and no copies: the projection, its norm (Pythagoras) and the normalisation ride behind one batch of
         // dot products; the second Gram-Schmidt pass is pf_orth_end's business in the rare step that needs it
-        k_dot_partial<<<dim3((unsigned)g->n_chunks, (unsigned)(count + 1)), PF_BLOCK, 0, st>>>(g->ws, g->n_pad, first, w, g->n_chunks,
-                                                                                               g->partials, count);
+        OrthArgs2 a2{};
+        a2.g[0] = orth_args(g, w, first, count, normalize);
+        k_orth_dots<<<dim3((unsigned)g->n_chunks, (unsigned)(count + 1), 1u), PF_BLOCK, 0, st>>>(a2);
         PF_HIP(hipGetLastError());
-        k_project_normalize<<<nblk(g->n_pad / 2), PF_BLOCK, 0, st>>>(g->ws, g->n_pad, first, count, w, g->partials, g->n_chunks, hsum,
-                                                                    nrm2, g->orth_host, normalize ? 1 : 0);
+        k_orth_project<<<dim3(nblk(g->n_pad / 2), 1u, 1u), PF_BLOCK, 0, st>>>(a2);
         PF_HIP(hipGetLastError());
     } else if (count == 0) {
         k_dot_partial<<<dim3((unsigned)g->n_chunks, 1u), PF_BLOCK, 0, st>>>(g->ws, g->n_pad, w, w, g->n_chunks, g->partials);
@@ -1085,6 +1146,32 @@ int pf_orth_begin(pf_graph* g, int32_t w, int32_t first, int32_t count, int32_t 
     }
     PF_HIP(hipEventRecord(g->orth_ev, st));
     g->orth_pending = count;
+    return PF_OK;
+}
+
+// pf_orth_begin for the two graphs of a pair (one ctx) behind the same two launches; each graph's result is collected
+// with its own pf_orth_end.  Shapes the fused kernels do not cover take one pf_orth_begin each.
+int pf_orth_begin2(pf_graph* ga, int32_t w_a, int32_t first_a, int32_t count_a, int32_t normalize_a, pf_graph* gb, int32_t w_b,
+                   int32_t first_b, int32_t count_b, int32_t normalize_b) {
+    PF_CHECK(ga != nullptr && gb != nullptr && ga != gb, PF_E_ARG, "pf_orth_begin2: two different graphs are needed");
+    if (ga->ctx != gb->ctx || count_a <= 0 || count_b <= 0 || count_a >= PF_ORTH_MAX || count_b >= PF_ORTH_MAX) {
+        PF_TRY(pf_orth_begin(ga, w_a, first_a, count_a, normalize_a));
+        return pf_orth_begin(gb, w_b, first_b, count_b, normalize_b);
+    }
+    PF_TRY(orth_prepare(ga, w_a, first_a, count_a, normalize_a));
+    PF_TRY(orth_prepare(gb, w_b, first_b, count_b, normalize_b));
+    hipStream_t st = ga->ctx->stream;
+    OrthArgs2 a2{};
+    a2.g[0] = orth_args(ga, w_a, first_a, count_a, normalize_a);
+    a2.g[1] = orth_args(gb, w_b, first_b, count_b, normalize_b);
+    k_orth_dots<<<dim3((unsigned)std::max(ga->n_chunks, gb->n_chunks), (unsigned)(std::max(count_a, count_b) + 1), 2u), PF_BLOCK, 0, st>>>(a2);
+    PF_HIP(hipGetLastError());
+    k_orth_project<<<dim3(nblk(std::max(ga->n_pad, gb->n_pad) / 2), 1u, 2u), PF_BLOCK, 0, st>>>(a2);
+    PF_HIP(hipGetLastError());
+    PF_HIP(hipEventRecord(ga->orth_ev, st));
+    PF_HIP(hipEventRecord(gb->orth_ev, st));
+    ga->orth_pending = count_a;
+    gb->orth_pending = count_b;
     return PF_OK;
 }
 
