@@ -130,6 +130,8 @@ int pf_lock_null_vectors(pf_graph* g, int32_t op, int32_t* n_locked);
 
 /* ---- eigensolver kernels (replace scipy eigs/ARPACK+SuperLU at graph.py:372) ------------- */
 int pf_spmv(pf_graph* g, int32_t op, int32_t src, int32_t dst);           /* dst = A src     */
+/* slots [dst_first, dst_first+count) = A slots [src_first, src_first+count), one call (the Rayleigh-Ritz step's A Z) */
+int pf_spmv_multi(pf_graph* g, int32_t op, int32_t src_first, int32_t dst_first, int32_t count);
 /* dst = T_degree((c I - A)/e) src / rho^degree : `degree` launches of the fused SpMV + three-term
  * recurrence kernel (scaled by rho >= 1 per step so that high degrees cannot overflow; rho = 1 is the
  * plain Chebyshev polynomial).  src is preserved; dst != src. */

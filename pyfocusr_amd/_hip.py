@@ -77,6 +77,7 @@ SIGNATURES = {
     "pf_mask_isolated": (C.c_int, [C.c_void_p, C.c_int32]),
     "pf_lock_null_vectors": (C.c_int, [C.c_void_p, C.c_int32, _i32p]),
     "pf_spmv": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
+    "pf_spmv_multi": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "pf_persist_enable": (C.c_int, [C.c_int]),
     "pf_persist_test_hook": (C.c_int, [C.c_int]),
     "pf_cheb": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double]),
@@ -622,6 +623,9 @@ class DeviceLaplacian(object):
 
     def spmv(self, src, dst):
         _check(self._lib.pf_spmv(self._h, self.op, int(src), int(dst)))
+
+    def spmv_multi(self, src_first, dst_first, count):
+        _check(self._lib.pf_spmv_multi(self._h, self.op, int(src_first), int(dst_first), int(count)))
 
     def cheb(self, src, dst, degree, c, e, rho=1.0):
         _check(self._lib.pf_cheb(self._h, self.op, int(src), int(dst), int(degree), float(c), float(e), float(rho)))

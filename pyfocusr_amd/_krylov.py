@@ -504,9 +504,12 @@ def _solve_gen(ops, n_wanted, symmetric, null_slots=0, cut=None, tol=1e-12, m_ma
         raise RuntimeError("workspace too small for Ritz extraction (q=%d, m_max=%d)" % (q, m_max))
     ops.combine(A0, j, U[:, :q], B0)  # Z -> region B
     HA = np.zeros((q, q))
-    for i in range(q):
-        ops.spmv(B0 + i, A0 + i)  # A z_i -> region A (Krylov basis no longer needed)
-        stats.matvecs += 1
+    if hasattr(ops, "spmv_multi"):
+        ops.spmv_multi(B0, A0, q)  # A Z -> region A (Krylov basis no longer needed), one library call
+    else:
+        for i in range(q):
+            ops.spmv(B0 + i, A0 + i)
+    stats.matvecs += q
     if hasattr(ops, "gram"):  # all q^2 inner products behind one synchronisation
         HA[:, :] = ops.gram(A0, q, B0, q).T
     else:

@@ -436,6 +436,57 @@ __global__ __launch_bounds__(PF_BLOCK) void k_resnorm_partial(const double* __re
     if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// the batched forms (pf_gram, pf_resnorms): one launch for all pairs / all vectors, k_dot_partial's and
+// k_resnorm_partial's sums in their order
+__global__ __launch_bounds__(PF_BLOCK) void k_gram_partial(const double* __restrict__ ws, int64_t n_pad, int32_t first_a, int32_t first_b,
+                                                           int32_t count_b, int64_t n_chunks, double* __restrict__ partial) {
+    __shared__ double red[PF_BLOCK / PF_WAVE];
+    const int p = blockIdx.y;  // pair (i, j): row i of the first block against row j of the second
+    const int i = p / count_b, j = p - i * count_b;
+    const double* v = ws + (int64_t)(first_b + j) * n_pad;
+    const double* w = ws + (int64_t)(first_a + i) * n_pad;
+    const int64_t lo = (int64_t)blockIdx.x * PF_DOT_CHUNK;
+    const int64_t hi = lo + PF_DOT_CHUNK < n_pad ? lo + PF_DOT_CHUNK : n_pad;
+    double s = 0.0;
+    for (int64_t r = lo + 2 * threadIdx.x; r < hi; r += 2 * PF_BLOCK) {
+        const double2 a = *reinterpret_cast<const double2*>(v + r);
+        const double2 c = *reinterpret_cast<const double2*>(w + r);
+        s += a.x * c.x;
+        s += a.y * c.y;
+    }
+#pragma unroll
+    for (int off = PF_WAVE / 2; off > 0; off >>= 1) s += __shfl_down(s, off, PF_WAVE);
+    if ((threadIdx.x & (PF_WAVE - 1)) == 0) red[threadIdx.x / PF_WAVE] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[(int64_t)p * n_chunks + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+constexpr int PF_RESNORMS_MAX = 64;
+struct LamArgs {
+    double lam[PF_RESNORMS_MAX];
+};
+__global__ __launch_bounds__(PF_BLOCK) void k_resnorms_partial(const double* __restrict__ ws, int64_t n_pad, int32_t ax_first,
+                                                               int32_t x_first, LamArgs la, int64_t n_chunks,
+                                                               double* __restrict__ partial) {
+    __shared__ double red[PF_BLOCK / PF_WAVE];
+    const int b = blockIdx.y;
+    const double* ax = ws + (int64_t)(ax_first + b) * n_pad;
+    const double* x = ws + (int64_t)(x_first + b) * n_pad;
+    const double lam = la.lam[b];
+    const int64_t lo = (int64_t)blockIdx.x * PF_DOT_CHUNK;
+    const int64_t hi = lo + PF_DOT_CHUNK < n_pad ? lo + PF_DOT_CHUNK : n_pad;
+    double s = 0.0;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += PF_BLOCK) {
+        const double r = ax[i] - lam * x[i];
+        s += r * r;
+    }
+#pragma unroll
+    for (int off = PF_WAVE / 2; off > 0; off >>= 1) s += __shfl_down(s, off, PF_WAVE);
+    if ((threadIdx.x & (PF_WAVE - 1)) == 0) red[threadIdx.x / PF_WAVE] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[(int64_t)b * n_chunks + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
 // ---- eigenvector post-processing -----------------------------------------------------------------
 struct VecStats {
     double sumsq, vmin, vmax, absmax, at_absmax;
@@ -940,6 +991,19 @@ int pf_spmv(pf_graph* g, int32_t op, int32_t src, int32_t dst) {
     return t.finish();
 }
 
+int pf_spmv_multi(pf_graph* g, int32_t op, int32_t src_first, int32_t dst_first, int32_t count) {
+    PF_CHECK(count >= 0, PF_E_ARG, "pf_spmv_multi: negative count");
+    PF_TRY(check_slots(g, src_first, count, "pf_spmv_multi"));
+    PF_TRY(check_slots(g, dst_first, count, "pf_spmv_multi"));
+    const double* vals = op_values(g, op);
+    PF_CHECK(vals != nullptr && (src_first + count <= dst_first || dst_first + count <= src_first), PF_E_ARG,
+             "pf_spmv_multi: operator %d unavailable or the slot ranges overlap", op);
+    if (count == 0) return PF_OK;
+    OpTimer t(g->ctx, count, (double)count * (double)op_bytes(g));
+    for (int32_t i = 0; i < count; ++i) PF_TRY(launch_op(g, vals, pf_slot(g, src_first + i), nullptr, pf_slot(g, dst_first + i), -1.0, 0.0, 0.0));
+    return t.finish();
+}
+
 int pf_cheb(pf_graph* g, int32_t op, int32_t src, int32_t dst, int32_t degree, double c, double e, double rho) {
     PF_TRY(check_slots(g, src, 1, "pf_cheb"));
     PF_TRY(check_slots(g, dst, 1, "pf_cheb"));
@@ -1271,10 +1335,13 @@ int pf_gram(pf_graph* g, int32_t first_a, int32_t count_a, int32_t first_b, int3
     PF_TRY(check_slots(g, first_a, count_a, "pf_gram"));
     PF_TRY(check_slots(g, first_b, count_b, "pf_gram"));
     PF_CHECK(out != nullptr && count_a > 0 && count_b > 0, PF_E_ARG, "pf_gram: bad argument");
-    PF_TRY(pf_reduce_ensure(g, std::max(count_b, (count_a * count_b + 7) / 8)));  // coef holds 8 x coef_cap doubles
+    PF_TRY(pf_reduce_ensure(g, count_a * count_b));  // partials: one column per pair
     hipStream_t st = g->ctx->stream;
-    for (int32_t i = 0; i < count_a; ++i)
-        PF_TRY(dots_device(g, first_a + i, first_b, count_b, g->coef + (size_t)i * count_b, nullptr, 0));
+    k_gram_partial<<<dim3((unsigned)g->n_chunks, (unsigned)(count_a * count_b)), PF_BLOCK, 0, st>>>(g->ws, g->n_pad, first_a, first_b, count_b,
+                                                                                                 g->n_chunks, g->partials);
+    PF_HIP(hipGetLastError());
+    k_dot_finish<<<(unsigned)(count_a * count_b), PF_WAVE, 0, st>>>(g->partials, g->n_chunks, g->coef, nullptr, 0);
+    PF_HIP(hipGetLastError());
     PF_HIP(hipMemcpyAsync(out, g->coef, sizeof(double) * (size_t)count_a * count_b, hipMemcpyDeviceToHost, st));
     PF_HIP(hipStreamSynchronize(st));
     return PF_OK;
@@ -1286,11 +1353,14 @@ int pf_resnorms(pf_graph* g, int32_t ax_first, int32_t x_first, const double* la
     PF_CHECK(out != nullptr && lam != nullptr && count > 0, PF_E_ARG, "pf_resnorms: bad argument");
     hipStream_t st = g->ctx->stream;
     PF_TRY(pf_reduce_ensure(g, count));
-    for (int32_t i = 0; i < count; ++i) {
-        k_resnorm_partial<<<(unsigned)g->n_chunks, PF_BLOCK, 0, st>>>(pf_slot(g, ax_first + i), pf_slot(g, x_first + i), lam[i], g->n_pad,
-                                                                      g->n_chunks, g->partials);
+    for (int32_t at = 0; at < count; at += PF_RESNORMS_MAX) {
+        const int32_t nb = std::min(count - at, PF_RESNORMS_MAX);
+        LamArgs la{};
+        for (int32_t i = 0; i < nb; ++i) la.lam[i] = lam[at + i];
+        k_resnorms_partial<<<dim3((unsigned)g->n_chunks, (unsigned)nb), PF_BLOCK, 0, st>>>(g->ws, g->n_pad, ax_first + at, x_first + at, la,
+                                                                                        g->n_chunks, g->partials);
         PF_HIP(hipGetLastError());
-        k_dot_finish<<<1, PF_WAVE, 0, st>>>(g->partials, g->n_chunks, g->coef + i, nullptr, 0);
+        k_dot_finish<<<(unsigned)nb, PF_WAVE, 0, st>>>(g->partials, g->n_chunks, g->coef + at, nullptr, 0);
         PF_HIP(hipGetLastError());
     }
     PF_HIP(hipMemcpyAsync(out, g->coef, sizeof(double) * count, hipMemcpyDeviceToHost, st));
