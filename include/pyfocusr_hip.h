@@ -167,6 +167,10 @@ int pf_orth_end(pf_graph* g, double* h, double* nrm);
  * graph's coefficients are collected with its own pf_orth_end. */
 int pf_orth_begin2(pf_graph* ga, int32_t w_a, int32_t first_a, int32_t count_a, int32_t normalize_a, pf_graph* gb, int32_t w_b,
                    int32_t first_b, int32_t count_b, int32_t normalize_b);
+/* pf_orth_begin2 and, queued right behind it, pf_cheb2 in one call (one outer step of a pipelined pair driver: the device
+ * does not wait for the host between the two).  orth[8] = {w, first, count, normalize} of a, then of b; cheb_i[8] =
+ * {op, src, dst, degree} of a, then of b; cheb_d[6] = {c, e, rho} of a, then of b. */
+int pf_orth_cheb2(pf_graph* ga, pf_graph* gb, const int32_t* orth, const int32_t* cheb_i, const double* cheb_d);
 /* 1 if the last pf_orth_end found that the first Gram-Schmidt pass had cancelled digits (|w'| < 0.3 |w|) and ran the
  * second pass itself, after everything queued behind pf_orth_begin: work queued in between that READ slot w (the next
  * filter application of a pipelined driver) saw the un-refined, un-normalised vector and has to be repeated.  Rare:

@@ -89,6 +89,7 @@ SIGNATURES = {
     "pf_orth_end": (C.c_int, [C.c_void_p, _f64p, _f64p]),
     "pf_orth_begin2": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                  C.c_int32]),
+    "pf_orth_cheb2": (C.c_int, [C.c_void_p, C.c_void_p, _i32p, _i32p, _f64p]),
     "pf_orth_redone": (C.c_int, [C.c_void_p]),
     "pf_scale": (C.c_int, [C.c_void_p, C.c_int32, C.c_double]),
     "pf_combine": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _f64p, C.c_int32, C.c_int32]),
@@ -658,6 +659,17 @@ class DeviceLaplacian(object):
         _check(self._lib.pf_orth_begin2(self._h, int(req[0]), int(req[1]), int(req[2]), int(bool(req[3])), other._h, int(req_other[0]),
                                         int(req_other[1]), int(req_other[2]), int(bool(req_other[3]))))
         self._orth_count, other._orth_count = int(req[2]), int(req_other[2])
+
+    def orth_cheb2(self, orth, req, other, orth_other, req_other):
+        """`orth_begin2` and, right behind it, `cheb2` in one library call (orth: (w, first, count, normalize); req as for
+        `cheb2`)."""
+        o = (C.c_int32 * 8)(int(orth[0]), int(orth[1]), int(orth[2]), int(bool(orth[3])), int(orth_other[0]), int(orth_other[1]),
+                            int(orth_other[2]), int(bool(orth_other[3])))
+        ci = (C.c_int32 * 8)(self.op, int(req[0]), int(req[1]), int(req[2]), other.op, int(req_other[0]), int(req_other[1]),
+                             int(req_other[2]))
+        cd = (C.c_double * 6)(float(req[3]), float(req[4]), float(req[5]), float(req_other[3]), float(req_other[4]), float(req_other[5]))
+        _check(self._lib.pf_orth_cheb2(self._h, other._h, o, ci, cd))
+        self._orth_count, other._orth_count = int(orth[2]), int(orth_other[2])
 
     def orth_end(self):
         h = np.empty(max(self._orth_count, 1), dtype=np.float64)

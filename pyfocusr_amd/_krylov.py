@@ -198,6 +198,9 @@ def drive(gen, ops):
             while True:
                 if req[0] == "orth":
                     ops.orth_begin(*req[1:])
+                elif req[0] == "orth+cheb":
+                    ops.orth_begin(*req[1])
+                    ops.cheb(*req[2])
                 else:
                     ops.cheb(*req)
                 req = g.send(None)
@@ -242,20 +245,35 @@ def _drive_pair_once(gens, ops):
 
     advance(0, True)
     advance(1, True)
-    def is_orth(i):
-        return gens[i] is not None and reqs[i][0] == "orth"
+    def kind(i):
+        return None if gens[i] is None else (reqs[i][0] if isinstance(reqs[i][0], str) else "cheb")
 
     pair_orth = hasattr(ops[0], "orth_begin2")
+    fused = hasattr(ops[0], "orth_cheb2")
     while gens[0] is not None or gens[1] is not None:
-        if is_orth(0) and is_orth(1) and pair_orth:  # both Gram-Schmidt steps behind the same two launches
-            ops[0].orth_begin2(reqs[0][1:], ops[1], reqs[1][1:])
+        k0, k1 = kind(0), kind(1)
+        if k0 == "orth+cheb" and k1 == "orth+cheb" and fused:
+            # one outer step of both solvers in one library call: both Gram-Schmidt steps in shared launches and, right
+            # behind them, the next filter application of both
+            ops[0].orth_cheb2(reqs[0][1], reqs[0][2], ops[1], reqs[1][1], reqs[1][2])
             advance(0)
             advance(1)
-        elif is_orth(0) or is_orth(1):
-            i = 0 if is_orth(0) else 1
-            ops[i].orth_begin(*reqs[i][1:])
-            advance(i)
-        elif gens[0] is not None and gens[1] is not None:
+        elif k0 in ("orth", "orth+cheb") or k1 in ("orth", "orth+cheb"):
+            # Gram-Schmidt steps first (shared launches if both graphs have one); a fused request leaves its filter part
+            both = k0 in ("orth", "orth+cheb") and k1 in ("orth", "orth+cheb")
+            todo = [0, 1] if both else [0 if k0 in ("orth", "orth+cheb") else 1]
+            parts = [reqs[i][1] if kind(i) == "orth+cheb" else reqs[i][1:] for i in todo]
+            if both and pair_orth:
+                ops[0].orth_begin2(parts[0], ops[1], parts[1])
+            else:
+                for i, part in zip(todo, parts):
+                    ops[i].orth_begin(*part)
+            for i in todo:
+                if kind(i) == "orth+cheb":
+                    reqs[i] = reqs[i][2]
+                else:
+                    advance(i)
+        elif k0 == "cheb" and k1 == "cheb":
             ops[0].cheb2(reqs[0], ops[1], reqs[1])
             advance(0)
             advance(1)
@@ -302,8 +320,9 @@ def _solve_gen(ops, n_wanted, symmetric, null_slots=0, cut=None, tol=1e-12, m_ma
                max_restarts=60, max_filter_resets=8, seed=0, strength=2.0, hi=2.0,
                nonsym_degree_cap=128, half_height=None, verbose=False, adapt_cut=False):
     """Generator form of the solver: yields `(src, dst, degree, c, e, rho)` whenever the Chebyshev filter has to be
-    applied (the only expensive device operation) and `("orth", w, first, count, normalize)` whenever a Gram-Schmidt
-    step has to be started (`ops.orth_begin`); it receives nothing back.  `drive` / `drive_pair` execute the requests -
+    applied (the only expensive device operation), `("orth", w, first, count, normalize)` whenever a Gram-Schmidt
+    step has to be started (`ops.orth_begin`), and `("orth+cheb", orth args, filter request)` for a Gram-Schmidt step with
+    the next filter application right behind it; it receives nothing back.  `drive` / `drive_pair` execute the requests -
     the pair driver in launches that two graphs share.  Its return value is the solver result.
 
     Smallest `n_wanted` non-null eigenpairs of the Laplacian held by `ops`.
@@ -398,11 +417,14 @@ def _solve_gen(ops, n_wanted, symmetric, null_slots=0, cut=None, tol=1e-12, m_ma
                     stats.matvecs += p
                 stats.outer_steps += 1
                 # CGS2 + normalisation entirely on the device; the coefficients come back asynchronously
-                yield ("orth", A0 + j + 1, A0, j + 1, True)  # ops.orth_begin(...), which a pair driver shares between two graphs
+                # the Gram-Schmidt step (ops.orth_begin: CGS + normalisation on the device, results come back asynchronously)
+                # and - to keep the device busy - the NEXT filter application, queued before this step's result is read
                 spec = j + 1 < m_max and not near  # (a speculative application after the last step would be wasted)
-                if spec:  # keep the device busy: queue the next filter application before reading this step's result
-                    yield (A0 + j + 1, A0 + j + 2, p, c, e, rho)
+                if spec:
+                    yield ("orth+cheb", (A0 + j + 1, A0, j + 1, True), (A0 + j + 1, A0 + j + 2, p, c, e, rho))
                     stats.matvecs += p
+                else:
+                    yield ("orth", A0 + j + 1, A0, j + 1, True)
                 h, beta = ops.orth_end()
                 if getattr(ops, "orth_redone", False):
                     stats.second_passes += 1

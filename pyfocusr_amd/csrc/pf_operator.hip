@@ -1105,6 +1105,18 @@ int pf_cheb2(pf_graph* ga, int32_t op_a, int32_t src_a, int32_t dst_a, int32_t d
     return t.finish();
 }
 
+// One outer step of a pipelined pair driver in ONE library call: the Gram-Schmidt step of both graphs (pf_orth_begin2) and,
+// queued right behind it, the next filter application of both (pf_cheb2) - the device then never waits for the host
+// between the two (two calls from Python leave it idle for ~15-25 us per step, a tenth of the filter application).
+//   orth[8]   = {w, first, count, normalize} of graph a, then of graph b
+//   cheb_i[8] = {op, src, dst, degree} of graph a, then of graph b;   cheb_d[6] = {c, e, rho} of a, then of b
+int pf_orth_cheb2(pf_graph* ga, pf_graph* gb, const int32_t* orth, const int32_t* cheb_i, const double* cheb_d) {
+    PF_CHECK(ga && gb && orth && cheb_i && cheb_d, PF_E_ARG, "pf_orth_cheb2: NULL argument");
+    PF_TRY(pf_orth_begin2(ga, orth[0], orth[1], orth[2], orth[3], gb, orth[4], orth[5], orth[6], orth[7]));
+    return pf_cheb2(ga, cheb_i[0], cheb_i[1], cheb_i[2], cheb_i[3], cheb_d[0], cheb_d[1], cheb_d[2], gb, cheb_i[4], cheb_i[5], cheb_i[6],
+                    cheb_i[7], cheb_d[3], cheb_d[4], cheb_d[5]);
+}
+
 int pf_dots(pf_graph* g, int32_t w, int32_t first, int32_t count, double* out) {
     PF_TRY(check_slots(g, w, 1, "pf_dots"));
     PF_TRY(check_slots(g, first, count, "pf_dots"));
