@@ -164,6 +164,7 @@ struct pf_graph {
     int32_t orth_host_cap = 0;
     int32_t orth_pending = -1;   // count of the orth in flight, -1 if none
     hipEvent_t orth_ev = nullptr;
+    hipEvent_t orth_wait = nullptr;  // the event pf_orth_end waits on: orth_ev, or the partner graph's after pf_orth_begin2
     int32_t orth_w = 0, orth_first = 0, orth_normalize = 0;  // arguments of the orth in flight (pf_orth_end's second pass)
     int32_t orth_redone = 0;     // the last pf_orth_end ran the second Gram-Schmidt pass itself
     // the last pf_finalize_vectors result stays in HBM (mesh order, [n][final_count] row-major) for pf_final_rows and

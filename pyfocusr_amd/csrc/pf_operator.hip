@@ -1221,6 +1221,7 @@ int pf_orth_begin(pf_graph* g, int32_t w, int32_t first, int32_t count, int32_t 
         PF_HIP(hipMemcpyAsync(g->orth_host + count, nrm2, sizeof(double), hipMemcpyDeviceToHost, st));
     }
     PF_HIP(hipEventRecord(g->orth_ev, st));
+    g->orth_wait = g->orth_ev;
     g->orth_pending = count;
     return PF_OK;
 }
@@ -1244,8 +1245,9 @@ int pf_orth_begin2(pf_graph* ga, int32_t w_a, int32_t first_a, int32_t count_a, 
     PF_HIP(hipGetLastError());
     k_orth_project<<<dim3(nblk(std::max(ga->n_pad, gb->n_pad) / 2), 1u, 2u), PF_BLOCK, 0, st>>>(a2);
     PF_HIP(hipGetLastError());
-    PF_HIP(hipEventRecord(ga->orth_ev, st));
-    PF_HIP(hipEventRecord(gb->orth_ev, st));
+    PF_HIP(hipEventRecord(ga->orth_ev, st));  // one event for both results: graph b waits on graph a's
+    ga->orth_wait = ga->orth_ev;
+    gb->orth_wait = ga->orth_ev;
     ga->orth_pending = count_a;
     gb->orth_pending = count_b;
     return PF_OK;
@@ -1257,7 +1259,7 @@ int pf_orth_end(pf_graph* g, double* h, double* nrm) {
     const int32_t count = g->orth_pending;
     PF_CHECK(h != nullptr || count == 0, PF_E_ARG, "pf_orth_end: h is NULL");
     PF_HIP(hipSetDevice(g->ctx->device));
-    PF_HIP(hipEventSynchronize(g->orth_ev));
+    PF_HIP(hipEventSynchronize(g->orth_wait));
     g->orth_pending = -1;
     g->orth_redone = 0;
     PF_TRY(pf_persist_check(g->ctx));
