@@ -409,7 +409,7 @@ def _solve_gen(ops, n_wanted, symmetric, null_slots=0, cut=None, tol=1e-12, m_ma
         restarts = 0
         while outcome is None:
             spec = False  # the filter application of the current step was already queued speculatively
-            near = False  # the last Ritz check was within ~3 digits of the tolerance: the next step probably converges
+            near = False  # the last Ritz check was within a digit of the tolerance: the next step almost certainly converges
             next_check, seen = 0, None  # (non-symmetric mode) step of the next Ritz check; (step, residual / tolerance) of the last
             while j < m_max and outcome is None:  # ---- expand
                 if not spec:
@@ -457,7 +457,10 @@ def _solve_gen(ops, n_wanted, symmetric, null_slots=0, cut=None, tol=1e-12, m_ma
                     if verbose:
                         print("  j=%d q=%d theta_min=%.4g |theta|max=%.3g max res=%.3e" % (
                             j, q, theta_min, np.max(np.abs(theta)), np.max(res)))
-                    near = n_real >= q_target and theta_min > band and np.all(res <= 1e3 * tol * max(theta_min, 1.0))
+                    # (within one digit: with the filter application at ~0.2 ms a stalled step costs about as much as a
+                    # wasted application, so speculation is only given up when convergence is all but certain; measured at
+                    # 250k: eigensolve 11.96 / 11.32 / 11.51 ms with 1e3 / 1e1 / never)
+                    near = n_real >= q_target and theta_min > band and np.all(res <= 1e1 * tol * max(theta_min, 1.0))
                     if n_real >= q_target and np.all(res <= tol * max(theta_min, 1.0)) and theta_min > band:
                         outcome = "converged"
                     elif not symmetric and not ellipse and np.max(np.abs(theta)) > 1e7 * max(theta_min, 1.0) and p > 16:

@@ -276,7 +276,11 @@ class Graph(object):
             sample = dev.point_rows(self.rand_idxs)  # the same rows from the copy in HBM: cheaper than a cache-cold host gather
         else:
             sample = self.points[self.rand_idxs, :]  # gathered once (the reference gathers the same rows three times)
-        return (sample - np.min(sample, axis=0)) / np.ptp(sample, axis=0)
+        # (sample - min) / ptp per coordinate, as graph.py:269-272 - on the transposed copy: reductions along the long,
+        # contiguous axis (numpy's axis-0 reductions of an (n, 3) array cost 0.1 ms each at n = 5000); same values
+        st = np.ascontiguousarray(sample.T)
+        lo = st.min(axis=1)
+        return np.ascontiguousarray(((st - lo[:, None]) / (st.max(axis=1) - lo)[:, None]).T)
 
     def get_list_rand_idxs(self, n_rand_samples, replace=False, force_randomization=False):
         if n_rand_samples > self.n_points:
