@@ -38,11 +38,11 @@ class eigsort(object):
         self.n_features = n_features
         self.target_as_reference = target_as_reference
 
-        # eigsort.py:34-41
-        self.rand_target_points = self.graph_target.get_rand_normalized_points()
-        self.rand_source_points = self.graph_source.get_rand_normalized_points()
-        self.rand_target_eig_vecs = self.graph_target.get_rand_eig_vecs()
-        self.rand_source_eig_vecs = self.graph_source.get_rand_eig_vecs()
+        # eigsort.py:34-41: the sampled points and eigenvector rows.  Gathered on first use (properties below): when both
+        # graphs still hold their eigenvectors and points on one device, the cost matrices are computed there
+        # (`_device_costs`) and the samples never have to come to the host.
+        self._samples = {}
+        self._device_result = None
 
         self.c_lambda = np.zeros((self.n_features, self.n_features))
         self.c_hist = np.zeros_like(self.c_lambda)
@@ -56,6 +56,47 @@ class eigsort(object):
         self.flipped_pairs = None
         self.idx_source_for_each_target_pt = None
         self.verbose = getattr(graph_target, "verbose", True)
+
+    def _sample(self, name, make):
+        if name not in self._samples:
+            self._samples[name] = make()
+        return self._samples[name]
+
+    rand_target_points = property(lambda self: self._sample("tp", self.graph_target.get_rand_normalized_points),
+                                  lambda self, v: self._samples.__setitem__("tp", v))
+    rand_source_points = property(lambda self: self._sample("sp", self.graph_source.get_rand_normalized_points),
+                                  lambda self, v: self._samples.__setitem__("sp", v))
+    rand_target_eig_vecs = property(lambda self: self._sample("tv", self.graph_target.get_rand_eig_vecs),
+                                    lambda self, v: self._samples.__setitem__("tv", v))
+    rand_source_eig_vecs = property(lambda self: self._sample("sv", self.graph_source.get_rand_eig_vecs),
+                                    lambda self, v: self._samples.__setitem__("sv", v))
+
+    def _device_costs(self):
+        """c_hist, c_hist_f, c_spatial, c_spatial_f and the spatial 1-NN indices from `pf_eigsort_costs`, or None when the
+        host path has to run: samples already in hand or assigned from outside, a graph without its device-resident
+        block / points / an up-to-date column map, different contexts, unequal or too large samples."""
+        if self._device_result is not None:
+            return self._device_result
+        if self._samples:
+            return None
+        devs = []
+        for g in (self.graph_target, self.graph_source):
+            fm, dev = getattr(g, "_final_map", None), getattr(g, "_device", None)
+            if (fm is None or dev is None or not getattr(dev, "_h", None) or not getattr(dev, "has_points", False)
+                    or self.n_features > len(fm[0]) or getattr(g, "rand_idxs", None) is None):
+                return None
+            devs.append(dev)
+        rt, rs = self.graph_target.rand_idxs, self.graph_source.rand_idxs
+        if devs[0].ctx is not devs[1].ctx or len(rt) != len(rs) or not 1 <= len(rt) <= 8192 or self.n_features > 16:
+            return None
+        from .graph import device_block_is_current
+
+        if not (device_block_is_current(self.graph_target) and device_block_is_current(self.graph_source)):
+            return None
+        (ct, st), (cs, ss) = self.graph_target._final_map, self.graph_source._final_map
+        k = self.n_features
+        self._device_result = devs[0].ctx.eigsort_costs(devs[0], devs[1], rt, rs, k, ct[:k], st[:k], cs[:k], ss[:k])
+        return self._device_result
 
     def _ctx(self):
         ctx = getattr(self.graph_target, "_ctx", None)
@@ -150,6 +191,10 @@ class eigsort(object):
         difference of their order statistics (identical to scipy's CDF integral up to
         summation rounding, ~1e-16 relative).  Unequal sizes use the same identity with the merged breakpoints of the
         two step quantile functions (`_w1_quantile_plan`)."""
+        dev = self._device_costs()
+        if dev is not None:
+            self.c_hist[:, :], self.c_hist_f[:, :] = dev[0][0], dev[0][1]
+            return
         eps = np.finfo(float).eps
         k = self.n_features
         log_t = [np.sort(np.log(self.rand_target_eig_vecs[:, i] + 0.5 + eps)) for i in range(k)]
@@ -174,6 +219,11 @@ class eigsort(object):
 
     def calc_c_spatial(self):
         """eigsort.py:191-233; the KDTree query runs on the GPU."""
+        dev = self._device_costs()
+        if dev is not None:
+            self.c_spatial[:, :], self.c_spatial_f[:, :] = dev[0][2], dev[0][3]
+            self.idx_source_for_each_target_pt = dev[1]
+            return
         idx = self._ctx().knn1(self.rand_source_points, self.rand_target_points)
         self.idx_source_for_each_target_pt = idx
         m = self.rand_target_eig_vecs.shape[0]

@@ -372,6 +372,17 @@ def _paired_spectra(ga, gb):
             print("Final eigenvalues of interest are: \n{}".format(g.eig_vals))
 
 
+def device_block_is_current(g):
+    """Guard against in-place edits of `g.eig_vecs` nobody told us about: 64 rows of the device-resident block (with the
+    recorded column permutation / sign flips) must agree exactly with the host array; otherwise the block is disowned."""
+    rows = np.linspace(0, g.n_points - 1, num=min(64, g.n_points)).astype(np.int64)
+    cols, signs = g._final_map
+    if np.array_equal(g._device.final_rows(rows)[:, cols] * signs, g.eig_vecs[rows][:, :len(cols)]):
+        return True
+    g._final_map = None
+    return False
+
+
 def spectral_knn(graph_target, graph_source, n_coords, weights=None):
     """focusr.py:351-353 on the spectral coordinates `eig_vecs[:, :n_coords] * weights` of two graphs WITHOUT the
     n x k coordinate arrays crossing PCIe: both graphs still hold the block their eigensolve left in HBM, and the
@@ -388,12 +399,8 @@ def spectral_knn(graph_target, graph_source, n_coords, weights=None):
         devs.append(dev)
     if devs[0].ctx is not devs[1].ctx:
         return None
-    for g, dev in zip((graph_target, graph_source), devs):
-        # guard against in-place edits of the host array nobody told us about: 64 rows must agree exactly
-        rows = np.linspace(0, g.n_points - 1, num=min(64, g.n_points)).astype(np.int64)
-        cols, signs = g._final_map
-        if not np.array_equal(dev.final_rows(rows)[:, cols] * signs, g.eig_vecs[rows][:, :len(cols)]):
-            g._final_map = None
+    for g in (graph_target, graph_source):
+        if not device_block_is_current(g):
             return None
     w = np.ones(n_coords) if weights is None else np.asarray(weights, dtype=np.float64)
     (ct, st), (cs, ss) = graph_target._final_map, graph_source._final_map

@@ -737,6 +737,51 @@ def test_eigsort_and_correspondence_from_golden_eigs(golden, ctx, pair, t, s, k,
     np.testing.assert_allclose(reg.spectral_weights, p["spectral_weights"], rtol=1e-12)
 
 
+@pytest.mark.parametrize("names,k,ns", [(("target_mesh", "source_mesh"), 5, 1500), (("target_mesh_15k", "source_mesh_15k"), 4, 5000),
+                                         (("target_mesh", "source_mesh"), 3, 4096)])
+def test_eigsort_costs_on_device(golden, ctx, names, k, ns):
+    """`pf_eigsort_costs` (c_hist, c_hist_f, c_spatial, c_spatial_f and the spatial 1-NN on the device, from the graphs'
+    resident eigenvector blocks) against the host path of the same class, which the reference-generated goldens pin
+    (test_eigsort_and_correspondence_from_golden_eigs): same samples, matrices to 1e-11, identical indices / matches."""
+    from pyfocusr_amd import Graph, eigsort
+    from pyfocusr_amd.graph import compute_spectra
+
+    def graphs():
+        np.random.seed(5)
+        gs_ = [Graph(mesh_of(golden(nm)), n_spectral_features=k, n_rand_samples=ns, ctx=ctx, verbose=False) for nm in names]
+        compute_spectra(gs_)
+        return gs_
+
+    results = []
+    for host in (False, True):
+        gt, gs = graphs()
+        sorter = eigsort(gt, gs, k, target_as_reference=True)
+        if host:
+            _ = sorter.rand_target_points  # samples in hand: the host path runs
+        else:
+            assert sorter._device_costs() is not None
+        Q = sorter.sort_eigenmaps()
+        assert (sorter._device_result is None) == host
+        results.append((sorter, Q, gs.eig_vecs.copy(), gs._final_map))
+        # a second sort on the now permuted / flipped maps: the device reads the block through the recorded map
+        again = eigsort(gt, gs, k, target_as_reference=True)
+        if host:
+            _ = again.rand_target_points
+        results[-1] += (again.sort_eigenmaps(), again)
+    (d, Qd, vd, fd, Qd2, d2), (h, Qh, vh, fh, Qh2, h2) = results
+    for a, b in ((d, h), (d2, h2)):
+        for name in ("c_lambda", "c_hist", "c_hist_f", "c_spatial", "c_spatial_f"):
+            np.testing.assert_allclose(getattr(a, name), getattr(b, name), rtol=1e-11, atol=0, err_msg=name)
+        assert np.array_equal(a.idx_source_for_each_target_pt, b.idx_source_for_each_target_pt)
+        assert np.array_equal(a.source_matches, b.source_matches) and a.flipped_pairs == b.flipped_pairs
+    np.testing.assert_allclose(Qd, Qh, rtol=1e-10)
+    np.testing.assert_allclose(Qd2, Qh2, rtol=1e-10)
+    assert np.array_equal(vd, vh) and np.array_equal(fd[0], fh[0]) and np.array_equal(fd[1], fh[1])
+    # lazily gathered samples are still there for whoever asks (eigsort.py:34-41)
+    assert d.rand_target_eig_vecs.shape == (min(ns, d.graph_target.n_points), d.graph_target.eig_vecs.shape[1])
+    assert d.rand_source_points.shape[1] == 3 and d.rand_source_points.min() == 0.0 and d.rand_source_points.max() == 1.0
+
+
 def test_focusr_end_to_end_5k(golden, ctx):
     """BASELINE config C1 through the public API: own Laplacian + own eigensolve + eigsort +
     KNN; the correspondence indices equal the reference's (up to sign-fixed eigenvectors)."""
