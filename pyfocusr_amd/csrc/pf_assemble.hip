@@ -42,7 +42,7 @@ __global__ __launch_bounds__(PF_BLOCK) void k_count_edges(const int32_t* __restr
 
 __global__ __launch_bounds__(PF_BLOCK) void k_scatter_edges(const int32_t* __restrict__ faces,
                                                             const double* __restrict__ pts, int64_t n_edges,
-                                                            int32_t vpf, const int32_t* __restrict__ start,
+                                                            int32_t vpf, int64_t n, const int32_t* __restrict__ start,
                                                             int32_t* __restrict__ cursor, int32_t* __restrict__ rcol,
                                                             double* __restrict__ rw, int32_t* __restrict__ flags) {
     const int64_t e = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
@@ -51,6 +51,7 @@ __global__ __launch_bounds__(PF_BLOCK) void k_scatter_edges(const int32_t* __res
     const int32_t k = (int32_t)(e - f * vpf);
     const int32_t src = faces[e];
     const int32_t dst = faces[f * vpf + (k + 1 == vpf ? 0 : k + 1)];
+    if (src < 0 || src >= n || dst < 0 || dst >= n || src == dst) return;  // flagged by k_count_edges; the host looks later
     const double dx = pts[3 * (int64_t)src + 0] - pts[3 * (int64_t)dst + 0];
     const double dy = pts[3 * (int64_t)src + 1] - pts[3 * (int64_t)dst + 1];
     const double dz = pts[3 * (int64_t)src + 2] - pts[3 * (int64_t)dst + 2];
@@ -198,7 +199,8 @@ __global__ __launch_bounds__(PF_BLOCK) void k_label_init(const int32_t* __restri
 
 __global__ __launch_bounds__(PF_BLOCK) void k_label_hook(const int32_t* __restrict__ rowptr,
                                                          const int32_t* __restrict__ col, int64_t n, int32_t* label,
-                                                         int32_t* differing) {
+                                                         int32_t* differing, const int32_t* prev) {
+    if (prev && *prev == 0) return;  // the previous round changed nothing: converged (rounds are queued ahead, unasked)
     const int64_t i = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
     bool any = false;
     if (i < n) {
@@ -216,7 +218,8 @@ __global__ __launch_bounds__(PF_BLOCK) void k_label_hook(const int32_t* __restri
     if (__any(any) && (threadIdx.x & (PF_WAVE - 1)) == 0) *differing = 1;
 }
 
-__global__ __launch_bounds__(PF_BLOCK) void k_label_compress(int32_t* label, int64_t n) {
+__global__ __launch_bounds__(PF_BLOCK) void k_label_compress(int32_t* label, int64_t n, const int32_t* prev = nullptr) {
+    if (prev && *prev == 0) return;
     const int64_t i = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
     if (i < n) label[i] = uf_find(label, (int32_t)i);
 }
@@ -356,7 +359,11 @@ __global__ __launch_bounds__(PF_BLOCK) void k_csr_split(const int32_t* __restric
 
 // Common tail of the builders: CSR(W) (or the off-diagonals of a general Laplacian), deg, g, sg are in
 // place; derive symmetry, statistics, components, the solver renumbering and the SELL-64 storage.
-int finish_graph(pf_graph* g, const double* d_pts, bool numeric_symmetry) {
+// `d_extra` / `h_extra` (8 ints, optional): device flags of the caller that ride in this function's one read-back; when
+// any is set the function returns at once (PF_OK, *extra_hit = true) and the caller reports ITS error.  `nnz_from_rowptr`:
+// g->nnz_w is read back here too (the mesh path sizes col / w by their upper bound instead of waiting for the count).
+int finish_graph(pf_graph* g, const double* d_pts, bool numeric_symmetry, const int32_t* d_extra = nullptr, int32_t* h_extra = nullptr,
+                 bool* extra_hit = nullptr, bool nnz_from_rowptr = false) {
     hipStream_t st = g->ctx->stream;
     const int64_t n = g->n;
     int32_t *flags = nullptr, *d_roots = nullptr, *round_flags = nullptr;
@@ -390,18 +397,16 @@ int finish_graph(pf_graph* g, const double* d_pts, bool numeric_symmetry) {
     k_label_compress<<<nblk(n), PF_BLOCK, 0, st>>>(g->label, n);
     PF_HIP(hipGetLastError());
     PF_HIP(hipMemsetAsync(round_flags, 0, sizeof(int32_t) * PF_CC_ROUNDS, st));
-    for (int round = 0, batch = 5;; batch = 3) {  // a converged round costs ~15 us: cheaper than asking after each one
-        PF_CHECK(round + batch <= PF_CC_ROUNDS, PF_E_HIP, "pf_graph_build: component labelling did not converge");
-        for (int b = 0; b < batch; ++b, ++round) {
-            k_label_hook<<<nblk(n), PF_BLOCK, 0, st>>>(g->rowptr, g->col, n, g->label, round_flags + round);
-            PF_HIP(hipGetLastError());
-            k_label_compress<<<nblk(n), PF_BLOCK, 0, st>>>(g->label, n);
-            PF_HIP(hipGetLastError());
-        }
-        int32_t differing = 0;
-        PF_HIP(hipMemcpyAsync(&differing, round_flags + round - 1, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-        PF_HIP(hipStreamSynchronize(st));
-        if (!differing) break;
+    // PF_CC_FIRST rounds are queued without asking: a round that follows a round without changes returns at once
+    // (~2 us instead of ~15), and whether the last one still changed something is read back with everything else below
+    constexpr int PF_CC_FIRST = 12;
+    int round = 0;
+    for (; round < PF_CC_FIRST; ++round) {
+        const int32_t* prev = round ? round_flags + round - 1 : nullptr;
+        k_label_hook<<<nblk(n), PF_BLOCK, 0, st>>>(g->rowptr, g->col, n, g->label, round_flags + round, prev);
+        PF_HIP(hipGetLastError());
+        k_label_compress<<<nblk(n), PF_BLOCK, 0, st>>>(g->label, n, prev);
+        PF_HIP(hipGetLastError());
     }
     k_collect_roots<<<nblk(n), PF_BLOCK, 0, st>>>(g->label, g->rowptr, n, d_roots, stats + 4);
     PF_HIP(hipGetLastError());
@@ -412,26 +417,62 @@ int finish_graph(pf_graph* g, const double* d_pts, bool numeric_symmetry) {
     PF_HIP(hipGetLastError());
     PF_HIP(hipMemsetAsync(width64 + g->n_slices, 0, sizeof(int64_t), st));
     PF_TRY(pf_exclusive_scan_i64(st, width64, g->slice_ptr, g->n_slices + 1));
-    int32_t h_stats[6];
+    // ONE read-back for everything the host has to know before it can size the SELL storage: the row statistics, the slice
+    // pointers, whether the labelling had converged, the first few component roots (a mesh usually has one), the caller's
+    // own flags and - for the mesh path - the number of stored entries
+    constexpr int PF_ROOTS_AHEAD = 16;
+    int32_t h_stats[6], h_roots[PF_ROOTS_AHEAD], differing = 0, nnz32 = 0;
     PF_HIP(hipMemcpyAsync(h_stats, stats, sizeof(int32_t) * 5, hipMemcpyDeviceToHost, st));
     g->h_slice_ptr.resize((size_t)g->n_slices + 1);  // the resident Chebyshev kernel sizes its LDS from this
     PF_HIP(hipMemcpyAsync(g->h_slice_ptr.data(), g->slice_ptr, sizeof(int64_t) * (g->n_slices + 1), hipMemcpyDeviceToHost, st));
-    PF_HIP(hipMemcpyAsync(&g->sell_entries, g->slice_ptr + g->n_slices, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    PF_HIP(hipMemcpyAsync(&differing, round_flags + PF_CC_FIRST - 1, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    PF_HIP(hipMemcpyAsync(h_roots, d_roots, sizeof(h_roots), hipMemcpyDeviceToHost, st));
+    if (d_extra) PF_HIP(hipMemcpyAsync(h_extra, d_extra, sizeof(int32_t) * 8, hipMemcpyDeviceToHost, st));
+    if (nnz_from_rowptr) PF_HIP(hipMemcpyAsync(&nnz32, g->rowptr + n, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     PF_HIP(hipStreamSynchronize(st));
+    g->sell_entries = g->h_slice_ptr[(size_t)g->n_slices];
+    if (nnz_from_rowptr) g->nnz_w = nnz32;
+    if (d_extra && extra_hit) {
+        *extra_hit = false;
+        for (int i = 0; i < 8; ++i) *extra_hit = *extra_hit || h_extra[i] != 0;
+        if (*extra_hit) return PF_OK;
+    }
+    int32_t n_roots = h_stats[4];
+    if (differing) {  // (rare: more than PF_CC_FIRST rounds) finish the labelling, collect the roots again
+        for (;;) {
+            PF_CHECK(round + 3 <= PF_CC_ROUNDS, PF_E_HIP, "pf_graph_build: component labelling did not converge");
+            for (int b = 0; b < 3; ++b, ++round) {
+                k_label_hook<<<nblk(n), PF_BLOCK, 0, st>>>(g->rowptr, g->col, n, g->label, round_flags + round, nullptr);
+                PF_HIP(hipGetLastError());
+                k_label_compress<<<nblk(n), PF_BLOCK, 0, st>>>(g->label, n);
+                PF_HIP(hipGetLastError());
+            }
+            PF_HIP(hipMemcpyAsync(&differing, round_flags + round - 1, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+            PF_HIP(hipStreamSynchronize(st));
+            if (!differing) break;
+        }
+        PF_HIP(hipMemsetAsync(stats + 4, 0, sizeof(int32_t), st));
+        k_collect_roots<<<nblk(n), PF_BLOCK, 0, st>>>(g->label, g->rowptr, n, d_roots, stats + 4);
+        PF_HIP(hipGetLastError());
+        PF_HIP(hipMemcpyAsync(&n_roots, stats + 4, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        PF_HIP(hipMemcpyAsync(h_roots, d_roots, sizeof(h_roots), hipMemcpyDeviceToHost, st));
+        PF_HIP(hipStreamSynchronize(st));
+    }
     g->n_isolated = h_stats[0];
     g->max_degree = h_stats[1];
     g->is_symmetric = h_stats[2] ? 0 : 1;
     g->n_oneway = h_stats[2];
-    const int32_t n_roots = h_stats[4];
     PF_CHECK(n_roots <= PF_MAX_ROOTS, PF_E_ARG, "pf_graph_build: %d connected components exceed the supported %d",
              n_roots, PF_MAX_ROOTS);
     g->n_components = n_roots;
     g->roots.resize(n_roots);
-    if (n_roots) {
+    if (n_roots > PF_ROOTS_AHEAD) {
         PF_HIP(hipMemcpyAsync(g->roots.data(), d_roots, sizeof(int32_t) * n_roots, hipMemcpyDeviceToHost, st));
         PF_HIP(hipStreamSynchronize(st));
-        std::sort(g->roots.begin(), g->roots.end());
+    } else {
+        for (int32_t i = 0; i < n_roots; ++i) g->roots[(size_t)i] = h_roots[i];
     }
+    std::sort(g->roots.begin(), g->roots.end());
     PF_TRY(dev_alloc(st, &g->scol, g->sell_entries));
     PF_TRY(dev_alloc(st, &g->sval_rw, g->sell_entries));
     if (g->is_symmetric) PF_TRY(dev_alloc(st, &g->sval_sym, g->sell_entries));
@@ -610,35 +651,31 @@ int pf_graph_build_device(pf_mesh* mesh, pf_graph** out) {
         k_count_edges<<<nblk(n_edges), PF_BLOCK, 0, st>>>(d_faces, n_edges, vpf, n, cnt, flags);
         PF_HIP(hipGetLastError());
     }
-    int32_t h_flags[8];
-    PF_HIP(hipMemcpyAsync(h_flags, flags, sizeof(h_flags), hipMemcpyDeviceToHost, st));
-    PF_HIP(hipStreamSynchronize(st));
-    PF_CHECK(!(h_flags[0] & 1), PF_E_ARG, "pf_graph_build: face index out of range [0,%lld)", (long long)n);
-    PF_CHECK(!(h_flags[0] & 2), PF_E_DEGENERATE, "pf_graph_build: a face repeats a vertex on one edge");
-
+    // No read-back on the way: faces the counting kernel flags (index out of range, repeated vertex) are skipped by the
+    // kernels behind it, col / w are sized by their upper bound (one entry per face edge; duplicates only shrink it),
+    // and the flags, the entry count and everything finish_graph needs come back in ONE synchronisation (each one costs
+    // ~30 us of idle device: 8 per mesh before, 2 now).
     PF_TRY(pf_exclusive_scan_i32(st, cnt, start, n + 1));
     if (n_edges) {
-        k_scatter_edges<<<nblk(n_edges), PF_BLOCK, 0, st>>>(d_faces, d_pts, n_edges, vpf, start, cursor, rcol, rw, flags);
+        k_scatter_edges<<<nblk(n_edges), PF_BLOCK, 0, st>>>(d_faces, d_pts, n_edges, vpf, n, start, cursor, rcol, rw, flags);
         PF_HIP(hipGetLastError());
-        PF_HIP(hipMemcpyAsync(h_flags, flags, sizeof(h_flags), hipMemcpyDeviceToHost, st));
-        PF_HIP(hipStreamSynchronize(st));
-        PF_CHECK(!(h_flags[0] & 4), PF_E_DEGENERATE,
-                 "pf_graph_build: an edge has zero length or non-finite coordinates (the reference would store an "
-                 "infinite weight, graph.py:177-178)");
     }
     k_sort_unique_rows<<<nblk(n), PF_BLOCK, 0, st>>>(start, n, rcol, rw, ucnt);
     PF_HIP(hipGetLastError());
     PF_TRY(pf_exclusive_scan_i32(st, ucnt, g->rowptr, n + 1));
-    int32_t nnz32 = 0;
-    PF_HIP(hipMemcpyAsync(&nnz32, g->rowptr + n, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    PF_HIP(hipStreamSynchronize(st));
-    g->nnz_w = nnz32;
-    PF_TRY(dev_alloc(st, &g->col, g->nnz_w));
-    PF_TRY(dev_alloc(st, &g->w, g->nnz_w));
-
+    PF_TRY(dev_alloc(st, &g->col, n_edges));
+    PF_TRY(dev_alloc(st, &g->w, n_edges));
     k_compact_rows<<<nblk(n), PF_BLOCK, 0, st>>>(start, g->rowptr, n, rcol, rw, g->col, g->w, g->deg, g->g, g->sg);
     PF_HIP(hipGetLastError());
-    PF_TRY(finish_graph(g, d_pts, false));
+    int32_t h_flags[8] = {0};
+    bool flagged = false;
+    PF_TRY(finish_graph(g, d_pts, false, flags, h_flags, &flagged, true));
+    PF_CHECK(!(h_flags[0] & 1), PF_E_ARG, "pf_graph_build: face index out of range [0,%lld)", (long long)n);
+    PF_CHECK(!(h_flags[0] & 2), PF_E_DEGENERATE, "pf_graph_build: a face repeats a vertex on one edge");
+    PF_CHECK(!(h_flags[0] & 4), PF_E_DEGENERATE,
+             "pf_graph_build: an edge has zero length or non-finite coordinates (the reference would store an "
+             "infinite weight, graph.py:177-178)");
+    PF_CHECK(!flagged, PF_E_HIP, "pf_graph_build: unexpected assembly flag");
     PF_TRY(dev_alloc(st, &g->pts, 3 * n));  // kept for pf_point_rows (the mesh object may go away before the graph)
     PF_HIP(hipMemcpyAsync(g->pts, d_pts, sizeof(double) * 3 * n, hipMemcpyDeviceToDevice, st));
     PF_HIP(hipEventRecord(ctx->ev1, st));
