@@ -140,6 +140,7 @@ void pf_destroy(pf_ctx* c) {
         hipEventDestroy(pr.second);
     }
     for (auto& pb : c->pinned_pool) hipHostFree(pb.second);
+    if (c->pinned_scratch) hipHostFree(c->pinned_scratch);
     for (hipEvent_t ev : c->event_pool) hipEventDestroy(ev);
     pf_persist_release(c);
     if (c->persist_abort) hipHostFree(c->persist_abort);

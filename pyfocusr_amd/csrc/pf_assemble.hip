@@ -14,6 +14,8 @@
 // the face list, one int atomic per edge) -> scan -> scatter (col, w) into per-vertex segments
 // -> per-vertex sort + unique -> scan -> compact into CSR and reduce deg -> symmetry probe ->
 // union-find components -> SELL-64 operator storage.
+#include <string.h>
+
 #include <algorithm>
 
 #include "pf_internal.h"
@@ -359,6 +361,38 @@ __global__ __launch_bounds__(PF_BLOCK) void k_csr_split(const int32_t* __restric
 
 // Common tail of the builders: CSR(W) (or the off-diagonals of a general Laplacian), deg, g, sg are in
 // place; derive symmetry, statistics, components, the solver renumbering and the SELL-64 storage.
+// everything small the host wants after the assembly kernels, packed into one block for one copy:
+// [0..5) row statistics, [5] labelling still changing, [6] stored entries (rowptr[n]), [8..16) the caller's flags,
+// [16..16 + PF_ROOTS_AHEAD) the first component roots
+constexpr int PF_ROOTS_AHEAD = 16;
+constexpr int PF_REPORT_INTS = 16 + PF_ROOTS_AHEAD;
+__global__ void k_report(const int32_t* __restrict__ stats, const int32_t* __restrict__ last_round, const int32_t* __restrict__ rowptr_n,
+                         const int32_t* __restrict__ extra, const int32_t* __restrict__ roots, int32_t* __restrict__ out) {
+    const int t = threadIdx.x;
+    if (t < 5) out[t] = stats[t];
+    if (t == 5) out[5] = *last_round;
+    if (t == 6) out[6] = rowptr_n ? *rowptr_n : 0;
+    if (t == 7) out[7] = 0;
+    if (t >= 8 && t < 16) out[t] = extra ? extra[t - 8] : 0;
+    if (t >= 16 && t < PF_REPORT_INTS) out[t] = roots[t - 16];
+}
+
+int pinned_scratch(pf_ctx* c, size_t bytes, void** out) {
+    if (bytes > c->pinned_scratch_bytes) {
+        if (c->pinned_scratch) {
+            PF_HIP(hipStreamSynchronize(c->stream));
+            PF_HIP(hipHostFree(c->pinned_scratch));
+            c->pinned_scratch = nullptr;
+            c->pinned_scratch_bytes = 0;
+        }
+        const size_t cap = std::max(bytes, (size_t)1 << 16);
+        PF_HIP(hipHostMalloc(&c->pinned_scratch, cap, hipHostMallocDefault));
+        c->pinned_scratch_bytes = cap;
+    }
+    *out = c->pinned_scratch;
+    return PF_OK;
+}
+
 // `d_extra` / `h_extra` (8 ints, optional): device flags of the caller that ride in this function's one read-back; when
 // any is set the function returns at once (PF_OK, *extra_hit = true) and the caller reports ITS error.  `nnz_from_rowptr`:
 // g->nnz_w is read back here too (the mesh path sizes col / w by their upper bound instead of waiting for the count).
@@ -417,19 +451,30 @@ int finish_graph(pf_graph* g, const double* d_pts, bool numeric_symmetry, const 
     PF_HIP(hipGetLastError());
     PF_HIP(hipMemsetAsync(width64 + g->n_slices, 0, sizeof(int64_t), st));
     PF_TRY(pf_exclusive_scan_i64(st, width64, g->slice_ptr, g->n_slices + 1));
-    // ONE read-back for everything the host has to know before it can size the SELL storage: the row statistics, the slice
-    // pointers, whether the labelling had converged, the first few component roots (a mesh usually has one), the caller's
-    // own flags and - for the mesh path - the number of stored entries
-    constexpr int PF_ROOTS_AHEAD = 16;
-    int32_t h_stats[6], h_roots[PF_ROOTS_AHEAD], differing = 0, nnz32 = 0;
-    PF_HIP(hipMemcpyAsync(h_stats, stats, sizeof(int32_t) * 5, hipMemcpyDeviceToHost, st));
-    g->h_slice_ptr.resize((size_t)g->n_slices + 1);  // the resident Chebyshev kernel sizes its LDS from this
-    PF_HIP(hipMemcpyAsync(g->h_slice_ptr.data(), g->slice_ptr, sizeof(int64_t) * (g->n_slices + 1), hipMemcpyDeviceToHost, st));
-    PF_HIP(hipMemcpyAsync(&differing, round_flags + PF_CC_FIRST - 1, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    PF_HIP(hipMemcpyAsync(h_roots, d_roots, sizeof(h_roots), hipMemcpyDeviceToHost, st));
-    if (d_extra) PF_HIP(hipMemcpyAsync(h_extra, d_extra, sizeof(int32_t) * 8, hipMemcpyDeviceToHost, st));
-    if (nnz_from_rowptr) PF_HIP(hipMemcpyAsync(&nnz32, g->rowptr + n, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    // ONE read-back (two copies into pinned memory) for everything the host has to know before it can size the SELL
+    // storage: the row statistics, whether the labelling had converged, the first few component roots (a mesh usually
+    // has one), the caller's own flags, the number of stored entries (mesh path) - and the slice pointers
+    int32_t* report = nullptr;
+    PF_TRY(dev_alloc(st, &report, PF_REPORT_INTS));
+    tmp.p.push_back(report);
+    k_report<<<1, PF_WAVE, 0, st>>>(stats, round_flags + PF_CC_FIRST - 1, nnz_from_rowptr ? g->rowptr + n : nullptr, d_extra, d_roots, report);
+    PF_HIP(hipGetLastError());
+    void* pin = nullptr;
+    const size_t slice_bytes = sizeof(int64_t) * (size_t)(g->n_slices + 1);
+    PF_TRY(pinned_scratch(g->ctx, slice_bytes + sizeof(int32_t) * PF_REPORT_INTS, &pin));
+    int32_t* h_report = reinterpret_cast<int32_t*>(static_cast<unsigned char*>(pin) + slice_bytes);
+    PF_HIP(hipMemcpyAsync(pin, g->slice_ptr, slice_bytes, hipMemcpyDeviceToHost, st));
+    PF_HIP(hipMemcpyAsync(h_report, report, sizeof(int32_t) * PF_REPORT_INTS, hipMemcpyDeviceToHost, st));
     PF_HIP(hipStreamSynchronize(st));
+    g->h_slice_ptr.resize((size_t)g->n_slices + 1);  // the resident Chebyshev kernel sizes its LDS from this
+    memcpy(g->h_slice_ptr.data(), pin, slice_bytes);
+    int32_t h_stats[6], h_roots[PF_ROOTS_AHEAD];
+    for (int i = 0; i < 5; ++i) h_stats[i] = h_report[i];
+    int32_t differing = h_report[5];
+    const int32_t nnz32 = h_report[6];
+    if (d_extra)
+        for (int i = 0; i < 8; ++i) h_extra[i] = h_report[8 + i];
+    for (int i = 0; i < PF_ROOTS_AHEAD; ++i) h_roots[i] = h_report[16 + i];
     g->sell_entries = g->h_slice_ptr[(size_t)g->n_slices];
     if (nnz_from_rowptr) g->nnz_w = nnz32;
     if (d_extra && extra_hit) {
@@ -502,8 +547,10 @@ void pf_graph_free(pf_graph* g) {
     pf_free(st, g->col);
     pf_free(st, g->w);
     pf_free(st, g->deg);
-    pf_free(st, g->g);
-    pf_free(st, g->sg);
+    if (!g->deg_block) {
+        pf_free(st, g->g);
+        pf_free(st, g->sg);
+    }
     pf_free(st, g->label);
     pf_free(st, g->perm);
     pf_free(st, g->iperm);
@@ -620,17 +667,19 @@ int pf_graph_build_device(pf_mesh* mesh, pf_graph** out) {
     const int32_t* d_faces = mesh->faces;
     int32_t *cnt = nullptr, *start = nullptr, *cursor = nullptr, *rcol = nullptr, *ucnt = nullptr, *flags = nullptr;
     double* rw = nullptr;
-    PF_TRY(scratch(&cnt, n + 1));
+    // (the counters that start from zero share one block, and so do deg / g / sg: two memsets instead of seven launches)
+    int32_t* zeroed = nullptr;
+    const int64_t zstride = (n + 1 + 7) & ~(int64_t)7;
+    PF_TRY(scratch(&zeroed, 3 * zstride + 8));
+    cnt = zeroed, cursor = zeroed + zstride, ucnt = zeroed + 2 * zstride, flags = zeroed + 3 * zstride;
     PF_TRY(scratch(&start, n + 1));
-    PF_TRY(scratch(&cursor, n + 1));
-    PF_TRY(scratch(&ucnt, n + 1));
     PF_TRY(scratch(&rcol, n_edges));
     PF_TRY(scratch(&rw, n_edges));
-    PF_TRY(scratch(&flags, 8));
     PF_TRY(dev_alloc(st, &g->rowptr, n + 1));
-    PF_TRY(dev_alloc(st, &g->deg, g->n_pad));
-    PF_TRY(dev_alloc(st, &g->g, g->n_pad));
-    PF_TRY(dev_alloc(st, &g->sg, g->n_pad));
+    PF_TRY(dev_alloc(st, &g->deg, 3 * g->n_pad));  // deg, g, sg: one allocation (g->g and g->sg point into it)
+    g->g = g->deg + g->n_pad;
+    g->sg = g->deg + 2 * g->n_pad;
+    g->deg_block = true;
     PF_TRY(dev_alloc(st, &g->diag, g->n_pad));
     PF_TRY(dev_alloc(st, &g->label, g->n_pad));
     PF_TRY(dev_alloc(st, &g->perm, g->n_pad));
@@ -638,13 +687,8 @@ int pf_graph_build_device(pf_mesh* mesh, pf_graph** out) {
     PF_TRY(dev_alloc(st, &g->smooth, g->n_pad));
     PF_TRY(dev_alloc(st, &g->slice_ptr, g->n_slices + 1));
 
-    PF_HIP(hipMemsetAsync(cnt, 0, sizeof(int32_t) * (n + 1), st));
-    PF_HIP(hipMemsetAsync(cursor, 0, sizeof(int32_t) * (n + 1), st));
-    PF_HIP(hipMemsetAsync(ucnt, 0, sizeof(int32_t) * (n + 1), st));
-    PF_HIP(hipMemsetAsync(flags, 0, sizeof(int32_t) * 8, st));
-    PF_HIP(hipMemsetAsync(g->deg, 0, sizeof(double) * g->n_pad, st));
-    PF_HIP(hipMemsetAsync(g->g, 0, sizeof(double) * g->n_pad, st));
-    PF_HIP(hipMemsetAsync(g->sg, 0, sizeof(double) * g->n_pad, st));
+    PF_HIP(hipMemsetAsync(zeroed, 0, sizeof(int32_t) * (size_t)(3 * zstride + 8), st));
+    PF_HIP(hipMemsetAsync(g->deg, 0, sizeof(double) * 3 * g->n_pad, st));
     PF_HIP(hipEventRecord(ctx->ev0, st));
 
     if (n_edges) {

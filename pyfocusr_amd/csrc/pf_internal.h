@@ -95,6 +95,8 @@ struct pf_ctx {
     // pinned host buffers and events of freed graphs, handed to the next graph (hipHostMalloc / hipHostFree and event
     // creation cost 0.1-0.2 ms each: more than a 250k-vertex assembly kernel)
     std::vector<std::pair<int32_t, double*>> pinned_pool;  // (capacity in doubles - 1, buffer)
+    void* pinned_scratch = nullptr;  // small read-backs land here (pinned: one DMA instead of a staged copy each)
+    size_t pinned_scratch_bytes = 0;
     std::vector<hipEvent_t> event_pool;                    // created with hipEventDisableTiming
     // allocator state
     std::multimap<size_t, void*> free_blocks;   // size -> block
@@ -172,6 +174,7 @@ struct pf_graph {
     double* final_vecs = nullptr;
     int32_t final_count = 0;
     double* pts = nullptr;  // [n][3] the mesh's points (graphs built from a mesh): pf_point_rows
+    bool deg_block = false; // g and sg live in deg's allocation (mesh path: one memset for the three)
 };
 
 // Caching device allocator, one cache per ctx (pf_api.hip).  Every use of a block is enqueued on

@@ -562,6 +562,22 @@ __global__ __launch_bounds__(PF_WAVE) void k_vec_stats_finish(const VecStats* __
     if (threadIdx.x == 0) out[b] = st;
 }
 
+// params[c] = {scale, vmin, vmax - vmin, shift} of vector c from its statistics (what pf_finalize_vectors documents:
+// unit 2-norm, the largest-|entry| positive, min-max to [-0.5, 0.5] if asked)
+__global__ void k_vec_params(const VecStats* __restrict__ fin, int32_t count, int32_t minmax, double* __restrict__ params) {
+    for (int c = threadIdx.x; c < count; c += blockDim.x) {
+        const VecStats s = fin[c];
+        const double sgn = s.at_absmax < 0.0 ? -1.0 : 1.0;
+        const double scale = sgn / sqrt(s.sumsq);
+        const double vmin = (sgn > 0 ? s.vmin : s.vmax) * scale;  // monotone map: exact min/max of the scaled vector
+        const double vmax = (sgn > 0 ? s.vmax : s.vmin) * scale;
+        params[4 * c + 0] = scale;
+        params[4 * c + 1] = minmax ? vmin : 0.0;
+        params[4 * c + 2] = minmax ? (vmax - vmin) : 0.0;
+        params[4 * c + 3] = minmax ? 0.5 : 0.0;
+    }
+}
+
 // out[i][c] = (x_c[i] * scale_c - off_c) * inv_c - half_c       (row-major n x count)
 __global__ __launch_bounds__(PF_BLOCK) void k_vec_apply(const double* __restrict__ ws, int64_t n_pad, int64_t n,
                                                         int32_t first, int32_t count, const double* __restrict__ sg,
@@ -1396,37 +1412,30 @@ int pf_finalize_vectors(pf_graph* g, int32_t first, int32_t count, int32_t from_
     PF_HIP(hipGetLastError());
     k_vec_stats_finish<<<(unsigned)count, PF_WAVE, 0, st>>>(part, g->n_chunks, fin);
     PF_HIP(hipGetLastError());
-    std::vector<VecStats> hs((size_t)count);
-    PF_HIP(hipMemcpyAsync(hs.data(), fin, sizeof(VecStats) * count, hipMemcpyDeviceToHost, st));
-    PF_HIP(hipStreamSynchronize(st));
-    std::vector<double> params(4 * (size_t)count);
-    for (int32_t c = 0; c < count; ++c) {
-        const VecStats& s = hs[c];
-        PF_CHECK(s.sumsq > 0.0 && isfinite(s.sumsq), PF_E_STATE, "pf_finalize_vectors: vector %d has norm^2 %g", c, s.sumsq);
-        const double sgn = s.at_absmax < 0.0 ? -1.0 : 1.0;
-        const double scale = sgn / sqrt(s.sumsq);
-        const double vmin = (sgn > 0 ? s.vmin : s.vmax) * scale;  // monotone map: exact min/max of the scaled vector
-        const double vmax = (sgn > 0 ? s.vmax : s.vmin) * scale;
-        params[4 * c + 0] = scale;
-        params[4 * c + 1] = minmax ? vmin : 0.0;
-        params[4 * c + 2] = minmax ? (vmax - vmin) : 0.0;
-        params[4 * c + 3] = minmax ? 0.5 : 0.0;
-    }
+    // scale / sign / min-max parameters straight from the statistics, on the device (no read-back in between: the
+    // statistics come to the host with the result and are checked then)
     double *d_params = nullptr, *d_out = nullptr;
     pf_free(st, g->final_vecs);  // the result stays resident (pf_final_rows, pf_knn1_graphs) until the next call
     g->final_vecs = nullptr;
     g->final_count = 0;
-    PF_HIP(pf_malloc(st, (void**)&d_params, sizeof(double) * params.size()));
+    PF_HIP(pf_malloc(st, (void**)&d_params, sizeof(double) * 4 * (size_t)count));
     hipError_t e = pf_malloc(st, (void**)&d_out, sizeof(double) * (size_t)g->n * count);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_params, params.data(), sizeof(double) * params.size(), hipMemcpyHostToDevice, st);
+    std::vector<VecStats> hs((size_t)count);
     if (e == hipSuccess) {
+        k_vec_params<<<1, PF_WAVE, 0, st>>>(fin, count, minmax, d_params);
         k_vec_apply<<<nblk(g->n), PF_BLOCK, 0, st>>>(g->ws, g->n_pad, g->n, first, count, g->sg, g->iperm, from_sym, d_params, d_out);
         e = hipGetLastError();
     }
+    if (e == hipSuccess) e = hipMemcpyAsync(hs.data(), fin, sizeof(VecStats) * count, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, sizeof(double) * (size_t)g->n * count, hipMemcpyDeviceToHost, st);
     hipError_t e2 = hipStreamSynchronize(st);
     pf_free(st, d_params);
-    if (e == hipSuccess && e2 == hipSuccess) {
+    bool sane = true;
+    int32_t bad = 0;
+    if (e == hipSuccess && e2 == hipSuccess)
+        for (int32_t c = 0; c < count && sane; ++c)
+            if (!(hs[c].sumsq > 0.0 && isfinite(hs[c].sumsq))) sane = false, bad = c;
+    if (e == hipSuccess && e2 == hipSuccess && sane) {
         g->final_vecs = d_out;
         g->final_count = count;
     } else {
@@ -1434,6 +1443,7 @@ int pf_finalize_vectors(pf_graph* g, int32_t first, int32_t count, int32_t from_
     }
     PF_HIP(e);
     PF_HIP(e2);
+    PF_CHECK(sane, PF_E_STATE, "pf_finalize_vectors: vector %d has norm^2 %g", bad, hs[(size_t)bad].sumsq);
     return PF_OK;
 }
 
