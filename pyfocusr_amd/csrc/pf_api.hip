@@ -19,6 +19,22 @@ static pf_ctx* ctx_of_stream(hipStream_t st) {
     return nullptr;
 }
 
+int pf_pinned_scratch(pf_ctx* c, size_t bytes, void** out) {
+    if (bytes > c->pinned_scratch_bytes) {
+        if (c->pinned_scratch) {
+            PF_HIP(hipStreamSynchronize(c->stream));
+            PF_HIP(hipHostFree(c->pinned_scratch));
+            c->pinned_scratch = nullptr;
+            c->pinned_scratch_bytes = 0;
+        }
+        const size_t cap = bytes > ((size_t)1 << 16) ? bytes : ((size_t)1 << 16);
+        PF_HIP(hipHostMalloc(&c->pinned_scratch, cap, hipHostMallocDefault));
+        c->pinned_scratch_bytes = cap;
+    }
+    *out = c->pinned_scratch;
+    return PF_OK;
+}
+
 hipError_t pf_malloc(hipStream_t st, void** p, size_t bytes) {
     *p = nullptr;
     pf_ctx* c = ctx_of_stream(st);

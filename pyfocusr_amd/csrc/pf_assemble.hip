@@ -377,22 +377,6 @@ __global__ void k_report(const int32_t* __restrict__ stats, const int32_t* __res
     if (t >= 16 && t < PF_REPORT_INTS) out[t] = roots[t - 16];
 }
 
-int pinned_scratch(pf_ctx* c, size_t bytes, void** out) {
-    if (bytes > c->pinned_scratch_bytes) {
-        if (c->pinned_scratch) {
-            PF_HIP(hipStreamSynchronize(c->stream));
-            PF_HIP(hipHostFree(c->pinned_scratch));
-            c->pinned_scratch = nullptr;
-            c->pinned_scratch_bytes = 0;
-        }
-        const size_t cap = std::max(bytes, (size_t)1 << 16);
-        PF_HIP(hipHostMalloc(&c->pinned_scratch, cap, hipHostMallocDefault));
-        c->pinned_scratch_bytes = cap;
-    }
-    *out = c->pinned_scratch;
-    return PF_OK;
-}
-
 // `d_extra` / `h_extra` (8 ints, optional): device flags of the caller that ride in this function's one read-back; when
 // any is set the function returns at once (PF_OK, *extra_hit = true) and the caller reports ITS error.  `nnz_from_rowptr`:
 // g->nnz_w is read back here too (the mesh path sizes col / w by their upper bound instead of waiting for the count).
@@ -461,7 +445,7 @@ int finish_graph(pf_graph* g, const double* d_pts, bool numeric_symmetry, const 
     PF_HIP(hipGetLastError());
     void* pin = nullptr;
     const size_t slice_bytes = sizeof(int64_t) * (size_t)(g->n_slices + 1);
-    PF_TRY(pinned_scratch(g->ctx, slice_bytes + sizeof(int32_t) * PF_REPORT_INTS, &pin));
+    PF_TRY(pf_pinned_scratch(g->ctx, slice_bytes + sizeof(int32_t) * PF_REPORT_INTS, &pin));
     int32_t* h_report = reinterpret_cast<int32_t*>(static_cast<unsigned char*>(pin) + slice_bytes);
     PF_HIP(hipMemcpyAsync(pin, g->slice_ptr, slice_bytes, hipMemcpyDeviceToHost, st));
     PF_HIP(hipMemcpyAsync(h_report, report, sizeof(int32_t) * PF_REPORT_INTS, hipMemcpyDeviceToHost, st));

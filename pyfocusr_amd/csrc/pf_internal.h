@@ -184,6 +184,9 @@ struct pf_graph {
 // hipFree synchronises the device).  Blocks go back to the driver in pf_destroy.
 int pf_timing_collect(pf_ctx* c);  // pf_api.hip: fold finished spans into op_ms / op_launches / op_bytes
 hipError_t pf_malloc(hipStream_t st, void** p, size_t bytes);
+// the ctx's pinned host block for small transfers, at least `bytes` large (valid until the next call that asks for more;
+// users synchronise with the stream before they return)
+int pf_pinned_scratch(pf_ctx* c, size_t bytes, void** out);
 void pf_free(hipStream_t st, void* p);
 
 // SELL-64 entry layout inside a slice of `width` entries per row: entries come in PAIRS per lane, so that one
