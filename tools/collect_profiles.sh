@@ -1,0 +1,33 @@
+#!/bin/bash
+# The measurement set behind profiles/r02_<tag>_*: run on the GPU box (gpurun), results land in gpurun_out/final/.
+#   bash tools/collect_profiles.sh
+# 1. python bench.py (the full line)   2. rocprofv3 kernel stats of the headline workload
+# 3. PMC passes (FETCH_SIZE, WRITE_SIZE separately; resident kernel, then PF_PERSIST=0 for the streaming kernel)
+# 4. tools/pmc_make_summary.py
+set -e
+root=${GRAFT_REPO_ROOT:-/root/repo}
+out=$root/gpurun_out/final
+rm -rf $out && mkdir -p $out
+cd /tmp && export TMPDIR=/tmp
+python3 $root/bench.py > $out/bench.json 2> $out/bench.err
+echo "bench done" > $out/progress.txt
+args="--steps 4 --warmup 2 --no-extras --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 $root/bench.py $args > $out/bench_under_rocprof.json 2> $out/rocprof.err
+cp $(ls $out/stats/*/*kernel_stats.csv | tail -1) $out/kernel_stats.csv
+python3 $root/tools/trace_gaps.py $(ls $out/stats/*/*kernel_trace.csv | tail -1) 0.6 > $out/gaps.txt
+python3 $root/tools/trace_timeline.py $(ls $out/stats/*/*kernel_trace.csv | tail -1) > $out/timeline_last_step.txt
+rm -rf $out/stats
+echo "stats done" >> $out/progress.txt
+pargs="--steps 2 --warmup 1 --no-extras --no-cpu-baseline"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python3 $root/bench.py $pargs > $out/pmc_fetch.json 2>> $out/rocprof.err
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python3 $root/bench.py $pargs > $out/pmc_write.json 2>> $out/rocprof.err
+echo "pmc resident done" >> $out/progress.txt
+sargs="--steps 1 --warmup 1 --no-extras --no-cpu-baseline"
+PF_PERSIST=0 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch_stream -- python3 $root/bench.py $sargs > $out/pmc_fetch_stream.json 2>> $out/rocprof.err
+PF_PERSIST=0 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_write_stream -- python3 $root/bench.py $sargs > $out/pmc_write_stream.json 2>> $out/rocprof.err
+echo "pmc streaming done" >> $out/progress.txt
+cd $root
+python3 tools/pmc_make_summary.py --fetch $out/pmc_fetch --write $out/pmc_write --fetch-stream $out/pmc_fetch_stream --write-stream $out/pmc_write_stream \
+    --stats $out/kernel_stats.csv --bench $out/bench_under_rocprof.json --out $out/pmc_summary.json
+rm -rf $out/pmc_fetch $out/pmc_write $out/pmc_fetch_stream $out/pmc_write_stream
+echo "all done" >> $out/progress.txt
