@@ -434,7 +434,7 @@ __global__ __launch_bounds__(BS) void k_knn_grid(const double* __restrict__ ref_
 // the wave - the minimum of that pair is unique, so the result does not depend on who found it or on how many extra
 // candidates were looked at: bit-identical to k_knn_grid and to a brute force.
 // Clouds that are far apart make the rectangle the whole grid: the scan is then a brute force whose loads are shared by
-// the group only - per 64 queries no more arithmetic than k_knn_grid's shared LDS tiles.  k_knn_grid serves k > 1.
+// the group only - per 64 queries no more arithmetic than k_knn_grid's shared LDS tiles.  k_knn_grid serves k > 1 and d >= 10.
 // queries per wave: their coordinates stay in registers (G x d doubles, wave-uniform)
 constexpr int knn_group(int d) { return d <= 4 ? 8 : (d <= 8 ? 4 : 2); }
 
@@ -595,7 +595,11 @@ int launch_knn_k(pf_ctx* c) {
     // shared scan: 1.60 -> 1.39 ms at 250k x 250k, d = 5), four waves for deep ones, whose large squares make the shared
     // LDS tiles the common case (1M x 1M, d = 10: 161 ms with 256 threads, 172 with 64).
     constexpr int BS = D <= 6 ? PF_WAVE : PF_BLOCK;
-    if constexpr (K == 1) {
+    // d >= 10 stays with the one-query-per-lane kernel: only two queries' coordinates fit a wave's scalar registers there, so
+    // a candidate load is shared by two queries instead of by a block, and the lane-per-query kernel's wave-level early
+    // exit after d/2 coordinates pays (measured, grouped / lane-per-query: unrelated 250k x 250k d = 6: 5.0 / 18.3 ms,
+    // d = 8: 14.1 / 25.6, d = 9: 29.7 / 35.7, d = 12: 114 / 56; 1M x 1M noisy copies d = 10: 545 / 333)
+    if constexpr (K == 1 && D <= 9) {
         const int64_t waves = (c->knn_nqry + knn_group(D) - 1) / knn_group(D);
         k_knn_coop<D><<<(unsigned)((waves + PF_BLOCK / PF_WAVE - 1) / (PF_BLOCK / PF_WAVE)), PF_BLOCK, 0, c->stream>>>(
             c->knn_ref_soa, c->knn_ref_ld, c->knn_ref_orig, c->knn_cell_start, c->knn_qry_s, c->knn_qry_orig, c->knn_nqry,
