@@ -173,3 +173,23 @@ class MatrixOps(NumpyOps):
 
     def lock_null_vectors(self):
         return 0
+
+
+class PairedNumpyOps(NumpyOps):
+    """`NumpyOps` with the pair entries of the device class (`orth_begin2`, `orth_cheb2`), so that the fused branches of
+    `_krylov.drive_pair` run in the CPU tests too; counts how often each was used."""
+
+    def __init__(self, W):
+        super().__init__(W)
+        self.pair_calls = {"orth_begin2": 0, "orth_cheb2": 0}
+
+    def orth_begin2(self, req, other, req_other):
+        self.pair_calls["orth_begin2"] += 1
+        self.orth_begin(*req)
+        other.orth_begin(*req_other)
+
+    def orth_cheb2(self, orth, req, other, orth_other, req_other):
+        self.pair_calls["orth_cheb2"] += 1
+        self.orth_begin(*orth)
+        other.orth_begin(*orth_other)
+        self.cheb2(req, other, req_other)

@@ -290,6 +290,18 @@ def test_lockstep_pair_driver_equals_single_solves(golden):
     for (lam, first, st), (lam1, first1, st1) in ((ra, single[0]), (rb, single[1])):
         assert np.array_equal(lam, lam1) and first == first1 and st.matvecs == st1.matvecs
     assert rb[2].filter_resets >= 1 and ra[2].degree != rb[2].degree
+    # the same with the device class's pair entries (one call per outer step of both solvers: both Gram-Schmidt steps and
+    # the next filter application; Gram-Schmidt steps alone where one solver does not speculate; single requests once
+    # the solvers have drifted apart or one has finished)
+    from _numpy_ops import PairedNumpyOps
+
+    pa, pb = PairedNumpyOps(orc.weighted_adjacency(a["points"], a["faces"])), PairedNumpyOps(orc.weighted_adjacency(b.points, b.faces))
+    ga = filtered_eigs_gen(pa, 4, True, null_slots=pa.lock_null_vectors())
+    gb = filtered_eigs_gen(pb, 4, True, null_slots=pb.lock_null_vectors(), cut=1e-7)
+    qa, qb = drive_pair(ga, pa, gb, pb)
+    for (lam, first, st), (lam1, first1, st1) in ((qa, single[0]), (qb, single[1])):
+        assert np.array_equal(lam, lam1) and first == first1 and st.matvecs == st1.matvecs
+    assert pa.pair_calls["orth_cheb2"] >= 10 and np.array_equal(pa.download_slots(qa[1], 4), oa.download_slots(ra[1], 4))
 
 
 def test_widen_rule_matches_reference_trace(golden):
