@@ -506,11 +506,22 @@ __global__ __launch_bounds__(PF_BLOCK) void k_knn_coop(const double* __restrict_
 #pragma unroll
                 for (int i = 0; i < G; ++i) {
                     double s = 0.0;
+                    constexpr int P = D >= 6 ? D / 2 : D;  // deep coordinates: most candidates are out after half of them
 #pragma unroll
-                    for (int c = 0; c < D; ++c) {  // dist2's operations, in its order
+                    for (int c = 0; c < P; ++c) {  // dist2's operations, in its order
                         const double df = q[i][c] - x[c];
                         const double sq = df * df;
                         s = (c == 0) ? sq : s + sq;
+                    }
+                    if constexpr (P < D) {
+                        // the partial sum is a prefix of the very same accumulation and only grows: if no candidate of
+                        // the chunk can still reach the query's bound, the other coordinates are not looked at
+                        if (!__any(s <= best[i])) continue;
+#pragma unroll
+                        for (int c = P; c < D; ++c) {
+                            const double df = q[i][c] - x[c];
+                            s = s + df * df;
+                        }
                     }
                     if (s < best[i] || (s == best[i] && o < bidx[i])) {  // (a candidate met twice changes nothing)
                         best[i] = s;
@@ -597,8 +608,9 @@ int launch_knn_k(pf_ctx* c) {
     constexpr int BS = D <= 6 ? PF_WAVE : PF_BLOCK;
     // d >= 10 stays with the one-query-per-lane kernel: only two queries' coordinates fit a wave's scalar registers there, so
     // a candidate load is shared by two queries instead of by a block, and the lane-per-query kernel's wave-level early
-    // exit after d/2 coordinates pays (measured, grouped / lane-per-query: unrelated 250k x 250k d = 6: 5.0 / 18.3 ms,
-    // d = 8: 14.1 / 25.6, d = 9: 29.7 / 35.7, d = 12: 114 / 56; 1M x 1M noisy copies d = 10: 545 / 333)
+    // exit after d/2 coordinates pays more (measured, grouped / lane-per-query: unrelated 250k x 250k d = 6: 4.2 / 18.3 ms,
+    // d = 8: 12.6 / 25.6, d = 9: 29.7 / 35.7, d = 12: 114 / 56; 1M x 1M noisy copies d = 10: 545 / 333; keeping 8 queries'
+    // coordinates and best lists in LDS instead was slower still: d = 10: 78 ms, d = 12: 139)
     if constexpr (K == 1 && D <= 9) {
         const int64_t waves = (c->knn_nqry + knn_group(D) - 1) / knn_group(D);
         k_knn_coop<D><<<(unsigned)((waves + PF_BLOCK / PF_WAVE - 1) / (PF_BLOCK / PF_WAVE)), PF_BLOCK, 0, c->stream>>>(
