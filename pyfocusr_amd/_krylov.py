@@ -295,22 +295,24 @@ class _NeedEllipse(Exception):
     complex outliers to carry): switch to the ellipse filter."""
 
 
-def filtered_eigs_gen(ops, n_wanted, symmetric, ellipse=None, **kw):
+def filtered_eigs_gen(ops, n_wanted, symmetric, ellipse=None, nulls_fresh=False, **kw):
     """Solver generator (see `_solve_gen`).  For a non-symmetric operator the cheap strategy — interval filter,
     complex outliers carried as dominant Ritz values — is tried first unless `ellipse` is True (the caller knows
     the graph has many one-way edges); if it fails the ellipse filter takes over."""
+    # (`nulls_fresh`: the caller has just written the null vectors into slots [0, null_slots) - the first attempt need not)
     if symmetric or ellipse is False:
-        return (yield from _solve_gen(ops, n_wanted, symmetric, **kw))
+        return (yield from _solve_gen(ops, n_wanted, symmetric, nulls_fresh=nulls_fresh, **kw))
     if ellipse is None:
         try:
-            return (yield from _solve_gen(ops, n_wanted, symmetric, **kw))
+            return (yield from _solve_gen(ops, n_wanted, symmetric, nulls_fresh=nulls_fresh, **kw))
         except _NeedEllipse:
-            pass
+            nulls_fresh = False
     half_height = 0.125 * kw.get("hi", 2.0)
     for _ in range(4):
         try:
-            return (yield from _solve_gen(ops, n_wanted, symmetric, half_height=half_height, **kw))
+            return (yield from _solve_gen(ops, n_wanted, symmetric, half_height=half_height, nulls_fresh=nulls_fresh, **kw))
         except _NeedEllipse:
+            nulls_fresh = False
             half_height *= 1.6  # outliers above the assumed strip: make the ellipse taller
     raise RuntimeError("filtered Krylov-Schur: could not enclose the complex spectrum of this non-normal Laplacian in an "
                        "ellipse (one-way edges: an open or non-manifold mesh); the eigenpairs were NOT computed")
@@ -318,7 +320,7 @@ def filtered_eigs_gen(ops, n_wanted, symmetric, ellipse=None, **kw):
 
 def _solve_gen(ops, n_wanted, symmetric, null_slots=0, cut=None, tol=1e-12, m_max=None,
                max_restarts=60, max_filter_resets=8, seed=0, strength=2.0, hi=2.0,
-               nonsym_degree_cap=128, half_height=None, verbose=False, adapt_cut=False):
+               nonsym_degree_cap=128, half_height=None, verbose=False, adapt_cut=False, nulls_fresh=False):
     """Generator form of the solver: yields `(src, dst, degree, c, e, rho)` whenever the Chebyshev filter has to be
     applied (the only expensive device operation), `("orth", w, first, count, normalize)` whenever a Gram-Schmidt
     step has to be started (`ops.orth_begin`), and `("orth+cheb", orth args, filter request)` for a Gram-Schmidt step with
@@ -338,7 +340,7 @@ def _solve_gen(ops, n_wanted, symmetric, null_slots=0, cut=None, tol=1e-12, m_ma
     n_active = n - ops.n_isolated
     stats = EigsStats()
     c0 = int(null_slots)
-    if c0 > 0 and ops.lock_null_vectors() != c0:  # (re)write slots [0, c0): a previous attempt's extraction reuses them
+    if c0 > 0 and not nulls_fresh and ops.lock_null_vectors() != c0:  # (re)write slots [0, c0): a previous attempt's extraction reuses them
         raise RuntimeError("null_slots does not match the graph's component count")
     n_wanted = int(min(n_wanted, max(n_active - c0, 0)))
     if n_wanted <= 0:

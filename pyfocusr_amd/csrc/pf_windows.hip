@@ -118,19 +118,33 @@ __global__ __launch_bounds__(PF_WIN_THREADS) void k_win_build(const int64_t* __r
             __syncthreads();
         }
     }
-    if (tid == 0) {  // unique, serial: <= 4096 steps once per window
-        int h = 0;
-        int32_t last = -1;
-        for (int i = 0; i < cap; ++i) {
-            const int32_t c = cand[i];
-            if (c == INT_MAX) break;
-            if (c != last) {
-                if (h < PF_WIN_GHOSTS) ghost[h] = c;
-                ++h;
-                last = c;
+    // unique: an entry that differs from its predecessor starts a new outside row; positions by ballot / popcount within a
+    // wave and a running total over the waves (a serial pass by one thread cost ~40 us of the kernel's 95)
+    {
+        __shared__ int wave_tot[PF_WIN_THREADS / PF_WAVE];
+        __shared__ int running;
+        if (tid == 0) running = 0;
+        __syncthreads();
+        for (int base = 0; base < cap; base += PF_WIN_THREADS) {  // (block-uniform trip count)
+            const int i = base + tid;
+            const int32_t c = i < cap ? cand[i] : INT_MAX;
+            const bool fresh = c != INT_MAX && (i == 0 || cand[i - 1] != c);
+            const unsigned long long m = __ballot(fresh);
+            const int before = __popcll(m & ((1ull << lane) - 1ull));
+            if (lane == 0) wave_tot[tid / PF_WAVE] = __popcll(m);
+            __syncthreads();
+            int off = running;
+            for (int w = 0; w < tid / PF_WAVE; ++w) off += wave_tot[w];
+            if (fresh && off + before < PF_WIN_GHOSTS) ghost[off + before] = c;
+            __syncthreads();
+            if (tid == 0) {
+                int t = running;
+                for (int w = 0; w < PF_WIN_THREADS / PF_WAVE; ++w) t += wave_tot[w];
+                running = t;
             }
+            __syncthreads();
         }
-        hcount = h;
+        if (tid == 0) hcount = running;
     }
     __syncthreads();
     const int h = hcount;

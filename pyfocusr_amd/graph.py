@@ -434,7 +434,7 @@ def _device_eigs_gen(dev, k, n_k_needed, k_buffer=1, minmax=False, verbose=False
         kw = dict(solver_kw)
         if not dev.symmetric and "ellipse" not in kw:
             kw["ellipse"] = True if getattr(dev, "n_oneway", 0) > 32 else None
-        lam, first, stats = yield from filtered_eigs_gen(dev, m_out + extra, dev.symmetric, null_slots=c0, **kw)
+        lam, first, stats = yield from filtered_eigs_gen(dev, m_out + extra, dev.symmetric, null_slots=c0, nulls_fresh=lock, **kw)
         found = stats.n_null - c0
         if found > extra and len(lam) < m_out:  # null vectors the component count did not predict
             extra = found
