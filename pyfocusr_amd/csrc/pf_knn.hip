@@ -648,7 +648,26 @@ int grow(hipStream_t st, T** p, int64_t* cap, int64_t need) {
     return PF_OK;
 }
 
-// sort one point set by grid cell: sorted keys, original indices, gathered rows
+// counting sort by cell key (keys < n_buckets): histogram, exclusive scan, scatter through per-bucket cursors.  The
+// order inside a bucket is whatever the atomics make it: the search does not care (the minimum of (distance, original
+// index) does not depend on the order candidates or queries are visited in).
+__global__ __launch_bounds__(PF_BLOCK) void k_bucket_count(const unsigned* __restrict__ keys, int64_t n, int32_t* __restrict__ hist) {
+    const int64_t i = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
+    if (i < n) atomicAdd(&hist[keys[i]], 1);
+}
+__global__ __launch_bounds__(PF_BLOCK) void k_bucket_scatter(const unsigned* __restrict__ keys, int64_t n, const int32_t* __restrict__ start,
+                                                             int32_t* __restrict__ cursor, unsigned* __restrict__ key_out,
+                                                             int32_t* __restrict__ orig_out) {
+    const int64_t i = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const unsigned k = keys[i];
+    const int32_t pos = start[k] + atomicAdd(&cursor[k], 1);
+    key_out[pos] = k;
+    orig_out[pos] = (int32_t)i;
+}
+
+// sort one point set by grid cell: sorted keys, original indices, gathered rows.  250k points: 5 small launches (~40 us)
+// where hipCUB's radix sort dispatches a merge sort of 17 launches (~107 us) for arrays below 1M items.
 int sort_points(pf_ctx* c, const double* pts, int64_t n, int d, int morton, int key_bits, unsigned* key_out, int32_t* orig_out,
                 double* rows_out) {
     hipStream_t st = c->stream;
@@ -663,9 +682,39 @@ int sort_points(pf_ctx* c, const double* pts, int64_t n, int d, int morton, int 
         k_cell_keys<<<nblk(n), PF_BLOCK, 0, st>>>(pts, n, d, (const KnnGrid*)c->knn_grid, morton, k0, v0);
         e = hipGetLastError();
     }
-    if (e == hipSuccess) e = hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, k0, key_out, v0, orig_out, (int)n, 0, key_bits, st);
-    if (e == hipSuccess) e = pf_malloc(st, &tmp, bytes);
-    if (e == hipSuccess) e = hipcub::DeviceRadixSort::SortPairs(tmp, bytes, k0, key_out, v0, orig_out, (int)n, 0, key_bits, st);
+    // keys are cell ids (row-major: < res^2) or Morton codes of cells (< 4^ceil(log2 res))
+    int64_t n_buckets = 1;
+    {
+        const int res = c->knn_res;
+        if (morton) {
+            int bits = 0;
+            while ((1 << bits) < res) ++bits;
+            n_buckets = (int64_t)1 << (2 * bits);
+        } else {
+            n_buckets = d == 1 ? res : (int64_t)res * res;
+        }
+    }
+    if (e == hipSuccess && n_buckets <= ((int64_t)1 << 22)) {
+        int32_t* hist = nullptr;  // [n_buckets + 1] counts, [n_buckets + 1] starts, [n_buckets] cursors
+        e = pf_malloc(st, (void**)&hist, sizeof(int32_t) * (size_t)(3 * n_buckets + 2));
+        tmp = hist;
+        if (e == hipSuccess) e = hipMemsetAsync(hist, 0, sizeof(int32_t) * (size_t)(3 * n_buckets + 2), st);
+        if (e == hipSuccess) {
+            int32_t* start = hist + n_buckets + 1;
+            int32_t* cursor = start + n_buckets + 1;
+            k_bucket_count<<<nblk(n), PF_BLOCK, 0, st>>>(k0, n, hist);
+            e = hipGetLastError();
+            if (e == hipSuccess && pf_exclusive_scan_i32(st, hist, start, n_buckets + 1) != PF_OK) e = hipErrorUnknown;
+            if (e == hipSuccess) {
+                k_bucket_scatter<<<nblk(n), PF_BLOCK, 0, st>>>(k0, n, start, cursor, key_out, orig_out);
+                e = hipGetLastError();
+            }
+        }
+    } else {
+        if (e == hipSuccess) e = hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, k0, key_out, v0, orig_out, (int)n, 0, key_bits, st);
+        if (e == hipSuccess) e = pf_malloc(st, &tmp, bytes);
+        if (e == hipSuccess) e = hipcub::DeviceRadixSort::SortPairs(tmp, bytes, k0, key_out, v0, orig_out, (int)n, 0, key_bits, st);
+    }
     if (e == hipSuccess) {
         k_gather_rows<<<nblk(n), PF_BLOCK, 0, st>>>(pts, orig_out, n, d, rows_out);
         e = hipGetLastError();
