@@ -59,6 +59,10 @@ typedef struct pf_graph_info {
     int64_t n_pad;         /* workspace slot stride in elements                     */
     int64_t n_oneway;      /* entries (i,j) of W without a matching (j,i): 0 iff symmetric;
                               every boundary edge of an open mesh is one (graph.py:178)      */
+    double spectral_bound; /* proven upper bound of the spectrum of L (and of S): 2 in general; for a closed triangle
+                              mesh (every edge in exactly two faces) 1 + (1 + sqrt(1 - 4 P_min)) / 2 with P_min the
+                              smallest 2abc / ((a+b)(a+c)(b+c)) over the faces' edge weights - the Chebyshev
+                              filter damps [cut, spectral_bound] instead of [cut, 2]                  */
 } pf_graph_info;
 
 typedef struct pf_timing {
@@ -176,6 +180,10 @@ int pf_orth_cheb2(pf_graph* ga, pf_graph* gb, const int32_t* orth, const int32_t
  * filter application of a pipelined driver) saw the un-refined, un-normalised vector and has to be repeated.  Rare:
  * never on the 250k blobs, a few times per solve right after a restart on small graphs. */
 int pf_orth_redone(pf_graph* g);
+/* on != 0: the second Gram-Schmidt pass runs whenever |w'| < 0.71 |w| (the classical constant) instead of 0.3 |w|: for
+ * iterations that come close to exhausting a small space (unfiltered solves of tiny graphs), where the loose criterion
+ * loses orthogonality.  Per graph; off by default. */
+int pf_orth_strict(pf_graph* g, int32_t on);
 int pf_scale(pf_graph* g, int32_t slot, double alpha);
 /* slots [dst_first, dst_first+k) = slots [src_first, src_first+m) * Y, Y row-major m x k; ranges must not overlap */
 int pf_combine(pf_graph* g, int32_t src_first, int32_t m, const double* Y, int32_t k, int32_t dst_first);

@@ -36,7 +36,8 @@ class PfError(RuntimeError):
 class GraphInfo(C.Structure):
     _fields_ = [("n", C.c_int64), ("n_faces", C.c_int64), ("nnz_w", C.c_int64), ("nnz_l", C.c_int64),
                 ("is_symmetric", C.c_int32), ("n_isolated", C.c_int32), ("n_components", C.c_int32),
-                ("max_degree", C.c_int32), ("sell_entries", C.c_int64), ("n_pad", C.c_int64), ("n_oneway", C.c_int64)]
+                ("max_degree", C.c_int32), ("sell_entries", C.c_int64), ("n_pad", C.c_int64), ("n_oneway", C.c_int64),
+                ("spectral_bound", C.c_double)]
 
 
 class EigsStats(C.Structure):
@@ -92,6 +93,7 @@ SIGNATURES = {
     "pf_orth_cheb2": (C.c_int, [C.c_void_p, C.c_void_p, _i32p, _i32p, _f64p]),
     "pf_eigsort_costs": (C.c_int, [C.c_void_p, C.c_void_p, _i64p, _i64p, C.c_int64, C.c_int32, _i32p, _f64p, _i32p, _f64p, _f64p, _i64p]),
     "pf_orth_redone": (C.c_int, [C.c_void_p]),
+    "pf_orth_strict": (C.c_int, [C.c_void_p, C.c_int32]),
     "pf_scale": (C.c_int, [C.c_void_p, C.c_int32, C.c_double]),
     "pf_combine": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _f64p, C.c_int32, C.c_int32]),
     "pf_resnorm": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_double, _f64p]),
@@ -582,6 +584,7 @@ class DeviceLaplacian(object):
         self.n_components = int(info.n_components)
         self.max_degree = int(info.max_degree)
         self.n_oneway = int(info.n_oneway)
+        self.spectral_bound = float(info.spectral_bound) if 0.0 < float(info.spectral_bound) <= 2.0 else 2.0
         self.op = PF_OP_SYM if self.symmetric else PF_OP_RW
         self.has_points = matrix is None
         self._rows = []
@@ -688,6 +691,10 @@ class DeviceLaplacian(object):
         cd = (C.c_double * 6)(float(req[3]), float(req[4]), float(req[5]), float(req_other[3]), float(req_other[4]), float(req_other[5]))
         _check(self._lib.pf_orth_cheb2(self._h, other._h, o, ci, cd))
         self._orth_count, other._orth_count = int(orth[2]), int(orth_other[2])
+
+    def orth_strict(self, on):
+        """Second Gram-Schmidt pass at the classical threshold (|w'| < 0.71 |w|) instead of the loose one (0.3)."""
+        _check(self._lib.pf_orth_strict(self._h, int(bool(on))))
 
     def orth_end(self):
         h = np.empty(max(self._orth_count, 1), dtype=np.float64)

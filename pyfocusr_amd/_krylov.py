@@ -398,6 +398,11 @@ def _solve_gen(ops, n_wanted, symmetric, null_slots=0, cut=None, tol=1e-12, m_ma
         else:
             c, e, p = choose_filter(cut, hi=hi, strength=strength, max_degree=degree_cap)
         stats.degree, stats.cut = p, cut
+        if hasattr(ops, "orth_strict"):
+            # an unfiltered iteration on a small graph runs until it nearly exhausts the space: the loose single-pass
+            # criterion of the device's Gram-Schmidt step loses orthogonality there; on small graphs in general the
+            # second pass costs nothing that matters
+            ops.orth_strict(plain or n_active < 4096)
         theta0 = _cheb_value_scaled(0.0, c, e, p, rho)
         bulk = 0.5 * (1.0 + rho ** (-2.0 * p))  # bound of the scaled polynomial on the damped set (1 for the interval)
         band = -1.0 if plain else 1.5 * bulk  # wanted Ritz values must clear the damped set (none in plain mode)

@@ -65,6 +65,51 @@ __global__ __launch_bounds__(PF_BLOCK) void k_scatter_edges(const int32_t* __res
     rw[slot] = wv;
 }
 
+// A rigorous upper bound for the spectrum of the normalised Laplacian of a closed triangle mesh, face by face.
+// If every undirected edge lies in exactly two triangles, W = sum over triangles t of A_t, the triangle's own adjacency
+// with half of each edge weight.  The normalised adjacency of a weighted triangle (weights a, b, c) has eigenvalues 1, mu1,
+// mu2 with mu1 + mu2 = -1 (zero trace) and mu1 mu2 = P := 2abc / ((a+b)(a+c)(b+c)) (the determinants; 0 < P <= 1/4, = 1/4
+// for equal weights), so its smallest one is mu_t = -(1 + sqrt(1 - 4 P)) / 2, and x^T A_t x >= mu_t x^T D_t x.  Summing over
+// the triangles (the D_t add up to D: each edge at a vertex is in two of them): x^T W x >= mu_min x^T D x, i.e.
+//   lambda_max(G^1/2 (D - W) G^1/2) <= 1 - mu_min = 1 + (1 + sqrt(1 - 4 P_min)) / 2
+// against the generic bound 2: 1.69 for the 250k blobs, 1.60 for the bundled 5k mesh (their lambda_max: 1.58, 1.49).  The
+// Chebyshev filter's degree scales with the square root of the interval it has to damp.  P is homogeneous of degree 0: the
+// weights themselves (1 / edge length) serve.  out: bits of min P (positive doubles order like their bit patterns).
+__global__ __launch_bounds__(PF_BLOCK) void k_face_bound(const int32_t* __restrict__ faces, const double* __restrict__ pts,
+                                                         int64_t n_faces, int64_t n, unsigned long long* __restrict__ out) {
+    __shared__ double red[PF_BLOCK / PF_WAVE];
+    const int64_t f = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
+    double p = 0.25;
+    if (f < n_faces) {
+        const int32_t i0 = faces[3 * f], i1 = faces[3 * f + 1], i2 = faces[3 * f + 2];
+        if (i0 >= 0 && i0 < n && i1 >= 0 && i1 < n && i2 >= 0 && i2 < n) {
+            double w[3];
+            const int32_t v[4] = {i0, i1, i2, i0};
+#pragma unroll
+            for (int e = 0; e < 3; ++e) {
+                const double dx = pts[3 * (int64_t)v[e]] - pts[3 * (int64_t)v[e + 1]];
+                const double dy = pts[3 * (int64_t)v[e] + 1] - pts[3 * (int64_t)v[e + 1] + 1];
+                const double dz = pts[3 * (int64_t)v[e] + 2] - pts[3 * (int64_t)v[e + 1] + 2];
+                w[e] = 1.0 / sqrt((dx * dx + dy * dy) + dz * dz);
+            }
+            const double q = 2.0 * w[0] * w[1] * w[2] / ((w[0] + w[1]) * (w[0] + w[2]) * (w[1] + w[2]));
+            p = (q > 0.0 && q < 0.25) ? q : (q >= 0.25 ? 0.25 : 0.0);  // (degenerate or non-finite: no bound from this face)
+        }
+    }
+#pragma unroll
+    for (int off = PF_WAVE / 2; off > 0; off >>= 1) {
+        const double o = __shfl_down(p, off, PF_WAVE);
+        p = o < p ? o : p;
+    }
+    if ((threadIdx.x & (PF_WAVE - 1)) == 0) red[threadIdx.x / PF_WAVE] = p;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double m = red[0];
+        for (int i = 1; i < PF_BLOCK / PF_WAVE; ++i) m = red[i] < m ? red[i] : m;
+        atomicMin(out, (unsigned long long)__double_as_longlong(m));
+    }
+}
+
 // one thread per vertex: insertion-sort its (col, w) segment by column, drop duplicate columns
 // (a directed edge listed by two faces carries the same weight), report the unique count.
 __global__ __launch_bounds__(PF_BLOCK) void k_sort_unique_rows(const int32_t* __restrict__ start, int64_t n,
@@ -365,23 +410,26 @@ __global__ __launch_bounds__(PF_BLOCK) void k_csr_split(const int32_t* __restric
 // [0..5) row statistics, [5] labelling still changing, [6] stored entries (rowptr[n]), [8..16) the caller's flags,
 // [16..16 + PF_ROOTS_AHEAD) the first component roots
 constexpr int PF_ROOTS_AHEAD = 16;
-constexpr int PF_REPORT_INTS = 16 + PF_ROOTS_AHEAD;
+constexpr int PF_REPORT_INTS = 16 + PF_ROOTS_AHEAD + 2;  // (+ the 64 bits of the face bound's P_min)
 __global__ void k_report(const int32_t* __restrict__ stats, const int32_t* __restrict__ last_round, const int32_t* __restrict__ rowptr_n,
-                         const int32_t* __restrict__ extra, const int32_t* __restrict__ roots, int32_t* __restrict__ out) {
+                         const int32_t* __restrict__ extra, const int32_t* __restrict__ roots, const int32_t* __restrict__ pmin_bits,
+                         int32_t* __restrict__ out) {
     const int t = threadIdx.x;
     if (t < 5) out[t] = stats[t];
     if (t == 5) out[5] = *last_round;
     if (t == 6) out[6] = rowptr_n ? *rowptr_n : 0;
     if (t == 7) out[7] = 0;
     if (t >= 8 && t < 16) out[t] = extra ? extra[t - 8] : 0;
-    if (t >= 16 && t < PF_REPORT_INTS) out[t] = roots[t - 16];
+    if (t >= 16 && t < 16 + PF_ROOTS_AHEAD) out[t] = roots[t - 16];
+    if (t >= 16 + PF_ROOTS_AHEAD && t < PF_REPORT_INTS) out[t] = pmin_bits ? pmin_bits[t - 16 - PF_ROOTS_AHEAD] : 0;
 }
 
 // `d_extra` / `h_extra` (8 ints, optional): device flags of the caller that ride in this function's one read-back; when
 // any is set the function returns at once (PF_OK, *extra_hit = true) and the caller reports ITS error.  `nnz_from_rowptr`:
 // g->nnz_w is read back here too (the mesh path sizes col / w by their upper bound instead of waiting for the count).
 int finish_graph(pf_graph* g, const double* d_pts, bool numeric_symmetry, const int32_t* d_extra = nullptr, int32_t* h_extra = nullptr,
-                 bool* extra_hit = nullptr, bool nnz_from_rowptr = false) {
+                 bool* extra_hit = nullptr, bool nnz_from_rowptr = false, const unsigned long long* d_pmin = nullptr,
+                 double* h_pmin = nullptr) {
     hipStream_t st = g->ctx->stream;
     const int64_t n = g->n;
     int32_t *flags = nullptr, *d_roots = nullptr, *round_flags = nullptr;
@@ -441,7 +489,8 @@ int finish_graph(pf_graph* g, const double* d_pts, bool numeric_symmetry, const 
     int32_t* report = nullptr;
     PF_TRY(dev_alloc(st, &report, PF_REPORT_INTS));
     tmp.p.push_back(report);
-    k_report<<<1, PF_WAVE, 0, st>>>(stats, round_flags + PF_CC_FIRST - 1, nnz_from_rowptr ? g->rowptr + n : nullptr, d_extra, d_roots, report);
+    k_report<<<1, PF_WAVE, 0, st>>>(stats, round_flags + PF_CC_FIRST - 1, nnz_from_rowptr ? g->rowptr + n : nullptr, d_extra, d_roots,
+                                    reinterpret_cast<const int32_t*>(d_pmin), report);
     PF_HIP(hipGetLastError());
     void* pin = nullptr;
     const size_t slice_bytes = sizeof(int64_t) * (size_t)(g->n_slices + 1);
@@ -459,6 +508,11 @@ int finish_graph(pf_graph* g, const double* d_pts, bool numeric_symmetry, const 
     if (d_extra)
         for (int i = 0; i < 8; ++i) h_extra[i] = h_report[8 + i];
     for (int i = 0; i < PF_ROOTS_AHEAD; ++i) h_roots[i] = h_report[16 + i];
+    if (d_pmin && h_pmin) {
+        unsigned long long bits = 0;
+        memcpy(&bits, h_report + 16 + PF_ROOTS_AHEAD, sizeof(bits));
+        memcpy(h_pmin, &bits, sizeof(bits));
+    }
     g->sell_entries = g->h_slice_ptr[(size_t)g->n_slices];
     if (nnz_from_rowptr) g->nnz_w = nnz32;
     if (d_extra && extra_hit) {
@@ -695,15 +749,35 @@ int pf_graph_build_device(pf_mesh* mesh, pf_graph** out) {
     PF_TRY(dev_alloc(st, &g->w, n_edges));
     k_compact_rows<<<nblk(n), PF_BLOCK, 0, st>>>(start, g->rowptr, n, rcol, rw, g->col, g->w, g->deg, g->g, g->sg);
     PF_HIP(hipGetLastError());
+    // the face-by-face bound of the spectrum (k_face_bound); it holds if every undirected edge lies in exactly two
+    // triangles: W symmetric and no directed edge listed twice - both known after the read-back
+    unsigned long long* pmin = nullptr;
+    double h_pmin = 0.0;
+    if (vpf == 3 && n_faces > 0) {
+        PF_TRY(scratch(&pmin, 1));
+        const double quarter = 0.25;
+        unsigned long long qbits = 0;
+        memcpy(&qbits, &quarter, sizeof(qbits));
+        PF_HIP(hipMemsetD32Async((hipDeviceptr_t)pmin, (int)(qbits & 0xffffffffu), 1, st));
+        PF_HIP(hipMemsetD32Async((hipDeviceptr_t)(reinterpret_cast<int32_t*>(pmin) + 1), (int)(qbits >> 32), 1, st));
+        k_face_bound<<<nblk(n_faces), PF_BLOCK, 0, st>>>(d_faces, d_pts, n_faces, n, pmin);
+        PF_HIP(hipGetLastError());
+    }
     int32_t h_flags[8] = {0};
     bool flagged = false;
-    PF_TRY(finish_graph(g, d_pts, false, flags, h_flags, &flagged, true));
+    PF_TRY(finish_graph(g, d_pts, false, flags, h_flags, &flagged, true, pmin, &h_pmin));
     PF_CHECK(!(h_flags[0] & 1), PF_E_ARG, "pf_graph_build: face index out of range [0,%lld)", (long long)n);
     PF_CHECK(!(h_flags[0] & 2), PF_E_DEGENERATE, "pf_graph_build: a face repeats a vertex on one edge");
     PF_CHECK(!(h_flags[0] & 4), PF_E_DEGENERATE,
              "pf_graph_build: an edge has zero length or non-finite coordinates (the reference would store an "
              "infinite weight, graph.py:177-178)");
     PF_CHECK(!flagged, PF_E_HIP, "pf_graph_build: unexpected assembly flag");
+    g->spectral_bound = 2.0;
+    if (pmin && g->is_symmetric && g->nnz_w == n_edges && h_pmin > 0.0 && h_pmin <= 0.25) {
+        const double disc = 1.0 - 4.0 * h_pmin;
+        const double b = (1.0 + (1.0 + sqrt(disc > 0.0 ? disc : 0.0)) / 2.0) * (1.0 + 1e-12);
+        g->spectral_bound = b < 2.0 ? b : 2.0;
+    }
     PF_TRY(dev_alloc(st, &g->pts, 3 * n));  // kept for pf_point_rows (the mesh object may go away before the graph)
     PF_HIP(hipMemcpyAsync(g->pts, d_pts, sizeof(double) * 3 * n, hipMemcpyDeviceToDevice, st));
     PF_HIP(hipEventRecord(ctx->ev1, st));
@@ -806,6 +880,7 @@ int pf_graph_get_info(pf_graph* g, pf_graph_info* o) {
     o->n_faces = g->n_faces;
     o->nnz_w = g->nnz_w;
     o->nnz_l = g->nnz_w + (g->n - g->n_isolated);
+    o->spectral_bound = g->spectral_bound;
     o->is_symmetric = g->is_symmetric;
     o->n_isolated = g->n_isolated;
     o->n_components = g->n_components;

@@ -95,7 +95,7 @@ int eigs_smallest_once(pf_graph* g, int32_t n_wanted, int32_t minmax, double* va
                        pf_eigs_stats* stats_out) {
     PF_CHECK(g && vals && vecs && n_out && n_wanted >= 1, PF_E_ARG, "pf_eigs_smallest: bad argument");
     PF_CHECK(g->is_symmetric, PF_E_STATE, "pf_eigs_smallest: W is not symmetric (one-way edges): use the Python driver");
-    const double hi = 2.0, strength = 2.0, tol = 1e-12;
+    const double hi = g->spectral_bound, strength = 2.0, tol = 1e-12;  // (2, or the face-by-face bound of a closed triangle mesh)
     const int64_t n_active = g->n - g->n_isolated;
     pf_eigs_stats st{};
     *n_out = 0;

@@ -432,6 +432,10 @@ def _device_eigs_gen(dev, k, n_k_needed, k_buffer=1, minmax=False, verbose=False
         # many one-way edges (an open mesh: every boundary edge) make L strongly non-normal: go straight to the
         # ellipse filter; a handful (the bundled 15k meshes) are cheaper to carry as outliers of the interval filter
         kw = dict(solver_kw)
+        if dev.symmetric:
+            # the filter damps [cut, hi]: hi = the operator's proven spectral bound (2 in general; ~1.6-1.7 for a closed
+            # triangle mesh, pf_graph_info.spectral_bound) - the degree goes with the square root of the interval
+            kw.setdefault("hi", getattr(dev, "spectral_bound", 2.0))
         if not dev.symmetric and "ellipse" not in kw:
             kw["ellipse"] = True if getattr(dev, "n_oneway", 0) > 32 else None
         lam, first, stats = yield from filtered_eigs_gen(dev, m_out + extra, dev.symmetric, null_slots=c0, nulls_fresh=lock, **kw)

@@ -312,6 +312,48 @@ def test_orth_one_pass_with_second_pass_on_demand(golden, devices):
     np.testing.assert_allclose(dev.download_slots(8, 1)[:, 0], noise / np.linalg.norm(noise), rtol=1e-14)
 
 
+def test_spectral_bound_from_the_faces(golden, hip, ctx):
+    """pf_graph_info.spectral_bound: for a closed triangle mesh (W symmetric, no directed edge listed twice) the
+    face-by-face bound 1 + (1 + sqrt(1 - 4 P_min)) / 2 - equal to the numpy formula, above the true lambda_max of
+    S = G^1/2 (D - W) G^1/2 (scipy), below 2; otherwise 2."""
+    from scipy.sparse.linalg import eigsh
+
+    from pyfocusr_amd.meshgen import blob_mesh
+
+    def formula(points, faces):
+        p = points[faces]
+        w = [1.0 / np.linalg.norm(p[:, i] - p[:, (i + 1) % 3], axis=1) for i in range(3)]
+        P = 2 * w[0] * w[1] * w[2] / ((w[0] + w[1]) * (w[0] + w[2]) * (w[1] + w[2]))
+        return 1 + (1 + np.sqrt(max(1 - 4 * P.min(), 0.0))) / 2
+
+    blob = blob_mesh(12000, seed=4)
+    for name, pts, faces in (("target_mesh", golden("target_mesh")["points"], golden("target_mesh")["faces"]),
+                             ("source_mesh", golden("source_mesh")["points"], golden("source_mesh")["faces"]),
+                             ("blob", blob.points, blob.faces)):
+        dev = hip.DeviceLaplacian(pts, faces, ctx=ctx)
+        assert dev.symmetric and dev.nnz_w == 3 * len(faces), name
+        np.testing.assert_allclose(dev.spectral_bound, formula(pts, faces), rtol=1e-11, err_msg=name)
+        W = orc.weighted_adjacency(pts, faces)
+        deg = np.asarray(W.sum(axis=1)).ravel()
+        s = np.sqrt(1.0 / (deg + 1e-8))
+        S = sparse.diags(s) @ (sparse.diags(deg) - W) @ sparse.diags(s)
+        lam_max = float(eigsh(S.tocsc(), k=1, which="LA", return_eigenvectors=False)[0])
+        assert lam_max < dev.spectral_bound < 1.9, (name, lam_max, dev.spectral_bound)
+        dev.close()
+    # not a closed manifold: one-way edges (bundled 15k meshes), a face listed twice, an open mesh -> the generic bound
+    g15 = golden("target_mesh_15k")
+    dev = hip.DeviceLaplacian(g15["points"], g15["faces"], ctx=ctx)
+    assert not dev.symmetric and dev.spectral_bound == 2.0
+    dev.close()
+    dup = np.concatenate([blob.faces, blob.faces[:1]])
+    dev = hip.DeviceLaplacian(blob.points, dup, ctx=ctx)
+    assert dev.symmetric and dev.nnz_w == 3 * len(blob.faces) and dev.spectral_bound == 2.0
+    dev.close()
+    dev = hip.DeviceLaplacian(blob.points, blob.faces[:-50], ctx=ctx)  # a hole: boundary edges are one-way
+    assert dev.spectral_bound == 2.0
+    dev.close()
+
+
 def test_null_vectors_and_finalize(golden, devices):
     for name in ("target_mesh", "source_mesh_15k"):
         g, dev = golden(name), devices(name)
