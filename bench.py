@@ -437,7 +437,7 @@ def main():
                 # (MI355X_MICROARCH.md, price list, "handoff-1to1": 0.8-1.0 us on an idle chip for <= 4 KB)
                 "handoff_floor_us_per_step": 1.0,
                 "frac_of_handoff_floor": 1.0 / (2e3 * kernel_ms / max(tm["persist_steps"], 1)),
-                "note": "frac is LDS bytes (8 B per gathered x + 16 B per row + 8 B per outside row, counted by the library) "
+                "note": "frac is LDS bytes (8 B per gathered x + 8 B per row + 8 B per outside row, counted by the library) "
                         "against the conflict-free ds_read_b64 peak; random 8-byte gathers conflict ~3-4x, and each step waits "
                         "for one memory-side hand-off (~1 us): the kernel is latency-bound, neither LDS- nor HBM-bandwidth-bound "
                         "(DESIGN.md section 4).  effective_algorithmic_GBps = SURVEY 8d bytes (12 nnz + 20 n + 4 per graph and step, "

@@ -526,9 +526,9 @@ int pf_persist_cheb(const pf_persist_args* a, const pf_persist_args* b, int* don
     for (int q = 0; q < ng; ++q) {
         pf_graph* g = in[q]->g;
         g->persist_phase = (g->persist_phase + in[q]->degree) & 3;
-        // LDS bytes of this launch: per step and row the own x (8) and the result (8), per stored entry the gathered x
-        // (8), per outside row its value written once (8); the entries themselves live in registers
-        if (lds_bytes) *lds_bytes += (double)in[q]->degree * (8.0 * (double)g->sell_entries + 16.0 * (double)g->n_pad + 8.0 * (double)g->px_gh_total);
+        // LDS bytes of this launch: per step and row the result written (8; the row's own x stays in a register), per
+        // stored entry the gathered x (8), per outside row its value written once (8); the entries live in registers
+        if (lds_bytes) *lds_bytes += (double)in[q]->degree * (8.0 * (double)g->sell_entries + 8.0 * (double)g->n_pad + 8.0 * (double)g->px_gh_total);
     }
     *done = 1;
     return PF_OK;
