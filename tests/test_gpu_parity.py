@@ -303,6 +303,18 @@ def test_orth_one_pass_with_second_pass_on_demand(golden, devices):
             np.testing.assert_allclose(got, r * scale, rtol=0, atol=(1e-13 if not expect_redo else 1e-8) * np.linalg.norm(r * scale), err_msg=label)
             if normalize:
                 np.testing.assert_allclose(np.linalg.norm(got), 1.0, rtol=1e-13)
+    # strict mode (pf_orth_strict: unfiltered / small solves): the classical threshold |w'| < 0.71 |w|
+    w = Qb @ np.array([0.8, 0.0, 0.5, 0.0, 0.3, 0.0]) + 0.75 * noise / np.linalg.norm(noise)  # |w'| / |w| ~ 0.6
+    for strict, expect_redo in ((False, False), (True, True), (False, False)):
+        dev.orth_strict(strict)
+        dev.upload(8, w)
+        dev.orth_begin(8, 0, 6, normalize=True)
+        h, nrm = dev.orth_end()
+        assert dev.orth_redone == expect_redo
+        r = w - Qb @ (Qb.T @ w)
+        assert 0.5 < nrm / np.linalg.norm(w) < 0.7
+        np.testing.assert_allclose(nrm, np.linalg.norm(r), rtol=1e-13)
+        np.testing.assert_allclose(dev.download_slots(8, 1)[:, 0], r / np.linalg.norm(r), rtol=0, atol=1e-13)
     # an empty basis: just the norm
     dev.upload(8, noise)
     dev.orth_begin(8, 0, 0, normalize=True)
