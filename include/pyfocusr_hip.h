@@ -236,12 +236,12 @@ int pf_knn1_blocks(pf_ctx* ctx, const double* ref_block, int64_t n_ref, int32_t 
                    int64_t n_qry, int32_t qry_stride, int32_t d, const int32_t* col_ref, const double* scale_ref,
                    const int32_t* col_qry, const double* scale_qry, int64_t* idx_out, double* d2_out);
 /* eigsort's cost matrices (eigsort.py:162-233) from the graphs' device-resident eigenvector blocks and point copies:
- * m <= 8192 sampled rows per graph (rows_t / rows_s, the same count for both), the first k eigenmaps of each as
+ * m_t / m_s <= 16384 sampled rows of the target / source graph (rows_t / rows_s), the first k eigenmaps of each as
  * final[:, col[c]] * sign[c] (the column permutation and sign flips earlier eigsort calls left, identity at first).
- * out[4][k][k] = c_hist, c_hist_f, c_spatial, c_spatial_f (row = target map, column = source map); idx_out[m] = the
+ * out[4][k][k] = c_hist, c_hist_f, c_spatial, c_spatial_f (row = target map, column = source map); idx_out[m_t] = the
  * sampled source point nearest to each sampled target point (min-max normalised xyz, eigsort.py:203-204). */
-int pf_eigsort_costs(pf_graph* g_target, pf_graph* g_source, const int64_t* rows_t, const int64_t* rows_s, int64_t m, int32_t k,
-                     const int32_t* col_t, const double* sign_t, const int32_t* col_s, const double* sign_s, double* out,
+int pf_eigsort_costs(pf_graph* g_target, pf_graph* g_source, const int64_t* rows_t, int64_t m_t, const int64_t* rows_s, int64_t m_s,
+                     int32_t k, const int32_t* col_t, const double* sign_t, const int32_t* col_s, const double* sign_s, double* out,
                      int64_t* idx_out);
 /* Device address and shape of the resident block ([n_rows][n_cols] row-major float64, owned by the graph, valid until
  * the next pf_finalize_vectors on it or pf_graph_free): lets a peer library (RCCL through torch) send it without a

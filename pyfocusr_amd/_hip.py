@@ -91,7 +91,8 @@ SIGNATURES = {
     "pf_orth_begin2": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                  C.c_int32]),
     "pf_orth_cheb2": (C.c_int, [C.c_void_p, C.c_void_p, _i32p, _i32p, _f64p]),
-    "pf_eigsort_costs": (C.c_int, [C.c_void_p, C.c_void_p, _i64p, _i64p, C.c_int64, C.c_int32, _i32p, _f64p, _i32p, _f64p, _f64p, _i64p]),
+    "pf_eigsort_costs": (C.c_int, [C.c_void_p, C.c_void_p, _i64p, C.c_int64, _i64p, C.c_int64, C.c_int32, _i32p, _f64p, _i32p, _f64p, _f64p,
+                                   _i64p]),
     "pf_orth_redone": (C.c_int, [C.c_void_p]),
     "pf_orth_strict": (C.c_int, [C.c_void_p, C.c_int32]),
     "pf_scale": (C.c_int, [C.c_void_p, C.c_int32, C.c_double]),
@@ -303,13 +304,13 @@ class Context(object):
         col_t = np.ascontiguousarray(col_t, dtype=np.int32)
         col_s = np.ascontiguousarray(col_s, dtype=np.int32)
         sign_t, sign_s = _c_f64(sign_t), _c_f64(sign_s)
-        if len(rows_t) != len(rows_s) or min(len(col_t), len(col_s), len(sign_t), len(sign_s)) < k:
-            raise ValueError("eigsort_costs: equal sample counts and k columns / signs per graph are needed")
+        if min(len(col_t), len(col_s), len(sign_t), len(sign_s)) < k:
+            raise ValueError("eigsort_costs: k columns / signs per graph are needed")
         out = np.empty((4, int(k), int(k)), dtype=np.float64)
         idx = np.empty(len(rows_t), dtype=np.int64)
-        _check(self._lib.pf_eigsort_costs(dev_t._h, dev_s._h, rows_t.ctypes.data_as(_i64p), rows_s.ctypes.data_as(_i64p), len(rows_t), int(k),
-                                          col_t.ctypes.data_as(_i32p), _f64(sign_t), col_s.ctypes.data_as(_i32p), _f64(sign_s), _f64(out),
-                                          idx.ctypes.data_as(_i64p)))
+        _check(self._lib.pf_eigsort_costs(dev_t._h, dev_s._h, rows_t.ctypes.data_as(_i64p), len(rows_t), rows_s.ctypes.data_as(_i64p),
+                                          len(rows_s), int(k), col_t.ctypes.data_as(_i32p), _f64(sign_t), col_s.ctypes.data_as(_i32p),
+                                          _f64(sign_s), _f64(out), idx.ctypes.data_as(_i64p)))
         return out, idx
 
     def knn1_blocks(self, ref_ptr, n_ref, ref_stride, qry_ptr, n_qry, qry_stride, col_ref, scale_ref, col_qry, scale_qry,

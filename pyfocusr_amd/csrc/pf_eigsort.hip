@@ -9,9 +9,11 @@
 // the eigensolve left them (the graphs' resident eigenvector blocks and point copies), and what comes back is
 // 4 k^2 numbers and the 1-NN indices.
 //
-//   c_hist[i][j]    = mean_r | sort(log(T_i + 0.5 + eps))[r] - sort(log(+-S_j + 0.5 + eps))[r] |      (eigsort.py:176-187:
-//                     scipy's wasserstein_distance of two equally sized samples IS the mean absolute difference of their
-//                     order statistics; log is monotone, so the raw values are sorted and log(-v + c) read in reverse)
+//   c_hist[i][j]    = W1( log(T_i + 0.5 + eps), log(+-S_j + 0.5 + eps) )      (eigsort.py:176-187, scipy's wasserstein_distance)
+//                     = the area between the two step quantile functions: target order statistic a holds on
+//                     (a/mt, (a+1)/mt], source order statistic b on (b/ms, (b+1)/ms] - every thread takes one a and the few
+//                     b it overlaps, on the integer grid of mt*ms; for mt == ms that is the mean absolute difference of
+//                     the order statistics.  log is monotone: the raw values are sorted, log(-v + c) read in reverse
 //   c_spatial[i][j] = sqrt( sum_r (+-S_j[idx[r]] - T_i[r])^2 ) / m,   idx = 1-NN of target sample point r among the
 //                     source sample points (eigsort.py:203-233)
 // Differences to the host path: the device's log (<= 1 ulp from libm's) and the order of the sums: ~1e-15 relative
@@ -19,6 +21,7 @@
 #include <float.h>
 #include <string.h>
 
+#include <mutex>
 #include <vector>
 
 #include "pf_internal.h"
@@ -30,7 +33,7 @@ extern "C" int pf_knn1_blocks(pf_ctx* c, const double* ref_block, int64_t n_ref,
 namespace {
 
 constexpr int ES_SORT_THREADS = 1024;
-constexpr int ES_MAX_SAMPLES = 8192;  // one column is sorted by one block in LDS
+constexpr int ES_MAX_SAMPLES = 16384;  // one column is sorted by one block in LDS (128 KB at the limit)
 constexpr int ES_RED_THREADS = 256;
 
 inline unsigned es_blocks(int64_t n) { return (unsigned)((n + PF_BLOCK - 1) / PF_BLOCK); }
@@ -86,10 +89,13 @@ __global__ __launch_bounds__(PF_BLOCK) void k_es_normalize(const double* __restr
 // +inf to a power of two), then the logs: lt / ls = log(v + 0.5 + eps) ascending, lsf = log(-v + 0.5 + eps) ascending
 // (= read from the descending end).
 __global__ __launch_bounds__(ES_SORT_THREADS) void k_es_sort_log(const double* __restrict__ vals_t, const double* __restrict__ vals_s,
-                                                                 int64_t m, int32_t k, int32_t n_pow2, double* __restrict__ lt,
+                                                                 int64_t mt, int64_t ms, int32_t k, double* __restrict__ lt,
                                                                  double* __restrict__ ls, double* __restrict__ lsf) {
     extern __shared__ double buf[];
     const int b = blockIdx.x;
+    const int64_t m = b < k ? mt : ms;
+    int n_pow2 = 2;
+    while (n_pow2 < m) n_pow2 <<= 1;
     const double* src = b < k ? vals_t + (int64_t)b * m : vals_s + (int64_t)(b - k) * m;
     for (int i = threadIdx.x; i < n_pow2; i += ES_SORT_THREADS) buf[i] = i < m ? src[i] : INFINITY;
     __syncthreads();
@@ -131,34 +137,42 @@ __device__ __forceinline__ double es_block_sum(double v, double* sh) {
     return r;
 }
 
-// block (i, j): out[0][i][j] = mean |lt_i - ls_j|, out[1][i][j] = mean |lt_i - lsf_j|
+// block (i, j): out[0][i][j] = W1(lt_i, ls_j), out[1][i][j] = W1(lt_i, lsf_j) (sorted samples of mt and ms values): thread
+// -> target order statistic a, which holds on [a ms, (a+1) ms) of the grid of mt*ms; the source statistics b it overlaps
 __global__ __launch_bounds__(ES_RED_THREADS) void k_es_w1(const double* __restrict__ lt, const double* __restrict__ ls,
-                                                          const double* __restrict__ lsf, int64_t m, int32_t k, double* __restrict__ out) {
+                                                          const double* __restrict__ lsf, int64_t mt, int64_t ms, int32_t k,
+                                                          double* __restrict__ out) {
     __shared__ double sh[ES_RED_THREADS];
     const int i = blockIdx.x / k, j = blockIdx.x - i * k;
-    double a = 0.0, f = 0.0;
-    for (int64_t r = threadIdx.x; r < m; r += ES_RED_THREADS) {
-        const double t = lt[(int64_t)i * m + r];
-        a += fabs(t - ls[(int64_t)j * m + r]);
-        f += fabs(t - lsf[(int64_t)j * m + r]);
+    const double unit = 1.0 / ((double)mt * (double)ms);
+    double acc = 0.0, accf = 0.0;
+    for (int64_t a = threadIdx.x; a < mt; a += ES_RED_THREADS) {
+        const double t = lt[(int64_t)i * mt + a];
+        const int64_t lo = a * ms, hi = lo + ms;
+        for (int64_t b = lo / mt; b < ms && b * mt < hi; ++b) {
+            const int64_t from = b * mt > lo ? b * mt : lo, to = (b + 1) * mt < hi ? (b + 1) * mt : hi;
+            const double len = (double)(to - from) * unit;
+            acc += len * fabs(t - ls[(int64_t)j * ms + b]);
+            accf += len * fabs(t - lsf[(int64_t)j * ms + b]);
+        }
     }
-    a = es_block_sum(a, sh);
-    f = es_block_sum(f, sh);
+    acc = es_block_sum(acc, sh);
+    accf = es_block_sum(accf, sh);
     if (threadIdx.x == 0) {
-        out[i * k + j] = a / (double)m;
-        out[k * k + i * k + j] = f / (double)m;
+        out[i * k + j] = acc;
+        out[k * k + i * k + j] = accf;
     }
 }
 
 // block (i, j): out[2][i][j] = sqrt(sum (S_j[idx] - T_i)^2) / m, out[3][i][j] the same with -S_j
 __global__ __launch_bounds__(ES_RED_THREADS) void k_es_spatial(const double* __restrict__ vals_t, const double* __restrict__ vals_s,
-                                                               const int64_t* __restrict__ idx, int64_t m, int32_t k,
+                                                               const int64_t* __restrict__ idx, int64_t m, int64_t ms, int32_t k,
                                                                double* __restrict__ out) {
     __shared__ double sh[ES_RED_THREADS];
     const int i = blockIdx.x / k, j = blockIdx.x - i * k;
     double a = 0.0, f = 0.0;
     for (int64_t r = threadIdx.x; r < m; r += ES_RED_THREADS) {
-        const double t = vals_t[(int64_t)i * m + r], s = vals_s[(int64_t)j * m + idx[r]];
+        const double t = vals_t[(int64_t)i * m + r], s = vals_s[(int64_t)j * ms + idx[r]];
         const double d0 = s - t, d1 = -s - t;
         a += d0 * d0;
         f += d1 * d1;
@@ -173,33 +187,43 @@ __global__ __launch_bounds__(ES_RED_THREADS) void k_es_spatial(const double* __r
 
 }  // namespace
 
-extern "C" int pf_eigsort_costs(pf_graph* gt, pf_graph* gs, const int64_t* rows_t, const int64_t* rows_s, int64_t m, int32_t k,
+extern "C" int pf_eigsort_costs(pf_graph* gt, pf_graph* gs, const int64_t* rows_t, int64_t mt, const int64_t* rows_s, int64_t ms, int32_t k,
                                 const int32_t* col_t, const double* sign_t, const int32_t* col_s, const double* sign_s, double* out,
                                 int64_t* idx_out) {
     PF_CHECK(gt && gs && rows_t && rows_s && col_t && sign_t && col_s && sign_s && out && idx_out, PF_E_ARG,
              "pf_eigsort_costs: NULL argument");
     PF_CHECK(gt->ctx == gs->ctx, PF_E_ARG, "pf_eigsort_costs: the two graphs must share one ctx");
-    PF_CHECK(m >= 1 && m <= ES_MAX_SAMPLES && k >= 1 && k <= 16, PF_E_ARG, "pf_eigsort_costs: %lld samples (1..%d), k = %d (1..16)",
-             (long long)m, ES_MAX_SAMPLES, k);
+    PF_CHECK(mt >= 1 && mt <= ES_MAX_SAMPLES && ms >= 1 && ms <= ES_MAX_SAMPLES && k >= 1 && k <= 16, PF_E_ARG,
+             "pf_eigsort_costs: %lld / %lld samples (1..%d), k = %d (1..16)", (long long)mt, (long long)ms, ES_MAX_SAMPLES, k);
     PF_CHECK(gt->final_vecs && gs->final_vecs, PF_E_STATE, "pf_eigsort_costs: no pf_finalize_vectors result is resident");
     PF_CHECK(gt->pts && gs->pts, PF_E_STATE, "pf_eigsort_costs: the graphs were not built from meshes");
     for (int32_t c = 0; c < k; ++c)
         PF_CHECK(col_t[c] >= 0 && col_t[c] < gt->final_count && col_s[c] >= 0 && col_s[c] < gs->final_count, PF_E_ARG,
                  "pf_eigsort_costs: column out of range");
-    for (int64_t r = 0; r < m; ++r)
-        PF_CHECK(rows_t[r] >= 0 && rows_t[r] < gt->n && rows_s[r] >= 0 && rows_s[r] < gs->n, PF_E_ARG,
-                 "pf_eigsort_costs: sample row out of range");
+    for (int64_t r = 0; r < mt; ++r) PF_CHECK(rows_t[r] >= 0 && rows_t[r] < gt->n, PF_E_ARG, "pf_eigsort_costs: sample row out of range");
+    for (int64_t r = 0; r < ms; ++r) PF_CHECK(rows_s[r] >= 0 && rows_s[r] < gs->n, PF_E_ARG, "pf_eigsort_costs: sample row out of range");
     pf_ctx* c = gt->ctx;
     PF_HIP(hipSetDevice(c->device));
     hipStream_t st = c->stream;
+    int32_t n_pow2 = 2;
+    while (n_pow2 < (mt > ms ? mt : ms)) n_pow2 <<= 1;
+    const size_t sort_lds = sizeof(double) * (size_t)n_pow2;
+    if (sort_lds > 64 * 1024) {
+        static std::once_flag once;
+        static hipError_t attr = hipSuccess;
+        std::call_once(once, [] {
+            attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k_es_sort_log), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)(sizeof(double) * ES_MAX_SAMPLES));
+        });
+        PF_HIP(attr);
+    }
 
     // one host block -> one upload: rows of both graphs, then columns and signs
-    const size_t rows_bytes = sizeof(int64_t) * (size_t)m;
-    const size_t head = 2 * rows_bytes;
+    const size_t head = sizeof(int64_t) * (size_t)(mt + ms);
     const size_t small = ((sizeof(int32_t) * 2 * k + 7) & ~(size_t)7) + sizeof(double) * 2 * k;
     std::vector<unsigned char> host(head + small);
-    memcpy(host.data(), rows_t, rows_bytes);
-    memcpy(host.data() + rows_bytes, rows_s, rows_bytes);
+    memcpy(host.data(), rows_t, sizeof(int64_t) * (size_t)mt);
+    memcpy(host.data() + sizeof(int64_t) * (size_t)mt, rows_s, sizeof(int64_t) * (size_t)ms);
     int32_t* hcol = reinterpret_cast<int32_t*>(host.data() + head);
     double* hsign = reinterpret_cast<double*>(host.data() + head + ((sizeof(int32_t) * 2 * k + 7) & ~(size_t)7));
     for (int32_t i = 0; i < k; ++i) {
@@ -208,9 +232,9 @@ extern "C" int pf_eigsort_costs(pf_graph* gt, pf_graph* gs, const int64_t* rows_
         hsign[i] = sign_t[i];
         hsign[k + i] = sign_s[i];
     }
-    // device scratch: [upload][vals_t k m][vals_s k m][raw_t 3m][raw_s 3m][norm_t 3m][norm_s 3m][lohi 12][lt][ls][lsf][out 4 k k]
-    const size_t km = (size_t)k * (size_t)m;
-    const size_t doubles = 2 * km + 12 * (size_t)m + 12 + 3 * km + 4 * (size_t)k * k;
+    // device scratch: [upload][vals_t k mt][vals_s k ms][raw_t 3 mt][raw_s 3 ms][norm_t][norm_s][lohi 12][lt k mt][ls k ms][lsf k ms][out 4 k k]
+    const size_t kt = (size_t)k * (size_t)mt, ks = (size_t)k * (size_t)ms;
+    const size_t doubles = 2 * kt + 3 * ks + 6 * (size_t)(mt + ms) + 12 + 4 * (size_t)k * k;
     unsigned char* d = nullptr;
     PF_HIP(pf_malloc(st, (void**)&d, host.size() + sizeof(double) * doubles));
     int rc = PF_OK;
@@ -223,41 +247,39 @@ extern "C" int pf_eigsort_costs(pf_graph* gt, pf_graph* gs, const int64_t* rows_
         };
         if (fail(hipMemcpyAsync(d, host.data(), host.size(), hipMemcpyHostToDevice, st))) break;
         const int64_t* d_rows_t = reinterpret_cast<const int64_t*>(d);
-        const int64_t* d_rows_s = d_rows_t + m;
+        const int64_t* d_rows_s = d_rows_t + mt;
         const int32_t* d_col = reinterpret_cast<const int32_t*>(d + head);
         const double* d_sign = reinterpret_cast<const double*>(d + head + ((sizeof(int32_t) * 2 * k + 7) & ~(size_t)7));
         double* base = reinterpret_cast<double*>(d + host.size());
         double* vals_t = base;
-        double* vals_s = vals_t + km;
-        double* raw_t = vals_s + km;
-        double* raw_s = raw_t + 3 * m;
-        double* norm_t = raw_s + 3 * m;
-        double* norm_s = norm_t + 3 * m;
-        double* lohi = norm_s + 3 * m;
+        double* vals_s = vals_t + kt;
+        double* raw_t = vals_s + ks;
+        double* raw_s = raw_t + 3 * mt;
+        double* norm_t = raw_s + 3 * ms;
+        double* norm_s = norm_t + 3 * mt;
+        double* lohi = norm_s + 3 * ms;
         double* lt = lohi + 12;
-        double* ls = lt + km;
-        double* lsf = ls + km;
-        double* d_out = lsf + km;
-        k_es_gather<<<es_blocks(m * (k + 3)), PF_BLOCK, 0, st>>>(gt->final_vecs, gt->final_count, gt->pts, d_rows_t, m, k, d_col, d_sign, vals_t,
-                                                                 raw_t);
-        k_es_gather<<<es_blocks(m * (k + 3)), PF_BLOCK, 0, st>>>(gs->final_vecs, gs->final_count, gs->pts, d_rows_s, m, k, d_col + k, d_sign + k,
-                                                                 vals_s, raw_s);
-        k_es_minmax<<<3, ES_RED_THREADS, 0, st>>>(raw_t, m, lohi);
-        k_es_minmax<<<3, ES_RED_THREADS, 0, st>>>(raw_s, m, lohi + 6);
-        k_es_normalize<<<es_blocks(3 * m), PF_BLOCK, 0, st>>>(raw_t, lohi, m, norm_t);
-        k_es_normalize<<<es_blocks(3 * m), PF_BLOCK, 0, st>>>(raw_s, lohi + 6, m, norm_s);
-        int32_t n_pow2 = 2;
-        while (n_pow2 < m) n_pow2 <<= 1;
-        k_es_sort_log<<<(unsigned)(2 * k), ES_SORT_THREADS, sizeof(double) * (size_t)n_pow2, st>>>(vals_t, vals_s, m, k, n_pow2, lt, ls, lsf);
-        k_es_w1<<<(unsigned)(k * k), ES_RED_THREADS, 0, st>>>(lt, ls, lsf, m, k, d_out);
+        double* ls = lt + kt;
+        double* lsf = ls + ks;
+        double* d_out = lsf + ks;
+        k_es_gather<<<es_blocks(mt * (k + 3)), PF_BLOCK, 0, st>>>(gt->final_vecs, gt->final_count, gt->pts, d_rows_t, mt, k, d_col, d_sign,
+                                                                  vals_t, raw_t);
+        k_es_gather<<<es_blocks(ms * (k + 3)), PF_BLOCK, 0, st>>>(gs->final_vecs, gs->final_count, gs->pts, d_rows_s, ms, k, d_col + k,
+                                                                  d_sign + k, vals_s, raw_s);
+        k_es_minmax<<<3, ES_RED_THREADS, 0, st>>>(raw_t, mt, lohi);
+        k_es_minmax<<<3, ES_RED_THREADS, 0, st>>>(raw_s, ms, lohi + 6);
+        k_es_normalize<<<es_blocks(3 * mt), PF_BLOCK, 0, st>>>(raw_t, lohi, mt, norm_t);
+        k_es_normalize<<<es_blocks(3 * ms), PF_BLOCK, 0, st>>>(raw_s, lohi + 6, ms, norm_s);
+        k_es_sort_log<<<(unsigned)(2 * k), ES_SORT_THREADS, sort_lds, st>>>(vals_t, vals_s, mt, ms, k, lt, ls, lsf);
+        k_es_w1<<<(unsigned)(k * k), ES_RED_THREADS, 0, st>>>(lt, ls, lsf, mt, ms, k, d_out);
         if (fail(hipGetLastError())) break;
         // the 3-D 1-NN of every target sample point among the source sample points (eigsort.py:203-204); its
         // synchronisation also covers everything queued above
         const int32_t cols3[3] = {0, 1, 2};
         const double ones3[3] = {1.0, 1.0, 1.0};
-        rc = pf_knn1_blocks(c, norm_s, m, 3, norm_t, m, 3, 3, cols3, ones3, cols3, ones3, idx_out, nullptr);
+        rc = pf_knn1_blocks(c, norm_s, ms, 3, norm_t, mt, 3, 3, cols3, ones3, cols3, ones3, idx_out, nullptr);
         if (rc != PF_OK) break;
-        k_es_spatial<<<(unsigned)(k * k), ES_RED_THREADS, 0, st>>>(vals_t, vals_s, c->knn_idx, m, k, d_out);
+        k_es_spatial<<<(unsigned)(k * k), ES_RED_THREADS, 0, st>>>(vals_t, vals_s, c->knn_idx, mt, ms, k, d_out);
         if (fail(hipGetLastError())) break;
         if (fail(hipMemcpyAsync(out, d_out, sizeof(double) * 4 * (size_t)k * k, hipMemcpyDeviceToHost, st))) break;
         if (fail(hipStreamSynchronize(st))) break;

@@ -12,6 +12,8 @@ costs, 2k^2 one-dimensional Wasserstein distances (sorts of m values; scipy, as
 in the reference), the Hungarian assignment on a k x k matrix — and stays on the
 host, as SURVEY.md §7 plans.
 """
+import functools
+
 import numpy as np
 from scipy.optimize import linear_sum_assignment
 
@@ -19,6 +21,7 @@ from . import _hip
 from .main import print_header
 
 
+@functools.lru_cache(maxsize=8)
 def _w1_quantile_plan(n, m):
     """W1 between two empirical distributions = integral over t in (0, 1) of |F_u^-1(t) - F_v^-1(t)| (the area between
     the CDFs, which scipy integrates along x, equals the area between the quantile functions).  Both quantile functions
@@ -74,7 +77,7 @@ class eigsort(object):
     def _device_costs(self):
         """c_hist, c_hist_f, c_spatial, c_spatial_f and the spatial 1-NN indices from `pf_eigsort_costs`, or None when the
         host path has to run: samples already in hand or assigned from outside, a graph without its device-resident
-        block / points / an up-to-date column map, different contexts, unequal or too large samples."""
+        block / points / an up-to-date column map, different contexts, samples of more than 16384 rows."""
         if self._device_result is not None:
             return self._device_result
         if self._samples:
@@ -87,7 +90,7 @@ class eigsort(object):
                 return None
             devs.append(dev)
         rt, rs = self.graph_target.rand_idxs, self.graph_source.rand_idxs
-        if devs[0].ctx is not devs[1].ctx or len(rt) != len(rs) or not 1 <= len(rt) <= 8192 or self.n_features > 16:
+        if devs[0].ctx is not devs[1].ctx or not (1 <= len(rt) <= 16384 and 1 <= len(rs) <= 16384) or self.n_features > 16:
             return None
         from .graph import device_block_is_current
 
@@ -197,9 +200,13 @@ class eigsort(object):
             return
         eps = np.finfo(float).eps
         k = self.n_features
-        log_t = [np.sort(np.log(self.rand_target_eig_vecs[:, i] + 0.5 + eps)) for i in range(k)]
-        log_s = [np.sort(np.log(self.rand_source_eig_vecs[:, j] + 0.5 + eps)) for j in range(k)]
-        log_sf = [np.sort(np.log(-self.rand_source_eig_vecs[:, j] + 0.5 + eps)) for j in range(k)]
+        # log is monotone: the raw columns are sorted (2k sorts instead of 3k), log(v + c) of the ascending values is
+        # ascending, and log(-v + c) ascending is the same read from the descending end - the same multisets of values
+        raw_t = [np.sort(self.rand_target_eig_vecs[:, i]) for i in range(k)]
+        raw_s = [np.sort(self.rand_source_eig_vecs[:, j]) for j in range(k)]
+        log_t = [np.log(c + 0.5 + eps) for c in raw_t]
+        log_s = [np.log(c + 0.5 + eps) for c in raw_s]
+        log_sf = [np.log(-c[::-1] + 0.5 + eps) for c in raw_s]
         n_t, n_s = self.rand_target_eig_vecs.shape[0], self.rand_source_eig_vecs.shape[0]
         if n_t != n_s:
             # samples of different size (both meshes sampled completely: 14 998 vs 14 996 vertices): the quantile form,

@@ -792,7 +792,11 @@ def test_eigsort_and_correspondence_from_golden_eigs(golden, ctx, pair, t, s, k,
 
 
 @pytest.mark.parametrize("names,k,ns", [(("target_mesh", "source_mesh"), 5, 1500), (("target_mesh_15k", "source_mesh_15k"), 4, 5000),
-                                         (("target_mesh", "source_mesh"), 3, 4096)])
+                                         (("target_mesh", "source_mesh"), 3, 4096),
+                                         # every vertex sampled: different counts per mesh (W1 on the merged breakpoints),
+                                         # and more than 8192 rows (the LDS sort beyond 64 KB)
+                                         (("target_mesh", "source_mesh"), 4, 10**9), (("target_mesh_15k", "source_mesh_15k"), 5, 10**9),
+                                         (("target_mesh_15k", "source_mesh"), 3, 10**9)])
 def test_eigsort_costs_on_device(golden, ctx, names, k, ns):
     """`pf_eigsort_costs` (c_hist, c_hist_f, c_spatial, c_spatial_f and the spatial 1-NN on the device, from the graphs'
     resident eigenvector blocks) against the host path of the same class, which the reference-generated goldens pin
