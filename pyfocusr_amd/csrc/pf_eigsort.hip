@@ -21,7 +21,6 @@
 #include <float.h>
 #include <string.h>
 
-#include <mutex>
 #include <vector>
 
 #include "pf_internal.h"
@@ -208,15 +207,9 @@ extern "C" int pf_eigsort_costs(pf_graph* gt, pf_graph* gs, const int64_t* rows_
     int32_t n_pow2 = 2;
     while (n_pow2 < (mt > ms ? mt : ms)) n_pow2 <<= 1;
     const size_t sort_lds = sizeof(double) * (size_t)n_pow2;
-    if (sort_lds > 64 * 1024) {
-        static std::once_flag once;
-        static hipError_t attr = hipSuccess;
-        std::call_once(once, [] {
-            attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k_es_sort_log), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)(sizeof(double) * ES_MAX_SAMPLES));
-        });
-        PF_HIP(attr);
-    }
+    if (sort_lds > 64 * 1024)  // (per device: set whenever it is needed, a host-side call of microseconds)
+        PF_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_es_sort_log), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)(sizeof(double) * ES_MAX_SAMPLES)));
 
     // one host block -> one upload: rows of both graphs, then columns and signs
     const size_t head = sizeof(int64_t) * (size_t)(mt + ms);
