@@ -150,6 +150,23 @@ int pf_spmv_multi(pf_graph* g, int32_t op, int32_t src_first, int32_t dst_first,
  * off for the process.  One ctx per process uses the path at a time (the first to get there, until it is destroyed);
  * other ctxs run one step per launch. */
 int pf_persist_enable(int on);
+/* Level 1 by default: single-graph recurrences (pf_cheb) on graphs with windows of 1024 rows (up to ~262k rows) whose
+ * windows see each other symmetrically (any symmetric W) exchange boundary values every SECOND step: a window repeats
+ * the odd steps of the outside rows it reads itself (k_cheb_resident2: one memory-side hand-off per two steps; 250k
+ * rows: 1.41 -> 1.24 us per step).  Level 2: paired recurrences (pf_cheb2) as well - measured slower than one step
+ * per exchange there (2.08 against 1.85 us per step of a 250k pair), kept for the record.  0: one step per exchange
+ * everywhere.  Bit-identical results at every level.  Environment: PF_PERSIST_S2=0/1/2; process-wide. */
+int pf_persist_two_step(int level);
+/* What the resident path is doing, for callers that want to know whether they are on the fast path. */
+typedef struct pf_persist_info {
+    int32_t enabled;           /* 1: filter applications use the resident kernels where a graph allows it             */
+    int32_t two_step;          /* the pf_persist_two_step level: 0, 1 (single-graph recurrences) or 2 (pairs too)      */
+    int32_t owner;             /* 1: `ctx` owns the path, 0: no ctx has used it yet, -1: another ctx of the process  */
+    int32_t timeouts;          /* waits that ran out since the process started (each reported as PF_E_PERSIST_TIMEOUT) */
+    int64_t launches;          /* resident launches of this process                                                   */
+    int64_t launches_two_step; /* ... of them with two steps per exchange                                             */
+} pf_persist_info;
+int pf_persist_state(pf_ctx* ctx /* nullable */, pf_persist_info* out);
 /* Test hook: the next n resident launches start with their abort flag raised (they give up at once and the
  * PF_E_PERSIST_TIMEOUT recovery runs).  Never needed in production. */
 int pf_persist_test_hook(int n_launches);

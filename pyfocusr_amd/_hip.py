@@ -80,6 +80,8 @@ SIGNATURES = {
     "pf_spmv": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
     "pf_spmv_multi": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "pf_persist_enable": (C.c_int, [C.c_int]),
+    "pf_persist_two_step": (C.c_int, [C.c_int]),
+    "pf_persist_state": (C.c_int, [C.c_void_p, C.c_void_p]),
     "pf_persist_test_hook": (C.c_int, [C.c_int]),
     "pf_cheb": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double]),
     "pf_cheb2": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double,
@@ -187,6 +189,25 @@ def persist_enable(on=True):
     """Process-wide switch of the resident Chebyshev kernel (operator in registers, x in LDS, one kernel per filter
     application; on by default, see csrc/pf_persist.hip).  Results are bit-identical either way."""
     _check(load_library().pf_persist_enable(int(bool(on))))
+
+
+def persist_two_step(level=1):
+    """Process-wide level of the two-steps-per-exchange form of the resident kernel (csrc/pf_persist.hip:
+    k_cheb_resident2): 0 off, 1 single-graph recurrences (default), 2 paired recurrences too.  Results are
+    bit-identical at every level."""
+    _check(load_library().pf_persist_two_step(int(level)))
+
+
+class _PersistInfo(C.Structure):
+    _fields_ = [("enabled", C.c_int32), ("two_step", C.c_int32), ("owner", C.c_int32), ("timeouts", C.c_int32),
+                ("launches", C.c_int64), ("launches_two_step", C.c_int64)]
+
+
+def persist_state(ctx=None):
+    """pf_persist_state as a dict: is the resident path on, who owns it, how many waits ran out, launch counters."""
+    info = _PersistInfo()
+    _check(load_library().pf_persist_state(None if ctx is None else ctx._h, C.byref(info)))
+    return {name: int(getattr(info, name)) for name, _ in _PersistInfo._fields_}
 
 
 def persist_test_hook(n_launches=1):

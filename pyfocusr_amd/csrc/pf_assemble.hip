@@ -578,6 +578,7 @@ void pf_graph_free(pf_graph* g) {
     hipSetDevice(g->ctx->device);
     hipStream_t st = g->ctx->stream;
     pf_free(st, g->persist_ring);
+    pf_free(st, g->persist_ring2);
     pf_free(st, g->final_vecs);
     pf_free(st, g->pts);
     pf_window_slots_free(g);

@@ -41,6 +41,8 @@ constexpr int PF_MAX_ROOTS = 4096; // components tracked explicitly
 constexpr int PF_WIN_THREADS = 1024; // threads of a window block of the resident Chebyshev kernel (pf_persist.hip)
 constexpr int PF_WIN_GHOSTS = 1024;  // outside rows a window may read (one per thread)
 constexpr int PF_WIN_MAX = 1024;     // windows per graph the window structures cover
+constexpr int PF_WIN_G1 = 512;       // ring-1 rows of a window whose recurrence the window repeats itself (k_cheb_resident2)
+constexpr int PF_WIN_GW = 16;        // entries per such row
 constexpr int PF_WS_TMPS = 4;      // temporaries behind the workspace slots (Chebyshev rotation)
 
 struct pf_ctx {
@@ -149,6 +151,21 @@ struct pf_graph {
     double* persist_ring = nullptr;  // [4][n_pad] hand-off buffers of the windows' boundary rows (sentinel when empty)
     int32_t persist_phase = 0;       // ring slot of step k of the next launch = (k + phase) & 3
     uint64_t persist_epoch = 0;      // ring known good for this value of the library's abort epoch
+    // two recurrence steps per exchange (k_cheb_resident2; windows of 1024 rows, symmetric neighbourhoods): a window
+    // also keeps the rows its ring-1 rows read (ring 2: px_gh_row continues with them behind ring 1) and the ring-1
+    // rows' own entries, computes the odd steps of ring 1 itself and exchanges every second step only
+    int32_t px2_state = -1;          // -1 not tried, 0 not covered, 1 ready
+    int32_t* px_gh_cnt2 = nullptr;   // [windows] rows of ring 2
+    int32_t* px_need2 = nullptr;     // [windows] leading rows some other window holds in ring 1 or 2
+    uint8_t* px_g1_w = nullptr;      // [windows][PF_WIN_G1] slice width of each ring-1 row
+    int32_t* px_g1_pos = nullptr;    // [windows][PF_WIN_GW][PF_WIN_G1] SELL index of its entries
+    uint16_t* px_g1_slot = nullptr;  // same shape: window-local slot of the entry's column (own | ring 1 | ring 2)
+    int32_t* px_g1_gw = nullptr;     // [windows] widest ring-1 row
+    std::vector<int32_t> h_px_gh_cnt2, h_px_g1_gw;
+    int64_t px_gh2_total = 0, px_g1_entries = 0;  // sums over the windows: ring-2 rows, entries of ring-1 rows
+    double* persist_ring2 = nullptr; // [4][n_pad] hand-off buffers of k_cheb_resident2 (slot of ROUND r = (r + phase2) & 3)
+    int32_t persist_phase2 = 0;
+    uint64_t persist_epoch2 = 0;
     int32_t is_symmetric = 0, n_isolated = 0, n_components = 0, max_degree = 0, n_oneway = 0;
     int32_t unit_g = 0;  // graph handed in as a matrix (pf_graph_from_matrix): G = I, the operator is the matrix itself
     std::vector<int32_t> roots; // roots of components with >= 2 vertices, ascending
@@ -233,4 +250,5 @@ int pf_persist_set(int on);
 void pf_persist_release(pf_ctx* ctx);  // pf_destroy: another ctx may take the resident path over
 // pf_windows.hip
 int pf_window_slots_prepare(pf_graph* g);  // px_* of the graph (see pf_graph)
+int pf_window_rings_prepare(pf_graph* g);  // the second-ring structures on top of them (px2_state)
 void pf_window_slots_free(pf_graph* g);

@@ -58,6 +58,8 @@ std::atomic<pf_ctx*> g_owner{nullptr};
 std::atomic<int> g_persist{-1};            // -1 undecided (environment PF_PERSIST=0 disables), 0 off, 1 on
 std::atomic<uint64_t> g_abort_epoch{1};    // bumped when a launch aborted: every graph's ring is refilled before reuse
 std::atomic<int> g_test_aborts{0};         // pf_persist_test_hook: launches that start with the abort flag raised
+std::atomic<int64_t> g_launches{0}, g_launches2{0};  // resident launches of this process (all; two steps per exchange)
+std::atomic<int> g_timeouts{0};            // waits that ran out
 
 constexpr int RX_THREADS = PF_WIN_THREADS;
 constexpr unsigned long long RX_EMPTY = 0xFFFFDEADFFFFDEADull;  // quiet NaN with a payload arithmetic never produces
@@ -351,6 +353,397 @@ __global__ __launch_bounds__(RX_THREADS) void k_cheb_resident(RxArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Two recurrence steps per exchange (k_cheb_resident2).
+//
+// A step of k_cheb_resident is bound by one memory-side hand-off (store lands ~0.5 us, load returns ~0.4 us) that the
+// interior rows cover only in part.  Here a window also keeps its RING 1 - the outside rows its own rows read - as
+// rows it computes itself (their entries and slots in LDS, pf_windows.hip: k_win_rings), and RING 2, the rows those
+// read.  A round = two steps:
+//   phase A  y_{2r-1} on the own rows AND on ring 1, from buffer 0 (own | ring 1 | ring 2 of y_{2r-2}) into buffer 1
+//   phase B  y_{2r} on the own rows, from buffer 1 (own | ring 1) into buffer 0; the leading rows that some other window
+//            holds in either ring are published (boundary rows and the rows behind them come first in a window,
+//            pf_reorder.hip), the interior rows are computed while they travel, then rings 1 and 2 of y_{2r} are fetched.
+// One hand-off per TWO steps, for ~20 % more rows in phase A.  A ring-1 row is computed from its owner's entries in its
+// owner's order (padding included): the same bits as the owner's.  The protocol of the hand-off is k_cheb_resident's,
+// with rounds in place of steps: the ring slot of round r is (r + phase) & 3, a window empties its slot of round r-2 in
+// round r, and a launch of R rounds (R = ceil(degree / 2); the last one publishes nothing) leaves exactly the slot of
+// round R-1 filled, which is "round 3" of the next launch at phase' = (phase + R) & 3.  Needs "A holds rows of B <=> B
+// holds rows of A" for both rings (k_win_rings_check; true whenever W is symmetric).  Own ring buffers: the set of
+// published rows differs from k_cheb_resident's, and the two kernels may alternate on one graph.
+struct Rx2Graph {
+    const int64_t* slice_ptr;
+    const int32_t* slot;      // [sell_entries] slots of the own rows' entries (own | ring 1)
+    const int32_t* gh_cnt;    // [windows] rows of ring 1
+    const int32_t* gh_cnt2;   // [windows] rows of ring 2
+    const int32_t* gh_row;    // [windows][PF_WIN_GHOSTS] ring 1, then ring 2
+    const int32_t* need2;     // [windows] leading rows other windows hold in a ring
+    const uint8_t* g1_w;      // [windows][PF_WIN_G1]
+    const int32_t* g1_pos;    // [windows][PF_WIN_GW][PF_WIN_G1]
+    const uint16_t* g1_slot;  // same shape
+    const int32_t* g1_gw;     // [windows]
+    const double* sval;
+    const double* diag;
+    const double* src;
+    double* dst;
+    double* ring;             // [4][n_pad]
+    int64_t n_pad;
+    int32_t n_windows;
+    int32_t degree;
+    int32_t phase;
+    double a1, a2, shift, beta;
+};
+
+struct Rx2Args {
+    Rx2Graph g[2];
+    uint32_t* abort_flag;
+    int32_t* host_abort;
+};
+
+#ifndef RX2_JR_PAIR
+#define RX2_JR_PAIR 8  // entries of a row kept in registers when a thread holds a row of each of two graphs
+#endif
+#define RX2_JR(ng) ((ng) == 2 ? RX2_JR_PAIR : 8)
+#ifndef RX2_GB
+#define RX2_GB 4  // entries of a ring-1 row whose LDS reads are in flight together
+#endif
+#ifndef RX2_HOLD1
+#define RX2_HOLD1 16  // one graph: first poll of a round held back by this many x 64 cycles
+#endif
+#ifndef RX2_HOLD2
+#define RX2_HOLD2 8   // two graphs: the same for the lower half's waves (they have just published; the upper half's arrive late anyway)
+#endif
+
+template <int NG>
+__global__ __launch_bounds__(RX_THREADS) void k_cheb_resident2(Rx2Args a) {
+#pragma clang fp contract(off)
+    constexpr int JR = RX2_JR(NG), RB = RX_THREADS, NW = 1;
+    constexpr int PH = RX_THREADS / NG;  // threads that look after one graph's outside rows (NG == 2: the halves of the block)
+    extern __shared__ __align__(16) unsigned char lds[];
+    __shared__ int s_state;
+    const unsigned G = gridDim.x, per_xcd = G >> 3;
+    const unsigned xcd = blockIdx.x & 7u;
+    const int32_t win = (int32_t)(xcd * per_xcd + (blockIdx.x >> 3));
+    const int tid = threadIdx.x;
+    const int lane = tid & (PF_WAVE - 1);
+    const int wave = tid >> 6;
+    const int qg = NG == 2 ? (tid >= PH ? 1 : 0) : 0;  // (wave-uniform) the graph whose outside rows this thread serves
+    const int lt = tid - qg * PH;
+
+    bool have[NG];
+    int32_t g1n[NG], gall[NG], need_r[NG], gwid[NG], g1p[NG], o0[NG], o1[NG];
+    int64_t row0[NG];
+    double *gval[NG], *gdiag[NG];
+    uint4* gslot8[NG];
+    unsigned short* gslotx[NG];
+    int32_t* glist[NG];
+    double v[NG][JR];
+    unsigned slp[NG][JR / 2];
+    double dg[NG], xc[NG];
+    int32_t width[NG], ovoff[NG];
+    int64_t sbase[NG];
+
+    int32_t* ovtab = reinterpret_cast<int32_t*>(lds);
+    size_t off = rx_table_bytes<NG, NW>();
+#pragma unroll
+    for (int q = 0; q < NG; ++q) {
+        const Rx2Graph& g = a.g[q];
+        have[q] = win < g.n_windows;
+        const int32_t wq = have[q] ? win : 0;
+        g1n[q] = have[q] ? g.gh_cnt[wq] : 0;
+        gall[q] = g1n[q] + (have[q] ? g.gh_cnt2[wq] : 0);
+        need_r[q] = have[q] ? ((g.need2[wq] + PF_WAVE - 1) & ~(PF_WAVE - 1)) : 0;
+        gwid[q] = have[q] ? g.g1_gw[wq] : 0;
+        g1p[q] = (g1n[q] + PF_WAVE - 1) & ~(PF_WAVE - 1);
+        row0[q] = (int64_t)wq * RB;
+        o0[q] = (int32_t)off;  // buffer 0: own | ring 1 | ring 2
+        off += have[q] ? (size_t)(RB + ((gall[q] + 1) & ~1)) * sizeof(double) : 0;
+        o1[q] = (int32_t)off;  // buffer 1: own | ring 1
+        off += have[q] ? (size_t)(RB + ((g1n[q] + 1) & ~1)) * sizeof(double) : 0;
+        gslot8[q] = reinterpret_cast<uint4*>(lds + off);  // (16-byte aligned: everything before it is a multiple of 16)
+        off += (size_t)g1p[q] * sizeof(uint4);
+        gval[q] = reinterpret_cast<double*>(lds + off);
+        off += (size_t)gwid[q] * g1p[q] * sizeof(double);
+        gdiag[q] = reinterpret_cast<double*>(lds + off);
+        off += (size_t)g1p[q] * sizeof(double);
+        glist[q] = reinterpret_cast<int32_t*>(lds + off);
+        off += (size_t)((gall[q] + 3) & ~3) * sizeof(int32_t);
+        gslotx[q] = reinterpret_cast<unsigned short*>(lds + off);
+        off += (size_t)(gwid[q] > 8 ? gwid[q] - 8 : 0) * g1p[q] * sizeof(unsigned short);
+        const int64_t row = row0[q] + tid;
+        const int64_t s = row >> 6;
+        sbase[q] = g.slice_ptr[s];
+        width[q] = __builtin_amdgcn_readfirstlane(have[q] ? (int32_t)((g.slice_ptr[s + 1] - sbase[q]) >> 6) : 0);
+        dg[q] = have[q] ? g.diag[row] : 0.0;
+        if (lane == 0) ovtab[q * 16 + wave] = width[q] > JR ? (width[q] - JR) * PF_WAVE : 0;
+    }
+    if (tid == 0) s_state = (int)__hip_atomic_load(a.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (tid == 0) {
+        int32_t run = 0;
+        for (int i = 0; i < NG * 16; ++i) {
+            const int32_t c = ovtab[i];
+            ovtab[i] = run;
+            run += c;
+        }
+        ovtab[NG * 16] = run;
+    }
+    __syncthreads();
+    if (s_state != 0) {
+        if (tid == 0) *a.host_abort = 1;
+        return;
+    }
+    double* ov_val = reinterpret_cast<double*>(lds + off);
+    unsigned short* ov_slot = reinterpret_cast<unsigned short*>(lds + off + (size_t)ovtab[NG * 16] * sizeof(double));
+
+    // ---- own rows: entries into registers (beyond JR per row: LDS), y_0 into buffer 0
+#pragma unroll
+    for (int q = 0; q < NG; ++q) {
+        const Rx2Graph& g = a.g[q];
+        const int32_t wd = width[q];
+        const int32_t pairs = wd >> 1;
+        const int64_t base = sbase[q];
+        ovoff[q] = __builtin_amdgcn_readfirstlane(ovtab[q * 16 + wave]);
+#pragma unroll
+        for (int p = 0; p < JR / 2; ++p) {
+            double2 vv = make_double2(0.0, 0.0);
+            int2 ss = make_int2(0, 0);
+            if (p < pairs) {
+                vv = *reinterpret_cast<const double2*>(g.sval + base + (int64_t)p * (2 * PF_WAVE) + 2 * lane);
+                ss = *reinterpret_cast<const int2*>(g.slot + base + (int64_t)p * (2 * PF_WAVE) + 2 * lane);
+            }
+            v[q][2 * p] = vv.x;
+            v[q][2 * p + 1] = vv.y;
+            slp[q][p] = (unsigned)ss.x | ((unsigned)ss.y << 16);
+        }
+        if (wd & 1) {
+            const int64_t idx = base + (int64_t)pairs * (2 * PF_WAVE) + lane;
+            const double tv = g.sval[idx];
+            const unsigned ts = (unsigned)g.slot[idx];
+            if (wd - 1 < JR) {
+#pragma unroll
+                for (int p = 0; p < JR / 2; ++p)
+                    if (2 * p == wd - 1) {
+                        v[q][2 * p] = tv;
+                        slp[q][p] = ts;
+                    }
+            } else {
+                const int32_t o = ovoff[q] + (wd - 1 - JR) * PF_WAVE + lane;
+                ov_val[o] = tv;
+                ov_slot[o] = (unsigned short)ts;
+            }
+        }
+        for (int p = JR / 2; p < pairs; ++p) {
+            const int64_t idx = base + (int64_t)p * (2 * PF_WAVE) + 2 * lane;
+            const double2 vv = *reinterpret_cast<const double2*>(g.sval + idx);
+            const int2 ss = *reinterpret_cast<const int2*>(g.slot + idx);
+            const int32_t o = ovoff[q] + (2 * p - JR) * PF_WAVE + lane;
+            ov_val[o] = vv.x;
+            ov_slot[o] = (unsigned short)ss.x;
+            ov_val[o + PF_WAVE] = vv.y;
+            ov_slot[o + PF_WAVE] = (unsigned short)ss.y;
+        }
+        xc[q] = have[q] ? g.src[row0[q] + tid] : 0.0;
+        if (have[q]) reinterpret_cast<double*>(lds + o0[q])[tid] = xc[q];
+    }
+    // ---- outside rows this thread serves: it fetches rows lt and lt + PH of graph qg's list and repeats the recurrence of
+    // ring-1 row lt.  That row's entries live in LDS (values entry-major, the first eight slots as one 16-byte record),
+    // as do its diagonal and the list; its two latest values are the row's places in the two buffers.
+    int32_t gwi = 0;
+    bool gf0 = false, gf1 = false, grow = false;
+#pragma unroll
+    for (int q = 0; q < NG; ++q) {
+        if (qg != q || !have[q]) continue;  // (wave-uniform)
+        const Rx2Graph& g = a.g[q];
+        double* b0 = reinterpret_cast<double*>(lds + o0[q]);
+        const int64_t lbase = (int64_t)win * PF_WIN_GHOSTS;
+        gf0 = lt < gall[q];
+        gf1 = lt + PH < gall[q];
+        grow = lt < g1n[q];
+        if (gf0) {
+            const int32_t r0 = g.gh_row[lbase + lt];
+            glist[q][lt] = r0;
+            b0[RB + lt] = g.src[r0];
+            if (grow) {
+                gwi = g.g1_w[(int64_t)win * PF_WIN_G1 + lt];
+                gdiag[q][lt] = g.diag[r0];
+                unsigned sl[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) sl[j] = 0u;
+                for (int32_t j = 0; j < gwi; ++j) {
+                    const int64_t o = ((int64_t)win * PF_WIN_GW + j) * PF_WIN_G1 + lt;
+                    gval[q][j * g1p[q] + lt] = g.sval[g.g1_pos[o]];
+                    const unsigned sj = g.g1_slot[o];
+                    if (j >= 8) gslotx[q][(j - 8) * g1p[q] + lt] = (unsigned short)sj;
+#pragma unroll
+                    for (int jj = 0; jj < 8; ++jj)
+                        if (jj == j) sl[jj] = sj;
+                }
+                gslot8[q][lt] = make_uint4(sl[0] | (sl[1] << 16), sl[2] | (sl[3] << 16), sl[4] | (sl[5] << 16), sl[6] | (sl[7] << 16));
+            }
+        }
+        if (gf1) {
+            const int32_t r1 = g.gh_row[lbase + lt + PH];
+            glist[q][lt + PH] = r1;
+            b0[RB + lt + PH] = g.src[r1];
+        }
+    }
+    __syncthreads();
+
+    int32_t n_steps = a.g[0].degree;
+    if (NG > 1 && a.g[1].degree > n_steps) n_steps = a.g[1].degree;
+    const int32_t rounds = (n_steps + 1) >> 1;
+    int32_t need_max = need_r[0];
+    if (NG > 1 && need_r[1] > need_max) need_max = need_r[1];
+    const bool early = (tid & ~(PF_WAVE - 1)) < need_max;
+
+    // one step of this thread's row of graph q: gathers from the buffer at LDS offset xo, y_{k-2} is what the target
+    // buffer still holds at the row's place.  (The buffer's address is hidden from the optimiser once per phase: with two
+    // fixed buffers it would keep both sets of gather addresses in registers across the loop and spill the entries.)
+    auto own_step = [&](int q, int32_t xo_in, int32_t yo_in, bool first) -> double {
+        const Rx2Graph& g = a.g[q];
+        int32_t xo = xo_in, yo = yo_in;
+        asm volatile("" : "+s"(xo), "+s"(yo));
+        const double* x = reinterpret_cast<const double*>(lds + xo);
+        double* y = reinterpret_cast<double*>(lds + yo);
+        const int32_t wd = width[q];
+        const double xi = xc[q];
+        const double prev = y[tid];
+        double acc = rx_row_dispatch<JR>(wd < JR ? wd : JR, x, dg[q], xi, v[q], slp[q]);
+        for (int j = JR; j < wd; ++j) {
+            const int32_t o = ovoff[q] + (j - JR) * PF_WAVE + lane;
+            acc = __builtin_fma(ov_val[o], x[ov_slot[o]], acc);
+        }
+        const double u = __builtin_fma(g.shift, xi, -acc);
+        double res;
+        if (first) {
+            res = g.a1 * u;
+        } else {
+            const double wp = g.beta * prev;
+            res = __builtin_fma(g.a2, u, -wp);
+        }
+        xc[q] = res;
+        y[tid] = res;
+        return res;
+    };
+
+    for (int32_t r = 1; r <= rounds; ++r) {
+        const int32_t kA = 2 * r - 1, kB = 2 * r;
+        // ---- phase A: step kA of ring 1 and of the own rows, buffer 0 -> buffer 1.  The ring-1 rows come first: their reads
+        // are two dependent LDS round trips (slots, then x), which the waves without such rows cover with their own rows
+#pragma unroll
+        for (int q = 0; q < NG; ++q) {
+            const Rx2Graph& g = a.g[q];
+            if (qg != q || !have[q] || kA >= g.degree) continue;  // (wave-uniform) ring 1 only if a phase B follows
+            if (grow) {
+                int32_t xo = o0[q], yo = o1[q];
+                asm volatile("" : "+s"(xo), "+s"(yo));
+                const double* x = reinterpret_cast<const double*>(lds + xo);
+                double* y = reinterpret_cast<double*>(lds + yo);
+                int32_t ld = g1p[q];
+                asm volatile("" : "+s"(ld));  // (entry addresses formed here, not kept in registers across the rounds)
+                const double* gv = gval[q] + lt;
+                const uint4 gsl = gslot8[q][lt];
+                const double gx = x[RB + lt];
+                const double gprev = y[RB + lt];
+                const unsigned sw[4] = {gsl.x, gsl.y, gsl.z, gsl.w};
+                double acc = gdiag[q][lt] * gx;
+#pragma unroll
+                for (int h = 0; h < 8; h += RX2_GB) {  // RX2_GB entries' reads in flight together (unused places read slot 0 / entry 0)
+                    double xs[RX2_GB], vs[RX2_GB];
+#pragma unroll
+                    for (int j = 0; j < RX2_GB; ++j) {
+                        xs[j] = x[((h + j) & 1) ? (sw[(h + j) >> 1] >> 16) : (sw[(h + j) >> 1] & 0xffffu)];
+                        vs[j] = gv[(h + j < gwi ? h + j : 0) * ld];
+                    }
+#pragma unroll
+                    for (int j = 0; j < RX2_GB; ++j)
+                        if (h + j < gwi) acc = __builtin_fma(vs[j], xs[j], acc);
+                }
+                for (int32_t j = 8; j < gwi; ++j) acc = __builtin_fma(gv[j * ld], x[gslotx[q][(j - 8) * ld + lt]], acc);
+                const double u = __builtin_fma(g.shift, gx, -acc);
+                double res;
+                if (kA == 1) {
+                    res = g.a1 * u;
+                } else {
+                    const double wp = g.beta * gprev;
+                    res = __builtin_fma(g.a2, u, -wp);
+                }
+                y[RB + lt] = res;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < NG; ++q) {
+            const Rx2Graph& g = a.g[q];
+            if (!have[q] || kA > g.degree) continue;  // (block-uniform)
+            const double res = own_step(q, o0[q], o1[q], kA == 1);
+            if (kA == g.degree) {  // an odd degree ends here
+                (g.dst + row0[q])[tid] = res;
+                if (tid < need_r[q])
+                    __hip_atomic_store(reinterpret_cast<unsigned long long*>(g.ring) + ((int64_t)((r + 2 + g.phase) & 3) * g.n_pad + row0[q]) + tid,
+                                       RX_EMPTY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        __syncthreads();
+        // ---- phase B: step kB of the own rows, buffer 1 -> buffer 0; leading rows published first
+        if (early) __builtin_amdgcn_s_setprio(3);
+#pragma unroll
+        for (int q = 0; q < NG; ++q) {
+            const Rx2Graph& g = a.g[q];
+            if (!have[q] || kB > g.degree) continue;  // (block-uniform)
+            const double res = own_step(q, o1[q], o0[q], false);
+            if (kB == g.degree) (g.dst + row0[q])[tid] = res;
+            if (tid < need_r[q]) {  // (wave-uniform)
+                unsigned long long* ring = reinterpret_cast<unsigned long long*>(g.ring) + row0[q];  // (uniform bases + the thread's index)
+                if (kB < g.degree)
+                    __hip_atomic_store(ring + (int64_t)((r + g.phase) & 3) * g.n_pad + tid, (unsigned long long)__double_as_longlong(res),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(ring + (int64_t)((r + 2 + g.phase) & 3) * g.n_pad + tid, RX_EMPTY, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        if (early) __builtin_amdgcn_s_setprio(0);
+        if (r == rounds) break;
+        // ---- rings 1 and 2 of step kB, straight from their owners' stores (two per thread in flight)
+#pragma unroll
+        for (int q = 0; q < NG; ++q) {
+            const Rx2Graph& g = a.g[q];
+            if (qg != q || !have[q] || kB >= g.degree) continue;  // (wave-uniform)
+            if (gf0) {
+                if (q == 0 && (NG == 1 ? RX2_HOLD1 : RX2_HOLD2) > 0) __builtin_amdgcn_s_sleep(NG == 1 ? RX2_HOLD1 : RX2_HOLD2);
+                const unsigned long long* p0 = reinterpret_cast<const unsigned long long*>(g.ring) + (int64_t)((r + g.phase) & 3) * g.n_pad;
+                const int32_t ghr0 = glist[q][lt];
+                const unsigned long long* p1 = p0 + (gf1 ? glist[q][lt + PH] : ghr0);
+                p0 += ghr0;
+                unsigned long long v0 = __hip_atomic_load(p0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                unsigned long long v1 = __hip_atomic_load(p1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                unsigned spins = 0;
+                while (v0 == RX_EMPTY || v1 == RX_EMPTY) {
+                    ++spins;
+                    if (spins > RX_SPIN_LIMIT ||
+                        ((spins & 63u) == 0u && __hip_atomic_load(a.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+                        __hip_atomic_store(a.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        s_state = 1;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                    if (v0 == RX_EMPTY) v0 = __hip_atomic_load(p0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (v1 == RX_EMPTY) v1 = __hip_atomic_load(p1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                double* b0 = reinterpret_cast<double*>(lds + o0[q]);
+                b0[RB + lt] = __longlong_as_double((long long)v0);
+                if (gf1) b0[RB + lt + PH] = __longlong_as_double((long long)v1);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (s_state != 0) {
+            if (tid == 0) *a.host_abort = 1;
+            return;
+        }
+    }
+}
+
 bool persist_enabled() {
     int v = g_persist.load();
     if (v < 0) {
@@ -395,9 +788,159 @@ int device_grid(int device) {
                 return;
             }
         }
+        for (int ng = 1; ng <= 2; ++ng) {
+            const void* fn = ng == 1 ? reinterpret_cast<const void*>(k_cheb_resident2<1>) : reinterpret_cast<const void*>(k_cheb_resident2<2>);
+            int per_cu = 0;
+            if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RX_LDS_LIMIT) != hipSuccess ||
+                hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, RX_THREADS, RX_LDS_LIMIT) != hipSuccess || per_cu < 1) {
+                (void)hipGetLastError();
+                return;
+            }
+        }
         f.grid = std::min(prop.multiProcessorCount, 256) & ~7;  // one block per CU, a multiple of the 8 XCDs
     });
     return f.grid;
+}
+
+// -1 undecided (environment PF_PERSIST_S2 = 0 / 1 / 2), 0 off, 1 single-graph launches (default), 2 paired launches too.
+// Measured on MI355X at 250k rows (profiles/r03_two_step_ablation.md): one graph 1.41 -> 1.24 us per step; a pair 1.85 ->
+// 2.08: with two graphs per block the step is bound by LDS issue and vector ALU work, not by the hand-off, and the
+// repeated ring-1 rows (20 LDS reads each against 10 of an own row) cost more than the saved hand-off.
+std::atomic<int> g_two_step{-1};
+int two_step_level() {
+    int v = g_two_step.load();
+    if (v < 0) {
+        const char* e = getenv("PF_PERSIST_S2");
+        v = e ? (e[0] == '0' ? 0 : (e[0] == '2' ? 2 : 1)) : 1;
+        g_two_step.store(v);
+    }
+    return v;
+}
+bool two_step_enabled() { return two_step_level() >= 1; }
+
+// LDS bytes of the fullest window of k_cheb_resident2 (layout as in the kernel); -1 if the graph(s) cannot use it
+int64_t lds_need2(pf_graph* ga, pf_graph* gb) {
+    const int jr = RX2_JR(gb ? 2 : 1);
+    pf_graph* gs[2] = {ga, gb};
+    const int ng = gb ? 2 : 1;
+    const int64_t RB = RX_THREADS;
+    const int64_t ph = RX_THREADS / ng;
+    const int64_t wa = ga->n_pad / RB, wb = gb ? gb->n_pad / RB : 0;
+    int64_t worst = 0;
+    for (int64_t w = 0; w < std::max(wa, wb); ++w) {
+        int64_t need = ((ng * 16 + 1) * 4 + 15) & ~15, ov = 0;
+        for (int q = 0; q < ng; ++q) {
+            pf_graph* g = gs[q];
+            if (g->px2_state != 1 || g->win_rows != RB || g->h_slice_ptr.empty() || (int64_t)g->h_px_gh_cnt.size() * RB != g->n_pad) return -1;
+            if (w >= g->n_pad / RB) continue;
+            const int64_t g1 = g->h_px_gh_cnt[(size_t)w], g2 = g->h_px_gh_cnt2[(size_t)w], gw = g->h_px_g1_gw[(size_t)w];
+            if (g1 > ph || g1 + g2 > 2 * ph) return -1;  // a thread repeats one ring-1 row and fetches two outside rows
+            const int64_t g1p = (g1 + PF_WAVE - 1) & ~(int64_t)(PF_WAVE - 1);
+            need += (RB + ((g1 + g2 + 1) & ~1)) * 8 + (RB + ((g1 + 1) & ~1)) * 8 + g1p * 16 + gw * g1p * 8 + g1p * 8 +
+                    ((g1 + g2 + 3) & ~3) * 4 + (gw > 8 ? gw - 8 : 0) * g1p * 2;
+            for (int64_t s = w * (RB / PF_WAVE); s < (w + 1) * (RB / PF_WAVE); ++s) {
+                const int64_t width = (g->h_slice_ptr[(size_t)s + 1] - g->h_slice_ptr[(size_t)s]) / PF_WAVE;
+                if (width > jr) ov += (width - jr) * PF_WAVE;
+            }
+        }
+        need += ov * 10 + 16;
+        worst = std::max(worst, need);
+    }
+    return worst;
+}
+
+// two steps per exchange, if both graphs and the sizes allow it: *done = 1 when launched
+int persist_cheb2(const pf_persist_args* a, const pf_persist_args* b, int64_t grid, int* done, double* lds_bytes) {
+    *done = 0;
+    pf_graph* ga = a->g;
+    pf_graph* gb = b ? b->g : nullptr;
+    pf_ctx* ctx = ga->ctx;
+    if (two_step_level() < (gb ? 2 : 1) || ga->win_rows != RX_THREADS) return PF_OK;
+    PF_TRY(pf_window_rings_prepare(ga));
+    if (gb) PF_TRY(pf_window_rings_prepare(gb));
+    if (ga->px2_state != 1 || (gb && gb->px2_state != 1)) return PF_OK;
+    const int64_t need = lds_need2(ga, gb);
+    if (need < 0 || (size_t)need > RX_LDS_LIMIT) return PF_OK;
+    {
+        pf_ctx* expected = nullptr;
+        if (!g_owner.compare_exchange_strong(expected, ctx) && expected != ctx) return PF_OK;
+    }
+    hipStream_t st = ctx->stream;
+    if (!ctx->persist_sync) {
+        PF_HIP(pf_malloc(st, (void**)&ctx->persist_sync, sizeof(uint32_t) * 32));
+        PF_HIP(hipMemsetAsync(ctx->persist_sync, 0, sizeof(uint32_t) * 32, st));
+        PF_HIP(hipHostMalloc((void**)&ctx->persist_abort, sizeof(int32_t), hipHostMallocDefault));
+        *ctx->persist_abort = 0;
+    }
+    const uint64_t epoch = g_abort_epoch.load();
+    const pf_persist_args* in[2] = {a, b};
+    const int ng = gb ? 2 : 1;
+    Rx2Args args{};
+    for (int q = 0; q < ng; ++q) {
+        pf_graph* g = in[q]->g;
+        if (!g->persist_ring2) {
+            PF_HIP(pf_malloc(st, (void**)&g->persist_ring2, sizeof(double) * 4 * (size_t)g->n_pad));
+            g->persist_epoch2 = 0;
+        }
+        if (g->persist_epoch2 != epoch) {
+            PF_HIP(hipMemsetD32Async((hipDeviceptr_t)g->persist_ring2, (int)RX_EMPTY32, (size_t)8 * (size_t)g->n_pad, st));
+            g->persist_epoch2 = epoch;
+            g->persist_phase2 = 0;
+        }
+        Rx2Graph& p = args.g[q];
+        p.slice_ptr = g->slice_ptr;
+        p.slot = g->px_slot;
+        p.gh_cnt = g->px_gh_cnt;
+        p.gh_cnt2 = g->px_gh_cnt2;
+        p.gh_row = g->px_gh_row;
+        p.need2 = g->px_need2;
+        p.g1_w = g->px_g1_w;
+        p.g1_pos = g->px_g1_pos;
+        p.g1_slot = g->px_g1_slot;
+        p.g1_gw = g->px_g1_gw;
+        p.sval = in[q]->vals;
+        p.diag = g->diag;
+        p.src = in[q]->src;
+        p.dst = in[q]->dst;
+        p.ring = g->persist_ring2;
+        p.n_pad = g->n_pad;
+        p.n_windows = (int32_t)(g->n_pad / g->win_rows);
+        p.degree = in[q]->degree;
+        p.phase = g->persist_phase2;
+        p.a1 = 1.0 / (in[q]->e * in[q]->rho);
+        p.a2 = 2.0 / (in[q]->e * in[q]->rho);
+        p.shift = in[q]->c;
+        p.beta = 1.0 / (in[q]->rho * in[q]->rho);
+    }
+    args.abort_flag = ctx->persist_sync;
+    args.host_abort = ctx->persist_abort;
+    if (g_test_aborts.load() > 0) {
+        g_test_aborts.fetch_sub(1);
+        PF_HIP(hipMemsetAsync(ctx->persist_sync, 1, sizeof(uint32_t), st));
+    }
+    if (ng == 2) k_cheb_resident2<2><<<dim3((unsigned)grid), dim3(RX_THREADS), (size_t)need, st>>>(args);
+    else k_cheb_resident2<1><<<dim3((unsigned)grid), dim3(RX_THREADS), (size_t)need, st>>>(args);
+    const hipError_t err = hipGetLastError();
+    if (err != hipSuccess) {
+        g_two_step.store(0);  // one step per exchange from now on
+        (void)hipGetLastError();
+        return PF_OK;
+    }
+    g_launches.fetch_add(1);
+    g_launches2.fetch_add(1);
+    for (int q = 0; q < ng; ++q) {
+        pf_graph* g = in[q]->g;
+        const int32_t d = in[q]->degree, rounds = (d + 1) / 2;
+        g->persist_phase2 = (g->persist_phase2 + rounds) & 3;
+        // LDS bytes: per step and own row the gathered x (8 per stored entry) and the result (8); per round the ring-1 rows'
+        // entries (value 8 + slot 2 + gathered x 8 each) and results (8), and the fetched rows of both rings (8)
+        if (lds_bytes)
+            *lds_bytes += (double)d * (8.0 * (double)g->sell_entries + 8.0 * (double)g->n_pad) +
+                          (double)(d / 2) * (18.0 * (double)g->px_g1_entries + 8.0 * (double)g->px_gh_total) +
+                          (double)((d - 1) / 2) * 8.0 * (double)(g->px_gh_total + g->px_gh2_total);
+    }
+    *done = 1;
+    return PF_OK;
 }
 
 // LDS bytes of the fullest window (layout as in k_cheb_resident); -1 if the graph(s) cannot use the kernel
@@ -435,6 +978,24 @@ int pf_persist_set(int on) {
 
 extern "C" int pf_persist_enable(int on) { return pf_persist_set(on); }
 
+// 1: two recurrence steps per exchange where a graph allows it (default), 0: one (k_cheb_resident)
+extern "C" int pf_persist_two_step(int level) {
+    g_two_step.store(level <= 0 ? 0 : (level >= 2 ? 2 : 1));
+    return PF_OK;
+}
+
+extern "C" int pf_persist_state(pf_ctx* ctx, pf_persist_info* out) {
+    PF_CHECK(out != nullptr, PF_E_ARG, "pf_persist_state: NULL argument");
+    pf_ctx* owner = g_owner.load();
+    out->enabled = persist_enabled() ? 1 : 0;
+    out->two_step = two_step_level();
+    out->owner = owner == nullptr ? 0 : (owner == ctx ? 1 : -1);
+    out->timeouts = g_timeouts.load();
+    out->launches = g_launches.load();
+    out->launches_two_step = g_launches2.load();
+    return PF_OK;
+}
+
 extern "C" int pf_persist_test_hook(int n_launches) {
     g_test_aborts.store(n_launches > 0 ? n_launches : 0);
     return PF_OK;
@@ -460,6 +1021,10 @@ int pf_persist_cheb(const pf_persist_args* a, const pf_persist_args* b, int* don
     const int64_t wa = ga->n_pad / ga->win_rows, wb = gb ? gb->n_pad / gb->win_rows : 0;
     const int64_t grid = (std::max(wa, wb) + 7) & ~(int64_t)7;
     if (grid > dev_grid) return PF_OK;
+    if (nw == 1) {
+        PF_TRY(persist_cheb2(a, b, grid, done, lds_bytes));
+        if (*done) return PF_OK;
+    }
     PF_TRY(pf_window_slots_prepare(ga));
     if (gb) PF_TRY(pf_window_slots_prepare(gb));
     if (ga->px_state != 1 || (gb && gb->px_state != 1)) return PF_OK;
@@ -523,6 +1088,7 @@ int pf_persist_cheb(const pf_persist_args* a, const pf_persist_args* b, int* don
         (void)hipGetLastError();
         return PF_OK;
     }
+    g_launches.fetch_add(1);
     for (int q = 0; q < ng; ++q) {
         pf_graph* g = in[q]->g;
         g->persist_phase = (g->persist_phase + in[q]->degree) & 3;
@@ -552,6 +1118,7 @@ int pf_persist_check(pf_ctx* ctx) {
         (void)hipGetLastError();
         g_persist.store(0);
         g_abort_epoch.fetch_add(1);
+        g_timeouts.fetch_add(1);
         PF_CHECK(false, PF_E_PERSIST_TIMEOUT,
                  "resident Chebyshev kernel: a wait for a neighbouring window ran out (device shared with another tenant?); "
                  "the filter applications since the last synchronisation are invalid, the stream is drained and the "

@@ -9,7 +9,7 @@
 //      that are close on the surface become close in index, a wave's 64 rows gather from a
 //      handful of lines;
 //   2. inside windows of g->win_rows (1024, 2048 or 4096) consecutive rows, a stable sort by
-//      (boundary first, descending degree): the 64 rows of a SELL slice then share one width and the
+//      (boundary rows first, then the rows one hop behind them, then descending degree): the 64 rows of a SELL slice then share one width and the
 //      padding disappears; and the rows of a window that other windows touch - or that touch other
 //      windows - are its FIRST rows, so that the resident Chebyshev kernel (pf_persist.hip), whose
 //      blocks own one window each, can compute and publish exactly those rows first and do the
@@ -126,7 +126,28 @@ __global__ __launch_bounds__(PF_BLOCK) void k_boundary_flags(const int32_t* __re
     if (mine) flag[r] = 1u;
 }
 
-// second key: window of win_rows Morton-consecutive rows, then boundary rows first, then descending degree
+// flag 2 for the positions one hop behind the boundary rows (rows a boundary row reads, or that read one): with two
+// recurrence steps per exchange (k_cheb_resident2) another window needs those as well, and a window publishes its leading
+// rows.  Only a sort heuristic: what is really published is derived from the windows' lists (pf_windows.hip).
+__global__ __launch_bounds__(PF_BLOCK) void k_second_ring_flags(const int32_t* __restrict__ order, const int32_t* __restrict__ rowptr,
+                                                                const int32_t* __restrict__ col, const int32_t* __restrict__ pos,
+                                                                int64_t n, unsigned* __restrict__ flag) {
+    const int64_t r = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
+    if (r >= n) return;
+    const int32_t old = order[r];
+    const bool boundary = flag[r] == 1u;
+    bool near = false;
+    for (int32_t a = rowptr[old]; a < rowptr[old + 1]; ++a) {
+        const int32_t rj = pos[col[a]];
+        const unsigned f = flag[rj];  // (0 may turn into 2 meanwhile; 1 never changes in this kernel)
+        if (boundary && f == 0u) flag[rj] = 2u;
+        near |= f == 1u;
+    }
+    if (!boundary && near) flag[r] = 2u;
+}
+
+// second key: window of win_rows Morton-consecutive rows, then boundary rows first, then the rows next to them, then
+// descending degree
 __global__ __launch_bounds__(PF_BLOCK) void k_degree_keys(const int32_t* __restrict__ order, const int32_t* __restrict__ rowptr,
                                                           const unsigned* __restrict__ flag, int64_t n, int32_t win_rows,
                                                           unsigned* __restrict__ keys) {
@@ -135,7 +156,8 @@ __global__ __launch_bounds__(PF_BLOCK) void k_degree_keys(const int32_t* __restr
     const int32_t old = order[r];
     int32_t d = rowptr[old + 1] - rowptr[old];
     d = d > 1023 ? 1023 : d;
-    keys[r] = ((unsigned)(r / win_rows) << 11) | (flag[r] ? 0u : 1024u) | (unsigned)(1023 - d);
+    const unsigned f = flag[r];
+    keys[r] = ((unsigned)(r / win_rows) << 12) | ((f == 1u ? 0u : (f == 2u ? 1u : 2u)) << 10) | (unsigned)(1023 - d);
 }
 
 // The second sort is local: the key's high bits are the window, and the rows already stand in window order (Morton
@@ -148,7 +170,7 @@ __global__ __launch_bounds__(1024) void k_sort_windows(const unsigned* __restric
     const int64_t r0 = (int64_t)blockIdx.x * win_rows;
     for (int i = threadIdx.x; i < n_pow2; i += 1024) {
         const int64_t r = r0 + i;
-        wbuf[i] = (i < win_rows && r < n) ? (((unsigned long long)(keys[r] & 2047u) << 32) | (unsigned)i) : ~0ull;
+        wbuf[i] = (i < win_rows && r < n) ? (((unsigned long long)(keys[r] & 4095u) << 32) | (unsigned)i) : ~0ull;
     }
     __syncthreads();
     for (int size = 2; size <= n_pow2; size <<= 1) {
@@ -245,7 +267,7 @@ int pf_compute_order(pf_graph* g, const double* d_pts) {
         if (fail(hipcub::DeviceRadixSort::SortPairs(nullptr, need, k0, k1, v0, v1, in, 0, 30, st))) break;
         tmp_bytes = need;
         const int32_t win_rows = g->win_rows;
-        int bits2 = 11;
+        int bits2 = 12;
         for (int64_t w = (n + win_rows - 1) / win_rows; w > 0; w >>= 1) ++bits2;
         if (fail(hipcub::DeviceRadixSort::SortPairs(nullptr, need, k0, k1, v0, v1, in, 0, bits2, st))) break;
         tmp_bytes = need > tmp_bytes ? need : tmp_bytes;
@@ -256,6 +278,7 @@ int pf_compute_order(pf_graph* g, const double* d_pts) {
         k_scatter_pos<<<nblk(n), PF_BLOCK, 0, st>>>(v1, n, v0);
         if (fail(hipMemsetAsync(k1, 0, sizeof(unsigned) * n, st))) break;
         k_boundary_flags<<<nblk(n), PF_BLOCK, 0, st>>>(v1, g->rowptr, g->col, v0, n, win_rows, k1);
+        k_second_ring_flags<<<nblk(n), PF_BLOCK, 0, st>>>(v1, g->rowptr, g->col, v0, n, k1);
         k_degree_keys<<<nblk(n), PF_BLOCK, 0, st>>>(v1, g->rowptr, k1, n, win_rows, k0);
         if (fail(hipGetLastError())) break;
         if (win_rows <= 4096) {

@@ -178,6 +178,186 @@ __global__ __launch_bounds__(PF_WIN_THREADS) void k_win_build(const int64_t* __r
     }
 }
 
+
+// ---- second ring (k_cheb_resident2: two recurrence steps per exchange)
+//
+// pass 3: one block per window A.  Ring 1 = the sorted outside rows A's own rows read (k_win_build).  Ring 2 = the rows
+// those read that are neither A's nor ring 1: sorted, appended to the window's list.  For every ring-1 row: the SELL
+// indices of its entries (padding included: the same operations in the same order as its owner's) and their
+// window-local slots (own row | win_rows + index in ring 1 | win_rows + |ring 1| + index in ring 2).  Which of a
+// window's leading rows some other window holds in either ring (need2), and who holds rows of whom (adj2).
+__global__ __launch_bounds__(PF_WIN_THREADS) void k_win_rings(const int64_t* __restrict__ slice_ptr, const int32_t* __restrict__ scol,
+                                                              int32_t win_rows, int32_t n_windows, const int32_t* __restrict__ gh_cnt,
+                                                              int32_t* __restrict__ gh_row, int32_t* __restrict__ gh_cnt2,
+                                                              int32_t* __restrict__ need2, uint32_t* __restrict__ adj2,
+                                                              uint8_t* __restrict__ g1_w, int32_t* __restrict__ g1_pos,
+                                                              uint16_t* __restrict__ g1_slot, int32_t* __restrict__ g1_gw,
+                                                              unsigned long long* __restrict__ totals, int32_t* __restrict__ flags) {
+    __shared__ int32_t ring1[PF_WIN_G1];
+    __shared__ int32_t cand[WB_CAP];
+    __shared__ int32_t ring2[PF_WIN_GHOSTS];
+    __shared__ uint32_t l_adj[WB_ADJ_WORDS];
+    __shared__ int32_t l_need[PF_WIN_MAX];
+    __shared__ int32_t cnt, hcount, wmax, entries;
+    const int tid = threadIdx.x;
+    const int lane = tid & (PF_WAVE - 1);
+    const int32_t A = (int32_t)blockIdx.x;
+    const int64_t r0 = (int64_t)A * win_rows;
+    const int32_t g1 = gh_cnt[A];
+    if (g1 > PF_WIN_G1) {  // block-uniform
+        if (tid == 0) atomicOr(flags, 1);
+        return;
+    }
+    if (tid == 0) cnt = 0, hcount = 0, wmax = 0, entries = 0;
+    for (int i = tid; i < g1; i += PF_WIN_THREADS) ring1[i] = gh_row[(int64_t)A * PF_WIN_GHOSTS + i];
+    for (int k = tid; k < WB_CAP; k += PF_WIN_THREADS) cand[k] = INT_MAX;
+    for (int i = tid; i < WB_ADJ_WORDS; i += PF_WIN_THREADS) l_adj[i] = 0u;
+    for (int i = tid; i < PF_WIN_MAX; i += PF_WIN_THREADS) l_need[i] = 0;
+    __syncthreads();
+    auto in_ring1 = [&](int32_t c, int* where) {
+        int lo = 0, hi = g1;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (ring1[mid] < c) lo = mid + 1;
+            else hi = mid;
+        }
+        *where = lo;
+        return lo < g1 && ring1[lo] == c;
+    };
+    for (int i = tid; i < g1; i += PF_WIN_THREADS) {
+        const int32_t row = ring1[i];
+        const int64_t s = row >> 6;
+        const int64_t base = slice_ptr[s];
+        const int32_t width = (int32_t)((slice_ptr[s + 1] - base) >> 6);
+        for (int32_t j = 0; j < width; ++j) {
+            const int32_t c = scol[pf_sell_index(base, width, j, row & (PF_WAVE - 1))];
+            int where;
+            if ((c < r0 || c >= r0 + win_rows) && !in_ring1(c, &where)) {
+                const int p = atomicAdd(&cnt, 1);
+                if (p < WB_CAP) cand[p] = c;
+            }
+        }
+        atomicMax(&wmax, width);
+        atomicAdd(&entries, width);
+    }
+    __syncthreads();
+    if (cnt > WB_CAP || wmax > PF_WIN_GW) {  // block-uniform
+        if (tid == 0) atomicOr(flags, 1);
+        return;
+    }
+    int cap = 64;
+    while (cap < cnt) cap <<= 1;
+    for (int k = 2; k <= cap; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < cap; i += PF_WIN_THREADS) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const int32_t a = cand[i], b = cand[ixj];
+                    const bool up = (i & k) == 0;
+                    if ((a > b) == up) {
+                        cand[i] = b;
+                        cand[ixj] = a;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    {
+        __shared__ int wave_tot[PF_WIN_THREADS / PF_WAVE];
+        __shared__ int running;
+        if (tid == 0) running = 0;
+        __syncthreads();
+        for (int base = 0; base < cap; base += PF_WIN_THREADS) {
+            const int i = base + tid;
+            const int32_t c = i < cap ? cand[i] : INT_MAX;
+            const bool fresh = c != INT_MAX && (i == 0 || cand[i - 1] != c);
+            const unsigned long long m = __ballot(fresh);
+            const int before = __popcll(m & ((1ull << lane) - 1ull));
+            if (lane == 0) wave_tot[tid / PF_WAVE] = __popcll(m);
+            __syncthreads();
+            int off = running;
+            for (int w = 0; w < tid / PF_WAVE; ++w) off += wave_tot[w];
+            if (fresh && off + before < PF_WIN_GHOSTS) ring2[off + before] = c;
+            __syncthreads();
+            if (tid == 0) {
+                int t = running;
+                for (int w = 0; w < PF_WIN_THREADS / PF_WAVE; ++w) t += wave_tot[w];
+                running = t;
+            }
+            __syncthreads();
+        }
+        if (tid == 0) hcount = running;
+    }
+    __syncthreads();
+    const int h = hcount;
+    if (g1 + h > PF_WIN_GHOSTS) {
+        if (tid == 0) atomicOr(flags, 1);
+        return;
+    }
+    if (tid == 0) {
+        gh_cnt2[A] = h;
+        g1_gw[A] = wmax;
+        atomicAdd(totals, (unsigned long long)h);
+        atomicAdd(totals + 1, (unsigned long long)entries);
+    }
+    for (int i = tid; i < h; i += PF_WIN_THREADS) gh_row[(int64_t)A * PF_WIN_GHOSTS + g1 + i] = ring2[i];
+    for (int i = tid; i < g1; i += PF_WIN_THREADS) {
+        const int32_t row = ring1[i];
+        const int64_t s = row >> 6;
+        const int64_t base = slice_ptr[s];
+        const int32_t width = (int32_t)((slice_ptr[s + 1] - base) >> 6);
+        g1_w[(int64_t)A * PF_WIN_G1 + i] = (uint8_t)width;
+        for (int32_t j = 0; j < width; ++j) {
+            const int64_t idx = pf_sell_index(base, width, j, row & (PF_WAVE - 1));
+            const int32_t c = scol[idx];
+            int32_t slot;
+            int where;
+            if (c >= r0 && c < r0 + win_rows) {
+                slot = (int32_t)(c - r0);
+            } else if (in_ring1(c, &where)) {
+                slot = win_rows + where;
+            } else {
+                int lo = 0, hi = h;
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (ring2[mid] < c) lo = mid + 1;
+                    else hi = mid;
+                }
+                slot = win_rows + g1 + lo;
+            }
+            const int64_t o = ((int64_t)A * PF_WIN_GW + j) * PF_WIN_G1 + i;
+            g1_pos[o] = (int32_t)idx;
+            g1_slot[o] = (uint16_t)slot;
+        }
+    }
+    for (int i = tid; i < g1 + h; i += PF_WIN_THREADS) {
+        const int32_t c = i < g1 ? ring1[i] : ring2[i - g1];
+        const int32_t B = c / win_rows;
+        atomicOr(&l_adj[B >> 5], 1u << (B & 31));
+        atomicMax(&l_need[B], c - B * win_rows + 1);
+    }
+    __syncthreads();
+    for (int i = tid; i < WB_ADJ_WORDS; i += PF_WIN_THREADS)
+        if (l_adj[i]) adj2[(int64_t)A * WB_ADJ_WORDS + i] = l_adj[i];
+    for (int32_t B = tid; B < n_windows; B += PF_WIN_THREADS)
+        if (l_need[B] > 0) atomicMax(&need2[B], l_need[B]);
+    if (tid == 0) atomicMax(&need2[A], 1);
+}
+
+// the hand-off protocol of the resident kernels needs "A holds rows of B" <=> "B holds rows of A" (see the header);
+// with a symmetric W it follows for both rings.  Anything else: this graph keeps one step per exchange.
+__global__ __launch_bounds__(PF_WIN_THREADS) void k_win_rings_check(const uint32_t* __restrict__ adj2, int32_t n_windows,
+                                                                    int32_t* __restrict__ flags) {
+    for (int64_t p = (int64_t)blockIdx.x * PF_WIN_THREADS + threadIdx.x; p < (int64_t)n_windows * n_windows;
+         p += (int64_t)gridDim.x * PF_WIN_THREADS) {
+        const int32_t A = (int32_t)(p / n_windows), B = (int32_t)(p % n_windows);
+        const bool ab = (adj2[(int64_t)A * WB_ADJ_WORDS + (B >> 5)] >> (B & 31)) & 1u;
+        const bool ba = (adj2[(int64_t)B * WB_ADJ_WORDS + (A >> 5)] >> (A & 31)) & 1u;
+        if (ab != ba) atomicOr(flags, 2);
+    }
+}
+
 }  // namespace
 
 // g->px_state: -1 not tried, 0 this graph is not covered (the callers have other paths), 1 ready
@@ -224,7 +404,84 @@ int pf_window_slots_prepare(pf_graph* g) {
     return PF_OK;
 }
 
+static void window_rings_free(pf_graph* g) {
+    hipStream_t st = g->ctx->stream;
+    pf_free(st, g->px_gh_cnt2);
+    pf_free(st, g->px_need2);
+    pf_free(st, g->px_g1_w);
+    pf_free(st, g->px_g1_pos);
+    pf_free(st, g->px_g1_slot);
+    pf_free(st, g->px_g1_gw);
+    g->px_gh_cnt2 = g->px_need2 = g->px_g1_pos = g->px_g1_gw = nullptr;
+    g->px_g1_w = nullptr;
+    g->px_g1_slot = nullptr;
+    g->h_px_gh_cnt2.clear();
+    g->h_px_g1_gw.clear();
+}
+
+// g->px2_state: -1 not tried, 0 not covered (one step per exchange stays available), 1 ready
+int pf_window_rings_prepare(pf_graph* g) {
+    if (g->px2_state >= 0) return PF_OK;
+    g->px2_state = 0;
+    PF_TRY(pf_window_slots_prepare(g));
+    if (g->px_state != 1 || g->win_rows != PF_WIN_THREADS) return PF_OK;
+    const int64_t nw = g->n_pad / g->win_rows;
+    hipStream_t st = g->ctx->stream;
+    int32_t* flags = nullptr;
+    uint32_t* adj2 = nullptr;
+    unsigned long long* totals = nullptr;
+    hipError_t e = pf_malloc(st, (void**)&flags, sizeof(int32_t));
+    if (e == hipSuccess) e = pf_malloc(st, (void**)&totals, 2 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = pf_malloc(st, (void**)&adj2, sizeof(uint32_t) * (size_t)nw * WB_ADJ_WORDS);
+    if (e == hipSuccess) e = pf_malloc(st, (void**)&g->px_gh_cnt2, sizeof(int32_t) * nw);
+    if (e == hipSuccess) e = pf_malloc(st, (void**)&g->px_need2, sizeof(int32_t) * nw);
+    if (e == hipSuccess) e = pf_malloc(st, (void**)&g->px_g1_gw, sizeof(int32_t) * nw);
+    if (e == hipSuccess) e = pf_malloc(st, (void**)&g->px_g1_w, (size_t)nw * PF_WIN_G1);
+    if (e == hipSuccess) e = pf_malloc(st, (void**)&g->px_g1_pos, sizeof(int32_t) * (size_t)nw * PF_WIN_GW * PF_WIN_G1);
+    if (e == hipSuccess) e = pf_malloc(st, (void**)&g->px_g1_slot, sizeof(uint16_t) * (size_t)nw * PF_WIN_GW * PF_WIN_G1);
+    if (e == hipSuccess) e = hipMemsetAsync(flags, 0, sizeof(int32_t), st);
+    if (e == hipSuccess) e = hipMemsetAsync(totals, 0, 2 * sizeof(unsigned long long), st);
+    if (e == hipSuccess) e = hipMemsetAsync(adj2, 0, sizeof(uint32_t) * (size_t)nw * WB_ADJ_WORDS, st);
+    if (e == hipSuccess) e = hipMemsetAsync(g->px_gh_cnt2, 0, sizeof(int32_t) * nw, st);
+    if (e == hipSuccess) e = hipMemsetAsync(g->px_need2, 0, sizeof(int32_t) * nw, st);
+    if (e == hipSuccess) e = hipMemsetAsync(g->px_g1_gw, 0, sizeof(int32_t) * nw, st);
+    // one pinned block for everything the host wants back: flag, totals, ring-2 counts, widest ring-1 rows
+    const size_t back = sizeof(int32_t) * (2 + 2 * (size_t)nw) + 2 * sizeof(unsigned long long);
+    void* pin = nullptr;
+    if (e == hipSuccess && pf_pinned_scratch(g->ctx, back, &pin) != PF_OK) e = hipErrorOutOfMemory;
+    if (e == hipSuccess) {
+        k_win_rings<<<(unsigned)nw, PF_WIN_THREADS, 0, st>>>(g->slice_ptr, g->scol, g->win_rows, (int32_t)nw, g->px_gh_cnt, g->px_gh_row,
+                                                             g->px_gh_cnt2, g->px_need2, adj2, g->px_g1_w, g->px_g1_pos, g->px_g1_slot,
+                                                             g->px_g1_gw, totals, flags);
+        k_win_rings_check<<<(unsigned)std::min<int64_t>((nw * nw + PF_WIN_THREADS - 1) / PF_WIN_THREADS, 64), PF_WIN_THREADS, 0, st>>>(
+            adj2, (int32_t)nw, flags);
+        e = hipGetLastError();
+    }
+    unsigned long long* p_tot = reinterpret_cast<unsigned long long*>(pin);
+    int32_t* p_i = reinterpret_cast<int32_t*>(p_tot + 2);
+    if (e == hipSuccess) e = hipMemcpyAsync(p_tot, totals, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(p_i, flags, sizeof(int32_t), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(p_i + 2, g->px_gh_cnt2, sizeof(int32_t) * nw, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(p_i + 2 + nw, g->px_g1_gw, sizeof(int32_t) * nw, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    pf_free(st, flags);
+    pf_free(st, adj2);
+    pf_free(st, totals);
+    if (e != hipSuccess || p_i[0] != 0) {
+        (void)hipGetLastError();
+        window_rings_free(g);
+        return PF_OK;
+    }
+    g->h_px_gh_cnt2.assign(p_i + 2, p_i + 2 + nw);
+    g->h_px_g1_gw.assign(p_i + 2 + nw, p_i + 2 + 2 * nw);
+    g->px_gh2_total = (int64_t)p_tot[0];
+    g->px_g1_entries = (int64_t)p_tot[1];
+    g->px2_state = 1;
+    return PF_OK;
+}
+
 void pf_window_slots_free(pf_graph* g) {
+    window_rings_free(g);
     hipStream_t st = g->ctx->stream;
     pf_free(st, g->px_slot);
     pf_free(st, g->px_gh_cnt);

@@ -1296,8 +1296,9 @@ def test_resident_kernel_bit_identical(golden, hip, ctx):
             g.ws_ensure(4)
             g.upload(0, rng.standard_normal(g.n))
 
-        def run(on):
+        def run(on, two_step=2):
             hip.persist_enable(on)
+            hip.persist_two_step(two_step)
             ctx.timing_enable(True)
             ctx.timing(reset=True)
             out = []
@@ -1314,13 +1315,22 @@ def test_resident_kernel_bit_identical(golden, hip, ctx):
             ctx.timing_enable(False)
             return out, tm
 
-        (a, tm_a), (b, tm_b) = run(False), run(True)
+        # one step per launch; resident with one step per exchange; resident with two steps per exchange where a graph
+        # allows it (symmetric W, 1024-row windows: the 60k, 250k and wide-row graphs here)
+        n2_before = hip.persist_state(ctx)["launches_two_step"]
+        (a, tm_a), (b, tm_b) = run(False), run(True, two_step=0)
+        assert hip.persist_state(ctx)["launches_two_step"] == n2_before
+        c, tm_c = run(True, two_step=2)
+        n2 = hip.persist_state(ctx)["launches_two_step"] - n2_before
         assert tm_a["persist_launches"] == 0 and tm_b["persist_launches"] >= 8 * len(graphs) + 6  # the path really ran
-        assert len(a) == len(b)
-        for i, (x, y) in enumerate(zip(a, b)):
+        assert tm_c["persist_launches"] == tm_b["persist_launches"] and n2 >= 8 * 4 + 3, n2  # 4 graphs alone, 3 of the pairs
+        assert len(a) == len(b) == len(c)
+        for i, (x, y, z) in enumerate(zip(a, b, c)):
             assert np.all(np.isfinite(x)) and np.array_equal(x, y), i
+            assert np.array_equal(x, z), ("two steps per exchange", i, float(np.max(np.abs(x - z))))
     finally:
-        hip.persist_enable(True)  # the default
+        hip.persist_enable(True)  # the defaults
+        hip.persist_two_step(1)
         for g in graphs:
             g.close()
 

@@ -15,7 +15,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("sizes", type=int, nargs="*", default=[250000])
 ap.add_argument("--degree", type=int, default=145)
 ap.add_argument("--reps", type=int, default=20)
-ap.add_argument("--modes", default="1,0")
+ap.add_argument("--modes", default="2,1,0", help="2: resident, two steps per exchange; 1: resident, one; 0: one step per launch")
 args = ap.parse_args()
 ctx = _hip.default_context()
 ctx.timing_enable(True)
@@ -30,6 +30,7 @@ for n in args.sizes:
     req = (0, 1, args.degree, 1.0001, 0.9999, 1.0)
     for mode in [int(x) for x in args.modes.split(",")]:
         _hip.persist_enable(bool(mode))
+        _hip.persist_two_step(2 if mode == 2 else 0)
         for label, fn in (("pair", lambda: devs[0].cheb2(req, devs[1], req)), ("single", lambda: devs[0].cheb(*req))):
             fn()
             ctx.sync()
@@ -39,7 +40,7 @@ for n in args.sizes:
             t = ctx.timing(reset=True)
             steps = args.reps * args.degree
             print("n=%d %s %-6s: %.3f us per step (%d resident launches, %d kernel launches)" % (
-                n, "resident" if mode else "1 step/launch", label, 1e3 * t["op_ms"] / steps, t["persist_launches"],
+                n, {2: "resident x2", 1: "resident", 0: "1 step/launch"}[mode], label, 1e3 * t["op_ms"] / steps, t["persist_launches"],
                 t["op_launches"]), flush=True)
     for d in devs:
         d.close()
