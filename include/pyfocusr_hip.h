@@ -20,6 +20,7 @@
 #ifndef PYFOCUSR_HIP_H
 #define PYFOCUSR_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -215,6 +216,17 @@ int pf_resnorms(pf_graph* g, int32_t ax_first, int32_t x_first, const double* la
  * out: host n x count row-major (numpy (n, count) C-order). */
 int pf_finalize_vectors(pf_graph* g, int32_t first, int32_t count, int32_t from_sym, int32_t minmax,
                         double* out);
+/* The same in two halves: _begin queues the kernels and - on the ctx's copy stream, behind an event - the download
+ * into `out` (pinned memory from pf_host_alloc: one DMA; a pageable destination is staged in chunks), and returns;
+ * the block is resident and usable by pf_final_rows / pf_knn1_graphs / pf_eigsort_costs at once, and later work on the
+ * ctx stream overlaps with the download.  _end waits for the download and checks the result (PF_E_STATE for a
+ * vanished vector); `out` must not be read before it returns.  No-op when nothing is pending.  pf_graph_free and the
+ * next _begin collect a pending download themselves. */
+int pf_finalize_vectors_begin(pf_graph* g, int32_t first, int32_t count, int32_t from_sym, int32_t minmax, double* out);
+int pf_finalize_vectors_end(pf_graph* g);
+/* Pinned (page-locked) host memory for results that should arrive by one DMA; independent of any ctx. */
+int pf_host_alloc(size_t bytes, void** out);
+int pf_host_free(void* p);
 /* The block written by the last pf_finalize_vectors stays resident in HBM.  out[t][c] = that block's row rows[t]
  * (n_rows x count, row-major): the sampled eigenvector rows of Graph.get_rand_eig_vecs (graph.py:266-267) without
  * touching the host copy. */

@@ -103,6 +103,10 @@ SIGNATURES = {
     "pf_gram": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _f64p]),
     "pf_resnorms": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _f64p, C.c_int32, _f64p]),
     "pf_finalize_vectors": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _f64p]),
+    "pf_finalize_vectors_begin": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _f64p]),
+    "pf_finalize_vectors_end": (C.c_int, [C.c_void_p]),
+    "pf_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
+    "pf_host_free": (C.c_int, [C.c_void_p]),
     "pf_final_rows": (C.c_int, [C.c_void_p, _i64p, C.c_int64, _f64p]),
     "pf_point_rows": (C.c_int, [C.c_void_p, _i64p, C.c_int64, _f64p]),
     "pf_spmv_host": (C.c_int, [C.c_void_p, C.c_int32, _f64p, _f64p]),
@@ -183,6 +187,57 @@ def load_library():
 
 
 PF_E_PERSIST_TIMEOUT = -5
+
+
+class _PinnedBlock(object):
+    """One hipHostMalloc block; goes back to the module's free list when the last array over it is collected."""
+    __slots__ = ("ptr", "nbytes")
+
+    def __init__(self, ptr, nbytes):
+        self.ptr, self.nbytes = ptr, nbytes
+
+    def __del__(self):
+        try:
+            _pinned_release(self.ptr, self.nbytes)
+        except Exception:  # noqa: BLE001 - interpreter shutdown
+            pass
+
+
+_pinned_free = {}  # nbytes -> [ptr]: blocks of collected arrays, reused by the next result of the same size
+_pinned_cached = [0]
+_PINNED_CACHE_BYTES = 1 << 30
+
+
+def _pinned_release(ptr, nbytes):
+    if _pinned_free is None or _lib is None:
+        return
+    if _pinned_cached[0] + nbytes <= _PINNED_CACHE_BYTES:
+        _pinned_free.setdefault(nbytes, []).append(ptr)
+        _pinned_cached[0] += nbytes
+    else:
+        _lib.pf_host_free(C.c_void_p(ptr))
+
+
+def pinned_empty(shape, dtype=np.float64):
+    """`np.empty(shape, dtype)` over page-locked host memory (pf_host_alloc): device results land in it by one DMA
+    instead of the runtime's chunked staging of a pageable destination (hipHostMalloc itself costs 0.1-1 ms: the blocks
+    of collected arrays are kept and reused).  Ordinary cacheable host memory for every other purpose."""
+    lib = load_library()
+    dtype = np.dtype(dtype)
+    count = int(np.prod(shape)) if len(shape) else 1
+    nbytes = max(count * dtype.itemsize, 1)
+    nbytes = (nbytes + 4095) & ~4095
+    free = _pinned_free.get(nbytes)
+    if free:
+        ptr = free.pop()
+        _pinned_cached[0] -= nbytes
+    else:
+        p = C.c_void_p()
+        _check(lib.pf_host_alloc(C.c_size_t(nbytes), C.byref(p)))
+        ptr = int(p.value)
+    buf = (C.c_char * nbytes).from_address(ptr)
+    buf._pf_block = _PinnedBlock(ptr, nbytes)  # the array's base keeps `buf`, and with it the block, alive
+    return np.frombuffer(buf, dtype=dtype, count=count).reshape(shape)
 
 
 def persist_enable(on=True):
@@ -760,12 +815,29 @@ class DeviceLaplacian(object):
         _check(self._lib.pf_resnorms(self._h, int(ax_first), int(x_first), _f64(lams), len(lams), _f64(out)))
         return out
 
-    def finalize_vectors(self, first, count, minmax):
-        out = np.empty((self.n, int(count)), dtype=np.float64)
-        _check(self._lib.pf_finalize_vectors(self._h, int(first), int(count), int(self.op == PF_OP_SYM), int(bool(minmax)),
-                                             _f64(out)))
+    def finalize_vectors(self, first, count, minmax, wait=True):
+        """Normalised eigenvectors of `count` slots -> (n, count) array in PINNED host memory (one DMA on the ctx's copy
+        stream).  `wait=False`: the array is returned while the download is still in flight - `finalize_wait()` before
+        anybody reads it (`Graph.eig_vecs` does); the device-resident twin of the block is usable at once."""
+        if os.environ.get("PF_FINAL_PAGEABLE") == "1":  # comparison switch: pageable destination, synchronous (the round-2 form)
+            out = np.empty((self.n, int(count)), dtype=np.float64)
+            _check(self._lib.pf_finalize_vectors(self._h, int(first), int(count), int(self.op == PF_OP_SYM), int(bool(minmax)), _f64(out)))
+            self._final_count = int(count)
+            return out
+        out = pinned_empty((self.n, int(count)))
+        _check(self._lib.pf_finalize_vectors_begin(self._h, int(first), int(count), int(self.op == PF_OP_SYM), int(bool(minmax)),
+                                                   _f64(out)))
         self._final_count = int(count)  # the same block stays resident on the device (final_rows, Context.knn1_graphs)
+        self._final_pending = True
+        if wait:
+            self.finalize_wait()
         return out
+
+    def finalize_wait(self):
+        """Collect the download a `finalize_vectors(..., wait=False)` left in flight (no-op otherwise)."""
+        if getattr(self, "_final_pending", False) and self._h:
+            self._final_pending = False
+            _check(self._lib.pf_finalize_vectors_end(self._h))
 
     def final_rows(self, rows):
         """Rows of the block the last `finalize_vectors` left on the device -> (len(rows), count) array."""

@@ -102,6 +102,18 @@ extern "C" {
 
 int pf_version(void) { return PF_VERSION; }
 
+int pf_host_alloc(size_t bytes, void** out) {
+    PF_CHECK(out != nullptr && bytes > 0, PF_E_ARG, "pf_host_alloc: bad argument");
+    *out = nullptr;
+    PF_HIP(hipHostMalloc(out, bytes, hipHostMallocDefault));
+    return PF_OK;
+}
+
+int pf_host_free(void* p) {
+    if (p) PF_HIP(hipHostFree(p));
+    return PF_OK;
+}
+
 const char* pf_last_error(void) { return g_err; }
 
 int pf_device_count(void) {
@@ -138,7 +150,10 @@ void pf_destroy(pf_ctx* c) {
     if (!c) return;
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
-    hipStreamSynchronize(c->stream);
+    if (c->copy_stream) {
+        hipStreamSynchronize(c->copy_stream);
+        hipStreamDestroy(c->copy_stream);
+    }
     for (auto& kv : c->free_blocks) hipFree(kv.second);
     for (auto& kv : c->live_blocks) hipFree(kv.first);  // graphs the caller forgot to free
     c->free_blocks.clear();
@@ -171,6 +186,7 @@ void* pf_stream(pf_ctx* c) { return c ? (void*)c->stream : nullptr; }
 int pf_sync(pf_ctx* c) {
     PF_CHECK(c != nullptr, PF_E_ARG, "pf_sync: ctx is NULL");
     PF_HIP(hipStreamSynchronize(c->stream));
+    if (c->copy_stream) PF_HIP(hipStreamSynchronize(c->copy_stream));
     return pf_persist_check(c);
 }
 

@@ -100,6 +100,10 @@ int eigs_smallest_once(pf_graph* g, int32_t n_wanted, int32_t minmax, double* va
     pf_eigs_stats st{};
     *n_out = 0;
     int32_t c0 = 0;
+    // The loose single-pass criterion of the device's Gram-Schmidt step is for the filtered iteration of large graphs; on
+    // small ones it can lose orthogonality (pf_orth_strict).  The setting is sticky per graph: set it here either way, so
+    // that this solve does not inherit what an earlier driver left behind.
+    PF_TRY(pf_orth_strict(g, n_active < 4096));
     PF_TRY(pf_lock_null_vectors(g, PF_OP_SYM, &c0));
     const int want = (int)std::min<int64_t>(n_wanted, std::max<int64_t>(n_active - c0, 0));
     if (want <= 0) {

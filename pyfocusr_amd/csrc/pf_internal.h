@@ -48,6 +48,7 @@ constexpr int PF_WS_TMPS = 4;      // temporaries behind the workspace slots (Ch
 struct pf_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t copy_stream = nullptr;  // downloads that overlap with work on `stream` (pf_finalize_vectors_begin)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timing = false;
     uint32_t* persist_sync = nullptr;  // device word(s) of the resident Chebyshev kernel: its abort flag (pf_persist.hip)
@@ -191,6 +192,12 @@ struct pf_graph {
     // pf_knn1_graphs: the spectral coordinates never have to come back from the host
     double* final_vecs = nullptr;
     int32_t final_count = 0;
+    // its download in flight (pf_finalize_vectors_begin / _end): copies on the ctx's copy stream between two events
+    int32_t final_pending = 0;         // > 0: column count of the result whose download pf_finalize_vectors_end has to collect
+    double* final_params = nullptr;    // device: per-column parameters + a private copy of the statistics
+    void* final_stats = nullptr;       // pinned: the statistics as they arrive
+    int32_t final_stats_cap = 0;
+    hipEvent_t final_ready = nullptr, final_done = nullptr;
     double* pts = nullptr;  // [n][3] the mesh's points (graphs built from a mesh): pf_point_rows
     bool deg_block = false; // g and sg live in deg's allocation (mesh path: one memset for the three)
     double spectral_bound = 2.0; // proven upper bound of the operator's spectrum (2: Gershgorin; less for closed triangle meshes)

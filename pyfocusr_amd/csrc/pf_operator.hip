@@ -1412,11 +1412,48 @@ int pf_resnorms(pf_graph* g, int32_t ax_first, int32_t x_first, const double* la
     return PF_OK;
 }
 
-int pf_finalize_vectors(pf_graph* g, int32_t first, int32_t count, int32_t from_sym, int32_t minmax, double* out) {
+// The eigenvector post-processing in two halves, so that the n x count download (10 MB per 250k-vertex graph) leaves the
+// critical path: _begin queues the kernels on the ctx stream and the copies on the ctx's COPY stream behind an event -
+// later work on the ctx stream (eigsort's cost matrices, the KNN, the partner graph's solve) overlaps with them - and
+// _end waits for the copies and checks the statistics.  The block itself is resident and usable on the device as soon as
+// _begin returns.  `out` should be pinned memory (pf_host_alloc): a pageable destination is staged in chunks by the
+// runtime (measured: ~12 gaps of 82 us per 250k pair).
+int pf_finalize_vectors_begin(pf_graph* g, int32_t first, int32_t count, int32_t from_sym, int32_t minmax, double* out) {
     PF_TRY(check_slots(g, first, count, "pf_finalize_vectors"));
     PF_CHECK(out != nullptr && count > 0, PF_E_ARG, "pf_finalize_vectors: bad argument");
     PF_CHECK(!from_sym || g->is_symmetric, PF_E_ARG, "pf_finalize_vectors: from_sym on an asymmetric graph");
-    hipStream_t st = g->ctx->stream;
+    PF_TRY(pf_finalize_vectors_end(g));  // an earlier result still on its way
+    pf_ctx* ctx = g->ctx;
+    hipStream_t st = ctx->stream;
+    if (!ctx->copy_stream) PF_HIP(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    // events and the pinned landing place of the statistics come from the ctx's pools (what freed graphs left behind:
+    // hipHostMalloc / hipHostFree and event creation cost 0.1-0.2 ms each)
+    for (hipEvent_t* ev : {&g->final_ready, &g->final_done}) {
+        if (*ev) continue;
+        if (!ctx->event_pool.empty()) {
+            *ev = ctx->event_pool.back();
+            ctx->event_pool.pop_back();
+        } else {
+            PF_HIP(hipEventCreateWithFlags(ev, hipEventDisableTiming));
+        }
+    }
+    const int32_t stat_doubles = (int32_t)(sizeof(VecStats) / sizeof(double)) * count;
+    if (stat_doubles > g->final_stats_cap + 2 || !g->final_stats) {
+        if (g->final_stats) ctx->pinned_pool.emplace_back(g->final_stats_cap, reinterpret_cast<double*>(g->final_stats));
+        g->final_stats = nullptr;
+        for (size_t i = 0; i < ctx->pinned_pool.size(); ++i)
+            if (ctx->pinned_pool[i].first + 2 >= stat_doubles) {
+                g->final_stats_cap = ctx->pinned_pool[i].first;
+                g->final_stats = ctx->pinned_pool[i].second;
+                ctx->pinned_pool.erase(ctx->pinned_pool.begin() + (long)i);
+                break;
+            }
+        if (!g->final_stats) {
+            const int32_t cap = std::max(stat_doubles, 384);
+            PF_HIP(hipHostMalloc((void**)&g->final_stats, sizeof(double) * (size_t)(cap + 2), hipHostMallocDefault));
+            g->final_stats_cap = cap;
+        }
+    }
     PF_TRY(pf_reduce_ensure(g, count));
     VecStats* part = reinterpret_cast<VecStats*>(g->partials);
     VecStats* fin = part + (size_t)count * g->n_chunks;
@@ -1431,33 +1468,60 @@ int pf_finalize_vectors(pf_graph* g, int32_t first, int32_t count, int32_t from_
     pf_free(st, g->final_vecs);  // the result stays resident (pf_final_rows, pf_knn1_graphs) until the next call
     g->final_vecs = nullptr;
     g->final_count = 0;
-    PF_HIP(pf_malloc(st, (void**)&d_params, sizeof(double) * 4 * (size_t)count));
+    // parameters, and a copy of the statistics that later reductions on the ctx stream cannot overwrite
+    PF_HIP(pf_malloc(st, (void**)&d_params, sizeof(double) * 4 * (size_t)count + sizeof(VecStats) * (size_t)count));
+    VecStats* d_stats = reinterpret_cast<VecStats*>(d_params + 4 * (size_t)count);
     hipError_t e = pf_malloc(st, (void**)&d_out, sizeof(double) * (size_t)g->n * count);
-    std::vector<VecStats> hs((size_t)count);
     if (e == hipSuccess) {
         k_vec_params<<<1, PF_WAVE, 0, st>>>(fin, count, minmax, d_params);
         k_vec_apply<<<nblk(g->n), PF_BLOCK, 0, st>>>(g->ws, g->n_pad, g->n, first, count, g->sg, g->iperm, from_sym, d_params, d_out);
         e = hipGetLastError();
     }
-    if (e == hipSuccess) e = hipMemcpyAsync(hs.data(), fin, sizeof(VecStats) * count, hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, sizeof(double) * (size_t)g->n * count, hipMemcpyDeviceToHost, st);
-    hipError_t e2 = hipStreamSynchronize(st);
-    pf_free(st, d_params);
-    bool sane = true;
-    int32_t bad = 0;
-    if (e == hipSuccess && e2 == hipSuccess)
-        for (int32_t c = 0; c < count && sane; ++c)
-            if (!(hs[c].sumsq > 0.0 && isfinite(hs[c].sumsq))) sane = false, bad = c;
-    if (e == hipSuccess && e2 == hipSuccess && sane) {
-        g->final_vecs = d_out;
-        g->final_count = count;
-    } else {
+    if (e == hipSuccess) e = hipMemcpyAsync(d_stats, fin, sizeof(VecStats) * count, hipMemcpyDeviceToDevice, st);
+    if (e == hipSuccess) e = hipEventRecord(g->final_ready, st);
+    if (e == hipSuccess) e = hipStreamWaitEvent(ctx->copy_stream, g->final_ready, 0);
+    if (e == hipSuccess) e = hipMemcpyAsync(g->final_stats, d_stats, sizeof(VecStats) * count, hipMemcpyDeviceToHost, ctx->copy_stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, sizeof(double) * (size_t)g->n * count, hipMemcpyDeviceToHost, ctx->copy_stream);
+    if (e == hipSuccess) e = hipEventRecord(g->final_done, ctx->copy_stream);
+    if (e != hipSuccess) {
+        (void)hipStreamSynchronize(ctx->copy_stream);
+        pf_free(st, d_params);
         pf_free(st, d_out);
+        PF_HIP(e);
+    }
+    g->final_vecs = d_out;
+    g->final_count = count;
+    g->final_params = d_params;
+    g->final_pending = count;
+    return PF_OK;
+}
+
+int pf_finalize_vectors_end(pf_graph* g) {
+    PF_CHECK(g != nullptr, PF_E_ARG, "pf_finalize_vectors_end: NULL graph");
+    if (g->final_pending <= 0) return PF_OK;
+    const int32_t count = g->final_pending;
+    g->final_pending = 0;
+    const hipError_t e = hipEventSynchronize(g->final_done);
+    pf_free(g->ctx->stream, g->final_params);
+    g->final_params = nullptr;
+    const VecStats* hs = reinterpret_cast<const VecStats*>(g->final_stats);
+    bool sane = e == hipSuccess;
+    int32_t bad = 0;
+    for (int32_t c = 0; c < count && sane; ++c)
+        if (!(hs[c].sumsq > 0.0 && isfinite(hs[c].sumsq))) sane = false, bad = c;
+    if (!sane) {
+        pf_free(g->ctx->stream, g->final_vecs);
+        g->final_vecs = nullptr;
+        g->final_count = 0;
     }
     PF_HIP(e);
-    PF_HIP(e2);
     PF_CHECK(sane, PF_E_STATE, "pf_finalize_vectors: vector %d has norm^2 %g", bad, hs[(size_t)bad].sumsq);
     return PF_OK;
+}
+
+int pf_finalize_vectors(pf_graph* g, int32_t first, int32_t count, int32_t from_sym, int32_t minmax, double* out) {
+    PF_TRY(pf_finalize_vectors_begin(g, first, count, from_sym, minmax, out));
+    return pf_finalize_vectors_end(g);
 }
 
 // out[t][c] = src[rows[t]][c] for a resident [n][width] block of the graph

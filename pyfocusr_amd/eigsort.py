@@ -98,7 +98,12 @@ class eigsort(object):
             return None
         (ct, st), (cs, ss) = self.graph_target._final_map, self.graph_source._final_map
         k = self.n_features
-        self._device_result = devs[0].ctx.eigsort_costs(devs[0], devs[1], rt, rs, k, ct[:k], st[:k], cs[:k], ss[:k])
+        try:
+            self._device_result = devs[0].ctx.eigsort_costs(devs[0], devs[1], rt, rs, k, ct[:k], st[:k], cs[:k], ss[:k])
+        except _hip.PfError as exc:
+            if getattr(exc, "code", None) == _hip.PF_E_PERSIST_TIMEOUT:
+                raise
+            return None  # e.g. a device whose LDS cannot hold one column's sort: the host path computes the same matrices
         return self._device_result
 
     def _ctx(self):

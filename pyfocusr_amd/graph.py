@@ -111,6 +111,7 @@ class Graph(object):
 
         self.eig_vals = None
         self._eig_vecs = None
+        self._eig_pending = False
         self._final_map = None  # (cols, signs): eig_vecs[:, c] == signs[c] * (device-resident block)[:, cols[c]], or None
         self.eig_val_gap = None
         self.eigs_stats = None
@@ -119,12 +120,18 @@ class Graph(object):
     # ------------------------------------------------------------------ eigenvectors: host array + device-resident twin
     @property
     def eig_vecs(self):
+        if self._eig_pending:  # the download the eigensolve queued is collected by the first reader
+            self._eig_pending = False
+            self._device.finalize_wait()
         return self._eig_vecs
 
     @eig_vecs.setter
     def eig_vecs(self, value):
         """Assigning eigenvectors from outside disconnects the host array from the block the solver left on the
         device (`_set_spectrum` is the one place that keeps them connected)."""
+        if self._eig_pending:
+            self._eig_pending = False
+            self._device.finalize_wait()
         self._eig_vecs = value
         self._final_map = None
 
@@ -133,6 +140,9 @@ class Graph(object):
         m = 0 if vecs is None else vecs.shape[1]
         on_device = self._device is not None and getattr(self._device, "_final_count", 0) == m and m > 0
         self._final_map = (np.arange(m), np.ones(m)) if on_device else None
+        # the (n, m) array is pinned memory that a copy stream is still filling (`DeviceLaplacian.finalize_vectors(wait=False)`):
+        # eigsort's cost matrices and the KNN read the device-resident twin meanwhile
+        self._eig_pending = bool(on_device and getattr(self._device, "_final_pending", False))
 
     # ------------------------------------------------------------------ device graph
     @property
@@ -248,6 +258,7 @@ class Graph(object):
             k_buffer=1,
             minmax=self.norm_eig_vecs is True,
             verbose=self.verbose,
+            wait=False,
         ))
         if self.verbose:
             print("All final eigenvalues are: \n{}".format(self.eig_vals))
@@ -260,11 +271,12 @@ class Graph(object):
 
     def get_rand_eig_vecs(self):
         fm = self._final_map
-        if fm is not None and self._device is not None and getattr(self._device, "_h", None):
+        if (fm is not None and self._device is not None and getattr(self._device, "_h", None)
+                and device_block_is_current(self)):  # (an unannounced in-place edit of eig_vecs disowns the block)
             # the sampled rows straight from the block the solver left in HBM: a random gather of rows of the
             # freshly downloaded (cache-cold) host array costs more than the whole device round trip
             rows = self._device.final_rows(self.rand_idxs)
-            cols, signs = fm
+            cols, signs = self._final_map
             if np.array_equal(cols, np.arange(len(cols))) and np.all(signs == 1.0):
                 return rows
             return rows[:, cols] * signs
@@ -375,6 +387,8 @@ def _paired_spectra(ga, gb):
 def device_block_is_current(g):
     """Guard against in-place edits of `g.eig_vecs` nobody told us about: 64 rows of the device-resident block (with the
     recorded column permutation / sign flips) must agree exactly with the host array; otherwise the block is disowned."""
+    if getattr(g, "_eig_pending", False):
+        return True  # the host array is still on its way: nobody can have edited it
     rows = np.linspace(0, g.n_points - 1, num=min(64, g.n_points)).astype(np.int64)
     cols, signs = g._final_map
     if np.array_equal(g._device.final_rows(rows)[:, cols] * signs, g.eig_vecs[rows][:, :len(cols)]):
@@ -444,12 +458,16 @@ def _device_eigs_gen(dev, k, n_k_needed, k_buffer=1, minmax=False, verbose=False
             extra = found
             continue
         break
-    vecs = dev.finalize_vectors(first, len(lam), minmax)
+    vecs = dev.finalize_vectors(first, len(lam), minmax, wait=False)  # callers: Graph._set_spectrum, or dev.finalize_wait()
     return lam, vecs, stats
 
 
-def _device_eigs(dev, k, n_k_needed, k_buffer=1, minmax=False, verbose=False, **solver_kw):
-    return drive(lambda: _device_eigs_gen(dev, k, n_k_needed, k_buffer, minmax, verbose, **solver_kw), dev)
+def _device_eigs(dev, k, n_k_needed, k_buffer=1, minmax=False, verbose=False, wait=True, **solver_kw):
+    """`wait=False`: the eigenvector array is returned while its download is still in flight (`dev.finalize_wait()`)."""
+    out = drive(lambda: _device_eigs_gen(dev, k, n_k_needed, k_buffer, minmax, verbose, **solver_kw), dev)
+    if wait and hasattr(dev, "finalize_wait"):
+        dev.finalize_wait()
+    return out
 
 
 def _device_from_matrix(matrix, ctx=None):

@@ -3,8 +3,11 @@ import sys
 
 import numpy as np
 import pytest
-import torch  # noqa: F401  (before anything loads libpyfocusr_hip.so: torch and the library must share ONE HIP runtime -
-#                whichever copy of libamdhip64 is loaded first serves both, and torch.cuda only comes up on its own copy)
+try:
+    import torch  # noqa: F401  (before anything loads libpyfocusr_hip.so: torch and the library must share ONE HIP runtime -
+    #               whichever copy of libamdhip64 is loaded first serves both, and torch.cuda only comes up on its own copy)
+except ImportError:  # the oracle / host-logic tests need no torch; the distributed tests skip themselves without it
+    torch = None
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if REPO not in sys.path:

@@ -330,7 +330,10 @@ class FakeDevice(NumpyOps):
         return dict(rowptr=W.indptr.astype(np.int32), colidx=W.indices.astype(np.int32), w=W.data,
                     l_offdiag=-(g[rows] * W.data), deg=self.deg, l_diag=g * self.deg)
 
-    def finalize_vectors(self, first, count, minmax):
+    def finalize_wait(self):
+        pass
+
+    def finalize_vectors(self, first, count, minmax, wait=True):
         X = self.download_slots(first, count)
         if self.symmetric:
             X = X * self.s[:, None]

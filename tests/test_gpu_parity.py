@@ -1461,6 +1461,21 @@ def test_eigs_smallest_single_c_call(golden, hip, ctx):
     assert np.max(np.linalg.norm(R, axis=0)) < 1e-10 and np.all(np.diff(vals) > 0)
     np.testing.assert_allclose(np.linalg.norm(vecs, axis=0), 1.0, rtol=1e-12)
     dev.close()
+    # small meshes (the strict second-pass rule of the Gram-Schmidt step applies below 4096 vertices, whatever an earlier
+    # solve left on the graph): eigenvalues against the oracle, residuals, orthonormality in the D-inner product of L
+    for n_small, seed in ((700, 5), (1500, 6), (3500, 7)):
+        m = blob_mesh(n_small, seed=seed)
+        dev = hip.DeviceLaplacian(m.points, m.faces, ctx=ctx)
+        dev.orth_strict(False)  # a previous driver's loose setting must not leak into the C driver
+        vals, vecs, st = dev.eigs_smallest(6)
+        ref = orc.graph_spectrum(m.points, m.faces, 6)
+        np.testing.assert_allclose(vals, ref["eig_vals"][:6], rtol=1e-8)
+        W, deg, d_inv, L = orc.graph_matrices(m.points, m.faces)
+        assert np.max(np.linalg.norm(L @ vecs - vecs * vals[None, :], axis=0)) < 1e-10 and st["max_residual"] < 1e-10
+        gram = vecs.T @ ((deg + 1e-8)[:, None] * vecs)  # L = G (D - W) is self-adjoint in the G^-1 inner product
+        off = gram - np.diag(np.diag(gram))
+        assert np.max(np.abs(off)) < 1e-9 * np.max(np.abs(np.diag(gram)))
+        dev.close()
     # refusals: one-way edges, tiny graphs
     g15 = golden("source_mesh_15k")
     dev = hip.DeviceLaplacian(g15["points"], g15["faces"], ctx=ctx)

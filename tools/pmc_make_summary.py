@@ -77,7 +77,7 @@ for label, needle, fdir, wdir in (("k_cheb_resident<2, 1, 8>", "k_cheb_resident<
     if label.startswith("k_cheb_resident") and bench.get("roofline", {}).get("steps_per_launch"):
         spl = bench["roofline"]["steps_per_launch"]
         entry.update(steps_per_launch_avg=spl, hbm_bytes_per_step=entry["hbm_bytes_per_launch"] / spl,
-                     hbm_bytes_per_launch_fixed=0.0,
+                     hbm_bytes_per_launch_fixed=0.0, lds_bytes_per_launch=bench["roofline"].get("lds_bytes_per_launch"),
                      note="per step of the pair; includes the once-per-launch load of the operators into registers spread over "
                           "the launch's steps; hand-off accesses are 8-byte agent-scope loads / stores (outside the guide's "
                           "calibration of FETCH_SIZE, which is for wide streaming reads)")

@@ -25,7 +25,7 @@ acc = defaultdict(list)
 # wrap the blocking ctypes entry points to see where the host waits
 calls = defaultdict(float)
 for name in ("orth_end", "orth_begin", "cheb2", "cheb", "finalize_vectors", "combine", "dots", "resnorm", "spmv", "copy",
-             "lock_null_vectors", "start_vector", "orth", "scale", "ws_ensure", "sync"):
+             "lock_null_vectors", "start_vector", "orth", "scale", "ws_ensure", "sync", "finalize_wait"):
     fn = getattr(_hip.DeviceLaplacian, name)
 
     def make(fn, name):
