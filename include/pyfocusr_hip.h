@@ -248,6 +248,15 @@ int pf_mean_filter(pf_graph* g, const double* values, int32_t ncols, int32_t ite
  * ref: n_ref x d, qry: n_qry x d row-major float64; idx_out[n_qry] int64; d2_out nullable. */
 int pf_knn1(pf_ctx* ctx, const double* ref, int64_t n_ref, const double* qry, int64_t n_qry, int32_t d,
             int64_t* idx_out, double* d2_out);
+/* How k = 1 searches prune (the results are the same bits either way).  0 (default): by depth - d <= 6 through a grid
+ * over the references' two widest axes (pf_knn.hip), d >= 7 through a hierarchy of bounding boxes over ALL d coordinates
+ * (pf_knn_tree.hip: leaves of 64 Morton-ordered points, supers of 64 leaves; what keeps deep, poorly aligned embeddings
+ * - BASELINE config C5, 1M x 1M, d = 10 - from degenerating into a brute force inside a 2-D rectangle); 1: always the
+ * grid; 2: always the hierarchy. */
+int pf_knn_mode(pf_ctx* ctx, int32_t mode);
+/* Visits of the last hierarchy search, summed over the waves (counted only while enable_counting was 1 for that search;
+ * the call also sets the switch for the searches to come). */
+int pf_knn_tree_stats(pf_ctx* ctx, int32_t enable_counting, int64_t* leaves_scanned, int64_t* supers_opened);
 /* k nearest neighbours (1 <= k <= 4, d <= 4), ascending by (distance, index): the 3-NN of
  * Focusr.get_weighted_final_node_locations (focusr.py:409-412).  idx_out / d2_out: n_qry x k row-major. */
 int pf_knn(pf_ctx* ctx, const double* ref, int64_t n_ref, const double* qry, int64_t n_qry, int32_t d, int32_t k,

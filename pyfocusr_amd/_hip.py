@@ -79,6 +79,8 @@ SIGNATURES = {
     "pf_lock_null_vectors": (C.c_int, [C.c_void_p, C.c_int32, _i32p]),
     "pf_spmv": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
     "pf_spmv_multi": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "pf_knn_mode": (C.c_int, [C.c_void_p, C.c_int32]),
+    "pf_knn_tree_stats": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "pf_persist_enable": (C.c_int, [C.c_int]),
     "pf_persist_two_step": (C.c_int, [C.c_int]),
     "pf_persist_state": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -334,6 +336,17 @@ class Context(object):
                     persist_steps=int(t.persist_steps), persist_bytes=t.persist_bytes, persist_lds_bytes=t.persist_lds_bytes)
 
     # ---- nearest neighbour -------------------------------------------------------------
+    def knn_mode(self, mode):
+        """How 1-NN searches prune: 0 by depth (grid for d <= 6, box hierarchy for d >= 7), 1 always the grid, 2 always
+        the hierarchy.  The results are the same bits."""
+        _check(self._lib.pf_knn_mode(self._h, int(mode)))
+
+    def knn_tree_stats(self, enable_counting=False):
+        """(leaves scanned, supers opened) of the last box-hierarchy search, if counting was on for it; sets the switch."""
+        a, b = C.c_int64(), C.c_int64()
+        _check(self._lib.pf_knn_tree_stats(self._h, int(bool(enable_counting)), C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
+
     def knn1(self, ref, qry, return_d2=False):
         """Index (int64) of the nearest `ref` row for every `qry` row."""
         ref, qry = _c_f64(ref), _c_f64(qry)

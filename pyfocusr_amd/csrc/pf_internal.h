@@ -45,6 +45,19 @@ constexpr int PF_WIN_G1 = 512;       // ring-1 rows of a window whose recurrence
 constexpr int PF_WIN_GW = 16;        // entries per such row
 constexpr int PF_WS_TMPS = 4;      // temporaries behind the workspace slots (Chebyshev rotation)
 
+// device buffers of the box hierarchy of pf_knn_tree.hip (1-NN for deep coordinates); they grow and stay with the ctx
+struct pf_knn_tree {
+    double* pts = nullptr;       // [n_leaf][d][64] leaves, coordinate-major
+    int32_t* orig = nullptr;     // [n_leaf][64] original reference indices
+    double* leaf_lo = nullptr;   // [2][n_sup][d][64] leaf boxes: lo, then hi
+    double* sup_lo = nullptr;    // [2][d][ns_pad] boxes of the supers
+    int32_t* qry_order = nullptr;  // queries along the references' Morton curve
+    void* grid = nullptr;        // TreeGrid
+    unsigned long long* counters = nullptr;
+    int64_t cap_pts = 0, cap_orig = 0, cap_leaf = 0, cap_sup = 0, cap_qry = 0;
+    bool count_visits = false;
+};
+
 struct pf_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -84,6 +97,8 @@ struct pf_ctx {
     int64_t* knn_idx = nullptr; // [n_qry]
     double* knn_d2 = nullptr;   // [n_qry]
     bool knn_ready = false, knn_done = false;
+    pf_knn_tree knn_tree;
+    int32_t knn_mode = 0;  // 0: by depth (box hierarchy for k = 1, d >= PF_KNN_TREE_MIN_D = 7), 1: always the grid, 2: always the hierarchy
     // operator timing: event pairs recorded around filter applications, resolved lazily in pf_timing_get so
     // that timing never blocks the host (the solver queues the next application while this one runs)
     struct TimedSpan {
@@ -240,6 +255,12 @@ int pf_compute_order(pf_graph* g, const double* d_pts);
 
 // Rows per window of the resident Chebyshev kernel: one window per block, at most 256 blocks.
 static inline int32_t pf_window_rows(int64_t n_pad) { return n_pad <= 262144 ? 1024 : (n_pad <= 524288 ? 2048 : 4096); }
+
+// pf_knn_tree.hip: the 1-NN search of pf_knn_run through a bounding-box hierarchy over all d coordinates
+// (spectral coordinates of 250k blob pairs, ms grid / hierarchy: d = 6: 1.15 / 1.90, 7: 1.98 / 1.91, 8: 29.5 / 8.8, 10: 6.3 / 2.1;
+// 1M pair, d = 10: 133 / 19.6 - profiles/r03_knn_hierarchy.md)
+constexpr int PF_KNN_TREE_MIN_D = 7;
+int pf_knn_tree_run(pf_ctx* c);
 
 // pf_persist.hip: a whole recurrence T_degree((c - A)/e)/rho^degree src -> dst in ONE kernel (operator in registers,
 // x in LDS, neighbouring windows hand their boundary rows over through memory)

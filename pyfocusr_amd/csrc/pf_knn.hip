@@ -810,6 +810,18 @@ int pf_knn_run(pf_ctx* c) {
     int cell_bits = 1;
     while (((int64_t)1 << cell_bits) < n_cells) ++cell_bits;
     k_extent<<<256, PF_BLOCK, 0, st>>>(c->knn_ref, c->knn_nref, d, c->knn_ext);
+    // deep coordinates (k = 1): a grid over two axes prunes two of d coordinates; the box hierarchy prunes with all of them
+    const bool tree = c->knn_k == 1 && (c->knn_mode == 2 || (c->knn_mode == 0 && d >= PF_KNN_TREE_MIN_D));
+    if (tree) {
+        PF_TRY(pf_knn_tree_run(c));
+        PF_HIP(hipEventRecord(c->ev1, st));
+        PF_HIP(hipEventSynchronize(c->ev1));
+        float tms = 0.f;
+        PF_HIP(hipEventElapsedTime(&tms, c->ev0, c->ev1));
+        c->knn_ms = tms;
+        c->knn_done = true;
+        return PF_OK;
+    }
     k_make_grid<<<1, 1, 0, st>>>(c->knn_ext, d, res, (KnnGrid*)c->knn_grid);
     PF_HIP(hipGetLastError());
     PF_TRY(sort_points(c, c->knn_ref, c->knn_nref, d, 0, cell_bits, c->knn_ref_key, c->knn_ref_orig, c->knn_ref_s));
@@ -847,6 +859,12 @@ int pf_knn_run(pf_ctx* c) {
     PF_HIP(hipEventElapsedTime(&ms, c->ev0, c->ev1));
     c->knn_ms = ms;
     c->knn_done = true;
+    return PF_OK;
+}
+
+int pf_knn_mode(pf_ctx* c, int32_t mode) {
+    PF_CHECK(c != nullptr && mode >= 0 && mode <= 2, PF_E_ARG, "pf_knn_mode: bad argument");
+    c->knn_mode = mode;
     return PF_OK;
 }
 

@@ -633,11 +633,58 @@ def test_knn_bit_exact(ctx, d, n_ref, n_qry):
     rng = np.random.default_rng(100 * d + n_ref)
     ref = rng.uniform(-0.5, 0.5, size=(n_ref, d))
     qry = rng.uniform(-0.5, 0.5, size=(n_qry, d))
-    idx, d2 = ctx.knn1(ref, qry, return_d2=True)
     bidx, bd2 = orc.knn1_bruteforce(ref, qry)
-    assert idx.dtype == np.int64
-    assert np.array_equal(idx, bidx)
-    assert np.array_equal(d2, bd2)  # same roundings: sum of squares left to right, no FMA
+    try:
+        for mode in (0, 1, 2):  # by depth (the default), the grid over two axes, the box hierarchy over all axes
+            ctx.knn_mode(mode)
+            idx, d2 = ctx.knn1(ref, qry, return_d2=True)
+            assert idx.dtype == np.int64
+            assert np.array_equal(idx, bidx), mode
+            assert np.array_equal(d2, bd2), mode  # same roundings: sum of squares left to right, no FMA
+    finally:
+        ctx.knn_mode(0)
+
+
+def test_knn_box_hierarchy(ctx):
+    """pf_knn_tree.hip (the default for d >= 7) where its pruning is stressed: embedded 2-manifolds at sizes with several
+    supers, exact ties on a lattice, duplicated references, queries that ARE references, clouds far apart (nothing
+    prunes), one leaf / one super / a ragged last leaf - bit-identical to the grid search and to brute force on samples."""
+    rng = np.random.default_rng(5)
+
+    def surface(n, d, shift, seed):
+        r = np.random.default_rng(seed)
+        u, v = r.uniform(0, 1, n), r.uniform(0, 1, n)
+        return np.stack([np.cos((c + 1) * u * 3.0) * np.sin((c % 3 + 1) * v * 2.0) for c in range(d)], axis=1) + shift
+
+    cases = []
+    for n, d in ((300000, 10), (70000, 7), (4097, 12), (64, 9), (65, 16), (1, 8)):
+        cases.append((surface(n, d, 0.0, n), surface(min(n, 40000) + 3, d, 0.05, n + 1)))
+    lat = np.round(rng.uniform(-0.5, 0.5, (20000, 8)) * 3) / 3
+    cases.append((lat, np.round(rng.uniform(-0.5, 0.5, (5000, 8)) * 3) / 3))  # ties: the lowest index must win
+    dup = surface(30000, 9, 0.0, 3)
+    dup[15000:] = dup[:15000]
+    cases.append((dup, dup[rng.integers(0, 30000, 7000)].copy()))  # duplicates; queries on references: d2 = 0, lowest index
+    cases.append((surface(50000, 10, 0.0, 4), surface(3000, 10, 9.0, 5)))  # far apart
+    try:
+        for ref, qry in cases:
+            ctx.knn_mode(2)
+            ti, td = ctx.knn1(ref, qry, return_d2=True)
+            ctx.knn_mode(1)
+            gi, gd = ctx.knn1(ref, qry, return_d2=True)
+            assert np.array_equal(ti, gi) and np.array_equal(td, gd), (ref.shape, qry.shape)
+            rows = np.unique(np.linspace(0, len(qry) - 1, 40).astype(np.int64))
+            bi, bd = orc.knn1_bruteforce(ref, qry[rows])
+            assert np.array_equal(ti[rows], bi) and np.array_equal(td[rows], bd)
+        assert np.array_equal(ctx.knn1(dup, dup[:15000].copy()), np.arange(15000))  # (mode 1 still set: the grid agrees)
+        ctx.knn_mode(2)
+        assert np.array_equal(ctx.knn1(dup, dup), np.concatenate([np.arange(15000), np.arange(15000)]))
+        ctx.knn_tree_stats(True)
+        ctx.knn1(cases[0][0], cases[0][1])
+        leaves, supers = ctx.knn_tree_stats(False)
+        # the point of the structure: a few dozen leaves per group of two queries out of 4688 (a brute force would scan all)
+        assert 0 < leaves < 0.03 * 4688 * (len(cases[0][1]) / 2)
+    finally:
+        ctx.knn_mode(0)
 
 
 def test_knn_ties_and_idempotence(ctx):
