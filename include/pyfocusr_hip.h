@@ -224,6 +224,10 @@ int pf_finalize_vectors(pf_graph* g, int32_t first, int32_t count, int32_t from_
  * next _begin collect a pending download themselves. */
 int pf_finalize_vectors_begin(pf_graph* g, int32_t first, int32_t count, int32_t from_sym, int32_t minmax, double* out);
 int pf_finalize_vectors_end(pf_graph* g);
+/* out[i][c] = block[i][col[c]] * sign[c] (c < count <= the block's column count, sign = +-1): the image on the host of
+ * eigsort's sign flips and column moves (eigsort.py:108-122), computed on the device from the resident block and copied
+ * like the first download (pinned `out`, copy stream; collected by pf_finalize_vectors_end).  The block stays as it is. */
+int pf_final_remap_begin(pf_graph* g, const int32_t* col, const double* sign, int32_t count, double* out);
 /* Pinned (page-locked) host memory for results that should arrive by one DMA; independent of any ctx. */
 int pf_host_alloc(size_t bytes, void** out);
 int pf_host_free(void* p);

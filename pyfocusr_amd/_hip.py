@@ -107,6 +107,7 @@ SIGNATURES = {
     "pf_finalize_vectors": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _f64p]),
     "pf_finalize_vectors_begin": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _f64p]),
     "pf_finalize_vectors_end": (C.c_int, [C.c_void_p]),
+    "pf_final_remap_begin": (C.c_int, [C.c_void_p, _i32p, _f64p, C.c_int32, _f64p]),
     "pf_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
     "pf_host_free": (C.c_int, [C.c_void_p]),
     "pf_final_rows": (C.c_int, [C.c_void_p, _i64p, C.c_int64, _f64p]),
@@ -845,6 +846,15 @@ class DeviceLaplacian(object):
         if wait:
             self.finalize_wait()
         return out
+
+    def final_remap(self, cols, signs, out):
+        """out[:, c] <- (device-resident block)[:, cols[c]] * signs[c], by a kernel and one DMA on the copy stream (`out`: the
+        pinned array `finalize_vectors` returned, all of its columns); `finalize_wait()` before anybody reads it."""
+        cols = np.ascontiguousarray(cols, dtype=np.int32)
+        signs = np.ascontiguousarray(signs, dtype=np.float64)
+        assert out.flags.c_contiguous and out.shape == (self.n, len(cols))
+        _check(self._lib.pf_final_remap_begin(self._h, cols.ctypes.data_as(_i32p), _f64(signs), len(cols), _f64(out)))
+        self._final_pending = True
 
     def finalize_wait(self):
         """Collect the download a `finalize_vectors(..., wait=False)` left in flight (no-op otherwise)."""

@@ -208,7 +208,7 @@ struct pf_graph {
     double* final_vecs = nullptr;
     int32_t final_count = 0;
     // its download in flight (pf_finalize_vectors_begin / _end): copies on the ctx's copy stream between two events
-    int32_t final_pending = 0;         // > 0: column count of the result whose download pf_finalize_vectors_end has to collect
+    int32_t final_pending = 0;         // > 0: column count of the result whose download pf_finalize_vectors_end has to collect; < 0: a remapped image
     double* final_params = nullptr;    // device: per-column parameters + a private copy of the statistics
     void* final_stats = nullptr;       // pinned: the statistics as they arrive
     int32_t final_stats_cap = 0;

@@ -1498,12 +1498,16 @@ int pf_finalize_vectors_begin(pf_graph* g, int32_t first, int32_t count, int32_t
 
 int pf_finalize_vectors_end(pf_graph* g) {
     PF_CHECK(g != nullptr, PF_E_ARG, "pf_finalize_vectors_end: NULL graph");
-    if (g->final_pending <= 0) return PF_OK;
+    if (g->final_pending == 0) return PF_OK;
     const int32_t count = g->final_pending;
     g->final_pending = 0;
     const hipError_t e = hipEventSynchronize(g->final_done);
     pf_free(g->ctx->stream, g->final_params);
     g->final_params = nullptr;
+    if (count < 0) {  // a remapped image of the block (pf_final_remap_begin)
+        PF_HIP(e);
+        return PF_OK;
+    }
     const VecStats* hs = reinterpret_cast<const VecStats*>(g->final_stats);
     bool sane = e == hipSuccess;
     int32_t bad = 0;
@@ -1522,6 +1526,55 @@ int pf_finalize_vectors_end(pf_graph* g) {
 int pf_finalize_vectors(pf_graph* g, int32_t first, int32_t count, int32_t from_sym, int32_t minmax, double* out) {
     PF_TRY(pf_finalize_vectors_begin(g, first, count, from_sym, minmax, out));
     return pf_finalize_vectors_end(g);
+}
+
+struct RemapArgs {
+    int32_t col[64];
+    double sign[64];
+};
+__global__ __launch_bounds__(PF_BLOCK) void k_final_remap(const double* __restrict__ fin, int64_t n, int32_t fc, int32_t count, RemapArgs m,
+                                                          double* __restrict__ out) {
+    const int64_t e = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
+    if (e >= n * count) return;
+    const int64_t i = e / count;
+    const int32_t c = (int32_t)(e - i * count);
+    out[e] = fin[i * fc + m.col[c]] * m.sign[c];  // (sign = +-1: exact)
+}
+
+// eigsort's sign flips and column moves (eigsort.py:108-122) applied to the resident block's image on the host:
+// out[i][c] = block[i][col[c]] * sign[c], computed on the device and copied on the copy stream - O(n k) strided host
+// work (0.25 ms at 250k x 5, several ms at 1M x 10) becomes one DMA that overlaps with the KNN.  Collected by
+// pf_finalize_vectors_end like the first download; the resident block itself is unchanged.
+int pf_final_remap_begin(pf_graph* g, const int32_t* col, const double* sign, int32_t count, double* out) {
+    PF_CHECK(g && col && sign && out, PF_E_ARG, "pf_final_remap_begin: NULL argument");
+    PF_TRY(pf_finalize_vectors_end(g));
+    PF_CHECK(g->final_vecs != nullptr, PF_E_STATE, "pf_final_remap_begin: no pf_finalize_vectors result is resident");
+    PF_CHECK(count >= 1 && count <= 64 && count <= g->final_count, PF_E_ARG, "pf_final_remap_begin: count %d out of range", count);
+    RemapArgs m{};
+    for (int32_t c = 0; c < count; ++c) {
+        PF_CHECK(col[c] >= 0 && col[c] < g->final_count, PF_E_ARG, "pf_final_remap_begin: column %d out of range", col[c]);
+        m.col[c] = col[c];
+        m.sign[c] = sign[c];
+    }
+    pf_ctx* ctx = g->ctx;
+    hipStream_t st = ctx->stream;
+    PF_CHECK(ctx->copy_stream && g->final_ready && g->final_done, PF_E_STATE, "pf_final_remap_begin: no download machinery (call after pf_finalize_vectors_begin)");
+    double* d_tmp = nullptr;
+    PF_HIP(pf_malloc(st, (void**)&d_tmp, sizeof(double) * (size_t)g->n * count));
+    k_final_remap<<<nblk(g->n * count), PF_BLOCK, 0, st>>>(g->final_vecs, g->n, g->final_count, count, m, d_tmp);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipEventRecord(g->final_ready, st);
+    if (e == hipSuccess) e = hipStreamWaitEvent(ctx->copy_stream, g->final_ready, 0);
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d_tmp, sizeof(double) * (size_t)g->n * count, hipMemcpyDeviceToHost, ctx->copy_stream);
+    if (e == hipSuccess) e = hipEventRecord(g->final_done, ctx->copy_stream);
+    if (e != hipSuccess) {
+        (void)hipStreamSynchronize(ctx->copy_stream);
+        pf_free(st, d_tmp);
+        PF_HIP(e);
+    }
+    g->final_params = d_tmp;   // freed by _end
+    g->final_pending = -count; // negative: a remapped image, nothing to check
+    return PF_OK;
 }
 
 // out[t][c] = src[rows[t]][c] for a resident [n][width] block of the graph

@@ -142,6 +142,10 @@ class eigsort(object):
             dst, src = np.asarray(source_matches), np.asarray(target_matches)
         mutated = self.graph_source if self.target_as_reference is True else self.graph_target
         fmap = getattr(mutated, "_final_map", None)  # the same flips / permutation for the graph's device-resident block
+        on_device = (fmap is not None and vecs is not None and (len(flip_cols) > 0 or not np.array_equal(dst, src))
+                     and getattr(mutated, "_remap_ready", lambda: False)())
+        if on_device:
+            vecs = None  # the host array is rewritten from the device block below (one DMA instead of strided host passes)
         for col in flip_cols:
             if vecs is not None:  # (None: a graph held on another rank / on the device only, see parallel.py)
                 np.negative(vecs[:, col], out=vecs[:, col])  # one strided pass, no temporary (x * -1 == -x bit for bit)
@@ -156,6 +160,8 @@ class eigsort(object):
                 fmap = (cols, signs)
         if fmap is not None:
             mutated._final_map = fmap
+        if on_device and not mutated._remap_host_image():
+            raise RuntimeError("eigsort: the device-resident eigenvector block vanished during eigen_sort")
         self.target_matches, self.source_matches = np.asarray(target_matches), np.asarray(source_matches)
         self.flipped_pairs = flipped_pairs
 

@@ -135,6 +135,26 @@ class Graph(object):
         self._eig_vecs = value
         self._final_map = None
 
+    def _remap_ready(self):
+        fm, dev, vecs = self._final_map, self._device, self._eig_vecs
+        return bool(fm is not None and dev is not None and getattr(dev, "_h", None) and vecs is not None
+                    and hasattr(dev, "final_remap") and vecs.shape == (self.n_points, len(fm[0])) and vecs.flags.c_contiguous
+                    and vecs.flags.writeable and getattr(dev, "_final_count", 0) == len(fm[0]))
+
+    def _remap_host_image(self):
+        """Rewrite the host array of `eig_vecs` IN PLACE as (device-resident block)[:, cols] * signs of `_final_map` - what
+        eigsort's sign flips and column moves (eigsort.py:108-122) make of it - by one kernel and one DMA that the next
+        reader collects.  False when the array is not the pinned image of the block (assigned from outside, closed device)."""
+        if not self._remap_ready():
+            return False
+        fm, dev, vecs = self._final_map, self._device, self._eig_vecs
+        if self._eig_pending:
+            self._eig_pending = False
+            dev.finalize_wait()
+        dev.final_remap(fm[0], fm[1], vecs)
+        self._eig_pending = True
+        return True
+
     def _set_spectrum(self, vals, vecs, stats):
         self.eig_vals, self._eig_vecs, self.eigs_stats = vals, vecs, stats
         m = 0 if vecs is None else vecs.shape[1]
