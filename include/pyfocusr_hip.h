@@ -313,9 +313,22 @@ typedef struct pf_eigs_stats {
     int32_t n_null;       /* eigenvalues <= 1e-10 found among the computed ones (= locked null vectors) */
     double cut;           /* lower end of the damped interval */
     double max_residual;  /* max ||S x - lambda x||_2 of the returned pairs */
+    int32_t second_passes; /* outer steps whose Gram-Schmidt projection cancelled digits (second pass run) */
+    int32_t reserved;
 } pf_eigs_stats;
 int pf_eigs_smallest(pf_graph* g, int32_t n_wanted, int32_t minmax, double* vals, double* vecs, int32_t* n_out,
                      pf_eigs_stats* stats);
+/* The two graphs of a pair (target and source mesh of focusr.py:134-170; one ctx, both symmetric) solved TOGETHER: the
+ * two iterations advance in lockstep, every Gram-Schmidt step and filter application that both have pending runs in
+ * launches the graphs share (pf_orth_cheb2: one library call and three launches per outer step of the pair), one graph
+ * finishes alone once its partner has converged.  res_a / res_b (nullable): ||S x - lambda x||_2 per returned pair.
+ * async_download = 1: the call returns with the eigenvector downloads still in flight (pf_finalize_vectors_begin into
+ * vecs_a / vecs_b, which should be pinned: pf_host_alloc) - pf_finalize_vectors_end(g) before reading them; the
+ * device-resident blocks are usable at once.  vals need room for n_wanted values, vecs for n * n_wanted; when a graph
+ * returns fewer pairs (*n_out < n_wanted) its vecs hold an n x *n_out block. */
+int pf_eigs_smallest2(pf_graph* ga, pf_graph* gb, int32_t n_wanted_a, int32_t n_wanted_b, int32_t minmax, int32_t async_download,
+                      double* vals_a, double* vecs_a, double* res_a, int32_t* n_out_a, pf_eigs_stats* stats_a,
+                      double* vals_b, double* vecs_b, double* res_b, int32_t* n_out_b, pf_eigs_stats* stats_b);
 
 /* ---- primitives of the row-partitioned solve (one large mesh over several GPUs; SURVEY 8e / BASELINE config C5).
  * The reference has no counterpart (scipy eigs on one core, graph.py:357-389).  pyfocusr_amd/rowpart.py drives them.

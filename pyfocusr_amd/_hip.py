@@ -42,7 +42,8 @@ class GraphInfo(C.Structure):
 
 class EigsStats(C.Structure):
     _fields_ = [("matvecs", C.c_int64), ("outer_steps", C.c_int32), ("restarts", C.c_int32), ("filter_resets", C.c_int32),
-                ("degree", C.c_int32), ("n_null", C.c_int32), ("cut", C.c_double), ("max_residual", C.c_double)]
+                ("degree", C.c_int32), ("n_null", C.c_int32), ("cut", C.c_double), ("max_residual", C.c_double),
+                ("second_passes", C.c_int32), ("reserved", C.c_int32)]
 
 
 class Timing(C.Structure):
@@ -124,6 +125,9 @@ SIGNATURES = {
     "pf_knn_run": (C.c_int, [C.c_void_p]),
     "pf_knn_download": (C.c_int, [C.c_void_p, _i64p, _f64p]),
     "pf_eigs_smallest": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _f64p, _f64p, C.POINTER(C.c_int32), C.POINTER(EigsStats)]),
+    "pf_eigs_smallest2": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                    _f64p, _f64p, _f64p, C.POINTER(C.c_int32), C.POINTER(EigsStats),
+                                    _f64p, _f64p, _f64p, C.POINTER(C.c_int32), C.POINTER(EigsStats)]),
     "pf_op_step": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double]),
     "pf_cheb_steps": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double,
                                 C.c_double, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
@@ -189,6 +193,8 @@ def load_library():
         return lib
 
 
+PF_E_DEGENERATE = -3
+PF_E_STATE = -4
 PF_E_PERSIST_TIMEOUT = -5
 
 
@@ -898,6 +904,31 @@ class DeviceLaplacian(object):
         m = n_out.value
         out = np.ascontiguousarray(vecs.reshape(-1)[: self.n * m].reshape(self.n, m))
         return vals[:m].copy(), out, {f: getattr(st, f) for f, _ in EigsStats._fields_}
+
+    def eigs_smallest2(self, other, n_wanted, n_wanted_other, minmax=False, wait=True):
+        """`pf_eigs_smallest2`: this graph and `other` (same ctx, both with symmetric W) solved together in ONE C call -
+        the pipelined pair driver in C++.  Returns two tuples (vals, vecs (n, m) in pinned memory, stats dict with a
+        `residuals` array).  `wait=False`: the eigenvector downloads are still in flight (`finalize_wait()` on each)."""
+        outs = []
+        for dev, m in ((self, int(n_wanted)), (other, int(n_wanted_other))):
+            outs.append((np.empty(m), pinned_empty((dev.n, m)), np.zeros(m), C.c_int32(), EigsStats()))
+        (va, xa, ra, na, sa), (vb, xb, rb, nb, sb) = outs
+        _check(self._lib.pf_eigs_smallest2(self._h, other._h, int(n_wanted), int(n_wanted_other), int(bool(minmax)), 0 if wait else 1,
+                                           _f64(va), _f64(xa), _f64(ra), C.byref(na), C.byref(sa),
+                                           _f64(vb), _f64(xb), _f64(rb), C.byref(nb), C.byref(sb)))
+        res = []
+        for dev, (vals, vecs, resid, n_out, st) in zip((self, other), outs):
+            m = n_out.value
+            dev._final_count = m
+            dev._final_pending = (not wait) and m > 0
+            if m != vecs.shape[1]:  # fewer pairs than asked for: the library wrote an (n, m) block
+                if dev._final_pending:
+                    dev.finalize_wait()
+                vecs = np.ascontiguousarray(vecs.reshape(-1)[: dev.n * m].reshape(dev.n, m))
+            stats = {f: getattr(st, f) for f, _ in EigsStats._fields_ if f != "reserved"}
+            stats["residuals"] = resid[:m].copy()
+            res.append((vals[:m].copy(), vecs, stats))
+        return res[0], res[1]
 
     # ---- primitives of the row-partitioned solve (pyfocusr_amd/rowpart.py)
     def op_step(self, x, prev, out, alpha, c, beta, op=None):

@@ -170,6 +170,9 @@ void pf_destroy(pf_ctx* c) {
         hipEventDestroy(pr.first);
         hipEventDestroy(pr.second);
     }
+    if (c->stage_ring) hipHostFree(c->stage_ring);
+    for (hipEvent_t ev : c->stage_ev)
+        if (ev) hipEventDestroy(ev);
     for (auto& pb : c->pinned_pool) hipHostFree(pb.second);
     if (c->pinned_scratch) hipHostFree(c->pinned_scratch);
     for (hipEvent_t ev : c->event_pool) hipEventDestroy(ev);

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include <map>
 #include <unordered_map>
 #include <vector>
@@ -43,6 +44,8 @@ constexpr int PF_WIN_GHOSTS = 1024;  // outside rows a window may read (one per 
 constexpr int PF_WIN_MAX = 1024;     // windows per graph the window structures cover
 constexpr int PF_WIN_G1 = 512;       // ring-1 rows of a window whose recurrence the window repeats itself (k_cheb_resident2)
 constexpr int PF_WIN_GW = 16;        // entries per such row
+constexpr int PF_STAGE_SLOTS = 8;   // pinned staging slots per ctx ...
+constexpr size_t PF_STAGE_BYTES = 32768;  // ... of this size each
 constexpr int PF_WS_TMPS = 4;      // temporaries behind the workspace slots (Chebyshev rotation)
 
 // device buffers of the box hierarchy of pf_knn_tree.hip (1-NN for deep coordinates); they grow and stay with the ctx
@@ -61,6 +64,9 @@ struct pf_knn_tree {
 struct pf_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    void* stage_ring = nullptr;         // pinned staging slots for small host-to-device payloads (pf_combine's coefficients)
+    hipEvent_t stage_ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    int stage_next = 0;
     hipStream_t copy_stream = nullptr;  // downloads that overlap with work on `stream` (pf_finalize_vectors_begin)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timing = false;
@@ -121,7 +127,13 @@ struct pf_ctx {
     std::unordered_map<void*, size_t> live_blocks;
 };
 
+inline uint64_t pf_next_uid() {
+    static std::atomic<uint64_t> next{1};
+    return next.fetch_add(1);
+}
+
 struct pf_graph {
+    uint64_t uid = pf_next_uid();  // never reused (unlike an address): remembered facts about a PAIR of graphs are keyed by it
     pf_ctx* ctx = nullptr;
     int64_t n = 0, n_pad = 0, n_faces = 0;
     int32_t vpf = 0;
@@ -179,6 +191,10 @@ struct pf_graph {
     int32_t* px_g1_gw = nullptr;     // [windows] widest ring-1 row
     std::vector<int32_t> h_px_gh_cnt2, h_px_g1_gw;
     int64_t px_gh2_total = 0, px_g1_entries = 0;  // sums over the windows: ring-2 rows, entries of ring-1 rows
+    int32_t single_applications = 0;   // single-graph resident applications so far (the rings are built at the third)
+    uint64_t lds_need_partner = 0;   // uid of the partner (own uid: alone) the remembered LDS need belongs to
+    uint64_t lds_need2_partner = 0;
+    int64_t lds_need_value = -2, lds_need2_value = -2;
     double* persist_ring2 = nullptr; // [4][n_pad] hand-off buffers of k_cheb_resident2 (slot of ROUND r = (r + phase2) & 3)
     int32_t persist_phase2 = 0;
     uint64_t persist_epoch2 = 0;

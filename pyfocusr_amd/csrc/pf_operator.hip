@@ -10,6 +10,7 @@
 // are bitwise reproducible run to run.
 #include <math.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include <algorithm>
 #include <vector>
@@ -1341,16 +1342,54 @@ int pf_combine(pf_graph* g, int32_t src_first, int32_t m, const double* Y, int32
     PF_TRY(check_slots(g, dst_first, k, "pf_combine"));
     PF_CHECK(Y != nullptr && m > 0 && k > 0, PF_E_ARG, "pf_combine: bad argument");
     PF_CHECK(src_first + m <= dst_first || dst_first + k <= src_first, PF_E_ARG, "pf_combine: overlapping ranges");
-    hipStream_t st = g->ctx->stream;
+    pf_ctx* ctx = g->ctx;
+    hipStream_t st = ctx->stream;
     double* dY = nullptr;
     PF_HIP(pf_malloc(st, (void**)&dY, sizeof(double) * (size_t)m * k));
-    hipError_t e = hipMemcpyAsync(dY, Y, sizeof(double) * (size_t)m * k, hipMemcpyHostToDevice, st);
+    // Y goes through one of a few pinned staging slots, so that the call need not wait for the copy (a synchronisation costs
+    // 30-50 us of idle device, and the tail of a solve has three of these calls); a slot is reused only after the copy
+    // that read it last has completed
+    const size_t bytes = sizeof(double) * (size_t)m * k;
+    const void* src = Y;
+    bool staged = false;
+    if (bytes <= PF_STAGE_BYTES) {
+        if (!ctx->stage_ring) {
+            if (hipHostMalloc(&ctx->stage_ring, (size_t)PF_STAGE_SLOTS * PF_STAGE_BYTES, hipHostMallocDefault) != hipSuccess) {
+                (void)hipGetLastError();
+                ctx->stage_ring = nullptr;
+            } else {
+                for (int i = 0; i < PF_STAGE_SLOTS; ++i) ctx->stage_ev[i] = nullptr;
+            }
+        }
+        if (ctx->stage_ring) {
+            const int slot = ctx->stage_next;
+            ctx->stage_next = (slot + 1) % PF_STAGE_SLOTS;
+            bool ok = true;
+            if (!ctx->stage_ev[slot]) ok = hipEventCreateWithFlags(&ctx->stage_ev[slot], hipEventDisableTiming) == hipSuccess;
+            else ok = hipEventSynchronize(ctx->stage_ev[slot]) == hipSuccess;
+            if (ok) {
+                void* dst = static_cast<unsigned char*>(ctx->stage_ring) + (size_t)slot * PF_STAGE_BYTES;
+                memcpy(dst, Y, bytes);
+                src = dst;
+                staged = true;
+                hipError_t es = hipMemcpyAsync(dY, src, bytes, hipMemcpyHostToDevice, st);
+                if (es == hipSuccess) es = hipEventRecord(ctx->stage_ev[slot], st);
+                if (es != hipSuccess) {
+                    pf_free(st, dY);
+                    PF_HIP(es);
+                }
+            } else {
+                (void)hipGetLastError();
+            }
+        }
+    }
+    hipError_t e = staged ? hipSuccess : hipMemcpyAsync(dY, Y, bytes, hipMemcpyHostToDevice, st);
     for (int32_t c0 = 0; c0 < k && e == hipSuccess; c0 += COMBINE_COLS) {
         const int32_t nc = std::min(COMBINE_COLS, k - c0);
         k_combine<<<nblk(g->n_pad), PF_BLOCK, 0, st>>>(g->ws, g->n_pad, src_first, m, dY, k, c0, nc, dst_first);
         e = hipGetLastError();
     }
-    hipError_t e2 = hipStreamSynchronize(st);  // Y is the caller's host buffer
+    hipError_t e2 = staged ? hipSuccess : hipStreamSynchronize(st);  // (not staged: Y is the caller's host buffer)
     pf_free(st, dY);
     PF_HIP(e);
     PF_HIP(e2);

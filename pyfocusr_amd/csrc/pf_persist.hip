@@ -856,10 +856,17 @@ int persist_cheb2(const pf_persist_args* a, const pf_persist_args* b, int64_t gr
     pf_graph* gb = b ? b->g : nullptr;
     pf_ctx* ctx = ga->ctx;
     if (two_step_level() < (gb ? 2 : 1) || ga->win_rows != RX_THREADS) return PF_OK;
+    // the second-ring structures cost ~0.1 ms to build (a kernel and a read-back): a graph pays that at its THIRD
+    // single-graph application, not for the one or two a paired solve leaves over when its partner converges first
+    if (!gb && ga->px2_state < 0 && ++ga->single_applications < 3) return PF_OK;
     PF_TRY(pf_window_rings_prepare(ga));
     if (gb) PF_TRY(pf_window_rings_prepare(gb));
     if (ga->px2_state != 1 || (gb && gb->px2_state != 1)) return PF_OK;
-    const int64_t need = lds_need2(ga, gb);
+    if (ga->lds_need2_partner != (gb ? gb->uid : ga->uid) || ga->lds_need2_value == -2) {
+        ga->lds_need2_value = lds_need2(ga, gb);
+        ga->lds_need2_partner = gb ? gb->uid : ga->uid;
+    }
+    const int64_t need = ga->lds_need2_value;
     if (need < 0 || (size_t)need > RX_LDS_LIMIT) return PF_OK;
     {
         pf_ctx* expected = nullptr;
@@ -1028,7 +1035,12 @@ int pf_persist_cheb(const pf_persist_args* a, const pf_persist_args* b, int* don
     PF_TRY(pf_window_slots_prepare(ga));
     if (gb) PF_TRY(pf_window_slots_prepare(gb));
     if (ga->px_state != 1 || (gb && gb->px_state != 1)) return PF_OK;
-    const int64_t need = lds_need(ga, gb, nw);
+    // (the LDS need of a graph or pair is a walk over every window's slices on the host: remembered per graph and partner)
+    if (ga->lds_need_partner != (gb ? gb->uid : ga->uid) || ga->lds_need_value == -2) {
+        ga->lds_need_value = lds_need(ga, gb, nw);
+        ga->lds_need_partner = gb ? gb->uid : ga->uid;
+    }
+    const int64_t need = ga->lds_need_value;
     if (need < 0 || (size_t)need > RX_LDS_LIMIT) return PF_OK;
     {
         pf_ctx* expected = nullptr;

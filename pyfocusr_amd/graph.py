@@ -24,6 +24,8 @@ uses `np.random.shuffle` (A7).  Extra node features (curvature, point-data
 arrays; graph.py:85-119,166-175,191-210) need VTK and are outside the hot path:
 non-empty feature lists raise `NotImplementedError`.
 """
+import os
+
 import numpy as np
 from scipy import sparse
 
@@ -383,6 +385,54 @@ def compute_spectra(graphs):
         raise errors[0]
 
 
+PAIR_DRIVER = os.environ.get("PF_PAIR_DRIVER", "c")  # "c": pf_eigs_smallest2 where it applies; "python": always _krylov.drive_pair
+
+
+def _paired_spectra_c(ga, gb):
+    """The paired solve behind ONE library call (`pf_eigs_smallest2`: the pair driver restated in C++, symmetric W only):
+    no interpreter between the launches of an outer step.  Returns False when the call does not cover the pair (an
+    asymmetric W, a graph too small for the filtered iteration, null vectors the component count did not predict, fewer
+    eigenpairs than the reference's widen-and-retry loop ends with): the Python driver then does the whole solve."""
+    from ._krylov import EigsStats
+
+    da, db = ga.device, gb.device
+    if (not hasattr(da, "eigs_smallest2") or da.ctx is not db.ctx or not (da.symmetric and db.symmetric)
+            or (ga.norm_eig_vecs is True) != (gb.norm_eig_vecs is True)
+            or not (getattr(da, "lock_nulls", True) and getattr(db, "lock_nulls", True))):
+        return False
+    plans = []
+    for g, dev in ((ga, da), (gb, db)):
+        n_null = dev.n_components + dev.n_isolated
+        k_final, retries = _widened_k(g.n_spectral_features + 1, g.n_spectral_features, 1, n_null, dev.n)
+        m_out = max(min(k_final - n_null, dev.n - n_null), 0)
+        if m_out == 0:
+            return False
+        plans.append((m_out, retries))
+    try:
+        ra, rb = da.eigs_smallest2(db, plans[0][0], plans[1][0], minmax=ga.norm_eig_vecs is True, wait=False)
+    except _hip.PfError as exc:
+        if getattr(exc, "code", None) in (_hip.PF_E_STATE, _hip.PF_E_DEGENERATE):
+            return False
+        raise
+    for dev, (m_out, _), (vals, vecs, st) in zip((da, db), plans, (ra, rb)):
+        if len(vals) != m_out or st["n_null"] != dev.n_components:
+            da.finalize_wait()
+            db.finalize_wait()
+            return False
+    for g, (m_out, retries), (vals, vecs, st) in zip((ga, gb), plans, (ra, rb)):
+        if g.verbose:
+            print("Starting!")
+            for _ in range(retries):
+                print("Not enough eigenvalues found, trying again with more eigenvalues!")
+                print("Starting!")
+        stats = EigsStats()
+        for key in ("matvecs", "outer_steps", "restarts", "filter_resets", "degree", "cut", "n_null", "second_passes"):
+            setattr(stats, key, st[key])
+        stats.residuals = st["residuals"]
+        g._set_spectrum(vals, vecs, stats)
+    return True
+
+
 def _paired_spectra(ga, gb):
     """Both spectra on ONE stream with the two Chebyshev recurrences advancing in shared kernel
     launches (`pf_cheb2`): a 250k-vertex filter step alone is a ~5 us kernel of which ~3 us is
@@ -390,6 +440,13 @@ def _paired_spectra(ga, gb):
     for g in (ga, gb):
         if g.verbose:
             print("Beginning Eigen Decomposition")
+    if PAIR_DRIVER == "c" and _paired_spectra_c(ga, gb):
+        for g in (ga, gb):
+            if g.verbose:
+                print("All final eigenvalues are: \n{}".format(g.eig_vals))
+                print("-" * 72)
+                print("Final eigenvalues of interest are: \n{}".format(g.eig_vals))
+        return
 
     def solver(g):  # a factory: `drive_pair` repeats both solves if the resident filter kernel had to give up
         return lambda: _device_eigs_gen(g.device, k=g.n_spectral_features + 1, n_k_needed=g.n_spectral_features,
