@@ -616,7 +616,7 @@ def test_pair_driver_in_c(golden, hip, ctx):
     for driver in ("c", "python"):
         graph_mod.PAIR_DRIVER = driver
         try:
-            gs = [Graph(mesh_of(golden(n)), n_spectral_features=5, n_rand_samples=10**9, ctx=ctx, verbose=False)
+            gs = [Graph(mesh_of(golden(n)), n_spectral_features=6, n_rand_samples=10**9, ctx=ctx, verbose=False)
                   for n in ("target_mesh", "source_mesh")]
             before = hip.persist_state(ctx)["launches"]
             compute_spectra(gs)
@@ -627,8 +627,8 @@ def test_pair_driver_in_c(golden, hip, ctx):
         finally:
             graph_mod.PAIR_DRIVER = "c"
     for (vc, xc, sc), (vp, xp, sp), name in zip(results["c"], results["python"], ("target_mesh", "source_mesh")):
-        np.testing.assert_allclose(vc, golden(name)["k5_eig_vals"], rtol=1e-8)
-        assert np.max(np.abs(xc - golden(name)["k5_eig_vecs"])) < 2e-9
+        np.testing.assert_allclose(vc, golden(name)["k6_eig_vals"], rtol=1e-8)
+        assert np.max(np.abs(xc - golden(name)["k6_eig_vecs"])) < 2e-9
         np.testing.assert_allclose(vc, vp, rtol=1e-10)
         assert np.max(np.abs(xc - xp)) < 1e-8
         assert sc.residuals.max() < 1e-10 and sc.degree == sp.degree and abs(sc.matvecs - sp.matvecs) <= 3 * sc.degree
@@ -657,13 +657,17 @@ def test_pair_driver_in_c(golden, hip, ctx):
     assert gs[0].eig_vals.shape == ref["eig_vals"].shape
     np.testing.assert_allclose(gs[0].eig_vals, ref["eig_vals"], rtol=1e-8)
     # what the call does not cover goes to the Python driver without a trace: an asymmetric partner, a tiny graph
-    small = [Graph(blob_mesh(150, seed=6), n_spectral_features=3, n_rand_samples=10**9, ctx=ctx, verbose=False),
-             Graph(blob_mesh(9000, seed=7), n_spectral_features=3, n_rand_samples=10**9, ctx=ctx, verbose=False)]
-    assert not graph_mod._paired_spectra_c(*small)
-    graph_mod._paired_spectra(*small)
-    for g, seed, n in zip(small, (6, 7), (150, 9000)):
-        m = blob_mesh(n, seed=seed)
-        np.testing.assert_allclose(g.eig_vals, orc.graph_spectrum(m.points, m.faces, 3)["eig_vals"], rtol=1e-8)
+    for n_small, covered in ((150, True), (40, False)):
+        small = [Graph(blob_mesh(n_small, seed=6), n_spectral_features=3, n_rand_samples=10**9, ctx=ctx, verbose=False),
+                 Graph(blob_mesh(9000, seed=7), n_spectral_features=3, n_rand_samples=10**9, ctx=ctx, verbose=False)]
+        assert graph_mod._paired_spectra_c(*small) == covered
+        if not covered:
+            graph_mod._paired_spectra(*small)
+        for g, seed, n in zip(small, (6, 7), (n_small, 9000)):
+            m = blob_mesh(n, seed=seed)
+            np.testing.assert_allclose(g.eig_vals, orc.graph_spectrum(m.points, m.faces, 3)["eig_vals"], rtol=1e-8)
+    g15 = Graph(mesh_of(golden("source_mesh_15k")), n_spectral_features=5, n_rand_samples=10**9, ctx=ctx, verbose=False)
+    assert not graph_mod._paired_spectra_c(g15, Graph(blob_mesh(9000, seed=7), n_spectral_features=5, n_rand_samples=10**9, ctx=ctx, verbose=False))
 
 
 def test_multi_component_and_recursive_eig(hip, ctx):
