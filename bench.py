@@ -47,14 +47,13 @@ def spmv_algorithmic_bytes(n, nnz_l):
 def hot_path_step(ctxs, mesh_t, mesh_s, k, n_samples, timers, keep_graphs=False):
     """Same calls as Focusr.__init__ + align_maps (focusr.py:134-170, 514-545) without ICP/CPD."""
     from pyfocusr_amd import Graph, eigsort
-    from pyfocusr_amd.graph import compute_spectra, spectral_knn
+    from pyfocusr_amd.graph import build_devices, compute_spectra, spectral_knn
 
     ctx = ctxs[0]
     t0 = time.perf_counter()
     graphs = [Graph(mesh, n_spectral_features=k, n_rand_samples=n_samples, ctx=c, verbose=False)
               for mesh, c in zip((mesh_t, mesh_s), ctxs)]
-    for g in graphs:
-        _ = g.device  # assembly from the resident mesh
+    build_devices(graphs)  # assembly from the resident meshes (one context: the two meshes side by side on two streams)
     for c in ctxs:
         c.sync()
     t1 = time.perf_counter()

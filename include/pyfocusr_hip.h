@@ -107,6 +107,10 @@ int pf_mesh_upload(pf_ctx* ctx, const double* pts, int64_t n, const int32_t* fac
                    int32_t verts_per_face, pf_mesh** out);
 void pf_mesh_free(pf_mesh* mesh);
 int pf_graph_build_device(pf_mesh* mesh, pf_graph** out);
+/* The two meshes of a pair assembled side by side (mesh a on the ctx stream, mesh b on a second stream of the ctx, the
+ * two builds' halves interleaved around their one synchronisation each): an assembly is ~75 small kernels that are
+ * mostly launch latency, and two of them overlap almost completely.  Same results as two pf_graph_build_device calls. */
+int pf_graph_build_device2(pf_mesh* mesh_a, pf_mesh* mesh_b, pf_graph** out_a, pf_graph** out_b);
 /* A device graph from a general sparse matrix A in CSR (sorted, unique columns; explicit diagonal optional)
  * instead of a mesh: what `recursive_eig(matrix, ...)` (graph.py:357-389) needs when it is handed a scipy
  * matrix.  PF_OP_RW applies A itself; is_symmetric reports A == A^T numerically (PF_OP_SYM is then the same

@@ -12,43 +12,112 @@ static thread_local char g_err[1024] = "";
 static std::mutex g_ctx_mutex;
 static std::vector<pf_ctx*> g_ctxs;
 
-static pf_ctx* ctx_of_stream(hipStream_t st) {
+static pf_ctx* ctx_of_stream(hipStream_t st, int* sid = nullptr) {
     std::lock_guard<std::mutex> lk(g_ctx_mutex);
-    for (pf_ctx* c : g_ctxs)
-        if (c->stream == st) return c;
+    for (pf_ctx* c : g_ctxs) {
+        if (c->stream == st || (c->stream_b && c->stream_b == st)) {
+            if (sid) *sid = c->stream == st ? 0 : 1;
+            return c;
+        }
+    }
     return nullptr;
 }
 
-int pf_pinned_scratch(pf_ctx* c, size_t bytes, void** out) {
-    if (bytes > c->pinned_scratch_bytes) {
-        if (c->pinned_scratch) {
-            PF_HIP(hipStreamSynchronize(c->stream));
-            PF_HIP(hipHostFree(c->pinned_scratch));
-            c->pinned_scratch = nullptr;
-            c->pinned_scratch_bytes = 0;
+int pf_pinned_scratch(pf_ctx* c, size_t bytes, void** out, int sid) {
+    void*& buf = sid ? c->pinned_scratch_b : c->pinned_scratch;
+    size_t& have = sid ? c->pinned_scratch_b_bytes : c->pinned_scratch_bytes;
+    if (bytes > have) {
+        if (buf) {
+            PF_HIP(hipStreamSynchronize(sid ? c->stream_b : c->stream));
+            PF_HIP(hipHostFree(buf));
+            buf = nullptr;
+            have = 0;
         }
         const size_t cap = bytes > ((size_t)1 << 16) ? bytes : ((size_t)1 << 16);
-        PF_HIP(hipHostMalloc(&c->pinned_scratch, cap, hipHostMallocDefault));
-        c->pinned_scratch_bytes = cap;
+        PF_HIP(hipHostMalloc(&buf, cap, hipHostMallocDefault));
+        have = cap;
     }
-    *out = c->pinned_scratch;
+    *out = buf;
+    return PF_OK;
+}
+
+hipStream_t pf_stream_b(pf_ctx* c) {
+    if (!c->stream_b) {
+        hipStream_t s = nullptr;
+        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&c->join_ev, hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            if (s) (void)hipStreamDestroy(s);
+            return nullptr;
+        }
+        std::lock_guard<std::mutex> lk(g_ctx_mutex);
+        c->stream_b = s;
+    }
+    return c->stream_b;
+}
+
+void pf_worker_run(pf_ctx* c, std::function<void()> task) {
+    std::unique_lock<std::mutex> lk(c->worker_mutex);
+    if (!c->worker.joinable()) {
+        c->worker = std::thread([c] {
+            (void)hipSetDevice(c->device);
+            std::unique_lock<std::mutex> l(c->worker_mutex);
+            for (;;) {
+                c->worker_cv.wait(l, [c] { return c->worker_stop || (c->worker_busy && c->worker_task); });
+                if (c->worker_stop) return;
+                std::function<void()> t = std::move(c->worker_task);
+                c->worker_task = nullptr;
+                l.unlock();
+                t();
+                l.lock();
+                c->worker_busy = false;
+                c->worker_cv.notify_all();
+            }
+        });
+    }
+    c->worker_cv.wait(lk, [c] { return !c->worker_busy; });
+    c->worker_task = std::move(task);
+    c->worker_busy = true;
+    c->worker_cv.notify_all();
+}
+
+void pf_worker_wait(pf_ctx* c) {
+    std::unique_lock<std::mutex> lk(c->worker_mutex);
+    c->worker_cv.wait(lk, [c] { return !c->worker_busy; });
+}
+
+int pf_streams_join(pf_ctx* c, int waiter_sid) {
+    PF_CHECK(c->stream_b != nullptr, PF_E_STATE, "pf_streams_join: no second stream");
+    hipStream_t waiter = waiter_sid ? c->stream_b : c->stream, other = waiter_sid ? c->stream : c->stream_b;
+    PF_HIP(hipEventRecord(c->join_ev, other));
+    PF_HIP(hipStreamWaitEvent(waiter, c->join_ev, 0));
+    c->alloc_epoch += 1;
+    c->visible[waiter_sid] = c->alloc_epoch;
     return PF_OK;
 }
 
 hipError_t pf_malloc(hipStream_t st, void** p, size_t bytes) {
     *p = nullptr;
-    pf_ctx* c = ctx_of_stream(st);
+    int sid = 0;
+    pf_ctx* c = ctx_of_stream(st, &sid);
     if (!c) return hipErrorInvalidValue;
+    std::lock_guard<std::mutex> lk(c->alloc_mutex);
     bytes = (std::max<size_t>(bytes, 1) + 255) & ~(size_t)255;
-    auto it = c->free_blocks.find(bytes);
-    if (it != c->free_blocks.end()) {
-        *p = it->second;
-        c->free_blocks.erase(it);
-    } else {
+    auto range = c->free_blocks.equal_range(bytes);
+    for (auto it = range.first; it != range.second; ++it) {
+        // released on this stream (ordered by it), or on the other one before this stream last waited for it
+        if (it->second.sid == sid || it->second.epoch < c->visible[sid]) {
+            *p = it->second.p;
+            c->free_blocks.erase(it);
+            break;
+        }
+    }
+    if (!*p) {
         hipError_t e = hipMalloc(p, bytes);
         if (e != hipSuccess) {  // give cached blocks back to the driver and retry once
-            (void)hipStreamSynchronize(st);
-            for (auto& kv : c->free_blocks) (void)hipFree(kv.second);
+            (void)hipStreamSynchronize(c->stream);
+            if (c->stream_b) (void)hipStreamSynchronize(c->stream_b);
+            for (auto& kv : c->free_blocks) (void)hipFree(kv.second.p);
             c->free_blocks.clear();
             e = hipMalloc(p, bytes);
             if (e != hipSuccess) return e;
@@ -60,11 +129,13 @@ hipError_t pf_malloc(hipStream_t st, void** p, size_t bytes) {
 
 void pf_free(hipStream_t st, void* p) {
     if (!p) return;
-    pf_ctx* c = ctx_of_stream(st);
+    int sid = 0;
+    pf_ctx* c = ctx_of_stream(st, &sid);
     if (!c) return;
+    std::lock_guard<std::mutex> lk(c->alloc_mutex);
     auto it = c->live_blocks.find(p);
     if (it == c->live_blocks.end()) return;  // not ours (or already released)
-    c->free_blocks.emplace(it->second, p);
+    c->free_blocks.emplace(it->second, pf_ctx::FreeBlock{p, sid, c->alloc_epoch});
     c->live_blocks.erase(it);
 }
 
@@ -154,7 +225,23 @@ void pf_destroy(pf_ctx* c) {
         hipStreamSynchronize(c->copy_stream);
         hipStreamDestroy(c->copy_stream);
     }
-    for (auto& kv : c->free_blocks) hipFree(kv.second);
+    if (c->worker.joinable()) {
+        {
+            std::unique_lock<std::mutex> lk(c->worker_mutex);
+            c->worker_cv.wait(lk, [c] { return !c->worker_busy; });
+            c->worker_stop = true;
+            c->worker_cv.notify_all();
+        }
+        c->worker.join();
+    }
+    if (c->stream_b) {
+        hipStreamSynchronize(c->stream_b);
+        hipStreamDestroy(c->stream_b);
+        hipEventDestroy(c->join_ev);
+        c->stream_b = nullptr;
+    }
+    if (c->pinned_scratch_b) hipHostFree(c->pinned_scratch_b);
+    for (auto& kv : c->free_blocks) hipFree(kv.second.p);
     for (auto& kv : c->live_blocks) hipFree(kv.first);  // graphs the caller forgot to free
     c->free_blocks.clear();
     c->live_blocks.clear();

@@ -17,6 +17,8 @@
 #include <string.h>
 
 #include <algorithm>
+#include <string>
+#include <thread>
 
 #include "pf_internal.h"
 
@@ -424,146 +426,322 @@ __global__ void k_report(const int32_t* __restrict__ stats, const int32_t* __res
     if (t >= 16 + PF_ROOTS_AHEAD && t < PF_REPORT_INTS) out[t] = pmin_bits ? pmin_bits[t - 16 - PF_ROOTS_AHEAD] : 0;
 }
 
-// `d_extra` / `h_extra` (8 ints, optional): device flags of the caller that ride in this function's one read-back; when
-// any is set the function returns at once (PF_OK, *extra_hit = true) and the caller reports ITS error.  `nnz_from_rowptr`:
+// `d_extra` / `h_extra` (8 ints, optional): device flags of the caller that ride in this job's one read-back; when
+// any is set end() returns at once (PF_OK, extra_hit = true) and the caller reports ITS error.  `nnz_from_rowptr`:
 // g->nnz_w is read back here too (the mesh path sizes col / w by their upper bound instead of waiting for the count).
+// Two halves around the ONE synchronisation of a build: begin() queues everything up to the read-back on the graph's
+// build stream and returns; end() waits, decides, and queues the SELL fill.  Two meshes of a pair run their halves
+// interleaved on two streams (pf_graph_build_device2): their ~75 small kernels each overlap on the device.
+struct FinishJob {
+    pf_graph* g = nullptr;
+    const double* d_pts = nullptr;
+    bool numeric_symmetry = false;
+    const int32_t* d_extra = nullptr;
+    int32_t* h_extra = nullptr;
+    bool extra_hit = false;
+    bool nnz_from_rowptr = false;
+    const unsigned long long* d_pmin = nullptr;
+    double* h_pmin = nullptr;
+    int sid = 0;  // 0: the ctx stream, 1: its second stream
+
+    static constexpr int PF_CC_ROUNDS = 128;
+    static constexpr int PF_CC_FIRST = 12;
+    hipStream_t st = nullptr;
+    int32_t *flags = nullptr, *d_roots = nullptr, *round_flags = nullptr, *stats = nullptr, *report = nullptr, *h_report = nullptr;
+    int64_t* width64 = nullptr;
+    void* pin = nullptr;
+    size_t slice_bytes = 0;
+    int round = 0;
+    std::vector<void*> tmp;
+
+    ~FinishJob() {
+        for (void* q : tmp) pf_free(st, q);
+    }
+
+    int begin() {
+        st = g->build_stream ? g->build_stream : g->ctx->stream;
+        const int64_t n = g->n;
+        PF_TRY(dev_alloc(st, &flags, 8));
+        tmp.push_back(flags);
+        PF_TRY(dev_alloc(st, &round_flags, PF_CC_ROUNDS));
+        tmp.push_back(round_flags);
+        PF_TRY(dev_alloc(st, &width64, g->n_slices + 1));
+        tmp.push_back(width64);
+        PF_TRY(dev_alloc(st, &d_roots, PF_MAX_ROOTS));
+        tmp.push_back(d_roots);
+        PF_HIP(hipMemsetAsync(flags, 0, sizeof(int32_t) * 8, st));
+        stats = flags + 2;  // [0] isolated, [1] max degree, [2] asym, [3] changed, [4] n_roots
+        k_row_stats<<<nblk(n), PF_BLOCK, 0, st>>>(g->rowptr, n, stats);
+        PF_HIP(hipGetLastError());
+        k_symmetry_probe<<<nblk(n), PF_BLOCK, 0, st>>>(g->rowptr, g->col, numeric_symmetry ? g->w : nullptr, n, stats + 2);
+        PF_HIP(hipGetLastError());
+
+        // components
+        k_label_init<<<nblk(g->n_pad), PF_BLOCK, 0, st>>>(g->rowptr, g->col, n, g->n_pad, g->label);
+        PF_HIP(hipGetLastError());
+        k_label_compress<<<nblk(n), PF_BLOCK, 0, st>>>(g->label, n);
+        PF_HIP(hipGetLastError());
+        PF_HIP(hipMemsetAsync(round_flags, 0, sizeof(int32_t) * PF_CC_ROUNDS, st));
+        // PF_CC_FIRST rounds are queued without asking: a round that follows a round without changes returns at once
+        // (~2 us instead of ~15), and whether the last one still changed something is read back with everything else below
+        for (round = 0; round < PF_CC_FIRST; ++round) {
+            const int32_t* prev = round ? round_flags + round - 1 : nullptr;
+            k_label_hook<<<nblk(n), PF_BLOCK, 0, st>>>(g->rowptr, g->col, n, g->label, round_flags + round, prev);
+            PF_HIP(hipGetLastError());
+            k_label_compress<<<nblk(n), PF_BLOCK, 0, st>>>(g->label, n, prev);
+            PF_HIP(hipGetLastError());
+        }
+        k_collect_roots<<<nblk(n), PF_BLOCK, 0, st>>>(g->label, g->rowptr, n, d_roots, stats + 4);
+        PF_HIP(hipGetLastError());
+
+        // solver-internal renumbering (Morton order, degree-sorted windows), then SELL-64 in that order
+        PF_TRY(pf_compute_order(g, d_pts));
+        k_slice_widths<<<nblk(g->n_pad), PF_BLOCK, 0, st>>>(g->rowptr, g->perm, n, g->n_slices, width64);
+        PF_HIP(hipGetLastError());
+        PF_HIP(hipMemsetAsync(width64 + g->n_slices, 0, sizeof(int64_t), st));
+        PF_TRY(pf_exclusive_scan_i64(st, width64, g->slice_ptr, g->n_slices + 1));
+        // ONE read-back (two copies into pinned memory) for everything the host has to know before it can size the SELL
+        // storage: the row statistics, whether the labelling had converged, the first few component roots (a mesh usually
+        // has one), the caller's own flags, the number of stored entries (mesh path) - and the slice pointers
+        PF_TRY(dev_alloc(st, &report, PF_REPORT_INTS));
+        tmp.push_back(report);
+        k_report<<<1, PF_WAVE, 0, st>>>(stats, round_flags + PF_CC_FIRST - 1, nnz_from_rowptr ? g->rowptr + n : nullptr, d_extra, d_roots,
+                                        reinterpret_cast<const int32_t*>(d_pmin), report);
+        PF_HIP(hipGetLastError());
+        slice_bytes = sizeof(int64_t) * (size_t)(g->n_slices + 1);
+        PF_TRY(pf_pinned_scratch(g->ctx, slice_bytes + sizeof(int32_t) * PF_REPORT_INTS, &pin, sid));
+        h_report = reinterpret_cast<int32_t*>(static_cast<unsigned char*>(pin) + slice_bytes);
+        PF_HIP(hipMemcpyAsync(pin, g->slice_ptr, slice_bytes, hipMemcpyDeviceToHost, st));
+        PF_HIP(hipMemcpyAsync(h_report, report, sizeof(int32_t) * PF_REPORT_INTS, hipMemcpyDeviceToHost, st));
+        return PF_OK;
+    }
+
+    int end() {
+        const int64_t n = g->n;
+        PF_HIP(hipStreamSynchronize(st));
+        g->h_slice_ptr.resize((size_t)g->n_slices + 1);  // the resident Chebyshev kernel sizes its LDS from this
+        memcpy(g->h_slice_ptr.data(), pin, slice_bytes);
+        int32_t h_stats[6], h_roots[PF_ROOTS_AHEAD];
+        for (int i = 0; i < 5; ++i) h_stats[i] = h_report[i];
+        int32_t differing = h_report[5];
+        const int32_t nnz32 = h_report[6];
+        if (d_extra)
+            for (int i = 0; i < 8; ++i) h_extra[i] = h_report[8 + i];
+        for (int i = 0; i < PF_ROOTS_AHEAD; ++i) h_roots[i] = h_report[16 + i];
+        if (d_pmin && h_pmin) {
+            unsigned long long bits = 0;
+            memcpy(&bits, h_report + 16 + PF_ROOTS_AHEAD, sizeof(bits));
+            memcpy(h_pmin, &bits, sizeof(bits));
+        }
+        g->sell_entries = g->h_slice_ptr[(size_t)g->n_slices];
+        if (nnz_from_rowptr) g->nnz_w = nnz32;
+        if (d_extra) {
+            extra_hit = false;
+            for (int i = 0; i < 8; ++i) extra_hit = extra_hit || h_extra[i] != 0;
+            if (extra_hit) return PF_OK;
+        }
+        int32_t n_roots = h_stats[4];
+        if (differing) {  // (rare: more than PF_CC_FIRST rounds) finish the labelling, collect the roots again
+            for (;;) {
+                PF_CHECK(round + 3 <= PF_CC_ROUNDS, PF_E_HIP, "pf_graph_build: component labelling did not converge");
+                for (int b = 0; b < 3; ++b, ++round) {
+                    k_label_hook<<<nblk(n), PF_BLOCK, 0, st>>>(g->rowptr, g->col, n, g->label, round_flags + round, nullptr);
+                    PF_HIP(hipGetLastError());
+                    k_label_compress<<<nblk(n), PF_BLOCK, 0, st>>>(g->label, n);
+                    PF_HIP(hipGetLastError());
+                }
+                PF_HIP(hipMemcpyAsync(&differing, round_flags + round - 1, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+                PF_HIP(hipStreamSynchronize(st));
+                if (!differing) break;
+            }
+            PF_HIP(hipMemsetAsync(stats + 4, 0, sizeof(int32_t), st));
+            k_collect_roots<<<nblk(n), PF_BLOCK, 0, st>>>(g->label, g->rowptr, n, d_roots, stats + 4);
+            PF_HIP(hipGetLastError());
+            PF_HIP(hipMemcpyAsync(&n_roots, stats + 4, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+            PF_HIP(hipMemcpyAsync(h_roots, d_roots, sizeof(h_roots), hipMemcpyDeviceToHost, st));
+            PF_HIP(hipStreamSynchronize(st));
+        }
+        g->n_isolated = h_stats[0];
+        g->max_degree = h_stats[1];
+        g->is_symmetric = h_stats[2] ? 0 : 1;
+        g->n_oneway = h_stats[2];
+        PF_CHECK(n_roots <= PF_MAX_ROOTS, PF_E_ARG, "pf_graph_build: %d connected components exceed the supported %d",
+                 n_roots, PF_MAX_ROOTS);
+        g->n_components = n_roots;
+        g->roots.resize(n_roots);
+        if (n_roots > PF_ROOTS_AHEAD) {
+            PF_HIP(hipMemcpyAsync(g->roots.data(), d_roots, sizeof(int32_t) * n_roots, hipMemcpyDeviceToHost, st));
+            PF_HIP(hipStreamSynchronize(st));
+        } else {
+            for (int32_t i = 0; i < n_roots; ++i) g->roots[(size_t)i] = h_roots[i];
+        }
+        std::sort(g->roots.begin(), g->roots.end());
+        PF_TRY(dev_alloc(st, &g->scol, g->sell_entries));
+        PF_TRY(dev_alloc(st, &g->sval_rw, g->sell_entries));
+        if (g->is_symmetric) PF_TRY(dev_alloc(st, &g->sval_sym, g->sell_entries));
+        k_fill_sell<<<nblk(g->n_pad), PF_BLOCK, 0, st>>>(g->rowptr, g->col, g->w, g->deg, g->g, g->sg, g->perm, g->iperm, n, g->n_pad,
+                                                         g->slice_ptr, g->scol, g->sval_rw, g->sval_sym, g->diag);
+        PF_HIP(hipGetLastError());
+        return PF_OK;
+    }
+};
+
 int finish_graph(pf_graph* g, const double* d_pts, bool numeric_symmetry, const int32_t* d_extra = nullptr, int32_t* h_extra = nullptr,
                  bool* extra_hit = nullptr, bool nnz_from_rowptr = false, const unsigned long long* d_pmin = nullptr,
                  double* h_pmin = nullptr) {
-    hipStream_t st = g->ctx->stream;
-    const int64_t n = g->n;
-    int32_t *flags = nullptr, *d_roots = nullptr, *round_flags = nullptr;
-    int64_t* width64 = nullptr;
-    constexpr int PF_CC_ROUNDS = 128;
-    struct Tmp {
-        hipStream_t st;
-        std::vector<void*> p;
-        ~Tmp() {
-            for (void* q : p) pf_free(st, q);
-        }
-    } tmp{st, {}};
-    PF_TRY(dev_alloc(st, &flags, 8));
-    tmp.p.push_back(flags);
-    PF_TRY(dev_alloc(st, &round_flags, PF_CC_ROUNDS));
-    tmp.p.push_back(round_flags);
-    PF_TRY(dev_alloc(st, &width64, g->n_slices + 1));
-    tmp.p.push_back(width64);
-    PF_TRY(dev_alloc(st, &d_roots, PF_MAX_ROOTS));
-    tmp.p.push_back(d_roots);
-    PF_HIP(hipMemsetAsync(flags, 0, sizeof(int32_t) * 8, st));
-    int32_t* stats = flags + 2;  // [0] isolated, [1] max degree, [2] asym, [3] changed, [4] n_roots
-    k_row_stats<<<nblk(n), PF_BLOCK, 0, st>>>(g->rowptr, n, stats);
-    PF_HIP(hipGetLastError());
-    k_symmetry_probe<<<nblk(n), PF_BLOCK, 0, st>>>(g->rowptr, g->col, numeric_symmetry ? g->w : nullptr, n, stats + 2);
-    PF_HIP(hipGetLastError());
-
-    // components
-    k_label_init<<<nblk(g->n_pad), PF_BLOCK, 0, st>>>(g->rowptr, g->col, n, g->n_pad, g->label);
-    PF_HIP(hipGetLastError());
-    k_label_compress<<<nblk(n), PF_BLOCK, 0, st>>>(g->label, n);
-    PF_HIP(hipGetLastError());
-    PF_HIP(hipMemsetAsync(round_flags, 0, sizeof(int32_t) * PF_CC_ROUNDS, st));
-    // PF_CC_FIRST rounds are queued without asking: a round that follows a round without changes returns at once
-    // (~2 us instead of ~15), and whether the last one still changed something is read back with everything else below
-    constexpr int PF_CC_FIRST = 12;
-    int round = 0;
-    for (; round < PF_CC_FIRST; ++round) {
-        const int32_t* prev = round ? round_flags + round - 1 : nullptr;
-        k_label_hook<<<nblk(n), PF_BLOCK, 0, st>>>(g->rowptr, g->col, n, g->label, round_flags + round, prev);
-        PF_HIP(hipGetLastError());
-        k_label_compress<<<nblk(n), PF_BLOCK, 0, st>>>(g->label, n, prev);
-        PF_HIP(hipGetLastError());
-    }
-    k_collect_roots<<<nblk(n), PF_BLOCK, 0, st>>>(g->label, g->rowptr, n, d_roots, stats + 4);
-    PF_HIP(hipGetLastError());
-
-    // solver-internal renumbering (Morton order, degree-sorted windows), then SELL-64 in that order
-    PF_TRY(pf_compute_order(g, d_pts));
-    k_slice_widths<<<nblk(g->n_pad), PF_BLOCK, 0, st>>>(g->rowptr, g->perm, n, g->n_slices, width64);
-    PF_HIP(hipGetLastError());
-    PF_HIP(hipMemsetAsync(width64 + g->n_slices, 0, sizeof(int64_t), st));
-    PF_TRY(pf_exclusive_scan_i64(st, width64, g->slice_ptr, g->n_slices + 1));
-    // ONE read-back (two copies into pinned memory) for everything the host has to know before it can size the SELL
-    // storage: the row statistics, whether the labelling had converged, the first few component roots (a mesh usually
-    // has one), the caller's own flags, the number of stored entries (mesh path) - and the slice pointers
-    int32_t* report = nullptr;
-    PF_TRY(dev_alloc(st, &report, PF_REPORT_INTS));
-    tmp.p.push_back(report);
-    k_report<<<1, PF_WAVE, 0, st>>>(stats, round_flags + PF_CC_FIRST - 1, nnz_from_rowptr ? g->rowptr + n : nullptr, d_extra, d_roots,
-                                    reinterpret_cast<const int32_t*>(d_pmin), report);
-    PF_HIP(hipGetLastError());
-    void* pin = nullptr;
-    const size_t slice_bytes = sizeof(int64_t) * (size_t)(g->n_slices + 1);
-    PF_TRY(pf_pinned_scratch(g->ctx, slice_bytes + sizeof(int32_t) * PF_REPORT_INTS, &pin));
-    int32_t* h_report = reinterpret_cast<int32_t*>(static_cast<unsigned char*>(pin) + slice_bytes);
-    PF_HIP(hipMemcpyAsync(pin, g->slice_ptr, slice_bytes, hipMemcpyDeviceToHost, st));
-    PF_HIP(hipMemcpyAsync(h_report, report, sizeof(int32_t) * PF_REPORT_INTS, hipMemcpyDeviceToHost, st));
-    PF_HIP(hipStreamSynchronize(st));
-    g->h_slice_ptr.resize((size_t)g->n_slices + 1);  // the resident Chebyshev kernel sizes its LDS from this
-    memcpy(g->h_slice_ptr.data(), pin, slice_bytes);
-    int32_t h_stats[6], h_roots[PF_ROOTS_AHEAD];
-    for (int i = 0; i < 5; ++i) h_stats[i] = h_report[i];
-    int32_t differing = h_report[5];
-    const int32_t nnz32 = h_report[6];
-    if (d_extra)
-        for (int i = 0; i < 8; ++i) h_extra[i] = h_report[8 + i];
-    for (int i = 0; i < PF_ROOTS_AHEAD; ++i) h_roots[i] = h_report[16 + i];
-    if (d_pmin && h_pmin) {
-        unsigned long long bits = 0;
-        memcpy(&bits, h_report + 16 + PF_ROOTS_AHEAD, sizeof(bits));
-        memcpy(h_pmin, &bits, sizeof(bits));
-    }
-    g->sell_entries = g->h_slice_ptr[(size_t)g->n_slices];
-    if (nnz_from_rowptr) g->nnz_w = nnz32;
-    if (d_extra && extra_hit) {
-        *extra_hit = false;
-        for (int i = 0; i < 8; ++i) *extra_hit = *extra_hit || h_extra[i] != 0;
-        if (*extra_hit) return PF_OK;
-    }
-    int32_t n_roots = h_stats[4];
-    if (differing) {  // (rare: more than PF_CC_FIRST rounds) finish the labelling, collect the roots again
-        for (;;) {
-            PF_CHECK(round + 3 <= PF_CC_ROUNDS, PF_E_HIP, "pf_graph_build: component labelling did not converge");
-            for (int b = 0; b < 3; ++b, ++round) {
-                k_label_hook<<<nblk(n), PF_BLOCK, 0, st>>>(g->rowptr, g->col, n, g->label, round_flags + round, nullptr);
-                PF_HIP(hipGetLastError());
-                k_label_compress<<<nblk(n), PF_BLOCK, 0, st>>>(g->label, n);
-                PF_HIP(hipGetLastError());
-            }
-            PF_HIP(hipMemcpyAsync(&differing, round_flags + round - 1, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-            PF_HIP(hipStreamSynchronize(st));
-            if (!differing) break;
-        }
-        PF_HIP(hipMemsetAsync(stats + 4, 0, sizeof(int32_t), st));
-        k_collect_roots<<<nblk(n), PF_BLOCK, 0, st>>>(g->label, g->rowptr, n, d_roots, stats + 4);
-        PF_HIP(hipGetLastError());
-        PF_HIP(hipMemcpyAsync(&n_roots, stats + 4, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-        PF_HIP(hipMemcpyAsync(h_roots, d_roots, sizeof(h_roots), hipMemcpyDeviceToHost, st));
-        PF_HIP(hipStreamSynchronize(st));
-    }
-    g->n_isolated = h_stats[0];
-    g->max_degree = h_stats[1];
-    g->is_symmetric = h_stats[2] ? 0 : 1;
-    g->n_oneway = h_stats[2];
-    PF_CHECK(n_roots <= PF_MAX_ROOTS, PF_E_ARG, "pf_graph_build: %d connected components exceed the supported %d",
-             n_roots, PF_MAX_ROOTS);
-    g->n_components = n_roots;
-    g->roots.resize(n_roots);
-    if (n_roots > PF_ROOTS_AHEAD) {
-        PF_HIP(hipMemcpyAsync(g->roots.data(), d_roots, sizeof(int32_t) * n_roots, hipMemcpyDeviceToHost, st));
-        PF_HIP(hipStreamSynchronize(st));
-    } else {
-        for (int32_t i = 0; i < n_roots; ++i) g->roots[(size_t)i] = h_roots[i];
-    }
-    std::sort(g->roots.begin(), g->roots.end());
-    PF_TRY(dev_alloc(st, &g->scol, g->sell_entries));
-    PF_TRY(dev_alloc(st, &g->sval_rw, g->sell_entries));
-    if (g->is_symmetric) PF_TRY(dev_alloc(st, &g->sval_sym, g->sell_entries));
-    k_fill_sell<<<nblk(g->n_pad), PF_BLOCK, 0, st>>>(g->rowptr, g->col, g->w, g->deg, g->g, g->sg, g->perm, g->iperm, n, g->n_pad,
-                                                     g->slice_ptr, g->scol, g->sval_rw, g->sval_sym, g->diag);
-    PF_HIP(hipGetLastError());
+    FinishJob f;
+    f.g = g, f.d_pts = d_pts, f.numeric_symmetry = numeric_symmetry, f.d_extra = d_extra, f.h_extra = h_extra;
+    f.nnz_from_rowptr = nnz_from_rowptr, f.d_pmin = d_pmin, f.h_pmin = h_pmin;
+    PF_TRY(f.begin());
+    PF_TRY(f.end());
+    if (extra_hit) *extra_hit = f.extra_hit;
     return PF_OK;
 }
+
+}  // namespace
+
+struct pf_mesh {
+    pf_ctx* ctx = nullptr;
+    double* pts = nullptr;    // [n][3]
+    int32_t* faces = nullptr; // [n_faces][vpf]
+    int64_t n = 0, n_faces = 0;
+    int32_t vpf = 0;
+};
+
+namespace {
+
+// The assembly of one mesh in two halves around its one synchronisation (see FinishJob)
+struct MeshBuild {
+    pf_mesh* mesh = nullptr;
+    pf_graph* g = nullptr;
+    int sid = 0;
+    hipStream_t st = nullptr;
+    std::vector<void*> tmp;
+    bool ok = false;
+    FinishJob fin;
+    int32_t h_flags[8] = {0};
+    double h_pmin = 0.0;
+    unsigned long long* pmin = nullptr;
+    int64_t n_edges = 0;
+
+    ~MeshBuild() {
+        for (void* p : tmp) pf_free(st, p);
+        if (!ok && g) {
+            g->build_stream = nullptr;
+            pf_graph_free(g);
+        }
+    }
+
+    template <typename T>
+    int scratch(T** p, int64_t count) {
+        int r = dev_alloc(st, p, count);
+        if (r == PF_OK) tmp.push_back((void*)*p);
+        return r;
+    }
+
+    int begin(pf_mesh* m, int stream_id) {
+        mesh = m;
+        sid = stream_id;
+        pf_ctx* ctx = mesh->ctx;
+        st = sid ? ctx->stream_b : ctx->stream;
+        const int64_t n = mesh->n, n_faces = mesh->n_faces;
+        const int32_t vpf = mesh->vpf;
+        n_edges = n_faces * vpf;
+        g = new pf_graph();
+        g->ctx = ctx;
+        g->build_stream = st;
+        g->n = n;
+        g->n_faces = n_faces;
+        g->vpf = vpf;
+        g->n_pad = (n + 4095) / 4096 * 4096;  // whole blocks of up to 512 rows, a multiple of 8 of them (XCD remap)
+        g->win_rows = pf_window_rows(g->n_pad);
+        g->n_slices = g->n_pad / PF_WAVE;
+        g->n_chunks = (g->n_pad + PF_DOT_CHUNK - 1) / PF_DOT_CHUNK;
+        const double* d_pts = mesh->pts;
+        const int32_t* d_faces = mesh->faces;
+        int32_t *cnt = nullptr, *start = nullptr, *cursor = nullptr, *rcol = nullptr, *ucnt = nullptr, *flags = nullptr;
+        double* rw = nullptr;
+        // (the counters that start from zero share one block, and so do deg / g / sg: two memsets instead of seven launches)
+        int32_t* zeroed = nullptr;
+        const int64_t zstride = (n + 1 + 7) & ~(int64_t)7;
+        PF_TRY(scratch(&zeroed, 3 * zstride + 8));
+        cnt = zeroed, cursor = zeroed + zstride, ucnt = zeroed + 2 * zstride, flags = zeroed + 3 * zstride;
+        PF_TRY(scratch(&start, n + 1));
+        PF_TRY(scratch(&rcol, n_edges));
+        PF_TRY(scratch(&rw, n_edges));
+        PF_TRY(dev_alloc(st, &g->rowptr, n + 1));
+        PF_TRY(dev_alloc(st, &g->deg, 3 * g->n_pad));  // deg, g, sg: one allocation (g->g and g->sg point into it)
+        g->g = g->deg + g->n_pad;
+        g->sg = g->deg + 2 * g->n_pad;
+        g->deg_block = true;
+        PF_TRY(dev_alloc(st, &g->diag, g->n_pad));
+        PF_TRY(dev_alloc(st, &g->label, g->n_pad));
+        PF_TRY(dev_alloc(st, &g->perm, g->n_pad));
+        PF_TRY(dev_alloc(st, &g->iperm, g->n_pad));
+        PF_TRY(dev_alloc(st, &g->smooth, g->n_pad));
+        PF_TRY(dev_alloc(st, &g->slice_ptr, g->n_slices + 1));
+
+        PF_HIP(hipMemsetAsync(zeroed, 0, sizeof(int32_t) * (size_t)(3 * zstride + 8), st));
+        PF_HIP(hipMemsetAsync(g->deg, 0, sizeof(double) * 3 * g->n_pad, st));
+        if (sid == 0) PF_HIP(hipEventRecord(ctx->ev0, st));
+
+        if (n_edges) {
+            k_count_edges<<<nblk(n_edges), PF_BLOCK, 0, st>>>(d_faces, n_edges, vpf, n, cnt, flags);
+            PF_HIP(hipGetLastError());
+        }
+        // No read-back on the way: faces the counting kernel flags (index out of range, repeated vertex) are skipped by the
+        // kernels behind it, col / w are sized by their upper bound (one entry per face edge; duplicates only shrink it),
+        // and the flags, the entry count and everything the second half needs come back in ONE synchronisation (each one
+        // costs ~30 us of idle device: 8 per mesh at first, 2 now).
+        PF_TRY(pf_exclusive_scan_i32(st, cnt, start, n + 1));
+        if (n_edges) {
+            k_scatter_edges<<<nblk(n_edges), PF_BLOCK, 0, st>>>(d_faces, d_pts, n_edges, vpf, n, start, cursor, rcol, rw, flags);
+            PF_HIP(hipGetLastError());
+        }
+        k_sort_unique_rows<<<nblk(n), PF_BLOCK, 0, st>>>(start, n, rcol, rw, ucnt);
+        PF_HIP(hipGetLastError());
+        PF_TRY(pf_exclusive_scan_i32(st, ucnt, g->rowptr, n + 1));
+        PF_TRY(dev_alloc(st, &g->col, n_edges));
+        PF_TRY(dev_alloc(st, &g->w, n_edges));
+        k_compact_rows<<<nblk(n), PF_BLOCK, 0, st>>>(start, g->rowptr, n, rcol, rw, g->col, g->w, g->deg, g->g, g->sg);
+        PF_HIP(hipGetLastError());
+        // the face-by-face bound of the spectrum (k_face_bound); it holds if every undirected edge lies in exactly two
+        // triangles: W symmetric and no directed edge listed twice - both known after the read-back
+        if (vpf == 3 && n_faces > 0) {
+            PF_TRY(scratch(&pmin, 1));
+            const double quarter = 0.25;
+            unsigned long long qbits = 0;
+            memcpy(&qbits, &quarter, sizeof(qbits));
+            PF_HIP(hipMemsetD32Async((hipDeviceptr_t)pmin, (int)(qbits & 0xffffffffu), 1, st));
+            PF_HIP(hipMemsetD32Async((hipDeviceptr_t)(reinterpret_cast<int32_t*>(pmin) + 1), (int)(qbits >> 32), 1, st));
+            k_face_bound<<<nblk(n_faces), PF_BLOCK, 0, st>>>(d_faces, d_pts, n_faces, n, pmin);
+            PF_HIP(hipGetLastError());
+        }
+        fin.g = g, fin.d_pts = d_pts, fin.numeric_symmetry = false, fin.d_extra = flags, fin.h_extra = h_flags;
+        fin.nnz_from_rowptr = true, fin.d_pmin = pmin, fin.h_pmin = &h_pmin, fin.sid = sid;
+        return fin.begin();
+    }
+
+    int end() {
+        const int64_t n = mesh->n;
+        PF_TRY(fin.end());
+        PF_CHECK(!(h_flags[0] & 1), PF_E_ARG, "pf_graph_build: face index out of range [0,%lld)", (long long)n);
+        PF_CHECK(!(h_flags[0] & 2), PF_E_DEGENERATE, "pf_graph_build: a face repeats a vertex on one edge");
+        PF_CHECK(!(h_flags[0] & 4), PF_E_DEGENERATE,
+                 "pf_graph_build: an edge has zero length or non-finite coordinates (the reference would store an "
+                 "infinite weight, graph.py:177-178)");
+        PF_CHECK(!fin.extra_hit, PF_E_HIP, "pf_graph_build: unexpected assembly flag");
+        g->spectral_bound = 2.0;
+        if (pmin && g->is_symmetric && g->nnz_w == n_edges && h_pmin > 0.0 && h_pmin <= 0.25) {
+            const double disc = 1.0 - 4.0 * h_pmin;
+            const double b = (1.0 + (1.0 + sqrt(disc > 0.0 ? disc : 0.0)) / 2.0) * (1.0 + 1e-12);
+            g->spectral_bound = b < 2.0 ? b : 2.0;
+        }
+        PF_TRY(dev_alloc(st, &g->pts, 3 * n));  // kept for pf_point_rows (the mesh object may go away before the graph)
+        PF_HIP(hipMemcpyAsync(g->pts, mesh->pts, sizeof(double) * 3 * n, hipMemcpyDeviceToDevice, st));
+        return PF_OK;
+    }
+};
 
 }  // namespace
 
@@ -615,13 +793,6 @@ void pf_graph_free(pf_graph* g) {
     delete g;
 }
 
-struct pf_mesh {
-    pf_ctx* ctx = nullptr;
-    double* pts = nullptr;    // [n][3]
-    int32_t* faces = nullptr; // [n_faces][vpf]
-    int64_t n = 0, n_faces = 0;
-    int32_t vpf = 0;
-};
 
 int pf_mesh_upload(pf_ctx* ctx, const double* pts, int64_t n, const int32_t* faces, int64_t n_faces, int32_t vpf,
                    pf_mesh** out) {
@@ -674,125 +845,86 @@ int pf_graph_build(pf_ctx* ctx, const double* pts, int64_t n, const int32_t* fac
 int pf_graph_build_device(pf_mesh* mesh, pf_graph** out) {
     PF_CHECK(mesh && out, PF_E_ARG, "pf_graph_build_device: NULL argument");
     pf_ctx* ctx = mesh->ctx;
-    const int64_t n = mesh->n, n_faces = mesh->n_faces;
-    const int32_t vpf = mesh->vpf;
     *out = nullptr;
     PF_HIP(hipSetDevice(ctx->device));
-    hipStream_t st = ctx->stream;
-    const int64_t n_edges = n_faces * vpf;
-
-    pf_graph* g = new pf_graph();
-    g->ctx = ctx;
-    g->n = n;
-    g->n_faces = n_faces;
-    g->vpf = vpf;
-    g->n_pad = (n + 4095) / 4096 * 4096;  // whole blocks of up to 512 rows, a multiple of 8 of them (XCD remap)
-    g->win_rows = pf_window_rows(g->n_pad);
-    g->n_slices = g->n_pad / PF_WAVE;
-    g->n_chunks = (g->n_pad + PF_DOT_CHUNK - 1) / PF_DOT_CHUNK;
-
-    struct Guard {
-        pf_graph* g;
-        std::vector<void*> tmp;
-        bool ok = false;
-        ~Guard() {
-            for (void* p : tmp) pf_free(g->ctx->stream, p);
-            if (!ok) pf_graph_free(g);
-        }
-    } guard{g};
-    auto scratch = [&](auto** p, int64_t count) -> int {
-        int r = dev_alloc(st, p, count);
-        if (r == PF_OK) guard.tmp.push_back((void*)*p);
-        return r;
-    };
-
-    const double* d_pts = mesh->pts;
-    const int32_t* d_faces = mesh->faces;
-    int32_t *cnt = nullptr, *start = nullptr, *cursor = nullptr, *rcol = nullptr, *ucnt = nullptr, *flags = nullptr;
-    double* rw = nullptr;
-    // (the counters that start from zero share one block, and so do deg / g / sg: two memsets instead of seven launches)
-    int32_t* zeroed = nullptr;
-    const int64_t zstride = (n + 1 + 7) & ~(int64_t)7;
-    PF_TRY(scratch(&zeroed, 3 * zstride + 8));
-    cnt = zeroed, cursor = zeroed + zstride, ucnt = zeroed + 2 * zstride, flags = zeroed + 3 * zstride;
-    PF_TRY(scratch(&start, n + 1));
-    PF_TRY(scratch(&rcol, n_edges));
-    PF_TRY(scratch(&rw, n_edges));
-    PF_TRY(dev_alloc(st, &g->rowptr, n + 1));
-    PF_TRY(dev_alloc(st, &g->deg, 3 * g->n_pad));  // deg, g, sg: one allocation (g->g and g->sg point into it)
-    g->g = g->deg + g->n_pad;
-    g->sg = g->deg + 2 * g->n_pad;
-    g->deg_block = true;
-    PF_TRY(dev_alloc(st, &g->diag, g->n_pad));
-    PF_TRY(dev_alloc(st, &g->label, g->n_pad));
-    PF_TRY(dev_alloc(st, &g->perm, g->n_pad));
-    PF_TRY(dev_alloc(st, &g->iperm, g->n_pad));
-    PF_TRY(dev_alloc(st, &g->smooth, g->n_pad));
-    PF_TRY(dev_alloc(st, &g->slice_ptr, g->n_slices + 1));
-
-    PF_HIP(hipMemsetAsync(zeroed, 0, sizeof(int32_t) * (size_t)(3 * zstride + 8), st));
-    PF_HIP(hipMemsetAsync(g->deg, 0, sizeof(double) * 3 * g->n_pad, st));
-    PF_HIP(hipEventRecord(ctx->ev0, st));
-
-    if (n_edges) {
-        k_count_edges<<<nblk(n_edges), PF_BLOCK, 0, st>>>(d_faces, n_edges, vpf, n, cnt, flags);
-        PF_HIP(hipGetLastError());
-    }
-    // No read-back on the way: faces the counting kernel flags (index out of range, repeated vertex) are skipped by the
-    // kernels behind it, col / w are sized by their upper bound (one entry per face edge; duplicates only shrink it),
-    // and the flags, the entry count and everything finish_graph needs come back in ONE synchronisation (each one costs
-    // ~30 us of idle device: 8 per mesh before, 2 now).
-    PF_TRY(pf_exclusive_scan_i32(st, cnt, start, n + 1));
-    if (n_edges) {
-        k_scatter_edges<<<nblk(n_edges), PF_BLOCK, 0, st>>>(d_faces, d_pts, n_edges, vpf, n, start, cursor, rcol, rw, flags);
-        PF_HIP(hipGetLastError());
-    }
-    k_sort_unique_rows<<<nblk(n), PF_BLOCK, 0, st>>>(start, n, rcol, rw, ucnt);
-    PF_HIP(hipGetLastError());
-    PF_TRY(pf_exclusive_scan_i32(st, ucnt, g->rowptr, n + 1));
-    PF_TRY(dev_alloc(st, &g->col, n_edges));
-    PF_TRY(dev_alloc(st, &g->w, n_edges));
-    k_compact_rows<<<nblk(n), PF_BLOCK, 0, st>>>(start, g->rowptr, n, rcol, rw, g->col, g->w, g->deg, g->g, g->sg);
-    PF_HIP(hipGetLastError());
-    // the face-by-face bound of the spectrum (k_face_bound); it holds if every undirected edge lies in exactly two
-    // triangles: W symmetric and no directed edge listed twice - both known after the read-back
-    unsigned long long* pmin = nullptr;
-    double h_pmin = 0.0;
-    if (vpf == 3 && n_faces > 0) {
-        PF_TRY(scratch(&pmin, 1));
-        const double quarter = 0.25;
-        unsigned long long qbits = 0;
-        memcpy(&qbits, &quarter, sizeof(qbits));
-        PF_HIP(hipMemsetD32Async((hipDeviceptr_t)pmin, (int)(qbits & 0xffffffffu), 1, st));
-        PF_HIP(hipMemsetD32Async((hipDeviceptr_t)(reinterpret_cast<int32_t*>(pmin) + 1), (int)(qbits >> 32), 1, st));
-        k_face_bound<<<nblk(n_faces), PF_BLOCK, 0, st>>>(d_faces, d_pts, n_faces, n, pmin);
-        PF_HIP(hipGetLastError());
-    }
-    int32_t h_flags[8] = {0};
-    bool flagged = false;
-    PF_TRY(finish_graph(g, d_pts, false, flags, h_flags, &flagged, true, pmin, &h_pmin));
-    PF_CHECK(!(h_flags[0] & 1), PF_E_ARG, "pf_graph_build: face index out of range [0,%lld)", (long long)n);
-    PF_CHECK(!(h_flags[0] & 2), PF_E_DEGENERATE, "pf_graph_build: a face repeats a vertex on one edge");
-    PF_CHECK(!(h_flags[0] & 4), PF_E_DEGENERATE,
-             "pf_graph_build: an edge has zero length or non-finite coordinates (the reference would store an "
-             "infinite weight, graph.py:177-178)");
-    PF_CHECK(!flagged, PF_E_HIP, "pf_graph_build: unexpected assembly flag");
-    g->spectral_bound = 2.0;
-    if (pmin && g->is_symmetric && g->nnz_w == n_edges && h_pmin > 0.0 && h_pmin <= 0.25) {
-        const double disc = 1.0 - 4.0 * h_pmin;
-        const double b = (1.0 + (1.0 + sqrt(disc > 0.0 ? disc : 0.0)) / 2.0) * (1.0 + 1e-12);
-        g->spectral_bound = b < 2.0 ? b : 2.0;
-    }
-    PF_TRY(dev_alloc(st, &g->pts, 3 * n));  // kept for pf_point_rows (the mesh object may go away before the graph)
-    PF_HIP(hipMemcpyAsync(g->pts, d_pts, sizeof(double) * 3 * n, hipMemcpyDeviceToDevice, st));
-    PF_HIP(hipEventRecord(ctx->ev1, st));
-    PF_HIP(hipStreamSynchronize(st));
+    MeshBuild job;
+    PF_TRY(job.begin(mesh, 0));
+    PF_TRY(job.end());
+    PF_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+    PF_HIP(hipStreamSynchronize(ctx->stream));
     float ms = 0.f;
     PF_HIP(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
     ctx->build_ms = ms;
-    guard.ok = true;
-    *out = g;
+    job.g->build_stream = nullptr;
+    job.ok = true;
+    *out = job.g;
     return PF_OK;
+}
+
+// The two meshes of a pair (target and source of focusr.py:134-170) assembled SIDE BY SIDE: mesh a on the ctx stream, mesh
+// b on the ctx's second stream, their halves interleaved (begin a, begin b, end a, end b).  An assembly is ~75 small
+// kernels (4-80 us each, most of them launch latency and one wave of blocks); two of them overlap almost completely.
+// Results are those of two pf_graph_build_device calls, bit for bit.  On return both graphs live on the ctx stream.
+int pf_graph_build_device2(pf_mesh* mesh_a, pf_mesh* mesh_b, pf_graph** out_a, pf_graph** out_b) {
+    PF_CHECK(mesh_a && mesh_b && out_a && out_b, PF_E_ARG, "pf_graph_build_device2: NULL argument");
+    PF_CHECK(mesh_a->ctx == mesh_b->ctx, PF_E_ARG, "pf_graph_build_device2: the two meshes must belong to one ctx");
+    pf_ctx* ctx = mesh_a->ctx;
+    *out_a = *out_b = nullptr;
+    PF_HIP(hipSetDevice(ctx->device));
+    if (!pf_stream_b(ctx)) {  // no second stream: one after the other
+        PF_TRY(pf_graph_build_device(mesh_a, out_a));
+        const int r = pf_graph_build_device(mesh_b, out_b);
+        if (r != PF_OK) {
+            pf_graph_free(*out_a);
+            *out_a = nullptr;
+        }
+        return r;
+    }
+    int rc = PF_OK;
+    {
+        MeshBuild a, b;
+        rc = pf_streams_join(ctx, 1);  // the second stream sees the uploads and may reuse what the first has released
+        if (rc == PF_OK) {
+            // the first halves are ~75 launches each, ~4 us of host time apiece: queued from two threads, or the second
+            // mesh would only start when the first one's kernels are nearly through (the ctx keeps ONE worker thread for
+            // this: a new thread's first HIP call costs ~0.3 ms)
+            int rc_b = PF_OK;
+            std::string err_b;
+            pf_worker_run(ctx, [&] {
+                rc_b = b.begin(mesh_b, 1);
+                if (rc_b != PF_OK) err_b = pf_last_error();  // (the message is thread-local)
+            });
+            rc = a.begin(mesh_a, 0);
+            pf_worker_wait(ctx);
+            if (rc == PF_OK && rc_b != PF_OK) {
+                rc = rc_b;
+                pf_set_error("%s", err_b.c_str());
+            }
+        }
+        if (rc == PF_OK) rc = a.end();
+        if (rc == PF_OK) rc = b.end();
+        // whatever happened, the first stream waits for the second before anything else is queued on it (the jobs'
+        // destructors release their temporaries after this line, and the graphs move to the first stream)
+        const int rj = pf_streams_join(ctx, 0);
+        if (rc == PF_OK) rc = rj;
+        if (rc == PF_OK) {
+            const hipError_t e1 = hipEventRecord(ctx->ev1, ctx->stream);
+            const hipError_t e2 = hipStreamSynchronize(ctx->stream);
+            float ms = 0.f;
+            if (e1 == hipSuccess && e2 == hipSuccess && hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) == hipSuccess) ctx->build_ms = ms;
+            else rc = PF_E_HIP, pf_set_error("pf_graph_build_device2: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
+        }
+        if (rc == PF_OK) {
+            a.g->build_stream = b.g->build_stream = nullptr;
+            a.ok = b.ok = true;
+            *out_a = a.g;
+            *out_b = b.g;
+        } else {
+            (void)hipStreamSynchronize(ctx->stream_b);
+            (void)hipStreamSynchronize(ctx->stream);
+        }
+    }
+    return rc;
 }
 
 int pf_graph_from_matrix(pf_ctx* ctx, int64_t n, const int32_t* rowptr, const int32_t* colidx, const double* values,

@@ -3,7 +3,11 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <atomic>
+#include <condition_variable>
+#include <functional>
 #include <map>
+#include <mutex>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -122,9 +126,30 @@ struct pf_ctx {
     void* pinned_scratch = nullptr;  // small read-backs land here (pinned: one DMA instead of a staged copy each)
     size_t pinned_scratch_bytes = 0;
     std::vector<hipEvent_t> event_pool;                    // created with hipEventDisableTiming
-    // allocator state
-    std::multimap<size_t, void*> free_blocks;   // size -> block
+    // allocator state.  Two streams may allocate: `stream`, and `stream_b` while a pair of meshes is assembled side by
+    // side (pf_graph_build_device2).  A cached block remembers the stream it was released on and the allocator epoch of
+    // that moment; the other stream may take it only once it has waited for the releasing stream after that release
+    // (pf_streams_join bumps the epoch and records what the waiter may now see).
+    struct FreeBlock {
+        void* p;
+        int sid;          // 0: stream, 1: stream_b
+        uint64_t epoch;   // alloc_epoch when it was released
+    };
+    std::multimap<size_t, FreeBlock> free_blocks;   // size -> block
     std::unordered_map<void*, size_t> live_blocks;
+    hipStream_t stream_b = nullptr;
+    std::mutex alloc_mutex;  // pf_malloc / pf_free: the second stream's job runs its first half on a thread of its own
+    // that thread: created once per ctx (a new thread's first HIP call costs ~0.3 ms of per-thread runtime set-up)
+    std::thread worker;
+    std::mutex worker_mutex;
+    std::condition_variable worker_cv;
+    std::function<void()> worker_task;
+    bool worker_busy = false, worker_stop = false;
+    hipEvent_t join_ev = nullptr;
+    uint64_t alloc_epoch = 1;
+    uint64_t visible[2] = {0, 0};  // stream sid may take the OTHER stream's blocks released before this epoch
+    void* pinned_scratch_b = nullptr;  // pf_pinned_scratch of stream_b's job
+    size_t pinned_scratch_b_bytes = 0;
 };
 
 inline uint64_t pf_next_uid() {
@@ -133,6 +158,7 @@ inline uint64_t pf_next_uid() {
 }
 
 struct pf_graph {
+    hipStream_t build_stream = nullptr;  // while the graph is being assembled: the stream its kernels and blocks belong to
     uint64_t uid = pf_next_uid();  // never reused (unlike an address): remembered facts about a PAIR of graphs are keyed by it
     pf_ctx* ctx = nullptr;
     int64_t n = 0, n_pad = 0, n_faces = 0;
@@ -243,7 +269,13 @@ int pf_timing_collect(pf_ctx* c);  // pf_api.hip: fold finished spans into op_ms
 hipError_t pf_malloc(hipStream_t st, void** p, size_t bytes);
 // the ctx's pinned host block for small transfers, at least `bytes` large (valid until the next call that asks for more;
 // users synchronise with the stream before they return)
-int pf_pinned_scratch(pf_ctx* c, size_t bytes, void** out);
+int pf_pinned_scratch(pf_ctx* c, size_t bytes, void** out, int sid = 0);
+// `waiter_sid` (0: stream, 1: stream_b) waits for everything queued on the other stream so far; afterwards it may reuse
+// the blocks the other stream has released, and use what the other stream has written
+int pf_streams_join(pf_ctx* c, int waiter_sid);
+hipStream_t pf_stream_b(pf_ctx* c);  // created on first use (nullptr on failure)
+void pf_worker_run(pf_ctx* c, std::function<void()> task);  // starts `task` on the ctx's worker thread (one at a time)
+void pf_worker_wait(pf_ctx* c);                             // until that task has returned
 void pf_free(hipStream_t st, void* p);
 
 // SELL-64 entry layout inside a slice of `width` entries per row: entries come in PAIRS per lane, so that one

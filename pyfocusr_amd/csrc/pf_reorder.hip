@@ -234,7 +234,7 @@ __global__ __launch_bounds__(PF_BLOCK) void k_smooth_start(const double* __restr
 
 // Fills g->perm [n_pad], g->iperm [n] and g->smooth [n_pad] (all already allocated).
 int pf_compute_order(pf_graph* g, const double* d_pts) {
-    hipStream_t st = g->ctx->stream;
+    hipStream_t st = g->build_stream ? g->build_stream : g->ctx->stream;
     const int64_t n = g->n;
     const int in = (int)n;
     unsigned long long* bbox = nullptr;

@@ -602,6 +602,51 @@ def test_paired_spectra_equal_single(golden, ctx):
         assert g.eigs_stats.matvecs == one.eigs_stats.matvecs
 
 
+def test_pair_build_side_by_side(golden, hip, ctx):
+    """`pf_graph_build_device2` (two meshes assembled on two streams, halves interleaved; blocks of the caching allocator
+    cross between the streams only behind a join): W, deg, L, the statistics and the solver-order operator equal to two
+    single builds bit for bit - for meshes of different size, repeatedly (blocks released on one stream come back on the
+    other), with other work queued in between; a bad mesh in either place fails cleanly."""
+    from pyfocusr_amd.meshgen import blob_mesh
+
+    cases = [(mesh_of(golden("target_mesh")), mesh_of(golden("source_mesh_15k"))),
+             (blob_mesh(60000, seed=41), blob_mesh(20000, seed=42)),
+             (blob_mesh(20000, seed=43), blob_mesh(60000, seed=44))]
+    rng = np.random.default_rng(3)
+    for rep in range(3):
+        for ma, mb in cases:
+            dm = [hip.DeviceMesh(m.points, m.faces, ctx=ctx) for m in (ma, mb)]
+            pa, pb = hip.DeviceLaplacian.build_pair(*dm)
+            for m, paired in ((ma, pa), (mb, pb)):
+                single = hip.DeviceLaplacian(m.points, m.faces, ctx=ctx)
+                hp, hs = paired.download(labels=True), single.download(labels=True)
+                for key in hs:
+                    assert np.array_equal(hp[key], hs[key]), key
+                assert (paired.symmetric, paired.n_isolated, paired.n_components, paired.max_degree, paired.n_oneway, paired.spectral_bound) == \
+                       (single.symmetric, single.n_isolated, single.n_components, single.max_degree, single.n_oneway, single.spectral_bound)
+                x = rng.standard_normal(m.points.shape[0])
+                assert np.array_equal(paired.spmv_host(x), single.spmv_host(x))  # the solver-order SELL operator too
+                single.close()
+            ctx.knn1(rng.uniform(size=(2000, 3)), rng.uniform(size=(500, 3)))  # other users of the allocator in between
+            pa.close()
+            pb.close()
+            for d in dm:
+                d.close()
+    good, bad = blob_mesh(3000, seed=45), blob_mesh(3000, seed=46)
+    bad_faces = bad.faces.copy()
+    bad_faces[7, 1] = 3000  # out of range
+    for order in (0, 1):
+        dm = [hip.DeviceMesh(good.points, good.faces, ctx=ctx), hip.DeviceMesh(bad.points, bad_faces, ctx=ctx)]
+        with pytest.raises(hip.PfError):
+            hip.DeviceLaplacian.build_pair(*(dm if order == 0 else dm[::-1]))
+        ok = hip.DeviceLaplacian.build_pair(dm[0], dm[0])  # the library is in working order afterwards
+        assert ok[0].n == 3000 and np.array_equal(ok[0].download()["w"], ok[1].download()["w"])
+        for o in ok:
+            o.close()
+        for d in dm:
+            d.close()
+
+
 def test_pair_driver_in_c(golden, hip, ctx):
     """`pf_eigs_smallest2` (the paired, pipelined solve behind ONE C call; what `compute_spectra` uses for two symmetric
     graphs): against the reference's golden eigenpairs, against the Python pair driver on the same graphs, against two

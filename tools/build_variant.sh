@@ -20,6 +20,6 @@ for f in $src/*.hip; do
   fi
 done
 for p in "${pids[@]}"; do wait $p; done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $out/libpyfocusr_hip_$name.so $out/obj_$name/*.o
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -pthread -o $out/libpyfocusr_hip_$name.so $out/obj_$name/*.o
 rm -rf $out/obj_$name
 echo built $out/libpyfocusr_hip_$name.so
