@@ -151,9 +151,11 @@ int pf_spmv_multi(pf_graph* g, int32_t op, int32_t src_first, int32_t dst_first,
  * Everything else runs one step per launch.  Results are bit-identical in all cases.  0 switches it off (also:
  * environment PF_PERSIST=0); process-wide.  Needs 4 x n_pad doubles of scratch per graph.  All blocks must be resident
  * together (grid <= CU count; an idle device): a wait that runs out (another tenant on the device) is reported as
- * PF_E_PERSIST_TIMEOUT at the next synchronising call, after the library has drained the stream and switched the path
- * off for the process.  One ctx per process uses the path at a time (the first to get there, until it is destroyed);
- * other ctxs run one step per launch. */
+ * PF_E_PERSIST_TIMEOUT at the next synchronising call, after the library has drained the stream and SUSPENDED the path:
+ * the next 64 filter applications run one step per launch, then the resident path is tried again (every further timeout
+ * doubles the suspension; pf_persist_enable(1) lifts it; pf_persist_state tells).  One ctx has resident kernels in
+ * flight at a time: the path belongs to the ctx that used it last, another ctx takes it over as soon as the owner's
+ * last resident launch has completed and runs one step per launch until then. */
 int pf_persist_enable(int on);
 /* Level 1 by default: single-graph recurrences (pf_cheb) on graphs with windows of 1024 rows (up to ~262k rows) whose
  * windows see each other symmetrically (any symmetric W) exchange boundary values every SECOND step: a window repeats
@@ -170,6 +172,13 @@ typedef struct pf_persist_info {
     int32_t timeouts;          /* waits that ran out since the process started (each reported as PF_E_PERSIST_TIMEOUT) */
     int64_t launches;          /* resident launches of this process                                                   */
     int64_t launches_two_step; /* ... of them with two steps per exchange                                             */
+    int32_t suspended_for;     /* > 0: a wait ran out; this many filter applications still run one step per launch
+                                  before the resident path is tried again (64 after the first timeout, doubled by every
+                                  further one; environment PF_PERSIST_REARM = the base, 0 = never again)              */
+    int32_t rearms;            /* suspensions that have ended                                                         */
+    int32_t owner_switches;    /* times the path moved from one ctx to another (the previous owner's launches had
+                                  completed; while they are in flight the other ctx runs one step per launch)         */
+    int32_t reserved;
 } pf_persist_info;
 int pf_persist_state(pf_ctx* ctx /* nullable */, pf_persist_info* out);
 /* Test hook: the next n resident launches start with their abort flag raised (they give up at once and the

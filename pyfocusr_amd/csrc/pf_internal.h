@@ -76,6 +76,7 @@ struct pf_ctx {
     bool timing = false;
     uint32_t* persist_sync = nullptr;  // device word(s) of the resident Chebyshev kernel: its abort flag (pf_persist.hip)
     int32_t* persist_abort = nullptr;  // pinned host word: a barrier wait ran out
+    hipEvent_t persist_done_ev = nullptr;  // recorded behind this ctx's latest resident launch (what a would-be owner of the path queries)
     double op_ms = 0.0;
     int64_t op_launches = 0;
     double op_bytes = 0.0;
@@ -320,7 +321,8 @@ struct pf_persist_args {
     int32_t degree;
     double c, e, rho;
 };
-int pf_persist_cheb(const pf_persist_args* a, const pf_persist_args* b /* nullable */, int* done, double* lds_bytes /* += */);
+int pf_persist_cheb(const pf_persist_args* a, const pf_persist_args* b /* nullable */, int* done, double* lds_bytes /* += */,
+                    bool first_try = true /* false: a further attempt for the same filter application (pf_cheb2's single-graph launches) */);
 int pf_persist_check(pf_ctx* ctx);  // PF_E_PERSIST_TIMEOUT (stream drained, path switched off) if a wait of an earlier launch ran out
 int pf_persist_set(int on);
 void pf_persist_release(pf_ctx* ctx);  // pf_destroy: another ctx may take the resident path over

@@ -1080,8 +1080,8 @@ int pf_cheb2(pf_graph* ga, int32_t op_a, int32_t src_a, int32_t dst_a, int32_t d
         // The pair does not fit one resident launch (windows of 2048+ rows: registers / LDS): each graph in its own
         // resident launch still beats one step per launch by far (1M rows: 2 x 4 us per step against 30 us shared).
         int done_a = 0, done_b = 0;
-        PF_TRY(pf_persist_cheb(&pa, nullptr, &done_a, &t.lds_bytes));
-        PF_TRY(pf_persist_cheb(&pb, nullptr, &done_b, &t.lds_bytes));
+        PF_TRY(pf_persist_cheb(&pa, nullptr, &done_a, &t.lds_bytes, false));
+        PF_TRY(pf_persist_cheb(&pb, nullptr, &done_b, &t.lds_bytes, false));
         if (done_a || done_b) {
             t.launches = done_a + done_b;
             t.persist_steps = (done_a ? degree_a : 0) + (done_b ? degree_b : 0);

@@ -41,9 +41,12 @@
 // A plain launch with grid <= CU count and one block per CU (checked against the occupancy query): all blocks are
 // resident on an idle device.  hipLaunchCooperativeKernel would add only the same size check at +15-19 us of host time
 // per launch (MI355X_MICROARCH.md, "coop-launch": identical residency), and cannot protect against another tenant either.
+#include <stdio.h>
 #include <stdlib.h>
 
 #include <algorithm>
+#include <climits>
+#include <cstdint>
 #include <atomic>
 #include <mutex>
 #include <vector>
@@ -60,6 +63,21 @@ std::atomic<uint64_t> g_abort_epoch{1};    // bumped when a launch aborted: ever
 std::atomic<int> g_test_aborts{0};         // pf_persist_test_hook: launches that start with the abort flag raised
 std::atomic<int64_t> g_launches{0}, g_launches2{0};  // resident launches of this process (all; two steps per exchange)
 std::atomic<int> g_timeouts{0};            // waits that ran out
+// After a timeout the path is SUSPENDED, not switched off for good: the next g_suspend_len filter applications run one step
+// per launch (enough for the repeated solve and the one after it), then the resident path is tried again; every further
+// timeout doubles the suspension (a device that stays shared ends up streaming almost always, one that was shared for a
+// moment gets its fast path back).  pf_persist_enable(1) lifts a suspension at once, PF_PERSIST_REARM=0 makes it permanent.
+std::atomic<int64_t> g_suspended{0};       // applications left before the path is tried again (0: not suspended)
+std::atomic<int> g_rearms{0}, g_owner_switches{0};
+int64_t suspend_length() {
+    static const int64_t base = [] {
+        const char* e = getenv("PF_PERSIST_REARM");
+        return e ? (int64_t)atoll(e) : (int64_t)64;
+    }();
+    if (base <= 0) return INT64_MAX / 2;
+    const int t = std::min(std::max(g_timeouts.load() - 1, 0), 10);
+    return base << t;
+}
 
 constexpr int RX_THREADS = PF_WIN_THREADS;
 constexpr unsigned long long RX_EMPTY = 0xFFFFDEADFFFFDEADull;  // quiet NaN with a payload arithmetic never produces
@@ -754,6 +772,46 @@ bool persist_enabled() {
     return v >= 1;
 }
 
+// a filter application is about to run: false while a suspension lasts (counted down here, once per application:
+// `first_try` is false for the further attempts pf_cheb2 makes for the same application)
+bool persist_available(bool first_try) {
+    if (!persist_enabled()) return false;
+    int64_t left = g_suspended.load();
+    if (left <= 0) return true;
+    if (first_try) {
+        left = g_suspended.fetch_sub(1) - 1;
+        if (left == 0) g_rearms.fetch_add(1);  // the NEXT application tries the resident path again
+    }
+    return false;
+}
+
+// Only one ctx may have resident kernels in flight (two grids would each get part of the CUs and wait for the rest).  The
+// path belongs to the ctx that used it last; another ctx takes it over when the owner's last resident launch has
+// completed, and runs this application one step per launch otherwise - it does not wait.
+bool persist_acquire(pf_ctx* ctx) {
+    pf_ctx* owner = g_owner.load();
+    if (owner == ctx) return true;
+    if (owner == nullptr) {
+        pf_ctx* expected = nullptr;
+        return g_owner.compare_exchange_strong(expected, ctx) || expected == ctx;
+    }
+    if (owner->persist_done_ev && hipEventQuery(owner->persist_done_ev) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;  // still running (or queued)
+    }
+    if (g_owner.compare_exchange_strong(owner, ctx)) {
+        g_owner_switches.fetch_add(1);
+        return true;
+    }
+    return false;
+}
+
+int persist_launched(pf_ctx* ctx) {  // the mark the next would-be owner looks at
+    if (!ctx->persist_done_ev) PF_HIP(hipEventCreateWithFlags(&ctx->persist_done_ev, hipEventDisableTiming));
+    PF_HIP(hipEventRecord(ctx->persist_done_ev, ctx->stream));
+    return PF_OK;
+}
+
 using RxKernel = void (*)(RxArgs);
 // entries of a row kept in registers, by kernel shape: 8 where the register file allows it (a thread holds NG x NW rows)
 constexpr int rx_jr(int ng, int nw) { return ng * nw <= 2 ? 8 : 4; }
@@ -868,10 +926,7 @@ int persist_cheb2(const pf_persist_args* a, const pf_persist_args* b, int64_t gr
     }
     const int64_t need = ga->lds_need2_value;
     if (need < 0 || (size_t)need > RX_LDS_LIMIT) return PF_OK;
-    {
-        pf_ctx* expected = nullptr;
-        if (!g_owner.compare_exchange_strong(expected, ctx) && expected != ctx) return PF_OK;
-    }
+    if (!persist_acquire(ctx)) return PF_OK;
     hipStream_t st = ctx->stream;
     if (!ctx->persist_sync) {
         PF_HIP(pf_malloc(st, (void**)&ctx->persist_sync, sizeof(uint32_t) * 32));
@@ -933,6 +988,7 @@ int persist_cheb2(const pf_persist_args* a, const pf_persist_args* b, int64_t gr
         (void)hipGetLastError();
         return PF_OK;
     }
+    PF_TRY(persist_launched(ctx));
     g_launches.fetch_add(1);
     g_launches2.fetch_add(1);
     for (int q = 0; q < ng; ++q) {
@@ -980,6 +1036,7 @@ int64_t lds_need(pf_graph* ga, pf_graph* gb, int nw) {
 
 int pf_persist_set(int on) {
     g_persist.store(on ? 1 : 0);
+    if (on) g_suspended.store(0);  // an explicit "on" lifts a suspension
     return PF_OK;
 }
 
@@ -1000,6 +1057,11 @@ extern "C" int pf_persist_state(pf_ctx* ctx, pf_persist_info* out) {
     out->timeouts = g_timeouts.load();
     out->launches = g_launches.load();
     out->launches_two_step = g_launches2.load();
+    const int64_t left = g_suspended.load();
+    out->suspended_for = (int32_t)std::min<int64_t>(std::max<int64_t>(left, 0), INT32_MAX);
+    out->rearms = g_rearms.load();
+    out->owner_switches = g_owner_switches.load();
+    out->reserved = 0;
     return PF_OK;
 }
 
@@ -1010,9 +1072,9 @@ extern "C" int pf_persist_test_hook(int n_launches) {
 
 // Runs the recurrence(s) in one kernel if the device, the sizes and the switch allow it.  *done = 1 when it was
 // launched; 0 means "use the one-step-per-launch path" (never an error by itself).
-int pf_persist_cheb(const pf_persist_args* a, const pf_persist_args* b, int* done, double* lds_bytes) {
+int pf_persist_cheb(const pf_persist_args* a, const pf_persist_args* b, int* done, double* lds_bytes, bool first_try) {
     *done = 0;
-    if (!persist_enabled()) return PF_OK;
+    if (!persist_available(first_try)) return PF_OK;
     pf_graph* ga = a->g;
     pf_graph* gb = b ? b->g : nullptr;
     pf_ctx* ctx = ga->ctx;
@@ -1042,10 +1104,7 @@ int pf_persist_cheb(const pf_persist_args* a, const pf_persist_args* b, int* don
     }
     const int64_t need = ga->lds_need_value;
     if (need < 0 || (size_t)need > RX_LDS_LIMIT) return PF_OK;
-    {
-        pf_ctx* expected = nullptr;
-        if (!g_owner.compare_exchange_strong(expected, ctx) && expected != ctx) return PF_OK;  // another ctx owns the path
-    }
+    if (!persist_acquire(ctx)) return PF_OK;  // another ctx has resident kernels in flight
     hipStream_t st = ctx->stream;
     if (!ctx->persist_sync) {
         PF_HIP(pf_malloc(st, (void**)&ctx->persist_sync, sizeof(uint32_t) * 32));
@@ -1100,6 +1159,7 @@ int pf_persist_cheb(const pf_persist_args* a, const pf_persist_args* b, int* don
         (void)hipGetLastError();
         return PF_OK;
     }
+    PF_TRY(persist_launched(ctx));
     g_launches.fetch_add(1);
     for (int q = 0; q < ng; ++q) {
         pf_graph* g = in[q]->g;
@@ -1128,13 +1188,17 @@ int pf_persist_check(pf_ctx* ctx) {
         (void)hipMemsetAsync(ctx->persist_sync, 0, sizeof(uint32_t) * 32, ctx->stream);
         (void)hipStreamSynchronize(ctx->stream);
         (void)hipGetLastError();
-        g_persist.store(0);
         g_abort_epoch.fetch_add(1);
         g_timeouts.fetch_add(1);
+        g_suspended.store(suspend_length());
+        static std::atomic<bool> said{false};
+        if (!said.exchange(true))
+            fprintf(stderr, "libpyfocusr_hip: a wait inside the resident Chebyshev kernel ran out (device shared with another tenant?); "
+                            "filter applications run one step per launch for a while (pf_persist_state tells)\n");
         PF_CHECK(false, PF_E_PERSIST_TIMEOUT,
                  "resident Chebyshev kernel: a wait for a neighbouring window ran out (device shared with another tenant?); "
-                 "the filter applications since the last synchronisation are invalid, the stream is drained and the "
-                 "one-step-per-launch path is used from now on: repeat the solve");
+                 "the filter applications since the last synchronisation are invalid, the stream is drained and the next "
+                 "filter applications run one step per launch (the resident path is tried again later): repeat the solve");
     }
     return PF_OK;
 }

@@ -955,7 +955,8 @@ def test_eigsort_and_correspondence_from_golden_eigs(golden, ctx, pair, t, s, k,
                                          (("target_mesh", "source_mesh"), 3, 4096),
                                          # every vertex sampled: different counts per mesh (W1 on the merged breakpoints),
                                          # and more than 8192 rows (the LDS sort beyond 64 KB)
-                                         (("target_mesh", "source_mesh"), 4, 10**9), (("target_mesh_15k", "source_mesh_15k"), 5, 10**9),
+                                         (("target_mesh", "source_mesh"), 4, 10**9), (("target_mesh", "source_mesh"), 6, 10**9),
+                                         (("target_mesh_15k", "source_mesh_15k"), 5, 10**9),
                                          (("target_mesh_15k", "source_mesh"), 3, 10**9)])
 def test_eigsort_costs_on_device(golden, ctx, names, k, ns):
     """`pf_eigsort_costs` (c_hist, c_hist_f, c_spatial, c_spatial_f and the spatial 1-NN on the device, from the graphs'
@@ -995,6 +996,16 @@ def test_eigsort_costs_on_device(golden, ctx, names, k, ns):
     np.testing.assert_allclose(Qd, Qh, rtol=1e-10)
     np.testing.assert_allclose(Qd2, Qh2, rtol=1e-10)
     assert np.array_equal(vd, vh) and np.array_equal(fd[0], fh[0]) and np.array_equal(fd[1], fh[1])
+    if names == ("target_mesh", "source_mesh") and k == 6 and ns >= 5000:
+        # the DEVICE path directly against the reference's own matrices (every vertex sampled: no randomness); what is left
+        # between them is the 2e-9 between the two sets of eigenvectors and the device's log
+        p5 = golden("pair_5k")
+        assert d._device_result is not None
+        for name in ("c_lambda", "c_hist", "c_hist_f", "c_spatial", "c_spatial_f"):
+            np.testing.assert_allclose(getattr(d, name), p5[name], rtol=2e-6, atol=1e-12, err_msg="device vs reference: " + name)
+        assert np.array_equal(d.idx_source_for_each_target_pt, p5["idx_spatial"])
+        np.testing.assert_allclose(Qd, p5["Q"], rtol=2e-6)
+        assert np.array_equal(d.source_matches, p5["source_matches"]) and np.array_equal(d.target_matches, p5["target_matches"])
     # lazily gathered samples are still there for whoever asks (eigsort.py:34-41)
     assert d.rand_target_eig_vecs.shape == (min(ns, d.graph_target.n_points), d.graph_target.eig_vecs.shape[1])
     assert d.rand_source_points.shape[1] == 3 and d.rand_source_points.min() == 0.0 and d.rand_source_points.max() == 1.0
@@ -1589,6 +1600,47 @@ def test_resident_kernel_timeout_is_survived(hip, ctx):
         hip.persist_enable(True)
         dev.cheb(0, 2, 20, 1.0, 1.0, 1.0)  # resident again (ring refilled after the abort): same bits
         assert np.array_equal(dev.download_slots(2, 1), ref)
+        # the suspension ends by itself: after a timeout the next 64 x 2^(timeouts so far - 1) applications (capped) run
+        # one step per launch, then the resident path is back without anybody asking
+        hip.persist_test_hook(1)
+        dev.cheb(0, 1, 20, 1.0, 1.0, 1.0)
+        with pytest.raises(hip.PfError):
+            ctx.sync()
+        st = hip.persist_state(ctx)
+        assert st["enabled"] == 1 and st["suspended_for"] >= 64 and st["timeouts"] >= 6
+        rearms, launches = st["rearms"], st["launches"]
+        for _ in range(st["suspended_for"]):
+            dev.cheb(0, 1, 8, 1.0, 1.0, 1.0)
+        ctx.sync()
+        st = hip.persist_state(ctx)
+        assert st["suspended_for"] == 0 and st["rearms"] == rearms + 1 and st["launches"] == launches  # all of them streamed
+        dev.cheb(0, 2, 20, 1.0, 1.0, 1.0)
+        ctx.sync()
+        assert hip.persist_state(ctx)["launches"] == launches + 1 and np.array_equal(dev.download_slots(2, 1), ref)
+        # a second context: the path moves to whoever uses it, once the previous owner's launches have completed
+        ctx2 = hip.Context(ctx.device)
+        try:
+            dev2 = hip.DeviceLaplacian(meshes[1].points, meshes[1].faces, ctx=ctx2)
+            dev2.ws_ensure(4)
+            dev2.upload(0, np.ones(dev2.n))
+            assert hip.persist_state(ctx)["owner"] == 1 and hip.persist_state(ctx2)["owner"] == -1
+            switches, launches = hip.persist_state(ctx)["owner_switches"], hip.persist_state(ctx)["launches"]
+            hip.persist_enable(False)
+            dev2.cheb(0, 1, 20, 1.0, 1.0, 1.0)
+            ref2 = dev2.download_slots(1, 1).copy()
+            hip.persist_enable(True)
+            dev2.cheb(0, 2, 20, 1.0, 1.0, 1.0)
+            ctx2.sync()
+            st = hip.persist_state(ctx2)
+            assert st["owner"] == 1 and st["owner_switches"] == switches + 1 and st["launches"] == launches + 1
+            assert np.array_equal(dev2.download_slots(2, 1), ref2)
+            dev.cheb(0, 2, 20, 1.0, 1.0, 1.0)  # ... and back
+            ctx.sync()
+            assert hip.persist_state(ctx)["owner"] == 1 and hip.persist_state(ctx)["launches"] == launches + 2
+            assert np.array_equal(dev.download_slots(2, 1), ref)
+            dev2.close()
+        finally:
+            ctx2.close()
         dev.close()
     finally:
         hip.persist_test_hook(0)
