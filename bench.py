@@ -35,7 +35,7 @@ METRIC = "lowest-k eigenpairs/sec + KNN-correspondence wall-clock, 250k-vertex m
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md, HBM)
 # LDS peak (MI355X_MICROARCH.md, LDS table): ds_read_b64 conflict-free = 256 B per clock and CU; 256 CUs; 2.4 GHz
 LDS_PEAK_GBS = 256.0 * 256 * 2.4
-PMC_SUMMARY = os.path.join("profiles", "r02_pmc_summary.json")
+PMC_SUMMARY = os.path.join("profiles", "r03_pmc_summary.json")
 
 
 def spmv_algorithmic_bytes(n, nnz_l):
@@ -310,6 +310,9 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=("nccl", "gloo"),
                     help="torch.distributed backend; gloo + --share-gpu rehearses the N>1 path on a 1-GPU box")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal only: every rank uses GPU 0")
+    ap.add_argument("--trace-calls", action="store_true",
+                    help="diagnostic: host wall time of the blocking library calls of the timed steps, summed per call name, "
+                         "under 'host_call_ms_per_step'")
     ap.add_argument("--streams", type=int, default=1, choices=(1, 2),
                     help="1: target and source Chebyshev recurrences in lockstep, two graphs per launch on one stream; "
                          "2: two host threads, one HIP stream each")
@@ -345,6 +348,22 @@ def main():
     from pyfocusr_amd.meshgen import blob_mesh
 
     _graph.PAIRED_LAUNCHES = args.pair == "on"
+    call_ms = {}
+    if args.trace_calls:
+        def _wrap(cls, name):
+            fn = getattr(cls, name)
+
+            def wrapped(self, *a, **kw):
+                t0 = time.perf_counter()
+                try:
+                    return fn(self, *a, **kw)
+                finally:
+                    call_ms[name] = call_ms.get(name, 0.0) + 1e3 * (time.perf_counter() - t0)
+            setattr(cls, name, wrapped)
+        for nm in ("finalize_wait", "final_remap", "eigs_smallest2", "final_rows", "point_rows"):
+            _wrap(_hip.DeviceLaplacian, nm)
+        for nm in ("eigsort_costs", "knn1_graphs", "sync"):
+            _wrap(_hip.Context, nm)
 
     ctx = _hip.Context(local)
     ctxs = [ctx, _hip.Context(local) if args.streams == 2 else ctx]  # one stream per mesh of the pair
@@ -367,6 +386,7 @@ def main():
         hot_path_step(ctxs, mesh_t, mesh_s, args.k, args.samples, timers)
     for key in timers:
         timers[key] = 0
+    call_ms.clear()
     for c in set(ctxs):
         c.timing(reset=True)
     barrier()
@@ -547,6 +567,8 @@ def main():
             "max_eig_residual": float(max_res),
             "roofline": roofline,
         }
+        if args.trace_calls:
+            out["host_call_ms_per_step"] = {k: v / args.steps for k, v in call_ms.items()}
         if roofline_stream is not None:
             out["roofline_streaming_kernel"] = roofline_stream
         if not args.no_extras:

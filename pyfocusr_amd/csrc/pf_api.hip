@@ -1,6 +1,7 @@
 // Context, error reporting and timing for libpyfocusr_hip.so.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -104,15 +105,22 @@ hipError_t pf_malloc(hipStream_t st, void** p, size_t bytes) {
     std::lock_guard<std::mutex> lk(c->alloc_mutex);
     bytes = (std::max<size_t>(bytes, 1) + 255) & ~(size_t)255;
     auto range = c->free_blocks.equal_range(bytes);
+    // a block released on this stream (ordered by it) first; else one the other stream released before this stream last
+    // waited for it (taking those first would drain the other stream's supply of exactly the sizes both use)
+    auto pick = range.second;
     for (auto it = range.first; it != range.second; ++it) {
-        // released on this stream (ordered by it), or on the other one before this stream last waited for it
-        if (it->second.sid == sid || it->second.epoch < c->visible[sid]) {
-            *p = it->second.p;
-            c->free_blocks.erase(it);
+        if (it->second.sid == sid) {
+            pick = it;
             break;
         }
+        if (pick == range.second && it->second.epoch < c->visible[sid]) pick = it;
+    }
+    if (pick != range.second) {
+        *p = pick->second.p;
+        c->free_blocks.erase(pick);
     }
     if (!*p) {
+        c->alloc_misses += 1;
         hipError_t e = hipMalloc(p, bytes);
         if (e != hipSuccess) {  // give cached blocks back to the driver and retry once
             (void)hipStreamSynchronize(c->stream);
@@ -219,6 +227,9 @@ int pf_create(int device, pf_ctx** out) {
 
 void pf_destroy(pf_ctx* c) {
     if (!c) return;
+    if (getenv("PF_DEBUG_ALLOC"))
+        fprintf(stderr, "libpyfocusr_hip: ctx %p: %lld device allocations went to the driver, %zu blocks cached at the end\n", (void*)c,
+                (long long)c->alloc_misses, c->free_blocks.size());
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
     if (c->copy_stream) {

@@ -454,9 +454,11 @@ struct FinishJob {
     int round = 0;
     std::vector<void*> tmp;
 
-    ~FinishJob() {
+    void release() {
         for (void* q : tmp) pf_free(st, q);
+        tmp.clear();
     }
+    ~FinishJob() { release(); }
 
     int begin() {
         st = g->build_stream ? g->build_stream : g->ctx->stream;
@@ -624,8 +626,13 @@ struct MeshBuild {
     unsigned long long* pmin = nullptr;
     int64_t n_edges = 0;
 
-    ~MeshBuild() {
+    void release() {  // the temporaries, under the stream that used them
         for (void* p : tmp) pf_free(st, p);
+        tmp.clear();
+        fin.release();
+    }
+    ~MeshBuild() {
+        release();
         if (!ok && g) {
             g->build_stream = nullptr;
             pf_graph_free(g);
@@ -903,8 +910,12 @@ int pf_graph_build_device2(pf_mesh* mesh_a, pf_mesh* mesh_b, pf_graph** out_a, p
         }
         if (rc == PF_OK) rc = a.end();
         if (rc == PF_OK) rc = b.end();
-        // whatever happened, the first stream waits for the second before anything else is queued on it (the jobs'
-        // destructors release their temporaries after this line, and the graphs move to the first stream)
+        // the temporaries go back before the join, so that the first stream may have the second one's from now on (a
+        // block is visible across streams only if it was released before the join)
+        a.release();
+        b.release();
+        // whatever happened, the first stream waits for the second before anything else is queued on it (and the graphs
+        // move to the first stream)
         const int rj = pf_streams_join(ctx, 0);
         if (rc == PF_OK) rc = rj;
         if (rc == PF_OK) {

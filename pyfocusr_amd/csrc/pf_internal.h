@@ -147,6 +147,7 @@ struct pf_ctx {
     std::function<void()> worker_task;
     bool worker_busy = false, worker_stop = false;
     hipEvent_t join_ev = nullptr;
+    int64_t alloc_misses = 0;  // allocations the cache could not serve (hipMalloc: 0.1-1 ms each)
     uint64_t alloc_epoch = 1;
     uint64_t visible[2] = {0, 0};  // stream sid may take the OTHER stream's blocks released before this epoch
     void* pinned_scratch_b = nullptr;  // pf_pinned_scratch of stream_b's job

@@ -5,12 +5,15 @@ same constructor, public cost matrices (`c_lambda`, `c_hist`, `c_hist_f`,
 `c_spatial`, `c_spatial_f`, `Q`) and in-place mutation of the non-reference
 graph's `eig_vecs` (its `eig_vals` are never permuted).
 
-Device work: the 3-D nearest-neighbour query of `calc_c_spatial`
-(eigsort.py:203-204, scipy KDTree in the reference) runs through `pf_knn1`.
-Everything else is k x k bookkeeping on <= n_rand_samples rows — eigenvalue
-costs, 2k^2 one-dimensional Wasserstein distances (sorts of m values; scipy, as
-in the reference), the Hungarian assignment on a k x k matrix — and stays on the
-host, as SURVEY.md §7 plans.
+Device work (`pf_eigsort_costs`, the default whenever both graphs still hold the eigenvector block their eigensolve
+left in HBM): the four sample-based cost matrices - `c_hist` / `c_hist_f` (eigsort.py:162-189: 2k^2 one-dimensional
+Wasserstein distances of log-transformed samples, as LDS sorts + order-statistic differences) and `c_spatial` /
+`c_spatial_f` (eigsort.py:191-233: differences at spatially nearest sampled vertices, a 3-D 1-NN) - from the sampled
+rows read where they are; the sign flips and column moves of `eigen_sort` (eigsort.py:108-122) are applied to the
+device block's column map and to its pinned host image by one kernel + one DMA (`Graph._remap_host_image`).
+Host work: `c_lambda` (k x k), the Hungarian assignment on a k x k matrix, and - when samples were assigned from
+outside, a graph has no device block, or the device refuses (> 16384 samples) - the same four matrices in numpy
+(sorted columns + one cached breakpoint plan for all W1 distances), which the reference-generated goldens pin to 1e-12.
 """
 import functools
 

@@ -1,9 +1,12 @@
 #!/bin/bash
-# The measurement set behind profiles/r02_<tag>_*: run on the GPU box (gpurun), results land in gpurun_out/final/.
+# The measurement set behind profiles/r03_<tag>_*: run on the GPU box (gpurun), results land in gpurun_out/final/.
 #   bash tools/collect_profiles.sh
-# 1. python bench.py (the full line)   2. rocprofv3 kernel stats of the headline workload
-# 3. PMC passes (FETCH_SIZE, WRITE_SIZE separately; resident kernel, then PF_PERSIST=0 for the streaming kernel)
-# 4. tools/pmc_make_summary.py
+# 1. python bench.py (the full line: headline + extras + measured CPU baseline)
+# 2. rocprofv3 kernel stats / gaps / timeline of the headline workload
+# 3. the same kernel stats with the resident path off (PF_PERSIST=0 in the environment of the rocprofv3 command itself):
+#    the streaming kernel k_sell_op2
+# 4. PMC passes (FETCH_SIZE, WRITE_SIZE separately; resident kernel, then PF_PERSIST=0 for the streaming kernel)
+# 5. tools/pmc_make_summary.py
 set -e
 root=${GRAFT_REPO_ROOT:-/root/repo}
 out=$root/gpurun_out/final
@@ -18,11 +21,15 @@ python3 $root/tools/trace_gaps.py $(ls $out/stats/*/*kernel_trace.csv | tail -1)
 python3 $root/tools/trace_timeline.py $(ls $out/stats/*/*kernel_trace.csv | tail -1) > $out/timeline_last_step.txt
 rm -rf $out/stats
 echo "stats done" >> $out/progress.txt
+sargs="--steps 1 --warmup 1 --no-extras --no-cpu-baseline"
+PF_PERSIST=0 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_stream -- python3 $root/bench.py $sargs > $out/bench_stream_under_rocprof.json 2>> $out/rocprof.err
+cp $(ls $out/stats_stream/*/*kernel_stats.csv | tail -1) $out/stream_kernel_stats.csv
+rm -rf $out/stats_stream
+echo "stream stats done" >> $out/progress.txt
 pargs="--steps 2 --warmup 1 --no-extras --no-cpu-baseline"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch -- python3 $root/bench.py $pargs > $out/pmc_fetch.json 2>> $out/rocprof.err
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_write -- python3 $root/bench.py $pargs > $out/pmc_write.json 2>> $out/rocprof.err
 echo "pmc resident done" >> $out/progress.txt
-sargs="--steps 1 --warmup 1 --no-extras --no-cpu-baseline"
 PF_PERSIST=0 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch_stream -- python3 $root/bench.py $sargs > $out/pmc_fetch_stream.json 2>> $out/rocprof.err
 PF_PERSIST=0 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_write_stream -- python3 $root/bench.py $sargs > $out/pmc_write_stream.json 2>> $out/rocprof.err
 echo "pmc streaming done" >> $out/progress.txt
