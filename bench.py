@@ -36,6 +36,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md, HBM)
 # LDS peak (MI355X_MICROARCH.md, LDS table): ds_read_b64 conflict-free = 256 B per clock and CU; 256 CUs; 2.4 GHz
 LDS_PEAK_GBS = 256.0 * 256 * 2.4
 PMC_SUMMARY = os.path.join("profiles", "r03_pmc_summary.json")
+TIMING_STRIDE = 4  # filter applications per HIP event pair
 
 
 def spmv_algorithmic_bytes(n, nnz_l):
@@ -368,7 +369,10 @@ def main():
     ctx = _hip.Context(local)
     ctxs = [ctx, _hip.Context(local) if args.streams == 2 else ctx]  # one stream per mesh of the pair
     for c in set(ctxs):
-        c.timing_enable(True)
+        # every TIMING_STRIDE-th filter application of the timed region carries a HIP event pair (the roofline entry's
+        # average launch duration); an event record costs ~5 us of device time, and a pair around each of the 36 applications
+        # of a step was 0.25 ms of the step it measures.  PF_BENCH_TIMING=0 / 1: none / all of them (A/B).
+        c.timing_enable(int(os.environ.get("PF_BENCH_TIMING", TIMING_STRIDE)))
     mesh_t, mesh_s = blob_mesh(args.n, seed=2 * rank), blob_mesh(args.n, seed=2 * rank + 1)
     for m, c in zip((mesh_t, mesh_s), ctxs):
         m._pf_device_mesh = _hip.DeviceMesh(m.points, m.faces, ctx=c)  # inputs resident in HBM
@@ -399,6 +403,7 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=tdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    timing_stride = max(int(os.environ.get("PF_BENCH_TIMING", TIMING_STRIDE)), 1)
     tms = [c.timing() for c in set(ctxs)]
     tm = dict(knn_ms=tms[0]["knn_ms"])
     for key in ("op_ms", "op_launches", "op_bytes", "persist_ms", "persist_launches", "persist_steps", "persist_bytes",
@@ -469,7 +474,9 @@ def main():
         # time against the LDS peak; `hbm_frac` from PMC traffic; the algorithmic figure stays as an EFFECTIVE rate,
         # never divided by a peak.  Otherwise (resident path off / not applicable): the streaming kernel, HBM roofline.
         resident = tm.get("persist_launches", 0) > 0 and tm["persist_ms"] > 0.5 * tm["op_ms"]
-        if resident:
+        if tm["op_ms"] <= 0.0:  # PF_BENCH_TIMING=0: no event pairs, no roofline entry (an A/B of what the events cost)
+            roofline = {"bound": None, "note": "operator timing switched off (PF_BENCH_TIMING=0)"}
+        elif resident:
             launches, kernel_ms = tm["persist_launches"], tm["persist_ms"]
             kernel_us = 1e3 * kernel_ms / max(launches, 1)
             lds_per_launch = tm["persist_lds_bytes"] / max(launches, 1)
@@ -501,7 +508,9 @@ def main():
                 if traffic is not None else (None if traffic_refused is None else "refused: " + PMC_SUMMARY + ": " + traffic_refused),
                 "hbm_frac": None if traffic is None else traffic / (kernel_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                 "lds_bytes_per_launch": lds_per_launch,
-                "avg_launch_us_hip_events": kernel_us, "launches": launches, "steps_per_launch": steps_per_launch,
+                "avg_launch_us_hip_events": kernel_us, "launches": launches, "launches_are": "the TIMED launches: one filter application in %d "
+                "carries the event pair" % timing_stride, "launches_per_step": launches * timing_stride / args.steps,
+                "steps_per_launch": steps_per_launch,
                 "us_per_step_of_the_pair": 2e3 * kernel_ms / max(tm["persist_steps"], 1),
                 "effective_algorithmic_GBps": tm["persist_bytes"] / max(launches, 1) / (kernel_us * 1e-6) / 1e9,
                 # the bound that does apply: every step contains one dependent memory-side hand-off between workgroups
@@ -562,7 +571,10 @@ def main():
             # eigenpairs/s of the eigensolve alone (Laplacian on the device -> normalised eigenpairs in
             # host memory), and the algorithmic bytes the operator kernel moved per step (sum over its launches)
             "eigensolve_only_eigenpairs_per_s": 2 * args.k * world / (timers["eigensolve"] / args.steps),
-            "operator_algorithmic_bytes_per_step": tm["op_bytes"] / args.steps,
+            # (the library accumulates the bytes of the TIMED applications: one in timing_stride)
+            "operator_algorithmic_bytes_per_step": tm["op_bytes"] * timing_stride / args.steps,
+            "filter_applications_timed": int(tm["op_launches"]) if tm.get("persist_launches", 0) > 0 else None,
+            "timing_stride": timing_stride,
             "knn_kernel_ms": tm["knn_ms"],
             "max_eig_residual": float(max_res),
             "roofline": roofline,

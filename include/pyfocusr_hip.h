@@ -89,7 +89,10 @@ int pf_create(int device, pf_ctx** out);
 void pf_destroy(pf_ctx* ctx);
 int pf_sync(pf_ctx* ctx);
 void* pf_stream(pf_ctx* ctx); /* the ctx's hipStream_t, so that a peer library (RCCL through torch) can enqueue on it */
-int pf_timing_enable(pf_ctx* ctx, int on);            /* time operator launches with HIP events on the ctx stream */
+/* time operator launches with HIP events on the ctx stream: on = 1 every filter application, on = N > 1 every N-th (an
+ * event record costs ~5 us of device time: two per application are 0.25 ms of a 13.5 ms pair step); the accumulated
+ * figures of pf_timing_get then cover the timed applications only */
+int pf_timing_enable(pf_ctx* ctx, int on);
 int pf_timing_get(pf_ctx* ctx, pf_timing* out, int reset);
 
 /* ---- Laplacian assembly --------------------------------------------------------------- */

@@ -335,7 +335,8 @@ class Context(object):
         return int(self._lib.pf_stream(self._h) or 0)
 
     def timing_enable(self, on=True):
-        _check(self._lib.pf_timing_enable(self._h, int(bool(on))))
+        """HIP-event timing of the filter applications: True / 1 every application, N > 1 every N-th, False off."""
+        _check(self._lib.pf_timing_enable(self._h, int(on)))
 
     def timing(self, reset=False):
         t = Timing()

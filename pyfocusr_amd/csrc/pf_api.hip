@@ -13,6 +13,25 @@ static thread_local char g_err[1024] = "";
 static std::mutex g_ctx_mutex;
 static std::vector<pf_ctx*> g_ctxs;
 
+// Small transfers of the hot path go through kernels that read or write PINNED host memory directly, not through
+// hipMemcpyAsync: a copy command shares the DMA engines with the eigenvector downloads (2 x 10 MB per 250k pair, in
+// flight on the copy stream while eigsort and the KNN run) and, depending on which engine the runtime picks in a given
+// process, waits behind them: 40 KB of eigsort results then cost 0.6 ms (seen in one process of three).
+__global__ __launch_bounds__(PF_BLOCK) void k_copy_words(const unsigned long long* __restrict__ src, unsigned long long* __restrict__ dst,
+                                                         size_t n) {
+    const size_t i = (size_t)blockIdx.x * PF_BLOCK + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
+
+int pf_copy_by_kernel(hipStream_t st, const void* src, void* dst, size_t bytes) {
+    if (bytes == 0) return PF_OK;
+    const size_t n = (bytes + 7) / 8;  // (both buffers are allocated in multiples of 8 bytes by their owners)
+    k_copy_words<<<(unsigned)((n + PF_BLOCK - 1) / PF_BLOCK), PF_BLOCK, 0, st>>>(static_cast<const unsigned long long*>(src),
+                                                                                 static_cast<unsigned long long*>(dst), n);
+    PF_HIP(hipGetLastError());
+    return PF_OK;
+}
+
 static pf_ctx* ctx_of_stream(hipStream_t st, int* sid = nullptr) {
     std::lock_guard<std::mutex> lk(g_ctx_mutex);
     for (pf_ctx* c : g_ctxs) {
@@ -25,11 +44,11 @@ static pf_ctx* ctx_of_stream(hipStream_t st, int* sid = nullptr) {
 }
 
 int pf_pinned_scratch(pf_ctx* c, size_t bytes, void** out, int sid) {
-    void*& buf = sid ? c->pinned_scratch_b : c->pinned_scratch;
-    size_t& have = sid ? c->pinned_scratch_b_bytes : c->pinned_scratch_bytes;
+    void*& buf = sid == 2 ? c->pinned_scratch_knn : (sid ? c->pinned_scratch_b : c->pinned_scratch);
+    size_t& have = sid == 2 ? c->pinned_scratch_knn_bytes : (sid ? c->pinned_scratch_b_bytes : c->pinned_scratch_bytes);
     if (bytes > have) {
         if (buf) {
-            PF_HIP(hipStreamSynchronize(sid ? c->stream_b : c->stream));
+            PF_HIP(hipStreamSynchronize(sid == 1 ? c->stream_b : c->stream));
             PF_HIP(hipHostFree(buf));
             buf = nullptr;
             have = 0;
@@ -42,10 +61,24 @@ int pf_pinned_scratch(pf_ctx* c, size_t bytes, void** out, int sid) {
     return PF_OK;
 }
 
+// A secondary stream of a ctx (second assembly, downloads) must not share a hardware queue with the ctx's main stream, or
+// what it carries simply queues up between the main stream's kernels.  The runtime hands out hardware queues from one
+// pool per priority level, shared by every stream of the process (torch's included), and which streams end up on one queue
+// differs from process to process (seen as: one process in three assembled the two meshes one after the other and ran the
+// eigenvector downloads in front of eigsort's kernels, +0.9 ms per step).  A stream of another priority comes from another
+// pool: never the main stream's queue.
+hipError_t pf_create_side_stream(hipStream_t* s) {
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least)
+        return hipStreamCreateWithPriority(s, hipStreamNonBlocking, greatest);
+    (void)hipGetLastError();
+    return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+}
+
 hipStream_t pf_stream_b(pf_ctx* c) {
     if (!c->stream_b) {
         hipStream_t s = nullptr;
-        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess ||
+        if (pf_create_side_stream(&s) != hipSuccess ||
             hipEventCreateWithFlags(&c->join_ev, hipEventDisableTiming) != hipSuccess) {
             (void)hipGetLastError();
             if (s) (void)hipStreamDestroy(s);
@@ -252,6 +285,7 @@ void pf_destroy(pf_ctx* c) {
         c->stream_b = nullptr;
     }
     if (c->pinned_scratch_b) hipHostFree(c->pinned_scratch_b);
+    if (c->pinned_scratch_knn) hipHostFree(c->pinned_scratch_knn);
     for (auto& kv : c->free_blocks) hipFree(kv.second.p);
     for (auto& kv : c->live_blocks) hipFree(kv.first);  // graphs the caller forgot to free
     c->free_blocks.clear();
@@ -295,6 +329,8 @@ int pf_sync(pf_ctx* c) {
 int pf_timing_enable(pf_ctx* c, int on) {
     PF_CHECK(c != nullptr, PF_E_ARG, "pf_timing_enable: ctx is NULL");
     c->timing = on != 0;
+    c->timing_stride = on > 1 ? on : 1;  // on = N > 1: every N-th filter application carries the event pair
+    c->timing_count = 0;
     return PF_OK;
 }
 

@@ -229,7 +229,12 @@ extern "C" int pf_eigsort_costs(pf_graph* gt, pf_graph* gs, const int64_t* rows_
     const size_t kt = (size_t)k * (size_t)mt, ks = (size_t)k * (size_t)ms;
     const size_t doubles = 2 * kt + 3 * ks + 6 * (size_t)(mt + ms) + 12 + 4 * (size_t)k * k;
     unsigned char* d = nullptr;
-    PF_HIP(pf_malloc(st, (void**)&d, host.size() + sizeof(double) * doubles));
+    // both small transfers of this call go through pinned memory and copy kernels (pf_copy_by_kernel: no DMA engine)
+    const size_t up_bytes = (host.size() + 7) & ~(size_t)7, out_bytes = sizeof(double) * 4 * (size_t)k * k;
+    unsigned char* pin = nullptr;
+    PF_TRY(pf_pinned_scratch(c, up_bytes + out_bytes, reinterpret_cast<void**>(&pin)));
+    memcpy(pin, host.data(), host.size());
+    PF_HIP(pf_malloc(st, (void**)&d, up_bytes + sizeof(double) * doubles));
     int rc = PF_OK;
     do {
         auto fail = [&](hipError_t e) {
@@ -238,12 +243,12 @@ extern "C" int pf_eigsort_costs(pf_graph* gt, pf_graph* gs, const int64_t* rows_
             rc = PF_E_HIP;
             return true;
         };
-        if (fail(hipMemcpyAsync(d, host.data(), host.size(), hipMemcpyHostToDevice, st))) break;
+        if ((rc = pf_copy_by_kernel(st, pin, d, up_bytes)) != PF_OK) break;
         const int64_t* d_rows_t = reinterpret_cast<const int64_t*>(d);
         const int64_t* d_rows_s = d_rows_t + mt;
         const int32_t* d_col = reinterpret_cast<const int32_t*>(d + head);
         const double* d_sign = reinterpret_cast<const double*>(d + head + ((sizeof(int32_t) * 2 * k + 7) & ~(size_t)7));
-        double* base = reinterpret_cast<double*>(d + host.size());
+        double* base = reinterpret_cast<double*>(d + up_bytes);
         double* vals_t = base;
         double* vals_s = vals_t + kt;
         double* raw_t = vals_s + ks;
@@ -274,8 +279,9 @@ extern "C" int pf_eigsort_costs(pf_graph* gt, pf_graph* gs, const int64_t* rows_
         if (rc != PF_OK) break;
         k_es_spatial<<<(unsigned)(k * k), ES_RED_THREADS, 0, st>>>(vals_t, vals_s, c->knn_idx, mt, ms, k, d_out);
         if (fail(hipGetLastError())) break;
-        if (fail(hipMemcpyAsync(out, d_out, sizeof(double) * 4 * (size_t)k * k, hipMemcpyDeviceToHost, st))) break;
+        if ((rc = pf_copy_by_kernel(st, d_out, pin + up_bytes, out_bytes)) != PF_OK) break;
         if (fail(hipStreamSynchronize(st))) break;
+        memcpy(out, pin + up_bytes, out_bytes);
     } while (0);
     if (rc != PF_OK) (void)hipStreamSynchronize(st);
     pf_free(st, d);

@@ -74,6 +74,8 @@ struct pf_ctx {
     hipStream_t copy_stream = nullptr;  // downloads that overlap with work on `stream` (pf_finalize_vectors_begin)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timing = false;
+    int timing_stride = 1;     // time every timing_stride-th filter application (an event record costs ~5 us of device time)
+    int64_t timing_count = 0;
     uint32_t* persist_sync = nullptr;  // device word(s) of the resident Chebyshev kernel: its abort flag (pf_persist.hip)
     int32_t* persist_abort = nullptr;  // pinned host word: a barrier wait ran out
     hipEvent_t persist_done_ev = nullptr;  // recorded behind this ctx's latest resident launch (what a would-be owner of the path queries)
@@ -152,6 +154,8 @@ struct pf_ctx {
     uint64_t visible[2] = {0, 0};  // stream sid may take the OTHER stream's blocks released before this epoch
     void* pinned_scratch_b = nullptr;  // pf_pinned_scratch of stream_b's job
     size_t pinned_scratch_b_bytes = 0;
+    void* pinned_scratch_knn = nullptr;  // ... and of the KNN's result read-back (which runs inside other users of the first)
+    size_t pinned_scratch_knn_bytes = 0;
 };
 
 inline uint64_t pf_next_uid() {
@@ -271,11 +275,15 @@ int pf_timing_collect(pf_ctx* c);  // pf_api.hip: fold finished spans into op_ms
 hipError_t pf_malloc(hipStream_t st, void** p, size_t bytes);
 // the ctx's pinned host block for small transfers, at least `bytes` large (valid until the next call that asks for more;
 // users synchronise with the stream before they return)
-int pf_pinned_scratch(pf_ctx* c, size_t bytes, void** out, int sid = 0);
+int pf_pinned_scratch(pf_ctx* c, size_t bytes, void** out, int sid = 0);  // sid 0: ctx stream, 1: stream_b's job, 2: the KNN read-back
+// src -> dst by a copy KERNEL on `st` (one of them pinned host memory, read or written in place: no DMA engine involved);
+// sizes rounded up to 8 bytes
+int pf_copy_by_kernel(hipStream_t st, const void* src, void* dst, size_t bytes);
 // `waiter_sid` (0: stream, 1: stream_b) waits for everything queued on the other stream so far; afterwards it may reuse
 // the blocks the other stream has released, and use what the other stream has written
 int pf_streams_join(pf_ctx* c, int waiter_sid);
 hipStream_t pf_stream_b(pf_ctx* c);  // created on first use (nullptr on failure)
+hipError_t pf_create_side_stream(hipStream_t* s);  // a stream that never shares a hardware queue with a ctx's main stream
 void pf_worker_run(pf_ctx* c, std::function<void()> task);  // starts `task` on the ctx's worker thread (one at a time)
 void pf_worker_wait(pf_ctx* c);                             // until that task has returned
 void pf_free(hipStream_t st, void* p);

@@ -26,6 +26,8 @@
 // the tiled brute force.
 #include <hipcub/hipcub.hpp>
 
+#include <string.h>
+
 #include <algorithm>
 
 #include "pf_internal.h"
@@ -873,7 +875,20 @@ int pf_knn_download(pf_ctx* c, int64_t* idx_out, double* d2_out) {
     PF_CHECK(c->knn_done, PF_E_STATE, "pf_knn_download: pf_knn_run has not completed");
     PF_HIP(hipSetDevice(c->device));
     const size_t count = (size_t)c->knn_nqry * c->knn_k;
-    PF_HIP(hipMemcpyAsync(idx_out, c->knn_idx, sizeof(int64_t) * count, hipMemcpyDeviceToHost, c->stream));
+    const size_t bytes = sizeof(int64_t) * count;
+    if (bytes * (d2_out ? 2 : 1) <= ((size_t)8 << 20)) {
+        // results of up to 8 MB come back through pinned memory and a copy kernel: no DMA engine, which the eigenvector
+        // downloads in flight on the copy stream may be holding (pf_copy_by_kernel)
+        unsigned char* pin = nullptr;
+        PF_TRY(pf_pinned_scratch(c, bytes * (d2_out ? 2 : 1), reinterpret_cast<void**>(&pin), 2));
+        PF_TRY(pf_copy_by_kernel(c->stream, c->knn_idx, pin, bytes));
+        if (d2_out) PF_TRY(pf_copy_by_kernel(c->stream, c->knn_d2, pin + bytes, bytes));
+        PF_HIP(hipStreamSynchronize(c->stream));
+        memcpy(idx_out, pin, bytes);
+        if (d2_out) memcpy(d2_out, pin + bytes, bytes);
+        return PF_OK;
+    }
+    PF_HIP(hipMemcpyAsync(idx_out, c->knn_idx, bytes, hipMemcpyDeviceToHost, c->stream));
     if (d2_out) PF_HIP(hipMemcpyAsync(d2_out, c->knn_d2, sizeof(double) * count, hipMemcpyDeviceToHost, c->stream));
     PF_HIP(hipStreamSynchronize(c->stream));
     return PF_OK;

@@ -852,6 +852,7 @@ struct OpTimer {
     double lds_bytes = 0.0;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     OpTimer(pf_ctx* ctx, int64_t n, double b) : c(ctx), launches(n), bytes(b), on(ctx->timing) {
+        if (on && ctx->timing_stride > 1) on = (ctx->timing_count++ % ctx->timing_stride) == 0;
         if (!on) return;
         if (c->spans_pending.size() >= 4096) (void)pf_timing_collect(c);  // bound the number of live events
         if (!c->spans_free.empty()) {
@@ -1464,7 +1465,7 @@ int pf_finalize_vectors_begin(pf_graph* g, int32_t first, int32_t count, int32_t
     PF_TRY(pf_finalize_vectors_end(g));  // an earlier result still on its way
     pf_ctx* ctx = g->ctx;
     hipStream_t st = ctx->stream;
-    if (!ctx->copy_stream) PF_HIP(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    if (!ctx->copy_stream) PF_HIP(pf_create_side_stream(&ctx->copy_stream));
     // events and the pinned landing place of the statistics come from the ctx's pools (what freed graphs left behind:
     // hipHostMalloc / hipHostFree and event creation cost 0.1-0.2 ms each)
     for (hipEvent_t* ev : {&g->final_ready, &g->final_done}) {
