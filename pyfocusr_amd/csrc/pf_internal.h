@@ -250,6 +250,8 @@ struct pf_graph {
     hipEvent_t orth_wait = nullptr;  // the event pf_orth_end waits on: orth_ev, or the partner graph's after pf_orth_begin2
     int32_t orth_w = 0, orth_first = 0, orth_normalize = 0;  // arguments of the orth in flight (pf_orth_end's second pass)
     int32_t orth_redone = 0;     // the last pf_orth_end ran the second Gram-Schmidt pass itself
+    double orth_serial = 0.0;    // tickets handed to the fused Gram-Schmidt kernels so far
+    double orth_ticket = 0.0;    // ticket of the step in flight (0: that step reports through orth_ev instead)
     double orth_thresh = 0.09;   // second pass when |w'|^2 < orth_thresh |w|^2 (0.5: strict, pf_orth_strict)
     // the last pf_finalize_vectors result stays in HBM (mesh order, [n][final_count] row-major) for pf_final_rows and
     // pf_knn1_graphs: the spectral coordinates never have to come back from the host

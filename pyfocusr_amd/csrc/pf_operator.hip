@@ -216,8 +216,9 @@ struct OrthArgs {
     double* partial;   // [count + 1][n_chunks]
     double* hsum;      // device copy of h
     double* nrm2;      // device copy of |w'|^2
-    double* host_out;  // pinned: h, |w'|^2, redo
+    double* host_out;  // pinned: h, |w'|^2, redo, then the ticket (written last: the host polls it)
     double thresh;     // second pass when |w'|^2 < thresh |w|^2
+    double ticket;     // this step's number (> 0)
 };
 struct OrthArgs2 {
     OrthArgs g[2];
@@ -283,6 +284,14 @@ __global__ __launch_bounds__(PF_BLOCK) void k_orth_project(OrthArgs2 a2) {
             *a.nrm2 = s_after;
             a.host_out[count] = s_after;
             a.host_out[count + 1] = s_redo;
+        }
+        // the ticket goes out behind everything else (system-scope fences + the block's barrier): the host polls it
+        // instead of waiting for an event behind the kernel - the coefficients are known long before the projection
+        // below has finished, and an event record would cost ~5 us of device time per step
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __hip_atomic_store(a.host_out + count + 2, a.ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
     const int64_t i = 2 * ((int64_t)blockIdx.x * PF_BLOCK + threadIdx.x);
@@ -1156,14 +1165,14 @@ static int orth_prepare(pf_graph* g, int32_t w, int32_t first, int32_t count, in
     PF_CHECK(g->orth_pending < 0, PF_E_STATE, "pf_orth_begin: a previous pf_orth_begin has not been collected");
     hipStream_t st = g->ctx->stream;
     PF_TRY(pf_reduce_ensure(g, count + 1));  // (+ the |w|^2 column)
-    if (count > g->orth_host_cap || !g->orth_host) {
+    if (count + 1 > g->orth_host_cap || !g->orth_host) {
         pf_ctx* c = g->ctx;
         if (g->orth_host) {
             PF_HIP(hipStreamSynchronize(st));
             c->pinned_pool.emplace_back(g->orth_host_cap, g->orth_host);
             g->orth_host = nullptr;
         }
-        const int32_t cap = std::max(count, 64);
+        const int32_t cap = std::max(count + 1, 64);  // (h, |w'|^2, verdict, ticket: count + 3 doubles of cap + 2)
         for (size_t i = 0; i < c->pinned_pool.size(); ++i)
             if (c->pinned_pool[i].first >= cap) {  // a buffer a freed graph left behind
                 g->orth_host_cap = c->pinned_pool[i].first;
@@ -1186,6 +1195,8 @@ static int orth_prepare(pf_graph* g, int32_t w, int32_t first, int32_t count, in
         }
     }
     g->orth_host[count + 1] = 0.0;     // the verdict slot; only k_orth_project ever raises it
+    g->orth_host[count + 2] = 0.0;     // the ticket slot
+    g->orth_ticket = 0.0;              // (set by the launch paths whose kernel writes a ticket)
     g->orth_w = w, g->orth_first = first, g->orth_normalize = normalize ? 1 : 0;
     return PF_OK;
 }
@@ -1201,6 +1212,9 @@ static OrthArgs orth_args(pf_graph* g, int32_t w, int32_t first, int32_t count, 
     a.nrm2 = g->coef + 2 * g->coef_cap;
     a.host_out = g->orth_host;
     a.thresh = g->orth_thresh;
+    g->orth_serial += 1.0;
+    a.ticket = g->orth_serial;
+    g->orth_ticket = a.ticket;  // pf_orth_end polls for it
     return a;
 }
 
@@ -1240,7 +1254,7 @@ int pf_orth_begin(pf_graph* g, int32_t w, int32_t first, int32_t count, int32_t 
         PF_HIP(hipMemcpyAsync(g->orth_host, hsum, sizeof(double) * count, hipMemcpyDeviceToHost, st));
         PF_HIP(hipMemcpyAsync(g->orth_host + count, nrm2, sizeof(double), hipMemcpyDeviceToHost, st));
     }
-    PF_HIP(hipEventRecord(g->orth_ev, st));
+    if (g->orth_ticket == 0.0) PF_HIP(hipEventRecord(g->orth_ev, st));  // (a ticketed step is polled for, not waited on)
     g->orth_wait = g->orth_ev;
     g->orth_pending = count;
     return PF_OK;
@@ -1265,9 +1279,9 @@ int pf_orth_begin2(pf_graph* ga, int32_t w_a, int32_t first_a, int32_t count_a, 
     PF_HIP(hipGetLastError());
     k_orth_project<<<dim3(nblk(std::max(ga->n_pad, gb->n_pad) / 2), 1u, 2u), PF_BLOCK, 0, st>>>(a2);
     PF_HIP(hipGetLastError());
-    PF_HIP(hipEventRecord(ga->orth_ev, st));  // one event for both results: graph b waits on graph a's
+    // (no event: both results carry tickets, pf_orth_end polls for them)
     ga->orth_wait = ga->orth_ev;
-    gb->orth_wait = ga->orth_ev;
+    gb->orth_wait = gb->orth_ev;
     ga->orth_pending = count_a;
     gb->orth_pending = count_b;
     return PF_OK;
@@ -1279,7 +1293,39 @@ int pf_orth_end(pf_graph* g, double* h, double* nrm) {
     const int32_t count = g->orth_pending;
     PF_CHECK(h != nullptr || count == 0, PF_E_ARG, "pf_orth_end: h is NULL");
     PF_HIP(hipSetDevice(g->ctx->device));
-    PF_HIP(hipEventSynchronize(g->orth_wait));
+    if (g->orth_ticket != 0.0) {
+        // the kernel's block 0 writes the results and then the ticket into the pinned buffer: poll for it (the stream is asked
+        // now and then whether it has run dry without a ticket - a failed launch must not hang the host)
+        volatile double* ticket = g->orth_host + count + 2;
+        bool got = false;
+        for (uint64_t spin = 0;; ++spin) {
+            if (__atomic_load_n(reinterpret_cast<volatile uint64_t*>(ticket), __ATOMIC_ACQUIRE) ==
+                *reinterpret_cast<const uint64_t*>(&g->orth_ticket)) {
+                got = true;
+                break;
+            }
+            if ((spin & 0xfff) == 0xfff) {
+                const hipError_t q = hipStreamQuery(g->ctx->stream);
+                if (q == hipSuccess) {  // everything queued has completed: the ticket is there, or never will be
+                    got = __atomic_load_n(reinterpret_cast<volatile uint64_t*>(ticket), __ATOMIC_ACQUIRE) ==
+                          *reinterpret_cast<const uint64_t*>(&g->orth_ticket);
+                    break;
+                }
+                if (q != hipErrorNotReady) {
+                    g->orth_pending = -1;
+                    PF_HIP(q);
+                }
+            }
+            __builtin_ia32_pause();
+        }
+        if (!got) {
+            g->orth_pending = -1;
+            PF_TRY(pf_persist_check(g->ctx));
+            PF_CHECK(false, PF_E_HIP, "pf_orth_end: the Gram-Schmidt step never reported (launch failure?)");
+        }
+    } else {
+        PF_HIP(hipEventSynchronize(g->orth_wait));
+    }
     g->orth_pending = -1;
     g->orth_redone = 0;
     PF_TRY(pf_persist_check(g->ctx));
