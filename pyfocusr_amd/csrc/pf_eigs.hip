@@ -227,7 +227,7 @@ struct Solver {
     // Krylov state  B V_j = V_j H + v_j b^T ; null vectors are locked exact Ritz pairs
     std::vector<double> H, b, theta, U, h;
     int j = 0, q = 0, restarts = 0, resets = 0;
-    bool spec = false, near_conv = false, have_seen = false;
+    bool spec = false, near_conv = false, have_seen = false, start_pending = false;
     int next_check = 0, seen_j = 0;
     double seen_worst = 0.0;
     enum { S_TOP, S_AFTER_CHEB, S_AFTER_ORTH, S_DONE } state = S_TOP;
@@ -245,9 +245,7 @@ struct Solver {
         // small ones it can lose orthogonality (pf_orth_strict).  The setting is sticky per graph: set here either way, so
         // that this solve does not inherit what an earlier driver left behind.
         PF_TRY(pf_orth_strict(g, n_active < 4096));
-        int32_t locked = 0;
-        PF_TRY(pf_lock_null_vectors(g, PF_OP_SYM, &locked));
-        c0 = locked;
+        c0 = g->n_components;  // one analytic null vector per component of >= 2 vertices (written below, once the workspace has its size)
         want = (int)std::min<int64_t>(n_wanted, std::max<int64_t>(n_active - c0, 0));
         if (want <= 0) {
             done = true;
@@ -261,7 +259,9 @@ struct Solver {
         m_max = (int)std::min<int64_t>(std::max(3 * q_target + 24, 48), n_active);
         reg = std::max(m_max + 1, 2 * q_target + 2);
         PF_TRY(pf_ws_ensure(g, 2 * reg));
-        PF_TRY(pf_lock_null_vectors(g, PF_OP_SYM, &locked));  // the workspace may have moved: rewrite slots [0, c0)
+        int32_t locked = 0;
+        PF_TRY(pf_lock_null_vectors(g, PF_OP_SYM, &locked));  // slots [0, c0)
+        PF_CHECK(locked == c0, PF_E_STATE, "pf_eigs_smallest: %d null vectors locked, %d components", locked, c0);
         A0 = 0, B0 = reg;
         cut = 12.0 * (want + 1) / (double)std::max<int64_t>(n_active, 1);
         H.assign((size_t)m_max * m_max, 0.0);
@@ -281,11 +281,11 @@ struct Solver {
         std::fill(b.begin(), b.end(), 0.0);
         for (int i = 0; i < c0; ++i) H[(size_t)i * m_max + i] = theta0;
         j = c0;
-        double nrm = 0.0;  // start vector, orthogonal to the locked null vectors
+        // start vector, orthogonal to the locked null vectors and normalised on the device; its coefficients are collected
+        // when the first filter application has been queued behind it (no synchronisation at the head of the solve)
         PF_TRY(pf_start_vector(g, A0 + j, seed++));
-        PF_TRY(pf_orth(g, A0 + j, A0, j, h.data(), &nrm));
-        PF_CHECK(nrm > 0.0, PF_E_DEGENERATE, "pf_eigs_smallest: start vector vanished");
-        PF_TRY(pf_scale(g, A0 + j, 1.0 / nrm));
+        PF_TRY(pf_orth_begin(g, A0 + j, A0, j, 1));
+        start_pending = true;
         restarts = 0;
         begin_expand();
         return PF_OK;
@@ -316,6 +316,16 @@ struct Solver {
                     state = S_AFTER_CHEB;
                     break;
                 case S_AFTER_CHEB: {
+                    if (start_pending) {
+                        start_pending = false;
+                        double nrm = 0.0;
+                        PF_TRY(pf_orth_end(g, h.data(), &nrm));
+                        PF_CHECK(nrm > 0.0 && isfinite(nrm), PF_E_DEGENERATE, "pf_eigs_smallest: start vector vanished");
+                        if (pf_orth_redone(g)) {  // refined after the filter application had read it: apply the filter again
+                            state = S_TOP;
+                            break;
+                        }
+                    }
                     st.outer_steps += 1;
                     // the Gram-Schmidt step and - to keep the device busy - the NEXT filter application, queued before this
                     // step's coefficients are read (a speculative application after the last step would be wasted)
