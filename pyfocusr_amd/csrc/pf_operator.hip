@@ -882,6 +882,25 @@ struct OpTimer {
     }
 };
 
+// `count` doubles of device memory to the host behind whatever is queued on the ctx stream, and wait for them: through
+// pinned memory and a copy kernel (pf_copy_by_kernel) - a copy COMMAND may queue behind the partner graph's eigenvector
+// download on a DMA engine
+int small_to_host(pf_graph* g, const double* d_src, double* out, size_t count) {
+    pf_ctx* c = g->ctx;
+    hipStream_t st = c->stream;
+    const size_t bytes = sizeof(double) * count;
+    void* pin = nullptr;
+    if (bytes <= ((size_t)1 << 16) && pf_pinned_scratch(c, bytes, &pin) == PF_OK) {
+        PF_TRY(pf_copy_by_kernel(st, d_src, pin, bytes));
+        PF_HIP(hipStreamSynchronize(st));
+        memcpy(out, pin, bytes);
+        return PF_OK;
+    }
+    PF_HIP(hipMemcpyAsync(out, d_src, bytes, hipMemcpyDeviceToHost, st));
+    PF_HIP(hipStreamSynchronize(st));
+    return PF_OK;
+}
+
 int dots_device(pf_graph* g, int32_t w, int32_t first, int32_t count, double* d_out, double* d_acc, int accumulate) {
     hipStream_t st = g->ctx->stream;
     PF_TRY(pf_reduce_ensure(g, count));
@@ -999,8 +1018,7 @@ int pf_lock_null_vectors(pf_graph* g, int32_t op, int32_t* n_locked) {
         PF_HIP(hipGetLastError());
         PF_TRY(dots_device(g, c, c, 1, g->coef, nullptr, 0));
         double nrm2 = 0.0;
-        PF_HIP(hipMemcpyAsync(&nrm2, g->coef, sizeof(double), hipMemcpyDeviceToHost, st));
-        PF_HIP(hipStreamSynchronize(st));
+        PF_TRY(small_to_host(g, g->coef, &nrm2, 1));
         PF_CHECK(nrm2 > 0.0, PF_E_STATE, "pf_lock_null_vectors: empty component %d", c);
         k_scale<<<nblk(g->n_pad), PF_BLOCK, 0, st>>>(pf_slot(g, c), g->n_pad, 1.0 / sqrt(nrm2));
         PF_HIP(hipGetLastError());
@@ -1152,9 +1170,7 @@ int pf_dots(pf_graph* g, int32_t w, int32_t first, int32_t count, double* out) {
     if (count == 0) return PF_OK;
     PF_TRY(pf_reduce_ensure(g, count));  // g->coef must exist before its address is taken
     PF_TRY(dots_device(g, w, first, count, g->coef, nullptr, 0));
-    PF_HIP(hipMemcpyAsync(out, g->coef, sizeof(double) * count, hipMemcpyDeviceToHost, g->ctx->stream));
-    PF_HIP(hipStreamSynchronize(g->ctx->stream));
-    return PF_OK;
+    return small_to_host(g, g->coef, out, (size_t)count);
 }
 
 // checks, pinned result buffer, event: everything of pf_orth_begin that comes before the launches
@@ -1471,9 +1487,7 @@ int pf_gram(pf_graph* g, int32_t first_a, int32_t count_a, int32_t first_b, int3
     PF_HIP(hipGetLastError());
     k_dot_finish<<<(unsigned)(count_a * count_b), PF_WAVE, 0, st>>>(g->partials, g->n_chunks, g->coef, nullptr, 0);
     PF_HIP(hipGetLastError());
-    PF_HIP(hipMemcpyAsync(out, g->coef, sizeof(double) * (size_t)count_a * count_b, hipMemcpyDeviceToHost, st));
-    PF_HIP(hipStreamSynchronize(st));
-    return PF_OK;
+    return small_to_host(g, g->coef, out, (size_t)count_a * count_b);
 }
 
 int pf_resnorms(pf_graph* g, int32_t ax_first, int32_t x_first, const double* lam, int32_t count, double* out) {
@@ -1492,8 +1506,7 @@ int pf_resnorms(pf_graph* g, int32_t ax_first, int32_t x_first, const double* la
         k_dot_finish<<<(unsigned)nb, PF_WAVE, 0, st>>>(g->partials, g->n_chunks, g->coef + at, nullptr, 0);
         PF_HIP(hipGetLastError());
     }
-    PF_HIP(hipMemcpyAsync(out, g->coef, sizeof(double) * count, hipMemcpyDeviceToHost, st));
-    PF_HIP(hipStreamSynchronize(st));
+    PF_TRY(small_to_host(g, g->coef, out, (size_t)count));
     for (int32_t i = 0; i < count; ++i) out[i] = sqrt(out[i] > 0.0 ? out[i] : 0.0);
     return PF_OK;
 }
