@@ -222,6 +222,36 @@ def c5_1m_k10(ctx, n=1000000, k=10, samples=5000, reps=2):
                 knn_rows_checked_bruteforce=int(len(rows)), knn_index_mismatches=bad)
 
 
+def single_graph_solve(ctx, mesh, k, reps=3):
+    """One mesh alone (what `Graph.get_graph_spectrum()` / `pf_eigs_smallest` run when there is no partner): the resident
+    filter kernel with two recurrence steps per exchange (the default for single graphs with 1024-row windows) against
+    one step per exchange; best of `reps` solves each, eigenvalues compared."""
+    from pyfocusr_amd import Graph, _hip
+
+    out, vals = {}, {}
+    try:
+        for level, name in ((1, "two_steps_per_exchange_ms"), (0, "one_step_per_exchange_ms")):
+            _hip.persist_two_step(level)
+            best = None
+            for _ in range(reps):
+                g = Graph(mesh, n_spectral_features=k, n_rand_samples=5000, ctx=ctx, verbose=False)
+                _ = g.device
+                ctx.sync()
+                t0 = time.perf_counter()
+                g.get_graph_spectrum()
+                _ = g.eig_vecs  # (collects the download)
+                dt = time.perf_counter() - t0
+                best = dt if best is None or dt < best else best
+                vals[level] = g.eig_vals.copy()
+                g.device.close()
+            out[name] = 1e3 * best
+    finally:
+        _hip.persist_two_step(1)
+    out["max_rel_eigenvalue_difference"] = float(np.max(np.abs(vals[1] / vals[0] - 1.0)))
+    out["workload"] = "eigensolve of ONE %d-vertex mesh, k=%d (no partner graph in the launches)" % (len(mesh.points), k)
+    return out
+
+
 def row_partition_step(ctx, dist, torch, mesh, k, s):
     """BASELINE config C5 layout (opt-in, `--row-partition S`): ONE mesh's rows split over all ranks, ghost zones of
     depth S, the Chebyshev recurrence exchanging boundary rows every S steps (pyfocusr_amd/rowpart.py).  Returns
@@ -591,6 +621,11 @@ def main():
             c2 = bundled_15k_pair(ctx, 5)
             if c2 is not None:
                 out["bundled_15k_pair"] = c2
+            try:
+                out["single_graph_solve"] = single_graph_solve(ctx, mesh_t, args.k)
+            except Exception as exc:  # noqa: BLE001
+                out["single_graph_solve"] = dict(error="%s: %s" % (type(exc).__name__, exc))
+                failed.append("single_graph_solve")
             try:
                 out["c5_1m_k10"] = c5_1m_k10(ctx)
             except Exception as exc:  # noqa: BLE001 - an extra: recorded, and the exit status says so

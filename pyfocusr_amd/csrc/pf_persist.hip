@@ -37,7 +37,7 @@
 //
 // Every wait is bounded: a lane that polls longer than a few seconds raises the abort flag, every other block sees it
 // in its own wait loop, the kernel drains, and the host reports PF_E_PERSIST_TIMEOUT at its next synchronising call
-// (pf_persist_check), with the stream drained and the path switched off, so the caller can simply repeat the solve.
+// (pf_persist_check), with the stream drained and the path suspended for a while (see g_suspended), so the caller can simply repeat the solve.
 // A plain launch with grid <= CU count and one block per CU (checked against the occupancy query): all blocks are
 // resident on an idle device.  hipLaunchCooperativeKernel would add only the same size check at +15-19 us of host time
 // per launch (MI355X_MICROARCH.md, "coop-launch": identical residency), and cannot protect against another tenant either.
@@ -1179,7 +1179,7 @@ void pf_persist_release(pf_ctx* ctx) {
 
 // Called wherever the library has just synchronised with the stream.  If a resident launch gave up: drain the stream
 // (launches queued behind the failed one give up at once: the flag is still raised), lower the flags, declare every
-// ring unknown, switch the path off for the process and report it - the results of the filter applications since the
+// ring unknown, SUSPEND the path (persist_available counts the suspension down) and report it - the results of the filter applications since the
 // last clean check are invalid, and repeating the solve (now one step per launch) is all the caller has to do.
 int pf_persist_check(pf_ctx* ctx) {
     if (ctx->persist_abort && *ctx->persist_abort) {

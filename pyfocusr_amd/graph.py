@@ -120,6 +120,10 @@ class Graph(object):
         self.rand_idxs = self.get_list_rand_idxs(n_rand_samples)
 
     # ------------------------------------------------------------------ eigenvectors: host array + device-resident twin
+    _eig_pending = False  # (class default: shells made with Graph.__new__ - parallel.py, bench.py - have no download in flight)
+    _eig_vecs = None
+    _final_map = None
+
     @property
     def eig_vecs(self):
         if self._eig_pending:  # the download the eigensolve queued is collected by the first reader
