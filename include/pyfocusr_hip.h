@@ -167,6 +167,11 @@ int pf_persist_enable(int on);
  * per exchange there (2.08 against 1.85 us per step of a 250k pair), kept for the record.  0: one step per exchange
  * everywhere.  Bit-identical results at every level.  Environment: PF_PERSIST_S2=0/1/2; process-wide. */
 int pf_persist_two_step(int level);
+/* On by default: a paired recurrence (pf_cheb2) on windows of 1024 rows whose outside-row lists fit half a block runs the
+ * kernel whose two halves take the graphs in opposite order (k_cheb_resident<2,1,8,true>), so that both graphs'
+ * boundary rows are handed over one row's latency into a step.  0: both graphs in the same order everywhere.
+ * Bit-identical results either way.  Environment: PF_PERSIST_HALVES=0/1; process-wide. */
+int pf_persist_pair_halves(int on);
 /* What the resident path is doing, for callers that want to know whether they are on the fast path. */
 typedef struct pf_persist_info {
     int32_t enabled;           /* 1: filter applications use the resident kernels where a graph allows it             */

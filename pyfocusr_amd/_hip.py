@@ -85,6 +85,7 @@ SIGNATURES = {
     "pf_knn_tree_stats": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "pf_persist_enable": (C.c_int, [C.c_int]),
     "pf_persist_two_step": (C.c_int, [C.c_int]),
+    "pf_persist_pair_halves": (C.c_int, [C.c_int]),
     "pf_persist_state": (C.c_int, [C.c_void_p, C.c_void_p]),
     "pf_persist_test_hook": (C.c_int, [C.c_int]),
     "pf_cheb": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double]),
@@ -261,6 +262,12 @@ def persist_two_step(level=1):
     k_cheb_resident2): 0 off, 1 single-graph recurrences (default), 2 paired recurrences too.  Results are
     bit-identical at every level."""
     _check(load_library().pf_persist_two_step(int(level)))
+
+
+def persist_pair_halves(on=True):
+    """Process-wide switch of the pair kernel whose halves take the two graphs in opposite order (csrc/pf_persist.hip:
+    k_cheb_resident<2,1,8,true>; on by default).  Results are bit-identical either way."""
+    _check(load_library().pf_persist_pair_halves(int(bool(on))))
 
 
 class _PersistInfo(C.Structure):

@@ -83,7 +83,11 @@ constexpr int RX_THREADS = PF_WIN_THREADS;
 constexpr unsigned long long RX_EMPTY = 0xFFFFDEADFFFFDEADull;  // quiet NaN with a payload arithmetic never produces
 constexpr unsigned RX_EMPTY32 = 0xFFFFDEADu;
 constexpr unsigned RX_SPIN_LIMIT = 4000000u;
+#ifdef RX_EXP_STAMPS
+constexpr size_t RX_LDS_LIMIT = 160 * 1024 - 512 - 1024;
+#else
 constexpr size_t RX_LDS_LIMIT = 160 * 1024 - 512;  // the kernels' static __shared__ lives in the remainder
+#endif
 
 struct RxGraph {
     const int64_t* slice_ptr;
@@ -107,7 +111,31 @@ struct RxArgs {
     RxGraph g[2];
     uint32_t* abort_flag;  // device word: some wait ran out (or the test hook raised it)
     int32_t* host_abort;   // pinned: set to 1 when this launch gave up
+    int32_t hold;          // first fetch of a step not before this many 10 ns ticks (s_memrealtime) after the step began;
+                           // 0: a fixed s_sleep behind the wave's rows instead
 };
+
+#ifdef RX_EXP_STAMPS  // diagnostic build only: cycle stamps of the one-step kernel's phases, per block and wave
+__device__ unsigned long long g_rx_stamps[256 * 16 * 10];
+// (accumulated in LDS by each wave's first lane, clock values cut to 32 bits: the kernel has no registers to spare)
+#define RX_STAMP(i) \
+    do { \
+        const unsigned now_ = (unsigned)__builtin_amdgcn_s_memtime(); \
+        if (lane == 0) s_st[wave][i] += now_ - st_prev; \
+        st_prev = now_; \
+    } while (0)
+#define RX_MARK(i) \
+    do { \
+        const unsigned now_ = (unsigned)__builtin_amdgcn_s_memtime(); \
+        if (lane == 0) s_st[wave][i] += now_ - st_top; \
+    } while (0)
+#else
+#define RX_STAMP(i)
+#define RX_MARK(i)
+#endif
+#ifndef RX_HOLD
+#define RX_HOLD 16
+#endif
 
 template <int NG, int NW>
 constexpr int rx_table_bytes() {
@@ -146,11 +174,18 @@ __device__ __forceinline__ double rx_row_dispatch(int w_uniform, const double* x
     }
 }
 
-template <int NG, int NW, int JR>
+// SW (a pair with one row per thread only): the block's two halves take the graphs in opposite order.  Graph 1's rows are
+// turned by half a window (thread t has row (t + 512) mod 1024), so each half's FIRST row is a low row of "its" graph -
+// the rows that are handed over - and both graphs' hand-offs are issued one row's latency into the step instead of
+// graph 1's behind graph 0's (a wave's row is one dependent chain: LDS reads, 8 fma, stores; ~0.3 us).  Each half also
+// fetches its own graph's outside rows.  Per-row arithmetic is untouched, so results are bit-identical.
+template <int NG, int NW, int JR, bool SW = false>
 __global__ __launch_bounds__(RX_THREADS) void k_cheb_resident(RxArgs a) {
+
     // The floating-point operations are spelled out (and contraction is off) so that they are the ones the compiler
     // forms for sell_op_block: acc = d x; acc = fma(v, x, acc)...; t = fma(c, x, -acc); r = fma(alpha, t, -(beta prev)).
 #pragma clang fp contract(off)
+    static_assert(!SW || (NG == 2 && NW == 1), "the halves swap graphs in the pair kernel with one row per thread");
     extern __shared__ __align__(16) unsigned char lds[];
     __shared__ int s_state;
     constexpr int RB = NW * RX_THREADS;
@@ -161,8 +196,11 @@ __global__ __launch_bounds__(RX_THREADS) void k_cheb_resident(RxArgs a) {
     const int lane = tid & (PF_WAVE - 1);
     const int wave = tid >> 6;
 
+    // slot q of this wave is graph gq(q); its row of that graph's window is rt[q] (+ w * RX_THREADS)
+    const int half = SW ? __builtin_amdgcn_readfirstlane(tid >> 9) : 0;
+#define RX_GQ(q) (SW ? ((q) ^ half) : (q))
     bool have[NG];
-    int32_t ghosts[NG], need_r[NG], xlen[NG], ghrow[NG], gh_lane[NG];
+    int32_t ghosts[NG], need_r[NG], xlen[NG], ghrow[NG], gh_lane[NG], rt[NG];
     int64_t row0[NG];
     double* xb[NG];
     double v[NG][NW][JR];
@@ -172,37 +210,47 @@ __global__ __launch_bounds__(RX_THREADS) void k_cheb_resident(RxArgs a) {
     int64_t sbase[NG][NW];
 
     int32_t* ovtab = reinterpret_cast<int32_t*>(lds);
-    size_t off = rx_table_bytes<NG, NW>();
+    // the graphs' x buffers lie in graph order behind the table, whichever half looks at them
+    int32_t gcount[NG];
+    size_t goff[NG + 1];
+    goff[0] = rx_table_bytes<NG, NW>();
+#pragma unroll
+    for (int j = 0; j < NG; ++j) {
+        const bool hj = win < a.g[j].n_windows;
+        gcount[j] = hj ? a.g[j].gh_cnt[win] : 0;
+        goff[j + 1] = goff[j] + (hj ? (size_t)2 * (RB + ((gcount[j] + 1) & ~1)) * sizeof(double) : 0);
+    }
+    const size_t off = goff[NG];
 #pragma unroll
     for (int q = 0; q < NG; ++q) {
-        const RxGraph& g = a.g[q];
+        const RxGraph& g = a.g[RX_GQ(q)];
         have[q] = win < g.n_windows;
         const int32_t wq = have[q] ? win : 0;
-        ghosts[q] = have[q] ? g.gh_cnt[wq] : 0;
+        ghosts[q] = SW ? (RX_GQ(q) ? gcount[NG - 1] : gcount[0]) : gcount[q];
         need_r[q] = have[q] ? ((g.need[wq] + PF_WAVE - 1) & ~(PF_WAVE - 1)) : 0;
         row0[q] = (int64_t)wq * RB;
+        rt[q] = SW ? ((tid + (RX_THREADS / 2) * RX_GQ(q)) & (RX_THREADS - 1)) : tid;
         // Which thread fetches which outside row.  One graph: thread t fetches row t.  Two graphs: the second graph's
         // rows are fetched by the waves of the block's upper half (thread 512 + t fetches row t) when both lists fit a
-        // half, so that the two graphs' polls are in flight TOGETHER instead of one round trip after the other
+        // half, so that the two graphs' polls are in flight TOGETHER instead of one round trip after the other.
+        // (SW: each half fetches the rows of its first graph; the host launches SW only when every list fits a half)
         gh_lane[q] = tid;
-        if (NG == 2) {
-            const int32_t g0 = win < a.g[0].n_windows ? a.g[0].gh_cnt[win] : 0;
-            const int32_t g1 = win < a.g[1].n_windows ? a.g[1].gh_cnt[win] : 0;
-            if (q == 1 && g0 <= RX_THREADS / 2 && g1 <= RX_THREADS / 2) gh_lane[q] = tid - RX_THREADS / 2;
+        if (SW) gh_lane[q] = q == 0 ? (tid & (RX_THREADS / 2 - 1)) : -1;
+        if (!SW && NG == 2) {
+            if (q == 1 && gcount[0] <= RX_THREADS / 2 && gcount[NG - 1] <= RX_THREADS / 2) gh_lane[q] = tid - RX_THREADS / 2;
         }
         ghrow[q] = (gh_lane[q] >= 0 && gh_lane[q] < ghosts[q]) ? g.gh_row[(int64_t)wq * PF_WIN_GHOSTS + gh_lane[q]] : 0;
         xlen[q] = have[q] ? RB + ((ghosts[q] + 1) & ~1) : 0;
-        xb[q] = reinterpret_cast<double*>(lds + off);
-        off += (size_t)2 * xlen[q] * sizeof(double);
+        xb[q] = reinterpret_cast<double*>(lds + (SW ? (RX_GQ(q) ? goff[NG - 1] : goff[0]) : goff[q]));
 #pragma unroll
         for (int w = 0; w < NW; ++w) {
-            const int64_t row = row0[q] + w * RX_THREADS + tid;
+            const int64_t row = row0[q] + w * RX_THREADS + rt[q];
             const int64_t s = row >> 6;
             sbase[q][w] = g.slice_ptr[s];
             width[q][w] = have[q] ? (int32_t)((g.slice_ptr[s + 1] - sbase[q][w]) >> 6) : 0;
             dg[q][w] = have[q] ? g.diag[row] : 0.0;
             pv[q][w] = 0.0;
-            if (lane == 0) ovtab[(q * NW + w) * 16 + wave] = width[q][w] > JR ? (width[q][w] - JR) * PF_WAVE : 0;
+            if (lane == 0) ovtab[(RX_GQ(q) * NW + w) * 16 + (rt[q] >> 6)] = width[q][w] > JR ? (width[q][w] - JR) * PF_WAVE : 0;
         }
     }
     if (tid == 0) s_state = (int)__hip_atomic_load(a.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -227,13 +275,13 @@ __global__ __launch_bounds__(RX_THREADS) void k_cheb_resident(RxArgs a) {
     // ---- this thread's rows: entries into registers (and, beyond JR per row, into LDS), x_0 into LDS
 #pragma unroll
     for (int q = 0; q < NG; ++q) {
-        const RxGraph& g = a.g[q];
+        const RxGraph& g = a.g[RX_GQ(q)];
 #pragma unroll
         for (int w = 0; w < NW; ++w) {
             const int32_t wd = width[q][w];
             const int32_t pairs = wd >> 1;
             const int64_t base = sbase[q][w];
-            ovoff[q][w] = ovtab[(q * NW + w) * 16 + wave];
+            ovoff[q][w] = ovtab[(RX_GQ(q) * NW + w) * 16 + (rt[q] >> 6)];
 #pragma unroll
             for (int p = 0; p < JR / 2; ++p) {
                 double2 vv = make_double2(0.0, 0.0);
@@ -273,31 +321,72 @@ __global__ __launch_bounds__(RX_THREADS) void k_cheb_resident(RxArgs a) {
                 ov_val[o + PF_WAVE] = vv.y;
                 ov_slot[o + PF_WAVE] = (unsigned short)ss.y;
             }
-            xc[q][w] = have[q] ? g.src[row0[q] + w * RX_THREADS + tid] : 0.0;
-            if (have[q]) xb[q][w * RX_THREADS + tid] = xc[q][w];
+            xc[q][w] = have[q] ? g.src[row0[q] + w * RX_THREADS + rt[q]] : 0.0;
+            if (have[q]) xb[q][w * RX_THREADS + rt[q]] = xc[q][w];
         }
         if (gh_lane[q] >= 0 && gh_lane[q] < ghosts[q]) xb[q][RB + gh_lane[q]] = g.src[ghrow[q]];
     }
     __syncthreads();
 
+    // the recurrences' scalars, per slot.  (SW: read through a wave-dependent index, they would be fetched from the
+    // argument segment again in every step - they are pinned to scalar registers here, once)
+    struct RxLoop {
+        double* ring;
+        double* dst;
+        int64_t n_pad;
+        int32_t degree, phase;
+        double shift, a1, a2, beta;
+    } L[NG];
+#pragma unroll
+    for (int q = 0; q < NG; ++q) {
+        const RxGraph& gg = a.g[RX_GQ(q)];
+        L[q].ring = gg.ring;
+        L[q].dst = gg.dst;
+        L[q].n_pad = gg.n_pad;
+        L[q].degree = gg.degree;
+        L[q].phase = gg.phase;
+        L[q].shift = gg.shift;
+        L[q].a1 = gg.a1;
+        L[q].a2 = gg.a2;
+        L[q].beta = gg.beta;
+        if (SW) {
+            long long s0 = __double_as_longlong(L[q].shift), s1 = __double_as_longlong(L[q].a1), s2 = __double_as_longlong(L[q].a2),
+                      s3 = __double_as_longlong(L[q].beta);
+            asm volatile("" : "+s"(L[q].ring), "+s"(L[q].dst), "+s"(L[q].n_pad), "+s"(L[q].degree), "+s"(L[q].phase));
+            asm volatile("" : "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3));
+            L[q].shift = __longlong_as_double(s0);
+            L[q].a1 = __longlong_as_double(s1);
+            L[q].a2 = __longlong_as_double(s2);
+            L[q].beta = __longlong_as_double(s3);
+        }
+    }
     int32_t n_steps = a.g[0].degree;
     if (NG > 1 && a.g[1].degree > n_steps) n_steps = a.g[1].degree;
-    int32_t need_max = need_r[0];
-    if (NG > 1 && need_r[1] > need_max) need_max = need_r[1];
-    const bool early = (tid & ~(PF_WAVE - 1)) < need_max;  // this wave owns boundary rows (its w = 0 rows)
+    bool early = (rt[0] & ~(PF_WAVE - 1)) < need_r[0];  // this wave owns boundary rows (its w = 0 rows)
+    if (NG > 1) early = early || (rt[NG - 1] & ~(PF_WAVE - 1)) < need_r[NG - 1];
     int cur = 0;
+#ifdef RX_EXP_STAMPS
+    __shared__ unsigned s_st[16][10];
+    if (lane < 10) s_st[wave][lane] = 0;
+    unsigned st_prev = (unsigned)__builtin_amdgcn_s_memtime(), st_top = 0;
+#endif
 
     for (int32_t k = 1; k <= n_steps; ++k) {
+        RX_STAMP(5);  // loop overhead (state check, branch)
+#ifdef RX_EXP_STAMPS
+        st_top = st_prev;
+#endif
         if (early) __builtin_amdgcn_s_setprio(3);
+        const unsigned step_top = (unsigned)__builtin_amdgcn_s_memrealtime();
 #pragma unroll
         for (int w = 0; w < NW; ++w) {
 #pragma unroll
             for (int q = 0; q < NG; ++q) {
-                const RxGraph& g = a.g[q];
-                if (!have[q] || k > g.degree) continue;  // (block-uniform) a graph whose recurrence is over sits the step out
+                const RxLoop& g = L[q];
+                if (!have[q] || k > g.degree) continue;  // (wave-uniform) a graph whose recurrence is over sits the step out
                 const double* x = xb[q] + (size_t)cur * xlen[q];
                 double* xn = xb[q] + (size_t)(cur ^ 1) * xlen[q];
-                const int32_t lr = w * RX_THREADS + tid;
+                const int32_t lr = w * RX_THREADS + rt[q];
                 const int32_t wd = width[q][w];
                 const double xi = xc[q][w];  // the row's own x: last step's result, still in its register
                 double acc = rx_row_dispatch<JR>(__builtin_amdgcn_readfirstlane(wd < JR ? wd : JR), x, dg[q][w], xi, v[q][w], slp[q][w]);
@@ -325,10 +414,12 @@ __global__ __launch_bounds__(RX_THREADS) void k_cheb_resident(RxArgs a) {
                                            (unsigned long long)__double_as_longlong(res), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     __hip_atomic_store(ring + (int64_t)((k + 2 + g.phase) & 3) * g.n_pad + row, RX_EMPTY, __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_AGENT);
+                    RX_MARK(6 + q);  // hand-off of graph q issued
                 }
             }
             if (w == 0 && early) __builtin_amdgcn_s_setprio(0);
         }
+        RX_STAMP(0);  // rows computed, hand-off stores issued
         if (k == n_steps) break;
         // ---- the outside values of step k, straight from their owners' stores.  The owners stored them about when this
         // block stored its own, and an agent-scope store takes ~0.5 us to land: a poll issued at once would just miss it
@@ -340,10 +431,18 @@ __global__ __launch_bounds__(RX_THREADS) void k_cheb_resident(RxArgs a) {
         bool slept = false;
 #pragma unroll
         for (int q = 0; q < NG; ++q) {
-            const RxGraph& g = a.g[q];
+            const RxLoop& g = L[q];
             if (have[q] && k < g.degree && gh_lane[q] >= 0 && gh_lane[q] < ghosts[q]) {
-                if (!slept && gh_lane[q] == tid) __builtin_amdgcn_s_sleep(16);  // (the upper half's waves arrive late anyway)
+                if (a.hold > 0) {
+                    // (asleep while more than 60 ns remain, then watching the clock)
+                    while ((int)((unsigned)a.hold - ((unsigned)__builtin_amdgcn_s_memrealtime() - step_top)) > 6) __builtin_amdgcn_s_sleep(1);
+                    while ((unsigned)__builtin_amdgcn_s_memrealtime() - step_top < (unsigned)a.hold) {
+                    }
+                } else if (RX_HOLD > 0 && !slept) {
+                    __builtin_amdgcn_s_sleep(RX_HOLD);  // (every wave that fetches, once)
+                }
                 slept = true;
+                RX_STAMP(1);  // hold-back
                 const unsigned long long* p =
                     reinterpret_cast<const unsigned long long*>(g.ring) + (int64_t)((k + g.phase) & 3) * g.n_pad + ghrow[q];
                 unsigned long long bits;
@@ -359,17 +458,37 @@ __global__ __launch_bounds__(RX_THREADS) void k_cheb_resident(RxArgs a) {
                     __builtin_amdgcn_s_sleep(1);
                 }
                 xb[q][(size_t)(cur ^ 1) * xlen[q] + RB + gh_lane[q]] = __longlong_as_double((long long)bits);
+#ifdef RX_EXP_STAMPS
+                if (lane == 0) {
+                    s_st[wave][8] += spins;                          // repeats of the wave's first lane
+                }
+                if (__ballot(spins > 0) != 0 && lane == 0) s_st[wave][9] += 1;  // steps in which some lane had to repeat
+#endif
             }
         }
+        RX_STAMP(2);  // polls returned (first tries and repeats)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's hand-offs and EMPTY stores are in memory (see header)
+        RX_STAMP(3);  // own stores drained
         __syncthreads();
+        RX_STAMP(4);  // barrier
         if (s_state != 0) {
             if (tid == 0) *a.host_abort = 1;
             return;
         }
         cur ^= 1;
     }
+#ifdef RX_EXP_STAMPS
+    if (lane == 0 && blockIdx.x < 256)
+        for (int i = 0; i < 10; ++i) g_rx_stamps[((size_t)blockIdx.x * 16 + wave) * 10 + i] = s_st[wave][i];
+#endif
 }
+
+#ifdef RX_EXP_STAMPS
+extern "C" int pf_persist_stamps(unsigned long long* out /* [256][16][10] */) {
+    PF_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rx_stamps), sizeof(unsigned long long) * 256 * 16 * 10));
+    return PF_OK;
+}
+#endif
 
 // ---------------------------------------------------------------------------------------------------------------
 // Two recurrence steps per exchange (k_cheb_resident2).
@@ -846,8 +965,10 @@ int device_grid(int device) {
                 return;
             }
         }
-        for (int ng = 1; ng <= 2; ++ng) {
-            const void* fn = ng == 1 ? reinterpret_cast<const void*>(k_cheb_resident2<1>) : reinterpret_cast<const void*>(k_cheb_resident2<2>);
+        for (int ng = 1; ng <= 3; ++ng) {
+            const void* fn = ng == 1   ? reinterpret_cast<const void*>(k_cheb_resident2<1>)
+                             : ng == 2 ? reinterpret_cast<const void*>(k_cheb_resident2<2>)
+                                       : reinterpret_cast<const void*>(k_cheb_resident<2, 1, rx_jr(2, 1), true>);
             int per_cu = 0;
             if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RX_LDS_LIMIT) != hipSuccess ||
                 hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, RX_THREADS, RX_LDS_LIMIT) != hipSuccess || per_cu < 1) {
@@ -1048,6 +1169,22 @@ extern "C" int pf_persist_two_step(int level) {
     return PF_OK;
 }
 
+// 1 (default): paired recurrences on windows of 1024 rows use the kernel whose halves take the graphs in opposite order
+std::atomic<int> g_pair_halves{-1};
+bool pair_halves_enabled() {
+    int v = g_pair_halves.load();
+    if (v < 0) {
+        const char* e = getenv("PF_PERSIST_HALVES");
+        v = (e && e[0] == '0') ? 0 : 1;
+        g_pair_halves.store(v);
+    }
+    return v != 0;
+}
+extern "C" int pf_persist_pair_halves(int on) {
+    g_pair_halves.store(on ? 1 : 0);
+    return PF_OK;
+}
+
 extern "C" int pf_persist_state(pf_ctx* ctx, pf_persist_info* out) {
     PF_CHECK(out != nullptr, PF_E_ARG, "pf_persist_state: NULL argument");
     pf_ctx* owner = g_owner.load();
@@ -1063,6 +1200,35 @@ extern "C" int pf_persist_state(pf_ctx* ctx, pf_persist_info* out) {
     out->owner_switches = g_owner_switches.load();
     out->reserved = 0;
     return PF_OK;
+}
+
+// When a block first asks for the outside values of a step, in 10 ns ticks after the step began (RxArgs::hold).
+// The values a neighbour handed over in this step land ~0.8 us into it; a fetch issued before that does not only come
+// back empty, it also delays the landing (250k pair: 1.58 us per step at the best hold, 1.81 one 85 ns earlier), while a
+// late one costs just its lateness - so the table sits a little to the right of the measured optimum
+// (tools/tune_hold.py; profiles/r03_hold_sweep.md).  Fewer windows: less traffic, earlier landing.
+// Environment PF_PERSIST_HOLD overrides (ticks; 0: the fixed s_sleep behind a wave's rows, as in round 2).
+struct HoldPoint {
+    int windows, ticks;
+};
+int hold_from(const HoldPoint* t, int n, int windows) {
+    if (windows <= t[0].windows) return t[0].ticks;
+    for (int i = 1; i < n; ++i)
+        if (windows <= t[i].windows)
+            return t[i - 1].ticks + (t[i].ticks - t[i - 1].ticks) * (windows - t[i - 1].windows) / (t[i].windows - t[i - 1].windows);
+    return t[n - 1].ticks;
+}
+int hold_ticks(int ng, int nw, bool halves, int windows) {
+    if (const char* e = getenv("PF_PERSIST_HOLD")) return atoi(e);
+    if (nw == 4) return 70;  // (700k..1M rows: a wave's four rows end later than that - the fetch follows them at once)
+    if (nw == 2) {
+        static const HoldPoint two_rows[] = {{147, 70}, {245, 74}};  // 300k..500k rows
+        return hold_from(two_rows, 2, windows);
+    }
+    static const HoldPoint single[] = {{20, 58}, {59, 64}, {147, 68}, {245, 73}};
+    static const HoldPoint pair[] = {{20, 80}, {59, 84}, {147, 88}, {245, 97}};
+    static const HoldPoint pair_halves[] = {{20, 72}, {59, 73}, {147, 80}, {245, 89}};
+    return ng == 1 ? hold_from(single, 4, windows) : (halves ? hold_from(pair_halves, 4, windows) : hold_from(pair, 4, windows));
 }
 
 extern "C" int pf_persist_test_hook(int n_launches) {
@@ -1105,6 +1271,12 @@ int pf_persist_cheb(const pf_persist_args* a, const pf_persist_args* b, int* don
     const int64_t need = ga->lds_need_value;
     if (need < 0 || (size_t)need > RX_LDS_LIMIT) return PF_OK;
     if (!persist_acquire(ctx)) return PF_OK;  // another ctx has resident kernels in flight
+    if (ng == 2 && nw == 1 && pair_halves_enabled()) {  // each half of a block fetches one graph's outside rows: they must fit
+        int32_t most = 0;
+        for (int32_t c : ga->h_px_gh_cnt) most = std::max(most, c);
+        for (int32_t c : gb->h_px_gh_cnt) most = std::max(most, c);
+        if (most <= RX_THREADS / 2) kernel = k_cheb_resident<2, 1, rx_jr(2, 1), true>;
+    }
     hipStream_t st = ctx->stream;
     if (!ctx->persist_sync) {
         PF_HIP(pf_malloc(st, (void**)&ctx->persist_sync, sizeof(uint32_t) * 32));
@@ -1148,6 +1320,7 @@ int pf_persist_cheb(const pf_persist_args* a, const pf_persist_args* b, int* don
     }
     args.abort_flag = ctx->persist_sync;
     args.host_abort = ctx->persist_abort;
+    args.hold = hold_ticks(ng, nw, kernel == k_cheb_resident<2, 1, rx_jr(2, 1), true>, (int)std::max(wa, wb));
     if (g_test_aborts.load() > 0) {  // pf_persist_test_hook: this launch finds the abort flag raised
         g_test_aborts.fetch_sub(1);
         PF_HIP(hipMemsetAsync(ctx->persist_sync, 1, sizeof(uint32_t), st));

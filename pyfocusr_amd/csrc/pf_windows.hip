@@ -11,6 +11,8 @@
 // step further, and it knows that from the values it receives itself; so "A reads B" has to imply "B reads A".  On
 // meshes whose W is symmetric it does.  One-way edges (graph.py:178 on open or non-manifold meshes) can break it at
 // window level; then B gets row 0 of A as an extra outside row (read every step, never used).
+#include <cstdio>
+#include <cstdlib>
 #include <algorithm>
 #include <climits>
 
@@ -400,6 +402,12 @@ int pf_window_slots_prepare(pf_graph* g) {
     }
     g->px_gh_total = 0;
     for (int32_t c : g->h_px_gh_cnt) g->px_gh_total += c;
+    if (getenv("PF_DEBUG_WINDOWS")) {
+        int32_t lo = 1 << 30, hi = 0;
+        for (int32_t c : g->h_px_gh_cnt) { lo = c < lo ? c : lo; hi = c > hi ? c : hi; }
+        fprintf(stderr, "pyfocusr_hip: %lld windows, outside rows per window %d..%d (mean %.0f)\n", (long long)nw, (int)lo, (int)hi,
+                (double)g->px_gh_total / (double)nw);
+    }
     g->px_state = 1;
     return PF_OK;
 }

@@ -1467,9 +1467,14 @@ def test_resident_kernel_bit_identical(golden, hip, ctx):
             g.ws_ensure(4)
             g.upload(0, rng.standard_normal(g.n))
 
-        def run(on, two_step=2):
+        def run(on, two_step=2, halves=True, hold=None):
             hip.persist_enable(on)
             hip.persist_two_step(two_step)
+            hip.persist_pair_halves(halves)
+            if hold is None:
+                os.environ.pop("PF_PERSIST_HOLD", None)
+            else:
+                os.environ["PF_PERSIST_HOLD"] = str(hold)
             ctx.timing_enable(True)
             ctx.timing(reset=True)
             out = []
@@ -1495,13 +1500,21 @@ def test_resident_kernel_bit_identical(golden, hip, ctx):
         n2 = hip.persist_state(ctx)["launches_two_step"] - n2_before
         assert tm_a["persist_launches"] == 0 and tm_b["persist_launches"] >= 8 * len(graphs) + 6  # the path really ran
         assert tm_c["persist_launches"] == tm_b["persist_launches"] and n2 >= 6 * 4 + 3, n2  # 4 graphs alone (from their third application on), 3+ of the pairs
-        assert len(a) == len(b) == len(c)
+        # the pair kernel with both halves of a block taking the graphs in the same order (b, c: opposite orders), and the
+        # first fetch of a step far too early (0.2 us) and by the fixed sleep of round 2 instead of the tuned table:
+        # timing knobs, never results
+        (d, tm_d), (e, _), (f, _) = run(True, two_step=0, halves=False), run(True, two_step=0, hold=20), run(True, two_step=0, hold=0)
+        assert tm_d["persist_launches"] == tm_b["persist_launches"]
+        assert len(a) == len(b) == len(c) == len(d) == len(e) == len(f)
         for i, (x, y, z) in enumerate(zip(a, b, c)):
             assert np.all(np.isfinite(x)) and np.array_equal(x, y), i
             assert np.array_equal(x, z), ("two steps per exchange", i, float(np.max(np.abs(x - z))))
+            assert np.array_equal(x, d[i]) and np.array_equal(x, e[i]) and np.array_equal(x, f[i]), ("halves / hold", i)
     finally:
         hip.persist_enable(True)  # the defaults
         hip.persist_two_step(1)
+        hip.persist_pair_halves(True)
+        os.environ.pop("PF_PERSIST_HOLD", None)
         for g in graphs:
             g.close()
 
