@@ -217,7 +217,7 @@ struct Solver {
     bool done = false;
     Request req;
     // configuration
-    double hi = 2.0, strength = 2.0, tol = 1e-12;
+    double hi = 2.0, strength = 1.8, tol = 1e-12;  // (strength and the cut below: as _krylov._solve_gen for symmetric graphs)
     int64_t n_active = 0;
     int c0 = 0, want = 0, q_target = 0, m_max = 0, reg = 0, A0 = 0, B0 = 0;
     // filter
@@ -263,7 +263,9 @@ struct Solver {
         PF_TRY(pf_lock_null_vectors(g, PF_OP_SYM, &locked));  // slots [0, c0)
         PF_CHECK(locked == c0, PF_E_STATE, "pf_eigs_smallest: %d null vectors locked, %d components", locked, c0);
         A0 = 0, B0 = reg;
-        cut = 12.0 * (want + 1) / (double)std::max<int64_t>(n_active, 1);
+        cut = 8.0 * (want + 1) / (double)std::max<int64_t>(n_active, 1);
+        if (const char* ev = getenv("PF_EIGS_CUT")) cut *= atof(ev) / 8.0;  // (experiments: the filter's placement ...
+        if (const char* ev = getenv("PF_EIGS_STRENGTH")) strength = atof(ev);  // ... and strength; results agree to tol)
         H.assign((size_t)m_max * m_max, 0.0);
         b.assign((size_t)m_max, 0.0);
         h.assign((size_t)m_max + 1, 0.0);

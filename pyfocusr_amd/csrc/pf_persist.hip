@@ -535,6 +535,7 @@ struct Rx2Args {
     Rx2Graph g[2];
     uint32_t* abort_flag;
     int32_t* host_abort;
+    int32_t hold;  // first fetch of a round not before this many 10 ns ticks after its phase B began; 0: a fixed s_sleep
 };
 
 #ifndef RX2_JR_PAIR
@@ -823,6 +824,7 @@ __global__ __launch_bounds__(RX_THREADS) void k_cheb_resident2(Rx2Args a) {
         }
         __syncthreads();
         // ---- phase B: step kB of the own rows, buffer 1 -> buffer 0; leading rows published first
+        const unsigned b_top = (unsigned)__builtin_amdgcn_s_memrealtime();
         if (early) __builtin_amdgcn_s_setprio(3);
 #pragma unroll
         for (int q = 0; q < NG; ++q) {
@@ -847,7 +849,13 @@ __global__ __launch_bounds__(RX_THREADS) void k_cheb_resident2(Rx2Args a) {
             const Rx2Graph& g = a.g[q];
             if (qg != q || !have[q] || kB >= g.degree) continue;  // (wave-uniform)
             if (gf0) {
-                if (q == 0 && (NG == 1 ? RX2_HOLD1 : RX2_HOLD2) > 0) __builtin_amdgcn_s_sleep(NG == 1 ? RX2_HOLD1 : RX2_HOLD2);
+                if (a.hold > 0) {
+                    while ((int)((unsigned)a.hold - ((unsigned)__builtin_amdgcn_s_memrealtime() - b_top)) > 6) __builtin_amdgcn_s_sleep(1);
+                    while ((unsigned)__builtin_amdgcn_s_memrealtime() - b_top < (unsigned)a.hold) {
+                    }
+                } else if (q == 0 && (NG == 1 ? RX2_HOLD1 : RX2_HOLD2) > 0) {
+                    __builtin_amdgcn_s_sleep(NG == 1 ? RX2_HOLD1 : RX2_HOLD2);
+                }
                 const unsigned long long* p0 = reinterpret_cast<const unsigned long long*>(g.ring) + (int64_t)((r + g.phase) & 3) * g.n_pad;
                 const int32_t ghr0 = glist[q][lt];
                 const unsigned long long* p1 = p0 + (gf1 ? glist[q][lt + PH] : ghr0);
@@ -1029,6 +1037,14 @@ int64_t lds_need2(pf_graph* ga, pf_graph* gb) {
 }
 
 // two steps per exchange, if both graphs and the sizes allow it: *done = 1 when launched
+// When a block first asks for the outside values of a round (see hold_ticks below): here for the two-step kernel, counted from the start of its phase B (environment PF_PERSIST_HOLD2)
+int hold_ticks2(int ng, int windows) {
+    if (const char* e = getenv("PF_PERSIST_HOLD2")) return atoi(e);
+    (void)ng;
+    (void)windows;
+    return 0;
+}
+
 int persist_cheb2(const pf_persist_args* a, const pf_persist_args* b, int64_t grid, int* done, double* lds_bytes) {
     *done = 0;
     pf_graph* ga = a->g;
@@ -1101,6 +1117,7 @@ int persist_cheb2(const pf_persist_args* a, const pf_persist_args* b, int64_t gr
         g_test_aborts.fetch_sub(1);
         PF_HIP(hipMemsetAsync(ctx->persist_sync, 1, sizeof(uint32_t), st));
     }
+    args.hold = hold_ticks2(ng, (int)grid);
     if (ng == 2) k_cheb_resident2<2><<<dim3((unsigned)grid), dim3(RX_THREADS), (size_t)need, st>>>(args);
     else k_cheb_resident2<1><<<dim3((unsigned)grid), dim3(RX_THREADS), (size_t)need, st>>>(args);
     const hipError_t err = hipGetLastError();

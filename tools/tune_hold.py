@@ -17,10 +17,12 @@ ap.add_argument("sizes", type=int, nargs="*", default=[250000])
 ap.add_argument("--holds", default="table,0,60,65,70,75,80,85,90,95")
 ap.add_argument("--degree", type=int, default=145)
 ap.add_argument("--reps", type=int, default=20)
+ap.add_argument("--two-step", action="store_true", help="the two-steps-per-exchange kernels (PF_PERSIST_HOLD2) instead")
 args = ap.parse_args()
 ctx = _hip.default_context()
 ctx.timing_enable(True)
-_hip.persist_two_step(0)
+_hip.persist_two_step(2 if args.two_step else 0)
+VAR = "PF_PERSIST_HOLD2" if args.two_step else "PF_PERSIST_HOLD"
 holds = args.holds.split(",")
 print("| n | kernel | " + " | ".join(str(h) for h in holds) + " |")
 print("|---|---|" + "---|" * len(holds))
@@ -39,10 +41,11 @@ for n in args.sizes:
         cells = []
         for h in holds:
             if h == "table":
-                os.environ.pop("PF_PERSIST_HOLD", None)
+                os.environ.pop(VAR, None)
             else:
-                os.environ["PF_PERSIST_HOLD"] = h
-            fn()
+                os.environ[VAR] = h
+            for _ in range(3):  # (a graph's rings for two steps per exchange are built at its third application)
+                fn()
             ctx.sync()
             ctx.timing(reset=True)
             for _ in range(args.reps):
