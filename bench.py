@@ -423,6 +423,7 @@ def main():
     call_ms.clear()
     for c in set(ctxs):
         c.timing(reset=True)
+        _hip.persist_clock(c, reset=True)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -435,6 +436,8 @@ def main():
         elapsed = float(t.item())
     timing_stride = max(int(os.environ.get("PF_BENCH_TIMING", TIMING_STRIDE)), 1)
     tms = [c.timing() for c in set(ctxs)]
+    clocks = [_hip.persist_clock(c) for c in set(ctxs)]  # every resident launch of the timed steps, on the device's own clock
+    clock_ms, clock_n = sum(x[0] for x in clocks), sum(x[1] for x in clocks)
     tm = dict(knn_ms=tms[0]["knn_ms"])
     for key in ("op_ms", "op_launches", "op_bytes", "persist_ms", "persist_launches", "persist_steps", "persist_bytes",
                 "persist_lds_bytes"):
@@ -512,7 +515,7 @@ def main():
             lds_per_launch = tm["persist_lds_bytes"] / max(launches, 1)
             achieved = lds_per_launch / (kernel_us * 1e-6) / 1e9
             steps_per_launch = tm["persist_steps"] / 2.0 / max(launches, 1)  # the library counts graph-steps: two per pair-step
-            entry = pmc.get("k_cheb_resident<2, 1, 8>", {})
+            entry = pmc.get("k_cheb_resident<2, 1, 8, true>", {})
             traffic = entry.get("hbm_bytes_per_step", None)
             traffic_refused = None
             if traffic is not None:
@@ -529,15 +532,20 @@ def main():
             traffic = None if traffic is None else traffic * steps_per_launch + entry.get("hbm_bytes_per_launch_fixed", 0.0)
             roofline = {
                 "bound": "lds",
-                "kernel": "k_cheb_resident<2, 1, 8> (a whole Chebyshev recurrence of both graphs of the pair per launch: one block "
-                          "per CU owns a 1024-row window of each graph, SELL-64 entries in registers, the window's x double-buffered "
-                          "in LDS, boundary rows handed to neighbouring windows through memory, value = message; f64)",
+                "kernel": "k_cheb_resident<2, 1, 8, true> (a whole Chebyshev recurrence of both graphs of the pair per launch: one "
+                          "block per CU owns a 1024-row window of each graph - its two halves take the graphs in opposite order - "
+                          "SELL-64 entries in registers, the window's x double-buffered in LDS, boundary rows handed to "
+                          "neighbouring windows through memory, value = message, first fetch of a step at a tuned time; f64)",
                 "achieved": achieved, "peak": LDS_PEAK_GBS, "unit": "GB/s", "frac": achieved / LDS_PEAK_GBS,
                 "traffic": traffic,
                 "traffic_source": (PMC_SUMMARY + " (rocprofv3 --pmc passes of this command, committed; not measured in this run)")
                 if traffic is not None else (None if traffic_refused is None else "refused: " + PMC_SUMMARY + ": " + traffic_refused),
                 "hbm_frac": None if traffic is None else traffic / (kernel_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                 "lds_bytes_per_launch": lds_per_launch,
+                # the same average on the device's 100 MHz clock inside the kernel (first to last instruction of block 0, ALL
+                # launches of the timed steps): what rocprofv3's kernel trace measures; the event pair adds the dispatch of
+                # the kernel and the event packets (~20 us)
+                "avg_launch_us_in_kernel_clock": None if clock_n == 0 else 1e3 * clock_ms / clock_n, "launches_in_kernel_clock": clock_n,
                 "avg_launch_us_hip_events": kernel_us, "launches": launches, "launches_are": "the TIMED launches: one filter application in %d "
                 "carries the event pair" % timing_stride, "launches_per_step": launches * timing_stride / args.steps,
                 "steps_per_launch": steps_per_launch,

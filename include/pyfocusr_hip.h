@@ -172,6 +172,11 @@ int pf_persist_two_step(int level);
  * boundary rows are handed over one row's latency into a step.  0: both graphs in the same order everywhere.
  * Bit-identical results either way.  Environment: PF_PERSIST_HALVES=0/1; process-wide. */
 int pf_persist_pair_halves(int on);
+/* The resident launches of `ctx` since the last reset as their first block saw them: how many completed, and their summed
+ * run time on the device's constant 100 MHz clock (read at the block's first and last instruction).  A cross-check of
+ * pf_timing.persist_ms, whose HIP event pairs also contain the dispatch of the kernel and the event packets themselves
+ * (~20 us per launch).  Synchronises the ctx stream. */
+int pf_persist_clock(pf_ctx* ctx, double* kernel_ms, int64_t* launches, int reset);
 /* What the resident path is doing, for callers that want to know whether they are on the fast path. */
 typedef struct pf_persist_info {
     int32_t enabled;           /* 1: filter applications use the resident kernels where a graph allows it             */

@@ -86,6 +86,7 @@ SIGNATURES = {
     "pf_persist_enable": (C.c_int, [C.c_int]),
     "pf_persist_two_step": (C.c_int, [C.c_int]),
     "pf_persist_pair_halves": (C.c_int, [C.c_int]),
+    "pf_persist_clock": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int]),
     "pf_persist_state": (C.c_int, [C.c_void_p, C.c_void_p]),
     "pf_persist_test_hook": (C.c_int, [C.c_int]),
     "pf_cheb": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double]),
@@ -268,6 +269,14 @@ def persist_pair_halves(on=True):
     """Process-wide switch of the pair kernel whose halves take the two graphs in opposite order (csrc/pf_persist.hip:
     k_cheb_resident<2,1,8,true>; on by default).  Results are bit-identical either way."""
     _check(load_library().pf_persist_pair_halves(int(bool(on))))
+
+
+def persist_clock(ctx, reset=False):
+    """(summed run time in ms, number) of ctx's completed resident launches since the last reset, on the device's own
+    100 MHz clock inside the kernel (csrc/pf_persist.hip: pf_persist_clock).  Synchronises the ctx stream."""
+    ms, n = C.c_double(0.0), C.c_int64(0)
+    _check(load_library().pf_persist_clock(ctx._h, C.byref(ms), C.byref(n), int(bool(reset))))
+    return ms.value, n.value
 
 
 class _PersistInfo(C.Structure):

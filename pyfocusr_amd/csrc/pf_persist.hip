@@ -111,6 +111,7 @@ struct RxArgs {
     RxGraph g[2];
     uint32_t* abort_flag;  // device word: some wait ran out (or the test hook raised it)
     int32_t* host_abort;   // pinned: set to 1 when this launch gave up
+    unsigned long long* clock;  // [2] device: sum of block 0's run times (10 ns ticks), launches counted
     int32_t hold;          // first fetch of a step not before this many 10 ns ticks (s_memrealtime) after the step began;
                            // 0: a fixed s_sleep behind the wave's rows instead
 };
@@ -188,6 +189,8 @@ __global__ __launch_bounds__(RX_THREADS) void k_cheb_resident(RxArgs a) {
     static_assert(!SW || (NG == 2 && NW == 1), "the halves swap graphs in the pair kernel with one row per thread");
     extern __shared__ __align__(16) unsigned char lds[];
     __shared__ int s_state;
+    __shared__ unsigned long long s_began;  // block 0: the launch's run time on the device's 100 MHz clock, for pf_persist_clock
+    if (blockIdx.x == 0 && threadIdx.x == 0) s_began = __builtin_amdgcn_s_memrealtime();
     constexpr int RB = NW * RX_THREADS;
     const unsigned G = gridDim.x, per_xcd = G >> 3;
     const unsigned xcd = blockIdx.x & 7u;
@@ -477,6 +480,10 @@ __global__ __launch_bounds__(RX_THREADS) void k_cheb_resident(RxArgs a) {
         }
         cur ^= 1;
     }
+    if (blockIdx.x == 0 && tid == 0) {
+        atomicAdd(a.clock, (unsigned long long)__builtin_amdgcn_s_memrealtime() - s_began);
+        atomicAdd(a.clock + 1, 1ull);
+    }
 #ifdef RX_EXP_STAMPS
     if (lane == 0 && blockIdx.x < 256)
         for (int i = 0; i < 10; ++i) g_rx_stamps[((size_t)blockIdx.x * 16 + wave) * 10 + i] = s_st[wave][i];
@@ -535,6 +542,7 @@ struct Rx2Args {
     Rx2Graph g[2];
     uint32_t* abort_flag;
     int32_t* host_abort;
+    unsigned long long* clock;  // as RxArgs::clock
     int32_t hold;  // first fetch of a round not before this many 10 ns ticks after its phase B began; 0: a fixed s_sleep
 };
 
@@ -559,6 +567,8 @@ __global__ __launch_bounds__(RX_THREADS) void k_cheb_resident2(Rx2Args a) {
     constexpr int PH = RX_THREADS / NG;  // threads that look after one graph's outside rows (NG == 2: the halves of the block)
     extern __shared__ __align__(16) unsigned char lds[];
     __shared__ int s_state;
+    __shared__ unsigned long long s_began;
+    if (blockIdx.x == 0 && threadIdx.x == 0) s_began = __builtin_amdgcn_s_memrealtime();
     const unsigned G = gridDim.x, per_xcd = G >> 3;
     const unsigned xcd = blockIdx.x & 7u;
     const int32_t win = (int32_t)(xcd * per_xcd + (blockIdx.x >> 3));
@@ -887,6 +897,10 @@ __global__ __launch_bounds__(RX_THREADS) void k_cheb_resident2(Rx2Args a) {
             return;
         }
     }
+    if (blockIdx.x == 0 && tid == 0) {
+        atomicAdd(a.clock, (unsigned long long)__builtin_amdgcn_s_memrealtime() - s_began);
+        atomicAdd(a.clock + 1, 1ull);
+    }
 }
 
 bool persist_enabled() {
@@ -1113,6 +1127,7 @@ int persist_cheb2(const pf_persist_args* a, const pf_persist_args* b, int64_t gr
     }
     args.abort_flag = ctx->persist_sync;
     args.host_abort = ctx->persist_abort;
+    args.clock = reinterpret_cast<unsigned long long*>(ctx->persist_sync + 8);
     if (g_test_aborts.load() > 0) {
         g_test_aborts.fetch_sub(1);
         PF_HIP(hipMemsetAsync(ctx->persist_sync, 1, sizeof(uint32_t), st));
@@ -1242,10 +1257,28 @@ int hold_ticks(int ng, int nw, bool halves, int windows) {
         static const HoldPoint two_rows[] = {{147, 70}, {245, 74}};  // 300k..500k rows
         return hold_from(two_rows, 2, windows);
     }
-    static const HoldPoint single[] = {{20, 58}, {59, 64}, {147, 68}, {245, 73}};
-    static const HoldPoint pair[] = {{20, 80}, {59, 84}, {147, 88}, {245, 97}};
-    static const HoldPoint pair_halves[] = {{20, 72}, {59, 73}, {147, 80}, {245, 89}};
+    static const HoldPoint single[] = {{20, 58}, {59, 64}, {147, 68}, {245, 72}};
+    static const HoldPoint pair[] = {{20, 80}, {59, 84}, {147, 89}, {245, 94}};
+    static const HoldPoint pair_halves[] = {{20, 72}, {59, 74}, {147, 82}, {245, 88}};
     return ng == 1 ? hold_from(single, 4, windows) : (halves ? hold_from(pair_halves, 4, windows) : hold_from(pair, 4, windows));
+}
+
+// Block 0's own view of the resident launches since the last reset: their number and their summed run time on the
+// device's 100 MHz clock (s_memrealtime at the first and last instruction of the block) - the kernel without the
+// dispatch and event packets that a HIP event pair around a launch also measures.  Synchronises the ctx stream.
+extern "C" int pf_persist_clock(pf_ctx* ctx, double* kernel_ms, int64_t* launches, int reset) {
+    PF_CHECK(ctx != nullptr && kernel_ms != nullptr && launches != nullptr, PF_E_ARG, "pf_persist_clock: NULL argument");
+    *kernel_ms = 0.0;
+    *launches = 0;
+    if (!ctx->persist_sync) return PF_OK;
+    unsigned long long h[2] = {0, 0};
+    PF_HIP(hipSetDevice(ctx->device));
+    PF_HIP(hipMemcpyAsync(h, ctx->persist_sync + 8, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    PF_HIP(hipStreamSynchronize(ctx->stream));
+    if (reset) PF_HIP(hipMemsetAsync(ctx->persist_sync + 8, 0, sizeof(h), ctx->stream));
+    *kernel_ms = (double)h[0] * 1e-5;  // 10 ns ticks
+    *launches = (int64_t)h[1];
+    return PF_OK;
 }
 
 extern "C" int pf_persist_test_hook(int n_launches) {
@@ -1337,6 +1370,7 @@ int pf_persist_cheb(const pf_persist_args* a, const pf_persist_args* b, int* don
     }
     args.abort_flag = ctx->persist_sync;
     args.host_abort = ctx->persist_abort;
+    args.clock = reinterpret_cast<unsigned long long*>(ctx->persist_sync + 8);
     args.hold = hold_ticks(ng, nw, kernel == k_cheb_resident<2, 1, rx_jr(2, 1), true>, (int)std::max(wa, wb));
     if (g_test_aborts.load() > 0) {  // pf_persist_test_hook: this launch finds the abort flag raised
         g_test_aborts.fetch_sub(1);

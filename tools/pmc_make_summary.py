@@ -58,7 +58,7 @@ if args.bench and os.path.exists(args.bench):
             if line.startswith("{"):
                 bench = json.loads(line)
 kernels = {}
-for label, needle, fdir, wdir in (("k_cheb_resident<2, 1, 8>", "k_cheb_resident<2, 1, 8>", args.fetch, args.write),
+for label, needle, fdir, wdir in (("k_cheb_resident<2, 1, 8, true>", "k_cheb_resident<2, 1, 8, true>", args.fetch, args.write),
                                   ("k_sell_op2<true>", "k_sell_op2<true>", args.fetch_stream, args.write_stream)):
     if not fdir or not wdir:
         continue
