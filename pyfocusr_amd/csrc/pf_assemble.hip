@@ -114,33 +114,60 @@ __global__ __launch_bounds__(PF_BLOCK) void k_face_bound(const int32_t* __restri
 
 // one thread per vertex: insertion-sort its (col, w) segment by column, drop duplicate columns
 // (a directed edge listed by two faces carries the same weight), report the unique count.
-__global__ __launch_bounds__(PF_BLOCK) void k_sort_unique_rows(const int32_t* __restrict__ start, int64_t n,
-                                                               int32_t* __restrict__ rcol, double* __restrict__ rw,
-                                                               int32_t* __restrict__ ucnt) {
-    const int64_t i = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
-    if (i >= n) return;
-    const int32_t b = start[i], e = start[i + 1];
+// The segments of a block's 256 vertices are one contiguous piece of rcol / rw (~3000 entries): it is staged in LDS by
+// the whole block (coalesced), every thread sorts its own segment there, and the piece goes back the same way - the
+// sort's ~40 dependent moves per row are LDS accesses instead of global ones (89 -> ~25 us at 250k vertices).  A block
+// whose piece does not fit (very high degrees) sorts in place in global memory, as before.
+constexpr int PF_SORT_CAP = 4096;  // entries staged per block: 48 KB
+template <typename C, typename W>
+__device__ __forceinline__ int32_t sort_unique_segment(C* c, W* v, int32_t b, int32_t e) {
     for (int32_t a = b + 1; a < e; ++a) {
-        const int32_t c = rcol[a];
-        const double v = rw[a];
+        const int32_t cc = c[a];
+        const double vv = v[a];
         int32_t p = a - 1;
-        while (p >= b && rcol[p] > c) {
-            rcol[p + 1] = rcol[p];
-            rw[p + 1] = rw[p];
+        while (p >= b && c[p] > cc) {
+            c[p + 1] = c[p];
+            v[p + 1] = v[p];
             --p;
         }
-        rcol[p + 1] = c;
-        rw[p + 1] = v;
+        c[p + 1] = cc;
+        v[p + 1] = vv;
     }
     int32_t u = 0;
     for (int32_t a = b; a < e; ++a) {
-        if (a == b || rcol[a] != rcol[b + u - 1]) {
-            rcol[b + u] = rcol[a];
-            rw[b + u] = rw[a];
+        if (a == b || c[a] != c[b + u - 1]) {
+            c[b + u] = c[a];
+            v[b + u] = v[a];
             ++u;
         }
     }
-    ucnt[i] = u;
+    return u;
+}
+
+__global__ __launch_bounds__(PF_BLOCK) void k_sort_unique_rows(const int32_t* __restrict__ start, int64_t n,
+                                                               int32_t* __restrict__ rcol, double* __restrict__ rw,
+                                                               int32_t* __restrict__ ucnt) {
+    __shared__ int32_t s_c[PF_SORT_CAP];
+    __shared__ double s_v[PF_SORT_CAP];
+    const int64_t i0 = (int64_t)blockIdx.x * PF_BLOCK;
+    const int64_t i = i0 + threadIdx.x;
+    const int64_t i1 = i0 + PF_BLOCK < n ? i0 + PF_BLOCK : n;
+    const int32_t lo = start[i0], hi = start[i1];  // (block-uniform)
+    if (hi - lo > PF_SORT_CAP) {
+        if (i < n) ucnt[i] = sort_unique_segment(rcol, rw, start[i], start[i + 1]);
+        return;
+    }
+    for (int32_t a = threadIdx.x; a < hi - lo; a += PF_BLOCK) {
+        s_c[a] = rcol[lo + a];
+        s_v[a] = rw[lo + a];
+    }
+    __syncthreads();
+    if (i < n) ucnt[i] = sort_unique_segment(s_c, s_v, start[i] - lo, start[i + 1] - lo);
+    __syncthreads();
+    for (int32_t a = threadIdx.x; a < hi - lo; a += PF_BLOCK) {
+        rcol[lo + a] = s_c[a];
+        rw[lo + a] = s_v[a];
+    }
 }
 
 __global__ __launch_bounds__(PF_BLOCK) void k_compact_rows(const int32_t* __restrict__ start,
@@ -198,9 +225,12 @@ __global__ __launch_bounds__(PF_BLOCK) void k_symmetry_probe(const int32_t* __re
                                                              const int32_t* __restrict__ col,
                                                              const double* __restrict__ values, int64_t n,
                                                              int32_t* __restrict__ asym) {
-    const int64_t i = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
+    // eight threads per row, each with every eighth entry: the binary searches of a row (three dependent gathers each, in
+    // rows that lie anywhere) are in flight together instead of one after the other (50 -> ~15 us at 250k vertices)
+    const int64_t t = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
+    const int64_t i = t >> 3;
     if (i >= n) return;
-    for (int32_t a = rowptr[i]; a < rowptr[i + 1]; ++a) {
+    for (int32_t a = rowptr[i] + (int32_t)(t & 7), e = rowptr[i + 1]; a < e; a += 8) {
         const int32_t j = col[a];
         int32_t lo = rowptr[j], hi = rowptr[j + 1] - 1;
         bool found = false;
@@ -342,6 +372,70 @@ __global__ __launch_bounds__(PF_BLOCK) void k_fill_sell(const int32_t* __restric
     }
 }
 
+// The same storage, one block per slice and one thread per stored ENTRY (round 3).  k_fill_sell walks a row's entries one
+// after the other - two dependent gathers each (the entry, then iperm / sg of its column), seven times in a row per
+// lane: 110-150 us for a 250k-vertex mesh whose vertices come in no particular order.  Here every entry of the slice is
+// its own thread: the row's facts sit in LDS, entry q of the slice is written by thread q (coalesced, the layout of
+// pf_sell_index inverted), and all gathers of a slice are in flight together.
+__global__ __launch_bounds__(PF_BLOCK) void k_fill_sell_entries(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                                const double* __restrict__ w, const double* __restrict__ deg,
+                                                                const double* __restrict__ g, const double* __restrict__ sg,
+                                                                const int32_t* __restrict__ perm, const int32_t* __restrict__ iperm,
+                                                                int64_t n, const int64_t* __restrict__ slice_ptr,
+                                                                int32_t* __restrict__ scol, double* __restrict__ sval_rw,
+                                                                double* __restrict__ sval_sym, double* __restrict__ diag) {
+    __shared__ int32_t s_b[PF_WAVE], s_cnt[PF_WAVE];
+    __shared__ double s_g[PF_WAVE], s_s[PF_WAVE];
+    const int64_t s = blockIdx.x;
+    const int64_t base = slice_ptr[s];
+    const int32_t width = (int32_t)((slice_ptr[s + 1] - base) / PF_WAVE);
+    const int t = threadIdx.x;
+    if (t < PF_WAVE) {
+        const int64_t row = s * PF_WAVE + t;
+        int32_t b = 0, cnt = 0;
+        double gi = 0.0, si = 0.0, d = 0.0;
+        if (row < n) {
+            const int32_t old = perm[row];
+            b = rowptr[old];
+            cnt = rowptr[old + 1] - b;
+            gi = g[old];
+            si = sg[old];
+            d = gi * deg[old];  // L_ii = g_i deg_i  (graph.py:226)
+        }
+        diag[row] = d;
+        s_b[t] = b;
+        s_cnt[t] = cnt;
+        s_g[t] = gi;
+        s_s[t] = si;
+    }
+    __syncthreads();
+    const int32_t pairs = width >> 1, total = width * PF_WAVE;
+    for (int32_t q = t; q < total; q += PF_BLOCK) {
+        int lane, j;
+        if (q < pairs * 2 * PF_WAVE) {
+            const int32_t r = q & (2 * PF_WAVE - 1);
+            lane = r >> 1;
+            j = 2 * (q / (2 * PF_WAVE)) + (r & 1);
+        } else {
+            lane = q - pairs * 2 * PF_WAVE;
+            j = width - 1;
+        }
+        const int64_t idx = base + q;  // == pf_sell_index(base, width, j, lane)
+        if (j < s_cnt[lane]) {
+            const int32_t a = s_b[lane] + j;
+            const int32_t c = col[a];
+            const double wv = w[a];
+            scol[idx] = iperm[c];
+            sval_rw[idx] = -(s_g[lane] * wv);  // L_ij = g_i * (0 - W_ij)
+            if (sval_sym) sval_sym[idx] = -(wv * (s_s[lane] * sg[c]));
+        } else {
+            scol[idx] = (int32_t)(s * PF_WAVE + lane);  // padding: zero weight on the row's own (in-window) column
+            sval_rw[idx] = 0.0;
+            if (sval_sym) sval_sym[idx] = 0.0;
+        }
+    }
+}
+
 __global__ __launch_bounds__(PF_BLOCK) void k_l_offdiag(const int32_t* __restrict__ rowptr, const double* __restrict__ w,
                                                         const double* __restrict__ g, int64_t n, double* __restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
@@ -475,7 +569,7 @@ struct FinishJob {
         stats = flags + 2;  // [0] isolated, [1] max degree, [2] asym, [3] changed, [4] n_roots
         k_row_stats<<<nblk(n), PF_BLOCK, 0, st>>>(g->rowptr, n, stats);
         PF_HIP(hipGetLastError());
-        k_symmetry_probe<<<nblk(n), PF_BLOCK, 0, st>>>(g->rowptr, g->col, numeric_symmetry ? g->w : nullptr, n, stats + 2);
+        k_symmetry_probe<<<nblk(8 * n), PF_BLOCK, 0, st>>>(g->rowptr, g->col, numeric_symmetry ? g->w : nullptr, n, stats + 2);
         PF_HIP(hipGetLastError());
 
         // components
@@ -581,8 +675,13 @@ struct FinishJob {
         PF_TRY(dev_alloc(st, &g->scol, g->sell_entries));
         PF_TRY(dev_alloc(st, &g->sval_rw, g->sell_entries));
         if (g->is_symmetric) PF_TRY(dev_alloc(st, &g->sval_sym, g->sell_entries));
-        k_fill_sell<<<nblk(g->n_pad), PF_BLOCK, 0, st>>>(g->rowptr, g->col, g->w, g->deg, g->g, g->sg, g->perm, g->iperm, n, g->n_pad,
-                                                         g->slice_ptr, g->scol, g->sval_rw, g->sval_sym, g->diag);
+        static const bool by_rows = [] { const char* e = getenv("PF_FILL_SELL_ROWS"); return e && e[0] == '1'; }();  // (A/B: a thread per row)
+        if (by_rows)
+            k_fill_sell<<<nblk(g->n_pad), PF_BLOCK, 0, st>>>(g->rowptr, g->col, g->w, g->deg, g->g, g->sg, g->perm, g->iperm, n, g->n_pad,
+                                                             g->slice_ptr, g->scol, g->sval_rw, g->sval_sym, g->diag);
+        else
+            k_fill_sell_entries<<<(unsigned)g->n_slices, PF_BLOCK, 0, st>>>(g->rowptr, g->col, g->w, g->deg, g->g, g->sg, g->perm, g->iperm, n,
+                                                                            g->slice_ptr, g->scol, g->sval_rw, g->sval_sym, g->diag);
         PF_HIP(hipGetLastError());
         return PF_OK;
     }

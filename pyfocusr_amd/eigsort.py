@@ -138,17 +138,19 @@ class eigsort(object):
         # (n, k) array when the assignment is the identity (the usual case) — at 250k vertices that copy
         # costs more than the rest of eigsort together.
         if self.target_as_reference is True:
-            vecs, flip_cols = self.graph_source.eig_vecs, [m1 for _, m1 in flipped_pairs]
+            flip_cols = [m1 for _, m1 in flipped_pairs]
             dst, src = np.asarray(target_matches), np.asarray(source_matches)
         else:
-            vecs, flip_cols = self.graph_target.eig_vecs, [m0 for m0, _ in flipped_pairs]
+            flip_cols = [m0 for m0, _ in flipped_pairs]
             dst, src = np.asarray(source_matches), np.asarray(target_matches)
         mutated = self.graph_source if self.target_as_reference is True else self.graph_target
+        changes = len(flip_cols) > 0 or not np.array_equal(dst, src)
         fmap = getattr(mutated, "_final_map", None)  # the same flips / permutation for the graph's device-resident block
-        on_device = (fmap is not None and vecs is not None and (len(flip_cols) > 0 or not np.array_equal(dst, src))
+        on_device = (fmap is not None and changes and getattr(mutated, "_eig_vecs", None) is not None
                      and getattr(mutated, "_remap_ready", lambda: False)())
-        if on_device:
-            vecs = None  # the host array is rewritten from the device block below (one DMA instead of strided host passes)
+        # the host array: rewritten from the device block below when that is possible (one DMA instead of strided host
+        # passes); read - which collects a download that may still be owed or in flight - only if it has to be changed here
+        vecs = mutated.eig_vecs if (changes and not on_device) else None
         for col in flip_cols:
             if vecs is not None:  # (None: a graph held on another rank / on the device only, see parallel.py)
                 np.negative(vecs[:, col], out=vecs[:, col])  # one strided pass, no temporary (x * -1 == -x bit for bit)
