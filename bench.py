@@ -546,6 +546,9 @@ def main():
                 # launches of the timed steps): what rocprofv3's kernel trace measures; the event pair adds the dispatch of
                 # the kernel and the event packets (~20 us)
                 "avg_launch_us_in_kernel_clock": None if clock_n == 0 else 1e3 * clock_ms / clock_n, "launches_in_kernel_clock": clock_n,
+                # when a block first asks for its neighbours' values, in 10 ns ticks after a step began: the library's table,
+                # adjusted by what this process measured on its first launches
+                "hold_back_ticks": _hip.persist_state(ctx)["hold_ticks"],
                 "avg_launch_us_hip_events": kernel_us, "launches": launches, "launches_are": "the TIMED launches: one filter application in %d "
                 "carries the event pair" % timing_stride, "launches_per_step": launches * timing_stride / args.steps,
                 "steps_per_launch": steps_per_launch,

@@ -191,7 +191,7 @@ typedef struct pf_persist_info {
     int32_t rearms;            /* suspensions that have ended                                                         */
     int32_t owner_switches;    /* times the path moved from one ctx to another (the previous owner's launches had
                                   completed; while they are in flight the other ctx runs one step per launch)         */
-    int32_t reserved;
+    int32_t hold_ticks;        /* the hold-back of the latest resident launch, 10 ns ticks after a step began (0: fixed sleep) */
 } pf_persist_info;
 int pf_persist_state(pf_ctx* ctx /* nullable */, pf_persist_info* out);
 /* Test hook: the next n resident launches start with their abort flag raised (they give up at once and the

@@ -282,7 +282,7 @@ def persist_clock(ctx, reset=False):
 class _PersistInfo(C.Structure):
     _fields_ = [("enabled", C.c_int32), ("two_step", C.c_int32), ("owner", C.c_int32), ("timeouts", C.c_int32),
                 ("launches", C.c_int64), ("launches_two_step", C.c_int64), ("suspended_for", C.c_int32), ("rearms", C.c_int32),
-                ("owner_switches", C.c_int32), ("reserved", C.c_int32)]
+                ("owner_switches", C.c_int32), ("hold_ticks", C.c_int32)]
 
 
 def persist_state(ctx=None):

@@ -1519,6 +1519,40 @@ def test_resident_kernel_bit_identical(golden, hip, ctx):
             g.close()
 
 
+def test_resident_hold_back_calibration(hip):
+    """The moment a block first asks for its neighbours' values is tried around the library's table value on a context's
+    first launches of a kernel shape and then kept (pf_persist.hip: HoldCalibration): the hold-backs used move, settle
+    within 12 ticks of where they began, and every launch - trial or not - returns the same bits."""
+    from pyfocusr_amd.meshgen import blob_mesh
+
+    os.environ.pop("PF_PERSIST_HOLD", None)
+    ctx = hip.Context(0)  # a fresh context: nothing calibrated yet
+    devs = []
+    try:
+        for s in (0, 1):
+            m = blob_mesh(60000, seed=20 + s)
+            d = hip.DeviceLaplacian(m.points, m.faces, ctx=ctx)
+            d.ws_ensure(4)
+            d.upload(0, np.random.default_rng(s).standard_normal(d.n))
+            devs.append(d)
+        hip.persist_two_step(0)
+        req = (0, 1, 60, 1.01, 0.99, 1.0)
+        holds, outs = [], []
+        for _ in range(40):
+            devs[0].cheb2(req, devs[1], req)
+            holds.append(hip.persist_state(ctx)["hold_ticks"])
+            outs.append((devs[0].download_slots(1, 1).copy(), devs[1].download_slots(1, 1).copy()))
+        assert holds[0] > 0 and len(set(holds[:12])) >= 3, holds  # the table's value and its neighbours were tried
+        assert len(set(holds[-8:])) == 1 and abs(holds[-1] - holds[0]) <= 12, holds  # ... and one was kept
+        for a, b in outs[1:]:
+            assert np.array_equal(a, outs[0][0]) and np.array_equal(b, outs[0][1])
+    finally:
+        hip.persist_two_step(1)
+        for d in devs:
+            d.close()
+        ctx.close()
+
+
 def test_resident_kernel_timeout_is_survived(hip, ctx):
     """A wait of the resident kernel that gives up (forced through the library's test hook) must not cost any caller
     the result: the library reports PF_E_PERSIST_TIMEOUT once, with its stream drained and the path switched off, and
