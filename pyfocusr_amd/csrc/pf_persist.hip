@@ -84,7 +84,9 @@ int64_t suspend_length() {
 constexpr int RX_THREADS = PF_WIN_THREADS;
 constexpr unsigned long long RX_EMPTY = 0xFFFFDEADFFFFDEADull;  // quiet NaN with a payload arithmetic never produces
 constexpr unsigned RX_EMPTY32 = 0xFFFFDEADu;
-constexpr unsigned RX_SPIN_LIMIT = 4000000u;
+// a wait gives up after this many repeated fetches (~0.5 us each: ~0.1 s; a launch lasts ~0.2 ms, and every block of the
+// grid is resident before the first wait - what a wait can run into is a device shared with another tenant)
+constexpr unsigned RX_SPIN_LIMIT = 200000u;
 #ifdef RX_EXP_STAMPS
 constexpr size_t RX_LDS_LIMIT = 160 * 1024 - 512 - 1024;
 #else
