@@ -264,14 +264,19 @@ __global__ __launch_bounds__(RX_THREADS) void k_cheb_resident(RxArgs a) {
     }
     if (tid == 0) s_state = (int)__hip_atomic_load(a.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
-    if (tid == 0) {  // exclusive prefix of the waves' overflow counts (<= 128 entries)
-        int32_t run = 0;
-        for (int i = 0; i < NG * NW * 16; ++i) {
-            const int32_t c = ovtab[i];
-            ovtab[i] = run;
-            run += c;
+    if (tid < PF_WAVE) {  // exclusive prefix of the waves' overflow counts (<= 128 entries): one wave, two entries per lane
+        constexpr int CNT = NG * NW * 16;
+        const int32_t c0 = 2 * lane < CNT ? ovtab[2 * lane] : 0, c1 = 2 * lane + 1 < CNT ? ovtab[2 * lane + 1] : 0;
+        int32_t inc = c0 + c1;
+#pragma unroll
+        for (int off = 1; off < PF_WAVE; off <<= 1) {
+            const int32_t up = __shfl_up(inc, off, PF_WAVE);
+            if (lane >= off) inc += up;
         }
-        ovtab[NG * NW * 16] = run;
+        const int32_t before = inc - c0 - c1;
+        if (2 * lane < CNT) ovtab[2 * lane] = before;
+        if (2 * lane + 1 < CNT) ovtab[2 * lane + 1] = before + c0;
+        if (lane == PF_WAVE - 1) ovtab[CNT] = inc;
     }
     __syncthreads();
     if (s_state != 0) {  // aborted before it began (test hook, or an earlier launch that is still being drained)
