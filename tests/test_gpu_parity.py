@@ -85,6 +85,45 @@ def test_laplacian_view_bit_exact(golden, ctx, name):
     assert np.array_equal(gr.normed_points, g["normed_points"])
 
 
+def test_assembly_hub_vertices(hip, ctx):
+    """Vertices of very high degree: a fan of 6000 triangles around one hub (its row alone exceeds what a block stages in
+    LDS for the per-vertex sort, so that block sorts in global memory) next to a second fan and a strip of ordinary
+    triangles, in shuffled vertex order.  CSR(W), degrees and L against the oracle, bit for bit; the SELL operator through
+    one product against scipy."""
+    from oracle import reference_port as orc
+
+    rng = np.random.default_rng(5)
+    n_rim = 6000
+    ang = np.linspace(0.0, 2.0 * np.pi, n_rim, endpoint=False)
+    rim = np.stack([np.cos(ang) * (1 + 0.1 * rng.random(n_rim)), np.sin(ang), 0.05 * rng.standard_normal(n_rim)], axis=1)
+    rim2 = rim * 0.5 + np.array([0.0, 0.0, 1.0])
+    pts = np.concatenate([[[0.0, 0.0, 0.3]], rim, [[0.0, 0.0, 1.4]], rim2])
+    hub2 = 1 + n_rim
+    faces = [[0, 1 + i, 1 + (i + 1) % n_rim] for i in range(n_rim)]
+    faces += [[hub2, hub2 + 1 + i, hub2 + 1 + (i + 1) % n_rim] for i in range(0, n_rim, 3)]  # an open fan: one-way edges too
+    faces += [[1 + i, hub2 + 1 + i, 1 + (i + 1) % n_rim] for i in range(0, n_rim, 2)]       # joins the two fans
+    faces = np.asarray(faces, dtype=np.int32)
+    perm = rng.permutation(len(pts))
+    inv = np.argsort(perm)
+    pts, faces = pts[perm], inv[faces].astype(np.int32)
+    W, deg, d_inv, L = orc.graph_matrices(pts, faces)
+    W, L = sparse.csr_matrix(W), sparse.csr_matrix(L)
+    W.sort_indices()
+    dev = hip.DeviceLaplacian(pts, faces, ctx=ctx)
+    try:
+        h = dev.download()
+        assert dev.max_degree >= n_rim
+        assert np.array_equal(h["rowptr"], W.indptr) and np.array_equal(h["colidx"], W.indices)
+        assert np.array_equal(h["w"], W.data) and np.array_equal(h["deg"], deg)
+        assert dev.symmetric == (abs(W - W.T).nnz == 0)
+        x = rng.standard_normal(len(pts))
+        y = dev.spmv_host(x, op=hip.PF_OP_RW)
+        ref = L @ x
+        assert np.max(np.abs(y - ref)) <= 1e-12 * np.max(np.abs(ref))
+    finally:
+        dev.close()
+
+
 def test_assembly_errors(hip, ctx):
     pts = np.random.default_rng(0).normal(size=(10, 3))
     with pytest.raises(hip.PfError) as e:
