@@ -303,6 +303,46 @@ __global__ __launch_bounds__(PF_BLOCK) void k_label_compress(int32_t* label, int
     if (i < n) label[i] = uf_find(label, (int32_t)i);
 }
 
+// One ROUND in one launch (round 3): a vertex first points itself at its current root (the flattening that used to be a
+// launch of its own), then hooks across its edges between ROOTS found by walking the pointers as they are at that moment.
+// Pointers only ever move to smaller vertices of the same component, so a walk terminates and whatever it returns is
+// an ancestor; a hook lost to a race is found again in the next round (the edge still joins two trees).  A round in
+// which no edge joined two roots wrote nothing but flattenings: the forest is final (k_label_compress flattens it once
+// more for the readers).  Half the launches of hook + compress, and fewer rounds (roots, not last round's stars).
+#ifndef PF_CC_SWEEPS
+#define PF_CC_SWEEPS 1
+#endif
+__global__ __launch_bounds__(PF_BLOCK) void k_label_round(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, int64_t n,
+                                                          int32_t* label, int32_t* differing, const int32_t* prev) {
+    if (prev && *prev == 0) return;  // the previous round changed nothing: converged (rounds are queued ahead, unasked)
+    const int64_t i = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
+    bool any = false;
+    if (i < n) {
+        const int32_t b = rowptr[i], e = rowptr[i + 1];
+        // (PF_CC_SWEEPS passes over the edges per launch; measured at 250k vertices: 3 passes make the first launches 96 / 78 us
+        // instead of 25 / 25 and save no round - the tail is the ~log2(trees) halvings, not work per launch - so: 1.  A launch of
+        // a nearly converged labelling is all launch latency,
+        // and a second pass already sees what the first one - of every other vertex too - has joined)
+        for (int sweep = 0; sweep < PF_CC_SWEEPS; ++sweep) {
+            int32_t fu = uf_find(label, (int32_t)i);
+            if (label[i] != fu) label[i] = fu;
+            bool again = false;
+            for (int32_t a = b; a < e; ++a) {
+                const int32_t fv = uf_find(label, col[a]);
+                if (fu != fv) {
+                    const int32_t lo = fu < fv ? fu : fv, hi = fu < fv ? fv : fu;
+                    label[hi] = lo;
+                    fu = lo;
+                    again = true;
+                }
+            }
+            any = any || again;
+            if (!again) break;
+        }
+    }
+    if (__any(any) && (threadIdx.x & (PF_WAVE - 1)) == 0) *differing = 1;
+}
+
 __global__ __launch_bounds__(PF_BLOCK) void k_collect_roots(const int32_t* __restrict__ label,
                                                             const int32_t* __restrict__ rowptr, int64_t n,
                                                             int32_t* __restrict__ roots, int32_t* __restrict__ n_roots) {
@@ -575,18 +615,16 @@ struct FinishJob {
         // components
         k_label_init<<<nblk(g->n_pad), PF_BLOCK, 0, st>>>(g->rowptr, g->col, n, g->n_pad, g->label);
         PF_HIP(hipGetLastError());
-        k_label_compress<<<nblk(n), PF_BLOCK, 0, st>>>(g->label, n);
-        PF_HIP(hipGetLastError());
         PF_HIP(hipMemsetAsync(round_flags, 0, sizeof(int32_t) * PF_CC_ROUNDS, st));
         // PF_CC_FIRST rounds are queued without asking: a round that follows a round without changes returns at once
         // (~2 us instead of ~15), and whether the last one still changed something is read back with everything else below
         for (round = 0; round < PF_CC_FIRST; ++round) {
             const int32_t* prev = round ? round_flags + round - 1 : nullptr;
-            k_label_hook<<<nblk(n), PF_BLOCK, 0, st>>>(g->rowptr, g->col, n, g->label, round_flags + round, prev);
-            PF_HIP(hipGetLastError());
-            k_label_compress<<<nblk(n), PF_BLOCK, 0, st>>>(g->label, n, prev);
+            k_label_round<<<nblk(n), PF_BLOCK, 0, st>>>(g->rowptr, g->col, n, g->label, round_flags + round, prev);
             PF_HIP(hipGetLastError());
         }
+        k_label_compress<<<nblk(n), PF_BLOCK, 0, st>>>(g->label, n);
+        PF_HIP(hipGetLastError());
         k_collect_roots<<<nblk(n), PF_BLOCK, 0, st>>>(g->label, g->rowptr, n, d_roots, stats + 4);
         PF_HIP(hipGetLastError());
 
@@ -641,11 +679,11 @@ struct FinishJob {
             for (;;) {
                 PF_CHECK(round + 3 <= PF_CC_ROUNDS, PF_E_HIP, "pf_graph_build: component labelling did not converge");
                 for (int b = 0; b < 3; ++b, ++round) {
-                    k_label_hook<<<nblk(n), PF_BLOCK, 0, st>>>(g->rowptr, g->col, n, g->label, round_flags + round, nullptr);
-                    PF_HIP(hipGetLastError());
-                    k_label_compress<<<nblk(n), PF_BLOCK, 0, st>>>(g->label, n);
+                    k_label_round<<<nblk(n), PF_BLOCK, 0, st>>>(g->rowptr, g->col, n, g->label, round_flags + round, nullptr);
                     PF_HIP(hipGetLastError());
                 }
+                k_label_compress<<<nblk(n), PF_BLOCK, 0, st>>>(g->label, n);
+                PF_HIP(hipGetLastError());
                 PF_HIP(hipMemcpyAsync(&differing, round_flags + round - 1, sizeof(int32_t), hipMemcpyDeviceToHost, st));
                 PF_HIP(hipStreamSynchronize(st));
                 if (!differing) break;
