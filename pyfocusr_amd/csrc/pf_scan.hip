@@ -76,6 +76,39 @@ __global__ __launch_bounds__(PF_BLOCK) void scan_block_apply(const T* __restrict
     }
 }
 
+// the same, with the block's offset summed by the block itself from the (unscanned) totals of the blocks before it:
+// up to SCAN_DIRECT_BLOCKS totals are few enough to be re-read by every block (123 for 250k elements), which saves the
+// launch that scanned them
+constexpr int64_t SCAN_DIRECT_BLOCKS = 4096;
+template <typename T>
+__global__ __launch_bounds__(PF_BLOCK) void scan_block_apply_direct(const T* __restrict__ in, T* __restrict__ out,
+                                                                    const T* __restrict__ totals, int64_t n) {
+    __shared__ T s_off;
+    T mine = 0;
+    for (int64_t b = threadIdx.x; b < blockIdx.x; b += PF_BLOCK) mine += totals[b];
+    T before;
+    (void)block_exclusive_scan(mine, &before);  // (integers: the order of the additions does not matter)
+    if (threadIdx.x == 0) s_off = before;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+    T v[SCAN_ITEMS];
+    T s = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        int64_t i = base + k;
+        v[k] = (i < n) ? in[i] : T(0);
+        s += v[k];
+    }
+    T total;
+    T run = block_exclusive_scan(s, &total) + s_off;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        int64_t i = base + k;
+        if (i < n) out[i] = run;
+        run += v[k];
+    }
+}
+
 template <typename T>
 int exclusive_scan(hipStream_t st, const T* in, T* out, int64_t n) {
     if (n <= 0) return PF_OK;
@@ -89,10 +122,16 @@ int exclusive_scan(hipStream_t st, const T* in, T* out, int64_t n) {
     PF_HIP(pf_malloc(st, (void**)&totals, sizeof(T) * blocks));
     scan_block_totals<T><<<(unsigned)blocks, PF_BLOCK, 0, st>>>(in, totals, n);
     PF_HIP(hipGetLastError());
-    int r = exclusive_scan<T>(st, totals, totals, blocks);
-    if (r == PF_OK) {
-        scan_block_apply<T><<<(unsigned)blocks, PF_BLOCK, 0, st>>>(in, out, totals, n);
+    int r = PF_OK;
+    if (blocks <= SCAN_DIRECT_BLOCKS) {
+        scan_block_apply_direct<T><<<(unsigned)blocks, PF_BLOCK, 0, st>>>(in, out, totals, n);
         if (hipGetLastError() != hipSuccess) r = PF_E_HIP;
+    } else {
+        r = exclusive_scan<T>(st, totals, totals, blocks);
+        if (r == PF_OK) {
+            scan_block_apply<T><<<(unsigned)blocks, PF_BLOCK, 0, st>>>(in, out, totals, n);
+            if (hipGetLastError() != hipSuccess) r = PF_E_HIP;
+        }
     }
     pf_free(st, totals);
     return r;
