@@ -251,8 +251,9 @@ __global__ __launch_bounds__(PF_BLOCK) void k_symmetry_probe(const int32_t* __re
 // Atomics on one address serialise at ~10 ns each on this part (measured: 4 k atomicMax on one word = 41 us), and every
 // union-find on the GPU ends up hammering the few surviving roots: atomicMin hooking took 1.0 ms and a
 // compare-and-swap union-find (the ECL-CC scheme) 1.6 ms for a 250k-vertex mesh.  So: no atomics at all.  Rounds of
-// (hook, flatten) on a forest of stars, in the manner of Soman et al. (2010): every edge whose ends sit in different
-// stars writes "larger root -> smaller root" with a plain store (any winner is a valid parent: it is smaller and in
+// hooking (k_label_round below; until round 3 a hook and a flatten launch per round on a forest of stars, in the manner
+// of Soman et al. 2010): every edge whose ends sit in different
+// trees writes "larger root -> smaller root" with a plain store (any winner is a valid parent: it is smaller and in
 // the same component, so the forest stays acyclic and every root with a smaller neighbouring star gets hooked), then
 // every vertex is pointed at its root again.  The number of stars falls geometrically; the round that sees no
 // differing edge proves the labelling, and the surviving root of a component is its smallest vertex index.
@@ -274,27 +275,6 @@ __global__ __launch_bounds__(PF_BLOCK) void k_label_init(const int32_t* __restri
     if (i < n)
         for (int32_t a = rowptr[i]; a < rowptr[i + 1]; ++a) m = min(m, col[a]);
     label[i] = m;  // parent <= child, equality for roots only: a forest
-}
-
-__global__ __launch_bounds__(PF_BLOCK) void k_label_hook(const int32_t* __restrict__ rowptr,
-                                                         const int32_t* __restrict__ col, int64_t n, int32_t* label,
-                                                         int32_t* differing, const int32_t* prev) {
-    if (prev && *prev == 0) return;  // the previous round changed nothing: converged (rounds are queued ahead, unasked)
-    const int64_t i = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
-    bool any = false;
-    if (i < n) {
-        int32_t fu = label[i];  // a root of the star forest this round started from (or a smaller one hooked since)
-        for (int32_t a = rowptr[i]; a < rowptr[i + 1]; ++a) {
-            const int32_t fv = label[col[a]];
-            if (fu != fv) {
-                const int32_t lo = fu < fv ? fu : fv, hi = fu < fv ? fv : fu;
-                label[hi] = lo;
-                fu = lo;
-                any = true;
-            }
-        }
-    }
-    if (__any(any) && (threadIdx.x & (PF_WAVE - 1)) == 0) *differing = 1;
 }
 
 __global__ __launch_bounds__(PF_BLOCK) void k_label_compress(int32_t* label, int64_t n, const int32_t* prev = nullptr) {
