@@ -26,8 +26,9 @@ namespace {
 
 __global__ __launch_bounds__(PF_BLOCK) void k_count_edges(const int32_t* __restrict__ faces, int64_t n_edges,
                                                           int32_t vpf, int64_t n, int32_t* __restrict__ cnt,
-                                                          int32_t* __restrict__ flags) {
+                                                          int32_t* __restrict__ flags, double* __restrict__ quarter) {
     const int64_t e = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
+    if (e == 0 && quarter) *quarter = 0.25;  // k_face_bound's running minimum starts there (instead of two fills of its own)
     if (e >= n_edges) return;
     const int64_t f = e / vpf;
     const int32_t k = (int32_t)(e - f * vpf);
@@ -529,12 +530,12 @@ constexpr int PF_ROOTS_AHEAD = 16;
 constexpr int PF_REPORT_INTS = 16 + PF_ROOTS_AHEAD + 2;  // (+ the 64 bits of the face bound's P_min)
 __global__ void k_report(const int32_t* __restrict__ stats, const int32_t* __restrict__ last_round, const int32_t* __restrict__ rowptr_n,
                          const int32_t* __restrict__ extra, const int32_t* __restrict__ roots, const int32_t* __restrict__ pmin_bits,
-                         int32_t* __restrict__ out) {
+                         const int32_t* __restrict__ order_overflow, int32_t* __restrict__ out) {
     const int t = threadIdx.x;
     if (t < 5) out[t] = stats[t];
     if (t == 5) out[5] = *last_round;
     if (t == 6) out[6] = rowptr_n ? *rowptr_n : 0;
-    if (t == 7) out[7] = 0;
+    if (t == 7) out[7] = *order_overflow;  // the renumbering by counting gave up (pf_compute_order): repeat it
     if (t >= 8 && t < 16) out[t] = extra ? extra[t - 8] : 0;
     if (t >= 16 && t < 16 + PF_ROOTS_AHEAD) out[t] = roots[t - 16];
     if (t >= 16 + PF_ROOTS_AHEAD && t < PF_REPORT_INTS) out[t] = pmin_bits ? pmin_bits[t - 16 - PF_ROOTS_AHEAD] : 0;
@@ -608,19 +609,28 @@ struct FinishJob {
         k_collect_roots<<<nblk(n), PF_BLOCK, 0, st>>>(g->label, g->rowptr, n, d_roots, stats + 4);
         PF_HIP(hipGetLastError());
 
-        // solver-internal renumbering (Morton order, degree-sorted windows), then SELL-64 in that order
-        PF_TRY(pf_compute_order(g, d_pts));
+        return queue_order(false);
+    }
+
+    // solver-internal renumbering (Morton order, degree-sorted windows), the slice widths in that order, and the ONE
+    // read-back (two copies into pinned memory) for everything the host has to know before it can size the SELL storage:
+    // the row statistics, whether the labelling had converged, the first few component roots (a mesh usually has one),
+    // the caller's own flags, the number of stored entries (mesh path), whether the renumbering by counting gave up -
+    // and the slice pointers.  `robust`: the second time round, with the general sort.
+    int queue_order(bool robust) {
+        const int64_t n = g->n;
+        PF_TRY(pf_compute_order(g, d_pts, robust ? nullptr : flags));  // (flags[0]: free for this; the statistics start at flags + 2)
+        if (robust) PF_HIP(hipMemsetAsync(flags, 0, sizeof(int32_t), st));
         k_slice_widths<<<nblk(g->n_pad), PF_BLOCK, 0, st>>>(g->rowptr, g->perm, n, g->n_slices, width64);
         PF_HIP(hipGetLastError());
         PF_HIP(hipMemsetAsync(width64 + g->n_slices, 0, sizeof(int64_t), st));
         PF_TRY(pf_exclusive_scan_i64(st, width64, g->slice_ptr, g->n_slices + 1));
-        // ONE read-back (two copies into pinned memory) for everything the host has to know before it can size the SELL
-        // storage: the row statistics, whether the labelling had converged, the first few component roots (a mesh usually
-        // has one), the caller's own flags, the number of stored entries (mesh path) - and the slice pointers
-        PF_TRY(dev_alloc(st, &report, PF_REPORT_INTS));
-        tmp.push_back(report);
+        if (!report) {
+            PF_TRY(dev_alloc(st, &report, PF_REPORT_INTS));
+            tmp.push_back(report);
+        }
         k_report<<<1, PF_WAVE, 0, st>>>(stats, round_flags + PF_CC_FIRST - 1, nnz_from_rowptr ? g->rowptr + n : nullptr, d_extra, d_roots,
-                                        reinterpret_cast<const int32_t*>(d_pmin), report);
+                                        reinterpret_cast<const int32_t*>(d_pmin), flags, report);
         PF_HIP(hipGetLastError());
         slice_bytes = sizeof(int64_t) * (size_t)(g->n_slices + 1);
         PF_TRY(pf_pinned_scratch(g->ctx, slice_bytes + sizeof(int32_t) * PF_REPORT_INTS, &pin, sid));
@@ -633,6 +643,11 @@ struct FinishJob {
     int end() {
         const int64_t n = g->n;
         PF_HIP(hipStreamSynchronize(st));
+        if (h_report[7] != 0) {  // vertices piled into one cell of the Morton grid: once more, with the general sort
+            if (getenv("PF_DEBUG_WINDOWS")) fprintf(stderr, "pyfocusr_hip: renumbering by counting gave up, repeating with the general sort\n");
+            PF_TRY(queue_order(true));
+            PF_HIP(hipStreamSynchronize(st));
+        }
         g->h_slice_ptr.resize((size_t)g->n_slices + 1);  // the resident Chebyshev kernel sizes its LDS from this
         memcpy(g->h_slice_ptr.data(), pin, slice_bytes);
         int32_t h_stats[6], h_roots[PF_ROOTS_AHEAD];
@@ -809,8 +824,10 @@ struct MeshBuild {
         PF_HIP(hipMemsetAsync(g->deg, 0, sizeof(double) * 3 * g->n_pad, st));
         if (sid == 0) PF_HIP(hipEventRecord(ctx->ev0, st));
 
+        const bool face_bound = vpf == 3 && n_faces > 0;
+        if (face_bound) PF_TRY(scratch(&pmin, 1));
         if (n_edges) {
-            k_count_edges<<<nblk(n_edges), PF_BLOCK, 0, st>>>(d_faces, n_edges, vpf, n, cnt, flags);
+            k_count_edges<<<nblk(n_edges), PF_BLOCK, 0, st>>>(d_faces, n_edges, vpf, n, cnt, flags, reinterpret_cast<double*>(pmin));
             PF_HIP(hipGetLastError());
         }
         // No read-back on the way: faces the counting kernel flags (index out of range, repeated vertex) are skipped by the
@@ -831,13 +848,7 @@ struct MeshBuild {
         PF_HIP(hipGetLastError());
         // the face-by-face bound of the spectrum (k_face_bound); it holds if every undirected edge lies in exactly two
         // triangles: W symmetric and no directed edge listed twice - both known after the read-back
-        if (vpf == 3 && n_faces > 0) {
-            PF_TRY(scratch(&pmin, 1));
-            const double quarter = 0.25;
-            unsigned long long qbits = 0;
-            memcpy(&qbits, &quarter, sizeof(qbits));
-            PF_HIP(hipMemsetD32Async((hipDeviceptr_t)pmin, (int)(qbits & 0xffffffffu), 1, st));
-            PF_HIP(hipMemsetD32Async((hipDeviceptr_t)(reinterpret_cast<int32_t*>(pmin) + 1), (int)(qbits >> 32), 1, st));
+        if (face_bound) {
             k_face_bound<<<nblk(n_faces), PF_BLOCK, 0, st>>>(d_faces, d_pts, n_faces, n, pmin);
             PF_HIP(hipGetLastError());
         }

@@ -312,7 +312,9 @@ int pf_exclusive_scan_i64(hipStream_t st, const int64_t* in, int64_t* out, int64
 int pf_reduce_ensure(pf_graph* g, int32_t count);
 
 // pf_reorder.hip
-int pf_compute_order(pf_graph* g, const double* d_pts);
+// d_overflow (device int, nullable): the Morton order by counting (pf_reorder.hip); set to 1 when a cell holds too many
+// vertices for that - the caller then repeats the call with nullptr (the general sort)
+int pf_compute_order(pf_graph* g, const double* d_pts, int32_t* d_overflow = nullptr);
 
 // Rows per window of the resident Chebyshev kernel: one window per block, at most 256 blocks.
 static inline int32_t pf_window_rows(int64_t n_pad) { return n_pad <= 262144 ? 1024 : (n_pad <= 524288 ? 2048 : 4096); }

@@ -230,10 +230,58 @@ __global__ __launch_bounds__(PF_BLOCK) void k_smooth_start(const double* __restr
     out[r] = v;
 }
 
+
+// ---- Morton order without a general sort (round 3) ------------------------------------------------------------------
+// hipCUB hands arrays below 1M items to rocPRIM's merge sort: 16 launches, ~100 us for a 250k-vertex mesh.  The keys here
+// are cell codes of points spread over a bounding box, so a counting sort by the key's leading bits leaves buckets of a few
+// dozen vertices at most, and a vertex finds its final place by counting the bucket mates that precede it in (key,
+// index) order - the order a stable sort of the keys gives, whatever order the atomics filled the bucket in.  Six
+// launches.  A bucket of more than PF_ORDER_BUCKET_MAX vertices (points piled into one cell) raises a flag instead: the
+// build learns of it in its one read-back and repeats the ordering with the general sort.
+constexpr int32_t PF_ORDER_BUCKET_MAX = 1024;
+
+__global__ __launch_bounds__(PF_BLOCK) void k_order_hist(const unsigned* __restrict__ keys, int64_t n, int shift, int32_t* __restrict__ hist) {
+    const int64_t i = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
+    if (i < n) atomicAdd(&hist[keys[i] >> shift], 1);
+}
+
+__global__ __launch_bounds__(PF_BLOCK) void k_order_scatter(const unsigned* __restrict__ keys, int64_t n, int shift,
+                                                            const int32_t* __restrict__ start, int32_t* __restrict__ cursor,
+                                                            unsigned* __restrict__ bkey, int32_t* __restrict__ bidx) {
+    const int64_t i = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const unsigned k = keys[i];
+    const int32_t b = (int32_t)(k >> shift);
+    const int32_t slot = start[b] + atomicAdd(&cursor[b], 1);
+    bkey[slot] = k;
+    bidx[slot] = (int32_t)i;
+}
+
+__global__ __launch_bounds__(PF_BLOCK) void k_order_rank(const unsigned* __restrict__ bkey, const int32_t* __restrict__ bidx, int64_t n,
+                                                         int shift, const int32_t* __restrict__ start, int32_t* __restrict__ order,
+                                                         int32_t* __restrict__ overflow) {
+    const int64_t s = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
+    if (s >= n) return;
+    const unsigned k = bkey[s];
+    const int32_t me = bidx[s];
+    const int32_t b = (int32_t)(k >> shift);
+    const int32_t lo = start[b], hi = start[b + 1];
+    if (hi - lo > PF_ORDER_BUCKET_MAX) {
+        if (s == lo) atomicOr(overflow, 1);
+        return;
+    }
+    int32_t before = 0;
+    for (int32_t a = lo; a < hi; ++a) {
+        const unsigned ka = bkey[a];
+        before += (ka < k || (ka == k && bidx[a] < me)) ? 1 : 0;
+    }
+    order[lo + before] = me;
+}
+
 }  // namespace
 
 // Fills g->perm [n_pad], g->iperm [n] and g->smooth [n_pad] (all already allocated).
-int pf_compute_order(pf_graph* g, const double* d_pts) {
+int pf_compute_order(pf_graph* g, const double* d_pts, int32_t* d_overflow) {
     hipStream_t st = g->build_stream ? g->build_stream : g->ctx->stream;
     const int64_t n = g->n;
     const int in = (int)n;
@@ -264,6 +312,7 @@ int pf_compute_order(pf_graph* g, const double* d_pts) {
             k_iota<<<nblk(n), PF_BLOCK, 0, st>>>(v0, n);
         }
         if (fail(hipGetLastError())) break;
+        const bool counting = d_pts != nullptr && d_overflow != nullptr && n >= 4096;  // (else: the general sort)
         if (fail(hipcub::DeviceRadixSort::SortPairs(nullptr, need, k0, k1, v0, v1, in, 0, 30, st))) break;
         tmp_bytes = need;
         const int32_t win_rows = g->win_rows;
@@ -273,7 +322,38 @@ int pf_compute_order(pf_graph* g, const double* d_pts) {
         tmp_bytes = need > tmp_bytes ? need : tmp_bytes;
         if (fail(pf_malloc(st, &tmp, tmp_bytes))) break;
         need = tmp_bytes;
-        if (fail(hipcub::DeviceRadixSort::SortPairs(tmp, need, k0, k1, v0, v1, in, 0, 30, st))) break;  // v1 = Morton order
+        if (counting) {
+            int bits = 12;
+            while (bits < 22 && ((int64_t)1 << bits) < 2 * n) ++bits;  // ~2 buckets per vertex, 4 M at most
+            const int shift = 30 - bits;
+            const int64_t nb = (int64_t)1 << bits;
+            int32_t* hist = nullptr;  // [nb + 1] counts, then [nb] cursors: one block, one fill
+            int32_t* bstart = nullptr;
+            if (fail(pf_malloc(st, (void**)&hist, sizeof(int32_t) * (size_t)(2 * nb + 2)))) break;
+            if (fail(pf_malloc(st, (void**)&bstart, sizeof(int32_t) * (size_t)(nb + 1)))) {
+                pf_free(st, hist);
+                break;
+            }
+            bool bad = fail(hipMemsetAsync(hist, 0, sizeof(int32_t) * (size_t)(2 * nb + 2), st));
+            if (!bad) {
+                k_order_hist<<<nblk(n), PF_BLOCK, 0, st>>>(k0, n, shift, hist);
+                bad = fail(hipGetLastError()) || pf_exclusive_scan_i32(st, hist, bstart, nb + 1) != PF_OK;
+            }
+            if (!bad) {
+                // k1 / v0: the bucketed keys and vertices (v0's identity is not needed any more: the index is the thread's own)
+                k_order_scatter<<<nblk(n), PF_BLOCK, 0, st>>>(k0, n, shift, bstart, hist + nb + 1, k1, v0);
+                k_order_rank<<<nblk(n), PF_BLOCK, 0, st>>>(k1, v0, n, shift, bstart, v1, d_overflow);
+                bad = fail(hipGetLastError());
+            }
+            pf_free(st, hist);
+            pf_free(st, bstart);
+            if (bad) {
+                if (rc == PF_OK) rc = PF_E_HIP;
+                break;
+            }
+        } else if (fail(hipcub::DeviceRadixSort::SortPairs(tmp, need, k0, k1, v0, v1, in, 0, 30, st))) {  // v1 = Morton order
+            break;
+        }
         // v0 <- Morton position of every vertex, k1 <- boundary flags (both are scratch until the second sort)
         k_scatter_pos<<<nblk(n), PF_BLOCK, 0, st>>>(v1, n, v0);
         if (fail(hipMemsetAsync(k1, 0, sizeof(unsigned) * n, st))) break;

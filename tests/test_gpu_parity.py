@@ -124,6 +124,33 @@ def test_assembly_hub_vertices(hip, ctx):
         dev.close()
 
 
+def test_assembly_piled_vertices(hip, ctx):
+    """Nearly all vertices in ONE cell of the renumbering's Morton grid (a tiny sphere next to two far-away vertices that
+    stretch the bounding box): the ordering by counting gives up, the build repeats it with the general sort in its one
+    extra synchronisation, and the operator is the oracle's all the same."""
+    from oracle import reference_port as orc
+    from pyfocusr_amd.meshgen import blob_mesh
+
+    m = blob_mesh(8000, seed=31)
+    pts = np.concatenate([m.points * 1e-3, [[900.0, 0.0, 0.0], [0.0, -700.0, 0.0], [0.0, 0.0, 800.0]]])
+    n0 = len(m.points)
+    faces = np.concatenate([m.faces, [[n0, n0 + 1, n0 + 2], [0, n0, n0 + 1]]]).astype(np.int32)
+    W, deg, d_inv, L = orc.graph_matrices(pts, faces)
+    L = sparse.csr_matrix(L)
+    dev = hip.DeviceLaplacian(pts, faces, ctx=ctx)
+    try:
+        x = np.random.default_rng(3).standard_normal(len(pts))
+        y = dev.spmv_host(x, op=hip.PF_OP_RW)
+        ref = L @ x
+        assert np.max(np.abs(y - ref)) <= 1e-12 * np.max(np.abs(ref))
+        h = dev.download()
+        Wc = sparse.csr_matrix(W)
+        Wc.sort_indices()
+        assert np.array_equal(h["rowptr"], Wc.indptr) and np.array_equal(h["colidx"], Wc.indices) and np.array_equal(h["w"], Wc.data)
+    finally:
+        dev.close()
+
+
 def test_assembly_errors(hip, ctx):
     pts = np.random.default_rng(0).normal(size=(10, 3))
     with pytest.raises(hip.PfError) as e:
