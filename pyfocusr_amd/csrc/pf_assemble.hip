@@ -349,6 +349,7 @@ __global__ __launch_bounds__(PF_BLOCK) void k_slice_widths(const int32_t* __rest
     for (int off = PF_WAVE / 2; off > 0; off >>= 1) c = max(c, __shfl_xor(c, off, PF_WAVE));
     const int64_t s = row / PF_WAVE;
     if ((threadIdx.x & (PF_WAVE - 1)) == 0 && s < n_slices) width64[s] = (int64_t)c * PF_WAVE;
+    if (row == 0) width64[n_slices] = 0;  // (the scan's extra element: no fill of its own)
 }
 
 __global__ __launch_bounds__(PF_BLOCK) void k_fill_sell(const int32_t* __restrict__ rowptr,
@@ -578,15 +579,14 @@ struct FinishJob {
     int begin() {
         st = g->build_stream ? g->build_stream : g->ctx->stream;
         const int64_t n = g->n;
-        PF_TRY(dev_alloc(st, &flags, 8));
+        PF_TRY(dev_alloc(st, &flags, 8 + PF_CC_ROUNDS));  // the flags and the labelling rounds' flags: one block, one fill
         tmp.push_back(flags);
-        PF_TRY(dev_alloc(st, &round_flags, PF_CC_ROUNDS));
-        tmp.push_back(round_flags);
+        round_flags = flags + 8;
         PF_TRY(dev_alloc(st, &width64, g->n_slices + 1));
         tmp.push_back(width64);
         PF_TRY(dev_alloc(st, &d_roots, PF_MAX_ROOTS));
         tmp.push_back(d_roots);
-        PF_HIP(hipMemsetAsync(flags, 0, sizeof(int32_t) * 8, st));
+        PF_HIP(hipMemsetAsync(flags, 0, sizeof(int32_t) * (8 + PF_CC_ROUNDS), st));
         stats = flags + 2;  // [0] isolated, [1] max degree, [2] asym, [3] changed, [4] n_roots
         k_row_stats<<<nblk(n), PF_BLOCK, 0, st>>>(g->rowptr, n, stats);
         PF_HIP(hipGetLastError());
@@ -596,7 +596,6 @@ struct FinishJob {
         // components
         k_label_init<<<nblk(g->n_pad), PF_BLOCK, 0, st>>>(g->rowptr, g->col, n, g->n_pad, g->label);
         PF_HIP(hipGetLastError());
-        PF_HIP(hipMemsetAsync(round_flags, 0, sizeof(int32_t) * PF_CC_ROUNDS, st));
         // PF_CC_FIRST rounds are queued without asking: a round that follows a round without changes returns at once
         // (~2 us instead of ~15), and whether the last one still changed something is read back with everything else below
         for (round = 0; round < PF_CC_FIRST; ++round) {
@@ -623,7 +622,6 @@ struct FinishJob {
         if (robust) PF_HIP(hipMemsetAsync(flags, 0, sizeof(int32_t), st));
         k_slice_widths<<<nblk(g->n_pad), PF_BLOCK, 0, st>>>(g->rowptr, g->perm, n, g->n_slices, width64);
         PF_HIP(hipGetLastError());
-        PF_HIP(hipMemsetAsync(width64 + g->n_slices, 0, sizeof(int64_t), st));
         PF_TRY(pf_exclusive_scan_i64(st, width64, g->slice_ptr, g->n_slices + 1));
         if (!report) {
             PF_TRY(dev_alloc(st, &report, PF_REPORT_INTS));

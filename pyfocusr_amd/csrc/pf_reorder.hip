@@ -67,7 +67,7 @@ __global__ __launch_bounds__(PF_BLOCK) void k_bbox(const double* __restrict__ pt
             v = threadIdx.x < 3 ? (o < v ? o : v) : (o > v ? o : v);
         }
         if (threadIdx.x < 3)
-            atomicMin(&bbox[threadIdx.x], v);
+            atomicMax(&bbox[threadIdx.x], ~v);  // (minima are kept inverted: the box starts as all zeroes)
         else
             atomicMax(&bbox[threadIdx.x], v);
     }
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(PF_BLOCK) void k_morton_keys(const double* __restri
     unsigned code = 0;
 #pragma unroll
     for (int a = 0; a < 3; ++a) {
-        const double lo = dec_f64(bbox[a]), hi = dec_f64(bbox[3 + a]);
+        const double lo = dec_f64(~bbox[a]), hi = dec_f64(bbox[3 + a]);
         const double ext = hi - lo;
         double t = ext > 0.0 ? (pts[3 * i + a] - lo) / ext : 0.0;
         t = t < 0.0 ? 0.0 : (t > 1.0 ? 1.0 : t);
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(PF_BLOCK) void k_smooth_start(const double* __restr
         double c[3];
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-            const double lo = dec_f64(bbox[a]), hi = dec_f64(bbox[3 + a]);
+            const double lo = dec_f64(~bbox[a]), hi = dec_f64(bbox[3 + a]);
             const double h = 0.5 * (hi - lo);
             c[a] = h > 0.0 ? (pts[3 * (int64_t)i + a] - 0.5 * (hi + lo)) / h : 0.0;
         }
@@ -299,11 +299,12 @@ int pf_compute_order(pf_graph* g, const double* d_pts, int32_t* d_overflow) {
         return e != hipSuccess;
     };
     do {
-        if (fail(pf_malloc(st, (void**)&bbox, 6 * sizeof(unsigned long long)))) break;
+        // the box (minima inverted, so that it starts as zeroes) and the boundary flags: one block, one fill
+        if (fail(pf_malloc(st, (void**)&bbox, 6 * sizeof(unsigned long long) + sizeof(unsigned) * (size_t)n))) break;
+        unsigned* bflag = reinterpret_cast<unsigned*>(bbox + 6);
         if (fail(pf_malloc(st, (void**)&k0, sizeof(unsigned) * n)) || fail(pf_malloc(st, (void**)&k1, sizeof(unsigned) * n))) break;
         if (fail(pf_malloc(st, (void**)&v0, sizeof(int32_t) * n)) || fail(pf_malloc(st, (void**)&v1, sizeof(int32_t) * n))) break;
-        if (fail(hipMemsetAsync(bbox, 0xff, 3 * sizeof(unsigned long long), st))) break;
-        if (fail(hipMemsetAsync(bbox + 3, 0x00, 3 * sizeof(unsigned long long), st))) break;
+        if (fail(hipMemsetAsync(bbox, 0, 6 * sizeof(unsigned long long) + sizeof(unsigned) * (size_t)n, st))) break;
         if (d_pts) {
             k_bbox<<<256, PF_BLOCK, 0, st>>>(d_pts, n, bbox);
             k_morton_keys<<<nblk(n), PF_BLOCK, 0, st>>>(d_pts, n, bbox, k0, v0);
@@ -354,12 +355,11 @@ int pf_compute_order(pf_graph* g, const double* d_pts, int32_t* d_overflow) {
         } else if (fail(hipcub::DeviceRadixSort::SortPairs(tmp, need, k0, k1, v0, v1, in, 0, 30, st))) {  // v1 = Morton order
             break;
         }
-        // v0 <- Morton position of every vertex, k1 <- boundary flags (both are scratch until the second sort)
+        // v0 <- Morton position of every vertex (scratch until the second sort); the boundary flags in their zeroed block
         k_scatter_pos<<<nblk(n), PF_BLOCK, 0, st>>>(v1, n, v0);
-        if (fail(hipMemsetAsync(k1, 0, sizeof(unsigned) * n, st))) break;
-        k_boundary_flags<<<nblk(n), PF_BLOCK, 0, st>>>(v1, g->rowptr, g->col, v0, n, win_rows, k1);
-        k_second_ring_flags<<<nblk(n), PF_BLOCK, 0, st>>>(v1, g->rowptr, g->col, v0, n, k1);
-        k_degree_keys<<<nblk(n), PF_BLOCK, 0, st>>>(v1, g->rowptr, k1, n, win_rows, k0);
+        k_boundary_flags<<<nblk(n), PF_BLOCK, 0, st>>>(v1, g->rowptr, g->col, v0, n, win_rows, bflag);
+        k_second_ring_flags<<<nblk(n), PF_BLOCK, 0, st>>>(v1, g->rowptr, g->col, v0, n, bflag);
+        k_degree_keys<<<nblk(n), PF_BLOCK, 0, st>>>(v1, g->rowptr, bflag, n, win_rows, k0);
         if (fail(hipGetLastError())) break;
         if (win_rows <= 4096) {
             int32_t n_pow2 = 2;
