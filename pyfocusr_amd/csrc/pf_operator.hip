@@ -1016,11 +1016,10 @@ int pf_lock_null_vectors(pf_graph* g, int32_t op, int32_t* n_locked) {
         k_null_vector<<<nblk(g->n_pad), PF_BLOCK, 0, st>>>(pf_slot(g, c), g->label, g->rowptr, g->deg, g->perm, g->n_pad,
                                                           g->roots[c], op == PF_OP_SYM && !g->unit_g);
         PF_HIP(hipGetLastError());
+        // normalised with the norm still on the device (the same 1 / sqrt as on the host: the same bits; a component has at
+        // least two vertices, so the norm is positive) - no wait at the head of a solve
         PF_TRY(dots_device(g, c, c, 1, g->coef, nullptr, 0));
-        double nrm2 = 0.0;
-        PF_TRY(small_to_host(g, g->coef, &nrm2, 1));
-        PF_CHECK(nrm2 > 0.0, PF_E_STATE, "pf_lock_null_vectors: empty component %d", c);
-        k_scale<<<nblk(g->n_pad), PF_BLOCK, 0, st>>>(pf_slot(g, c), g->n_pad, 1.0 / sqrt(nrm2));
+        k_scale_rsqrt<<<nblk(g->n_pad), PF_BLOCK, 0, st>>>(pf_slot(g, c), g->n_pad, g->coef);
         PF_HIP(hipGetLastError());
     }
     *n_locked = nc;

@@ -12,6 +12,7 @@
 // meshes whose W is symmetric it does.  One-way edges (graph.py:178 on open or non-manifold meshes) can break it at
 // window level; then B gets row 0 of A as an extra outside row (read every step, never used).
 #include <cstdio>
+#include <cstring>
 #include <cstdlib>
 #include <algorithm>
 #include <climits>
@@ -375,12 +376,12 @@ int pf_window_slots_prepare(pf_graph* g) {
     hipError_t e = pf_malloc(st, (void**)&flags, sizeof(int32_t));
     if (e == hipSuccess) e = pf_malloc(st, (void**)&adj, sizeof(uint32_t) * (size_t)nw * WB_ADJ_WORDS);
     if (e == hipSuccess) e = pf_malloc(st, (void**)&g->px_slot, sizeof(int32_t) * (size_t)g->sell_entries);
-    if (e == hipSuccess) e = pf_malloc(st, (void**)&g->px_gh_cnt, sizeof(int32_t) * nw);
+    if (e == hipSuccess) e = pf_malloc(st, (void**)&g->px_gh_cnt, sizeof(int32_t) * (size_t)(nw + 4));  // [nw] counts, then the builder's flag
     if (e == hipSuccess) e = pf_malloc(st, (void**)&g->px_need, sizeof(int32_t) * nw);
     if (e == hipSuccess) e = pf_malloc(st, (void**)&g->px_gh_row, sizeof(int32_t) * nw * PF_WIN_GHOSTS);
     if (e == hipSuccess) e = hipMemsetAsync(flags, 0, sizeof(int32_t), st);
     if (e == hipSuccess) e = hipMemsetAsync(adj, 0, sizeof(uint32_t) * (size_t)nw * WB_ADJ_WORDS, st);
-    if (e == hipSuccess) e = hipMemsetAsync(g->px_gh_cnt, 0, sizeof(int32_t) * nw, st);
+    if (e == hipSuccess) e = hipMemsetAsync(g->px_gh_cnt, 0, sizeof(int32_t) * (size_t)(nw + 4), st);
     if (e == hipSuccess) e = hipMemsetAsync(g->px_need, 0, sizeof(int32_t) * nw, st);
     int32_t h_flag = 1;
     g->h_px_gh_cnt.assign((size_t)nw, 0);
@@ -390,9 +391,25 @@ int pf_window_slots_prepare(pf_graph* g) {
                                                              g->px_gh_cnt, g->px_gh_row, flags);
         e = hipGetLastError();
     }
-    if (e == hipSuccess) e = hipMemcpyAsync(&h_flag, flags, sizeof(int32_t), hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipMemcpyAsync(g->h_px_gh_cnt.data(), g->px_gh_cnt, sizeof(int32_t) * nw, hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    // the counts and the flag in ONE read-back through pinned memory and a copy kernel (two copies into pageable memory
+    // were two staged transfers with the host in between: ~60 us per graph at the head of a solve)
+    if (e == hipSuccess) {
+        const int64_t tail = (nw + 1) & ~(int64_t)1;  // (8-byte aligned behind the counts)
+        e = hipMemcpyAsync(g->px_gh_cnt + tail, flags, sizeof(int32_t), hipMemcpyDeviceToDevice, st);
+        void* pin = nullptr;
+        const size_t bytes = sizeof(int32_t) * (size_t)(tail + 2);
+        if (e == hipSuccess && pf_pinned_scratch(g->ctx, bytes, &pin) == PF_OK && pf_copy_by_kernel(st, g->px_gh_cnt, pin, bytes) == PF_OK) {
+            e = hipStreamSynchronize(st);
+            if (e == hipSuccess) {
+                memcpy(g->h_px_gh_cnt.data(), pin, sizeof(int32_t) * (size_t)nw);
+                h_flag = static_cast<const int32_t*>(pin)[tail];
+            }
+        } else if (e == hipSuccess) {
+            e = hipMemcpyAsync(&h_flag, flags, sizeof(int32_t), hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess) e = hipMemcpyAsync(g->h_px_gh_cnt.data(), g->px_gh_cnt, sizeof(int32_t) * nw, hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
+        }
+    }
     pf_free(st, flags);
     pf_free(st, adj);
     if (e != hipSuccess || h_flag) {
