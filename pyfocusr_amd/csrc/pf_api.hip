@@ -66,11 +66,16 @@ int pf_pinned_scratch(pf_ctx* c, size_t bytes, void** out, int sid) {
 // pool per priority level, shared by every stream of the process (torch's included), and which streams end up on one queue
 // differs from process to process (seen as: one process in three assembled the two meshes one after the other and ran the
 // eigenvector downloads in front of eigsort's kernels, +0.9 ms per step).  A stream of another priority comes from another
-// pool: never the main stream's queue.
-hipError_t pf_create_side_stream(hipStream_t* s) {
+// pool: never the main stream's queue.  The same holds among the side streams: the second assembly's stream and the
+// copy stream, both at the greatest priority, shared a queue in one process of three again once the step had become
+// short enough to show it (round 3: 12.1-12.9 ms instead of 11.4) - the copy stream now takes the LEAST priority, a third
+// pool: 20 of 20 processes within 11.27-11.56 ms, and the downloads no longer get in front of eigsort's kernels at all.
+hipError_t pf_create_side_stream(hipStream_t* s, bool low) {
     int least = 0, greatest = 0;
-    if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least)
-        return hipStreamCreateWithPriority(s, hipStreamNonBlocking, greatest);
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least) {
+        static const bool all_high = [] { const char* e = getenv("PF_SIDE_STREAMS_HIGH"); return e && e[0] == '1'; }();  // (A/B)
+        return hipStreamCreateWithPriority(s, hipStreamNonBlocking, (low && !all_high) ? least : greatest);
+    }
     (void)hipGetLastError();
     return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
 }

@@ -286,7 +286,7 @@ int pf_copy_by_kernel(hipStream_t st, const void* src, void* dst, size_t bytes);
 // the blocks the other stream has released, and use what the other stream has written
 int pf_streams_join(pf_ctx* c, int waiter_sid);
 hipStream_t pf_stream_b(pf_ctx* c);  // created on first use (nullptr on failure)
-hipError_t pf_create_side_stream(hipStream_t* s);  // a stream that never shares a hardware queue with a ctx's main stream
+hipError_t pf_create_side_stream(hipStream_t* s, bool low = false);  // low: the least priority (a third pool of queues: the copy stream)  // a stream that never shares a hardware queue with a ctx's main stream
 void pf_worker_run(pf_ctx* c, std::function<void()> task);  // starts `task` on the ctx's worker thread (one at a time)
 void pf_worker_wait(pf_ctx* c);                             // until that task has returned
 void pf_free(hipStream_t st, void* p);

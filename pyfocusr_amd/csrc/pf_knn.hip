@@ -593,6 +593,71 @@ __global__ __launch_bounds__(PF_BLOCK) void k_knn_coop(const double* __restrict_
     }
 }
 
+// ---- small problems (both sets <= PF_KNN_SMALL points, k = 1): the exhaustive scan in ONE launch -----------------------------
+// eigsort's 3-D search among 5000 sample points (eigsort.py:203-204) spent ~20 launches on building a grid for a kernel
+// of 38 us.  Here a wave owns a few queries (coordinates wave-uniform), its lanes scan every 64th reference against all
+// of them, and a lexicographic (distance, index) reduction across the wave picks the winner: dist2's operations in its
+// order, lowest index on ties - the same bits and indices as every other path.
+constexpr int64_t PF_KNN_SMALL = 16384;
+constexpr int knn_small_group(int d) { return d <= 4 ? 8 : 4; }
+
+template <int D>
+__global__ __launch_bounds__(PF_BLOCK) void k_knn_small(const double* __restrict__ ref, int64_t n_ref, const double* __restrict__ qry,
+                                                        int64_t n_qry, int64_t* __restrict__ idx_out, double* __restrict__ d2_out) {
+    constexpr int G = knn_small_group(D);
+    const int lane = threadIdx.x & (PF_WAVE - 1);
+    const int64_t group = (int64_t)blockIdx.x * (PF_BLOCK / PF_WAVE) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x / PF_WAVE));
+    const int64_t q0 = group * G;
+    if (q0 >= n_qry) return;  // (wave-uniform)
+    const int nq = n_qry - q0 < G ? (int)(n_qry - q0) : G;
+    double q[G][D], best[G];
+    int32_t bidx[G];
+#pragma unroll
+    for (int i = 0; i < G; ++i) {
+        const int64_t qi = q0 + (i < nq ? i : nq - 1);
+#pragma unroll
+        for (int c = 0; c < D; ++c) q[i][c] = qry[qi * D + c];
+        best[i] = INFINITY;
+        bidx[i] = 0x7fffffff;
+    }
+    for (int64_t r = lane; r < n_ref; r += PF_WAVE) {
+        double x[D];
+#pragma unroll
+        for (int c = 0; c < D; ++c) x[c] = ref[r * D + c];
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            double s = 0.0;
+#pragma unroll
+            for (int c = 0; c < D; ++c) {  // dist2's operations, in its order
+                const double df = q[i][c] - x[c];
+                const double sq = df * df;
+                s = (c == 0) ? sq : s + sq;
+            }
+            if (s < best[i]) {  // (a lane meets its references in rising order: the first of equals stays)
+                best[i] = s;
+                bidx[i] = (int32_t)r;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < G; ++i) {
+        wave_argmin(best[i], bidx[i]);
+        if (lane == i && i < nq) {
+            idx_out[q0 + i] = bidx[i];
+            d2_out[q0 + i] = best[i];
+        }
+    }
+}
+
+template <int D>
+static int launch_knn_small(pf_ctx* c) {
+    const int64_t groups = (c->knn_nqry + knn_small_group(D) - 1) / knn_small_group(D);
+    k_knn_small<D><<<(unsigned)((groups + PF_BLOCK / PF_WAVE - 1) / (PF_BLOCK / PF_WAVE)), PF_BLOCK, 0, c->stream>>>(
+        c->knn_ref, c->knn_nref, c->knn_qry, c->knn_nqry, c->knn_idx, c->knn_d2);
+    PF_HIP(hipGetLastError());
+    return PF_OK;
+}
+
 __global__ __launch_bounds__(PF_BLOCK) void k_gather_rows_soa(const double* __restrict__ pts, const int32_t* __restrict__ order,
                                                               int64_t n, int d, int64_t ld, double* __restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
@@ -805,6 +870,28 @@ int pf_knn_run(pf_ctx* c) {
     hipStream_t st = c->stream;
     const int d = c->knn_d;
     PF_HIP(hipEventRecord(c->ev0, st));
+    if (c->knn_k == 1 && c->knn_mode == 0 && d <= 8 && c->knn_nref <= PF_KNN_SMALL && c->knn_nqry <= PF_KNN_SMALL) {
+        int r = PF_E_ARG;
+        switch (d) {
+            case 1: r = launch_knn_small<1>(c); break;
+            case 2: r = launch_knn_small<2>(c); break;
+            case 3: r = launch_knn_small<3>(c); break;
+            case 4: r = launch_knn_small<4>(c); break;
+            case 5: r = launch_knn_small<5>(c); break;
+            case 6: r = launch_knn_small<6>(c); break;
+            case 7: r = launch_knn_small<7>(c); break;
+            case 8: r = launch_knn_small<8>(c); break;
+            default: break;
+        }
+        PF_TRY(r);
+        PF_HIP(hipEventRecord(c->ev1, st));
+        PF_HIP(hipEventSynchronize(c->ev1));
+        float sms = 0.f;
+        PF_HIP(hipEventElapsedTime(&sms, c->ev0, c->ev1));
+        c->knn_ms = sms;
+        c->knn_done = true;
+        return PF_OK;
+    }
     PF_HIP(hipMemsetAsync(c->knn_ext, 0xff, 16 * sizeof(unsigned long long), st));
     PF_HIP(hipMemsetAsync(c->knn_ext + 16, 0x00, 16 * sizeof(unsigned long long), st));
     const int res = c->knn_res;

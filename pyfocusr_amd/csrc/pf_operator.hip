@@ -1523,7 +1523,7 @@ int pf_finalize_vectors_begin(pf_graph* g, int32_t first, int32_t count, int32_t
     PF_TRY(pf_finalize_vectors_end(g));  // an earlier result still on its way
     pf_ctx* ctx = g->ctx;
     hipStream_t st = ctx->stream;
-    if (!ctx->copy_stream) PF_HIP(pf_create_side_stream(&ctx->copy_stream));
+    if (!ctx->copy_stream) PF_HIP(pf_create_side_stream(&ctx->copy_stream, true));
     // events and the pinned landing place of the statistics come from the ctx's pools (what freed graphs left behind:
     // hipHostMalloc / hipHostFree and event creation cost 0.1-0.2 ms each)
     for (hipEvent_t* ev : {&g->final_ready, &g->final_done}) {
