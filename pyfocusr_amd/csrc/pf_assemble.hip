@@ -889,6 +889,10 @@ void pf_graph_free(pf_graph* g) {
     hipSetDevice(g->ctx->device);
     hipStream_t st = g->ctx->stream;
     (void)pf_finalize_vectors_end(g);  // a download still in flight reads final_vecs
+    {
+        auto& dq = g->ctx->deferred;
+        dq.erase(std::remove(dq.begin(), dq.end(), g), dq.end());
+    }
     if (g->final_stats) g->ctx->pinned_pool.emplace_back(g->final_stats_cap, reinterpret_cast<double*>(g->final_stats));
     if (g->final_ready) g->ctx->event_pool.push_back(g->final_ready);
     if (g->final_done) g->ctx->event_pool.push_back(g->final_done);

@@ -150,6 +150,7 @@ struct pf_ctx {
     std::function<void()> worker_task;
     bool worker_busy = false, worker_stop = false;
     hipEvent_t join_ev = nullptr;
+    std::vector<pf_graph*> deferred;  // graphs with a download that is not queued yet
     int64_t alloc_misses = 0;  // allocations the cache could not serve (hipMalloc: 0.1-1 ms each)
     uint64_t alloc_epoch = 1;
     uint64_t visible[2] = {0, 0};  // stream sid may take the OTHER stream's blocks released before this epoch
@@ -264,6 +265,13 @@ struct pf_graph {
     void* final_stats = nullptr;       // pinned: the statistics as they arrive
     int32_t final_stats_cap = 0;
     hipEvent_t final_ready = nullptr, final_done = nullptr;
+    // the host image that is still owed: a download that has not been queued yet (released behind the next long kernel,
+    // pf_downloads_release; or by whoever collects it first)
+    const double* dl_src = nullptr;
+    double* dl_dst = nullptr;
+    size_t dl_bytes = 0;
+    int32_t final_check = 0;      // columns whose statistics pf_finalize_vectors_end still has to look at
+    double* final_tmp = nullptr;  // device: the remapped image on its way to the host
     double* pts = nullptr;  // [n][3] the mesh's points (graphs built from a mesh): pf_point_rows
     bool deg_block = false; // g and sg live in deg's allocation (mesh path: one memset for the three)
     double spectral_bound = 2.0; // proven upper bound of the operator's spectrum (2: Gershgorin; less for closed triangle meshes)
@@ -282,6 +290,7 @@ int pf_pinned_scratch(pf_ctx* c, size_t bytes, void** out, int sid = 0);  // sid
 // src -> dst by a copy KERNEL on `st` (one of them pinned host memory, read or written in place: no DMA engine involved);
 // sizes rounded up to 8 bytes
 int pf_copy_by_kernel(hipStream_t st, const void* src, void* dst, size_t bytes);
+int pf_downloads_release(pf_ctx* c);  // queue every download of the ctx that was held back (behind what the ctx stream holds now)
 // `waiter_sid` (0: stream, 1: stream_b) waits for everything queued on the other stream so far; afterwards it may reuse
 // the blocks the other stream has released, and use what the other stream has written
 int pf_streams_join(pf_ctx* c, int waiter_sid);

@@ -902,6 +902,7 @@ int pf_knn_run(pf_ctx* c) {
     // deep coordinates (k = 1): a grid over two axes prunes two of d coordinates; the box hierarchy prunes with all of them
     const bool tree = c->knn_k == 1 && (c->knn_mode == 2 || (c->knn_mode == 0 && d >= PF_KNN_TREE_MIN_D));
     if (tree) {
+        if (c->knn_nqry >= 32768) PF_TRY(pf_downloads_release(c));
         PF_TRY(pf_knn_tree_run(c));
         PF_HIP(hipEventRecord(c->ev1, st));
         PF_HIP(hipEventSynchronize(c->ev1));
@@ -921,6 +922,8 @@ int pf_knn_run(pf_ctx* c) {
         PF_HIP(hipGetLastError());
     }
     PF_TRY(sort_points(c, c->knn_qry, c->knn_nqry, d, 1, 32, c->knn_qry_key, c->knn_qry_orig, c->knn_qry_s));
+    // a large search is the long kernel behind which the eigenvector downloads that were held back may leave
+    if (c->knn_nqry >= 32768) PF_TRY(pf_downloads_release(c));
     int r = PF_E_ARG;
     switch (d) {
         case 1: r = launch_knn<1>(c); break;

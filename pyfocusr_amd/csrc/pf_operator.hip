@@ -1516,6 +1516,33 @@ int pf_resnorms(pf_graph* g, int32_t ax_first, int32_t x_first, const double* la
 // _end waits for the copies and checks the statistics.  The block itself is resident and usable on the device as soon as
 // _begin returns.  `out` should be pinned memory (pf_host_alloc): a pageable destination is staged in chunks by the
 // runtime (measured: ~12 gaps of 82 us per 250k pair).
+static bool downloads_deferred() {
+    static const bool on = [] { const char* v = getenv("PF_DOWNLOAD_DEFER"); return !(v && v[0] == '0'); }();
+    return on;
+}
+
+// the owed image of g goes onto the copy stream, behind everything the ctx stream holds at this moment
+static int queue_download(pf_graph* g) {
+    pf_ctx* ctx = g->ctx;
+    auto it = std::find(ctx->deferred.begin(), ctx->deferred.end(), g);
+    if (it != ctx->deferred.end()) ctx->deferred.erase(it);
+    if (!g->dl_src) return PF_OK;
+    const double* src = g->dl_src;
+    g->dl_src = nullptr;
+    PF_HIP(hipEventRecord(g->final_ready, ctx->stream));
+    PF_HIP(hipStreamWaitEvent(ctx->copy_stream, g->final_ready, 0));
+    // (the runtime's copy: a download kernel of our own with a few blocks, at the copy stream's low priority, only got CUs
+    // when the search had finished - KNN stage 1.50 ms instead of 1.20)
+    PF_HIP(hipMemcpyAsync(g->dl_dst, src, g->dl_bytes, hipMemcpyDeviceToHost, ctx->copy_stream));
+    PF_HIP(hipEventRecord(g->final_done, ctx->copy_stream));
+    return PF_OK;
+}
+
+extern "C++" int pf_downloads_release(pf_ctx* c) {
+    while (!c->deferred.empty()) PF_TRY(queue_download(c->deferred.back()));
+    return PF_OK;
+}
+
 int pf_finalize_vectors_begin(pf_graph* g, int32_t first, int32_t count, int32_t from_sym, int32_t minmax, double* out) {
     PF_TRY(check_slots(g, first, count, "pf_finalize_vectors"));
     PF_CHECK(out != nullptr && count > 0, PF_E_ARG, "pf_finalize_vectors: bad argument");
@@ -1579,7 +1606,6 @@ int pf_finalize_vectors_begin(pf_graph* g, int32_t first, int32_t count, int32_t
     if (e == hipSuccess) e = hipEventRecord(g->final_ready, st);
     if (e == hipSuccess) e = hipStreamWaitEvent(ctx->copy_stream, g->final_ready, 0);
     if (e == hipSuccess) e = hipMemcpyAsync(g->final_stats, d_stats, sizeof(VecStats) * count, hipMemcpyDeviceToHost, ctx->copy_stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, sizeof(double) * (size_t)g->n * count, hipMemcpyDeviceToHost, ctx->copy_stream);
     if (e == hipSuccess) e = hipEventRecord(g->final_done, ctx->copy_stream);
     if (e != hipSuccess) {
         (void)hipStreamSynchronize(ctx->copy_stream);
@@ -1591,18 +1617,36 @@ int pf_finalize_vectors_begin(pf_graph* g, int32_t first, int32_t count, int32_t
     g->final_count = count;
     g->final_params = d_params;
     g->final_pending = count;
+    g->final_check = count;
+    // The n x count image itself is OWED, not queued: while a 10 MB download runs, the next kernel boundary of the ctx
+    // stream waits for it to drain (kernel trace: the partner's k_vec_params, eigsort's k_es_minmax and the search's first
+    // kernel each took the download's 180 us) - beside small dependent kernels a download costs what it would cost in
+    // line.  It leaves behind the next LONG kernel (pf_downloads_release: the 1-NN search), or when somebody collects it.
+    g->dl_src = d_out;
+    g->dl_dst = out;
+    g->dl_bytes = sizeof(double) * (size_t)g->n * count;
+    if (downloads_deferred()) {
+        if (std::find(ctx->deferred.begin(), ctx->deferred.end(), g) == ctx->deferred.end()) ctx->deferred.push_back(g);
+    } else {
+        PF_TRY(queue_download(g));
+    }
     return PF_OK;
 }
 
 int pf_finalize_vectors_end(pf_graph* g) {
     PF_CHECK(g != nullptr, PF_E_ARG, "pf_finalize_vectors_end: NULL graph");
     if (g->final_pending == 0) return PF_OK;
-    const int32_t count = g->final_pending;
     g->final_pending = 0;
+    const int32_t count = g->final_check;
+    g->final_check = 0;
+    int rc = queue_download(g);  // (nobody released it: now)
     const hipError_t e = hipEventSynchronize(g->final_done);
     pf_free(g->ctx->stream, g->final_params);
     g->final_params = nullptr;
-    if (count < 0) {  // a remapped image of the block (pf_final_remap_begin)
+    pf_free(g->ctx->stream, g->final_tmp);
+    g->final_tmp = nullptr;
+    PF_TRY(rc);
+    if (count <= 0) {  // only a remapped image of a block whose statistics have been looked at
         PF_HIP(e);
         return PF_OK;
     }
@@ -1645,7 +1689,9 @@ __global__ __launch_bounds__(PF_BLOCK) void k_final_remap(const double* __restri
 // pf_finalize_vectors_end like the first download; the resident block itself is unchanged.
 int pf_final_remap_begin(pf_graph* g, const int32_t* col, const double* sign, int32_t count, double* out) {
     PF_CHECK(g && col && sign && out, PF_E_ARG, "pf_final_remap_begin: NULL argument");
-    PF_TRY(pf_finalize_vectors_end(g));
+    // An image that is still owed to the same array is simply replaced by the remapped one (its statistics are looked at
+    // when that is collected); one that is in flight, or owed to another array, is collected first.
+    if (!(g->dl_src && g->dl_dst == out)) PF_TRY(pf_finalize_vectors_end(g));
     PF_CHECK(g->final_vecs != nullptr, PF_E_STATE, "pf_final_remap_begin: no pf_finalize_vectors result is resident");
     PF_CHECK(count >= 1 && count <= 64 && count <= g->final_count, PF_E_ARG, "pf_final_remap_begin: count %d out of range", count);
     RemapArgs m{};
@@ -1660,18 +1706,22 @@ int pf_final_remap_begin(pf_graph* g, const int32_t* col, const double* sign, in
     double* d_tmp = nullptr;
     PF_HIP(pf_malloc(st, (void**)&d_tmp, sizeof(double) * (size_t)g->n * count));
     k_final_remap<<<nblk(g->n * count), PF_BLOCK, 0, st>>>(g->final_vecs, g->n, g->final_count, count, m, d_tmp);
-    hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipEventRecord(g->final_ready, st);
-    if (e == hipSuccess) e = hipStreamWaitEvent(ctx->copy_stream, g->final_ready, 0);
-    if (e == hipSuccess) e = hipMemcpyAsync(out, d_tmp, sizeof(double) * (size_t)g->n * count, hipMemcpyDeviceToHost, ctx->copy_stream);
-    if (e == hipSuccess) e = hipEventRecord(g->final_done, ctx->copy_stream);
+    const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
-        (void)hipStreamSynchronize(ctx->copy_stream);
         pf_free(st, d_tmp);
         PF_HIP(e);
     }
-    g->final_params = d_tmp;   // freed by _end
-    g->final_pending = -count; // negative: a remapped image, nothing to check
+    pf_free(st, g->final_tmp);  // (an earlier remapped image that was never sent: behind its last use in stream order)
+    g->final_tmp = d_tmp;
+    g->dl_src = d_tmp;
+    g->dl_dst = out;
+    g->dl_bytes = sizeof(double) * (size_t)g->n * count;
+    g->final_pending = count;
+    if (downloads_deferred()) {
+        if (std::find(ctx->deferred.begin(), ctx->deferred.end(), g) == ctx->deferred.end()) ctx->deferred.push_back(g);
+    } else {
+        PF_TRY(queue_download(g));
+    }
     return PF_OK;
 }
 

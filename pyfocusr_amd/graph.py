@@ -154,9 +154,8 @@ class Graph(object):
         if not self._remap_ready():
             return False
         fm, dev, vecs = self._final_map, self._device, self._eig_vecs
-        if self._eig_pending:
-            self._eig_pending = False
-            dev.finalize_wait()
+        # (an image of the block that is still owed to `vecs` is replaced by the remapped one; one in flight is collected
+        # first - both inside pf_final_remap_begin)
         dev.final_remap(fm[0], fm[1], vecs)
         self._eig_pending = True
         return True
