@@ -101,6 +101,14 @@ __global__ __launch_bounds__(PF_OP_BLOCK) void k_sell_op(OpArgs a) {
     sell_op_block<HAS_PREV>(a, blockIdx.x);
 }
 
+// the plain product for `gridDim.y` consecutive workspace slots in one launch (the Rayleigh-Ritz tail of a solve: S Z for
+// the 6-11 Ritz vectors was one launch per vector, each mostly launch latency): block row y takes slot y
+__global__ __launch_bounds__(PF_OP_BLOCK) void k_sell_op_slots(OpArgs a, int64_t slot_stride) {
+    a.x += (int64_t)blockIdx.y * slot_stride;
+    a.out += (int64_t)blockIdx.y * slot_stride;
+    sell_op_block<false>(a, blockIdx.x);
+}
+
 // the same step for two independent graphs in one launch (target and source mesh of a pair run
 // their Chebyshev recurrences in lockstep): a 250k-vertex step alone is ~5 us, of which ~3 us is
 // launch/ramp latency; two per launch amortise it.
@@ -1045,7 +1053,11 @@ int pf_spmv_multi(pf_graph* g, int32_t op, int32_t src_first, int32_t dst_first,
              "pf_spmv_multi: operator %d unavailable or the slot ranges overlap", op);
     if (count == 0) return PF_OK;
     OpTimer t(g->ctx, count, (double)count * (double)op_bytes(g));
-    for (int32_t i = 0; i < count; ++i) PF_TRY(launch_op(g, vals, pf_slot(g, src_first + i), nullptr, pf_slot(g, dst_first + i), -1.0, 0.0, 0.0));
+    {
+        const OpArgs a = op_args(g, vals, pf_slot(g, src_first), nullptr, pf_slot(g, dst_first), -1.0, 0.0, 0.0);
+        k_sell_op_slots<<<dim3(a.n_blocks, (unsigned)count), PF_OP_BLOCK, 0, g->ctx->stream>>>(a, g->n_pad);
+        PF_HIP(hipGetLastError());
+    }
     return t.finish();
 }
 
