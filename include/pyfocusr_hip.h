@@ -247,7 +247,11 @@ int pf_finalize_vectors(pf_graph* g, int32_t first, int32_t count, int32_t from_
  * the block is resident and usable by pf_final_rows / pf_knn1_graphs / pf_eigsort_costs at once, and later work on the
  * ctx stream overlaps with the download.  _end waits for the download and checks the result (PF_E_STATE for a
  * vanished vector); `out` must not be read before it returns.  No-op when nothing is pending.  pf_graph_free and the
- * next _begin collect a pending download themselves. */
+ * next _begin collect a pending download themselves.  Since round 3 the n x count image may be held back: it is queued
+ * behind the next long kernel of the ctx (a 1-NN search of >= 32768 queries) or by _end, whichever comes first - beside
+ * the small kernels that follow a solve a 10 MB download costs what it would cost in line.  `out` must therefore stay
+ * allocated until _end (or pf_graph_free) has returned; pf_host_free of a block that is still owed its image cancels
+ * the download.  PF_DOWNLOAD_DEFER=0: queued at once, as before. */
 int pf_finalize_vectors_begin(pf_graph* g, int32_t first, int32_t count, int32_t from_sym, int32_t minmax, double* out);
 int pf_finalize_vectors_end(pf_graph* g);
 /* out[i][c] = block[i][col[c]] * sign[c] (c < count <= the block's column count, sign = +-1): the image on the host of

@@ -722,8 +722,9 @@ class DeviceLaplacian(object):
         if getattr(self, "_h", None):
             for rows in getattr(self, "_rows", []):
                 rows.close()
-            self._lib.pf_graph_free(self._h)
+            self._lib.pf_graph_free(self._h)  # (collects a download that is still owed or in flight)
             self._h = None
+            self._final_out = None
 
     def __del__(self):
         try:
@@ -881,6 +882,10 @@ class DeviceLaplacian(object):
                                                    _f64(out)))
         self._final_count = int(count)  # the same block stays resident on the device (final_rows, Context.knn1_graphs)
         self._final_pending = True
+        # the download may not even be queued yet (the library holds it back until a long kernel runs): the array must
+        # outlive it whatever the caller does with its own reference - a pinned block that is freed under an owed
+        # download is a write into unmapped memory from the device
+        self._final_out = out
         if wait:
             self.finalize_wait()
         return out
@@ -893,12 +898,16 @@ class DeviceLaplacian(object):
         assert out.flags.c_contiguous and out.shape == (self.n, len(cols))
         _check(self._lib.pf_final_remap_begin(self._h, cols.ctypes.data_as(_i32p), _f64(signs), len(cols), _f64(out)))
         self._final_pending = True
+        self._final_out = out
 
     def finalize_wait(self):
         """Collect the download a `finalize_vectors(..., wait=False)` left in flight (no-op otherwise)."""
         if getattr(self, "_final_pending", False) and self._h:
             self._final_pending = False
-            _check(self._lib.pf_finalize_vectors_end(self._h))
+            try:
+                _check(self._lib.pf_finalize_vectors_end(self._h))
+            finally:
+                self._final_out = None
 
     def final_rows(self, rows):
         """Rows of the block the last `finalize_vectors` left on the device -> (len(rows), count) array."""
@@ -953,6 +962,7 @@ class DeviceLaplacian(object):
             m = n_out.value
             dev._final_count = m
             dev._final_pending = (not wait) and m > 0
+            dev._final_out = vecs if dev._final_pending else None  # (kept alive until the download has been collected)
             if m != vecs.shape[1]:  # fewer pairs than asked for: the library wrote an (n, m) block
                 if dev._final_pending:
                     dev.finalize_wait()

@@ -227,7 +227,25 @@ int pf_host_alloc(size_t bytes, void** out) {
 }
 
 int pf_host_free(void* p) {
-    if (p) PF_HIP(hipHostFree(p));
+    if (!p) return PF_OK;
+    // a download that is still OWED to this block (pf_finalize_vectors_begin holds it back) must never be queued: the
+    // device would write into unmapped memory; one that is in flight is waited for
+    {
+        std::lock_guard<std::mutex> lk(g_ctx_mutex);
+        for (pf_ctx* c : g_ctxs) {
+            for (size_t i = 0; i < c->deferred.size();) {
+                pf_graph* g = c->deferred[i];
+                if (g->dl_src && g->dl_dst == p) {
+                    g->dl_src = nullptr;
+                    c->deferred.erase(c->deferred.begin() + (long)i);
+                } else {
+                    ++i;
+                }
+            }
+            if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
+        }
+    }
+    PF_HIP(hipHostFree(p));
     return PF_OK;
 }
 

@@ -267,7 +267,10 @@ __global__ __launch_bounds__(PF_BLOCK) void k_order_rank(const unsigned* __restr
     const int32_t b = (int32_t)(k >> shift);
     const int32_t lo = start[b], hi = start[b + 1];
     if (hi - lo > PF_ORDER_BUCKET_MAX) {
+        // the build will repeat the ordering - but the kernels queued behind this one still run on what is written here:
+        // it has to be a permutation (the bucket as the atomics filled it), never what the buffer happened to hold
         if (s == lo) atomicOr(overflow, 1);
+        order[s] = me;
         return;
     }
     int32_t before = 0;

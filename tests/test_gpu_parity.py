@@ -131,6 +131,10 @@ def test_assembly_piled_vertices(hip, ctx):
     from oracle import reference_port as orc
     from pyfocusr_amd.meshgen import blob_mesh
 
+    # (a first build leaves out-of-range numbers in the allocator's cached blocks: whatever the abandoned ordering does not
+    # write itself would be read as vertex indices by the kernels queued behind it)
+    junk = hip.DeviceLaplacian(blob_mesh(40000, seed=30).points * 3.0, blob_mesh(40000, seed=30).faces, ctx=ctx)
+    junk.close()
     m = blob_mesh(8000, seed=31)
     pts = np.concatenate([m.points * 1e-3, [[900.0, 0.0, 0.0], [0.0, -700.0, 0.0], [0.0, 0.0, 800.0]]])
     n0 = len(m.points)
