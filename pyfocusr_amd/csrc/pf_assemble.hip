@@ -17,6 +17,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <string>
 #include <thread>
 
@@ -1027,12 +1028,24 @@ int pf_graph_build_device2(pf_mesh* mesh_a, pf_mesh* mesh_b, pf_graph** out_a, p
             // this: a new thread's first HIP call costs ~0.3 ms)
             int rc_b = PF_OK;
             std::string err_b;
+            static const bool dbg = getenv("PF_DEBUG_BUILD") != nullptr;
+            using clk = std::chrono::steady_clock;
+            const clk::time_point t0 = clk::now();
+            clk::time_point tb0 = t0, tb1 = t0;
             pf_worker_run(ctx, [&] {
+                tb0 = clk::now();
                 rc_b = b.begin(mesh_b, 1);
+                tb1 = clk::now();
                 if (rc_b != PF_OK) err_b = pf_last_error();  // (the message is thread-local)
             });
             rc = a.begin(mesh_a, 0);
+            const clk::time_point ta1 = clk::now();
             pf_worker_wait(ctx);
+            if (dbg) {
+                auto us = [&](clk::time_point t) { return std::chrono::duration<double, std::micro>(t - t0).count(); };
+                fprintf(stderr, "pf_build2: worker began %.0f us after the call, ended %.0f; main thread's half ended %.0f; joined %.0f\n", us(tb0),
+                        us(tb1), us(ta1), us(clk::now()));
+            }
             if (rc == PF_OK && rc_b != PF_OK) {
                 rc = rc_b;
                 pf_set_error("%s", err_b.c_str());
