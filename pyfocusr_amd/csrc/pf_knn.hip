@@ -817,7 +817,8 @@ static int knn_prepare(pf_ctx* c, int64_t n_ref, int64_t n_qry, int32_t d) {
     c->knn_ref_ld = (n_ref + PF_WAVE - 1) & ~(int64_t)(PF_WAVE - 1);
     PF_TRY(grow(st, &c->knn_ref_soa, &c->knn_cap_ref_soa, c->knn_ref_ld * d));
     // grid resolution: ~4 references per cell if they were spread over the plane
-    int res = (int)sqrt((double)n_ref / 4.0);
+    static const double per_cell = [] { const char* e = getenv("PF_KNN_PER_CELL"); const double v = e ? atof(e) : 0.0; return v > 0.0 ? v : 4.0; }();
+    int res = (int)sqrt((double)n_ref / per_cell);
     res = res < 4 ? 4 : (res > 2048 ? 2048 : res);
     c->knn_res = res;
     PF_TRY(grow(st, &c->knn_cell_start, &c->knn_cap_cell, (int64_t)res * res + 2));
