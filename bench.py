@@ -54,10 +54,15 @@ def hot_path_step(ctxs, mesh_t, mesh_s, k, n_samples, timers, keep_graphs=False)
     t0 = time.perf_counter()
     graphs = [Graph(mesh, n_spectral_features=k, n_rand_samples=n_samples, ctx=c, verbose=False)
               for mesh, c in zip((mesh_t, mesh_s), ctxs)]
+    ta = time.perf_counter()
     build_devices(graphs)  # assembly from the resident meshes (one context: the two meshes side by side on two streams)
+    tb = time.perf_counter()
     for c in ctxs:
         c.sync()
     t1 = time.perf_counter()
+    if "assembly_detail" in timers:  # (PF_BENCH_DETAIL=1: where the assembly stage's time is, host side)
+        for key, dt in (("graph_objects", ta - t0), ("build_devices", tb - ta), ("sync", t1 - tb)):
+            timers["assembly_detail"][key] = timers["assembly_detail"].get(key, 0.0) + dt
     compute_spectra(graphs)  # target and source concurrently, one HIP stream each
     t2 = time.perf_counter()
     timers["assembly"] += t1 - t0
@@ -415,11 +420,13 @@ def main():
             dist.barrier()
 
     timers = dict(assembly=0.0, eigensolve=0.0, eigsort=0.0, knn=0.0, matvecs=0)
+    if os.environ.get("PF_BENCH_DETAIL") == "1":
+        timers["assembly_detail"] = {}
     np.random.seed(1234 + rank)
     for _ in range(args.warmup):
         hot_path_step(ctxs, mesh_t, mesh_s, args.k, args.samples, timers)
     for key in timers:
-        timers[key] = 0
+        timers[key] = {} if key == "assembly_detail" else 0
     call_ms.clear()
     for c in set(ctxs):
         c.timing(reset=True)
@@ -608,6 +615,8 @@ def main():
                        "n_vertices": n, "n_faces": 2 * n - 4, "k": args.k, "parallelism": "%d independent pair(s)" % world},
             "breakdown_ms_per_step": {key: 1e3 * timers[key] / args.steps
                                       for key in ("assembly", "eigensolve", "eigsort", "knn")},
+            **({"assembly_detail_ms_per_step": {k2: 1e3 * v2 / args.steps for k2, v2 in timers["assembly_detail"].items()}}
+               if "assembly_detail" in timers else {}),
             "matvecs_per_step": timers["matvecs"] / args.steps,
             # eigenpairs/s of the eigensolve alone (Laplacian on the device -> normalised eigenpairs in
             # host memory), and the algorithmic bytes the operator kernel moved per step (sum over its launches)

@@ -83,7 +83,8 @@ hipError_t pf_create_side_stream(hipStream_t* s, bool low) {
 hipStream_t pf_stream_b(pf_ctx* c) {
     if (!c->stream_b) {
         hipStream_t s = nullptr;
-        if (pf_create_side_stream(&s) != hipSuccess ||
+        static const bool b_low = [] { const char* e = getenv("PF_STREAM_B_LOW"); return e && e[0] == '1'; }();  // (A/B)
+        if (pf_create_side_stream(&s, b_low) != hipSuccess ||
             hipEventCreateWithFlags(&c->join_ev, hipEventDisableTiming) != hipSuccess) {
             (void)hipGetLastError();
             if (s) (void)hipStreamDestroy(s);

@@ -578,6 +578,11 @@ struct FinishJob {
     ~FinishJob() { release(); }
 
     int begin() {
+        PF_TRY(begin_stats_and_labels());
+        return queue_order(false);
+    }
+
+    int begin_stats_and_labels() {
         st = g->build_stream ? g->build_stream : g->ctx->stream;
         const int64_t n = g->n;
         PF_TRY(dev_alloc(st, &flags, 8 + PF_CC_ROUNDS));  // the flags and the labelling rounds' flags: one block, one fill
@@ -608,8 +613,7 @@ struct FinishJob {
         PF_HIP(hipGetLastError());
         k_collect_roots<<<nblk(n), PF_BLOCK, 0, st>>>(g->label, g->rowptr, n, d_roots, stats + 4);
         PF_HIP(hipGetLastError());
-
-        return queue_order(false);
+        return PF_OK;
     }
 
     // solver-internal renumbering (Morton order, degree-sorted windows), the slice widths in that order, and the ONE
@@ -777,7 +781,19 @@ struct MeshBuild {
         return r;
     }
 
+    // The first half in four phases (a pair's two builds are queued phase by phase from ONE thread, see
+    // pf_graph_build_device2); begin() runs them in a row.
+    static constexpr int N_PHASES = 4;
+    int32_t *b_cnt = nullptr, *b_start = nullptr, *b_cursor = nullptr, *b_rcol = nullptr, *b_ucnt = nullptr, *b_flags = nullptr;
+    double* b_rw = nullptr;
+
     int begin(pf_mesh* m, int stream_id) {
+        PF_TRY(prepare(m, stream_id));
+        for (int k = 0; k < N_PHASES; ++k) PF_TRY(phase(k));
+        return PF_OK;
+    }
+
+    int prepare(pf_mesh* m, int stream_id) {
         mesh = m;
         sid = stream_id;
         pf_ctx* ctx = mesh->ctx;
@@ -795,65 +811,77 @@ struct MeshBuild {
         g->win_rows = pf_window_rows(g->n_pad);
         g->n_slices = g->n_pad / PF_WAVE;
         g->n_chunks = (g->n_pad + PF_DOT_CHUNK - 1) / PF_DOT_CHUNK;
+        return PF_OK;
+    }
+
+    int phase(int k) {
+        pf_ctx* ctx = mesh->ctx;
+        const int64_t n = mesh->n, n_faces = mesh->n_faces;
+        const int32_t vpf = mesh->vpf;
         const double* d_pts = mesh->pts;
         const int32_t* d_faces = mesh->faces;
-        int32_t *cnt = nullptr, *start = nullptr, *cursor = nullptr, *rcol = nullptr, *ucnt = nullptr, *flags = nullptr;
-        double* rw = nullptr;
-        // (the counters that start from zero share one block, and so do deg / g / sg: two memsets instead of seven launches)
-        int32_t* zeroed = nullptr;
-        const int64_t zstride = (n + 1 + 7) & ~(int64_t)7;
-        PF_TRY(scratch(&zeroed, 3 * zstride + 8));
-        cnt = zeroed, cursor = zeroed + zstride, ucnt = zeroed + 2 * zstride, flags = zeroed + 3 * zstride;
-        PF_TRY(scratch(&start, n + 1));
-        PF_TRY(scratch(&rcol, n_edges));
-        PF_TRY(scratch(&rw, n_edges));
-        PF_TRY(dev_alloc(st, &g->rowptr, n + 1));
-        PF_TRY(dev_alloc(st, &g->deg, 3 * g->n_pad));  // deg, g, sg: one allocation (g->g and g->sg point into it)
-        g->g = g->deg + g->n_pad;
-        g->sg = g->deg + 2 * g->n_pad;
-        g->deg_block = true;
-        PF_TRY(dev_alloc(st, &g->diag, g->n_pad));
-        PF_TRY(dev_alloc(st, &g->label, g->n_pad));
-        PF_TRY(dev_alloc(st, &g->perm, g->n_pad));
-        PF_TRY(dev_alloc(st, &g->iperm, g->n_pad));
-        PF_TRY(dev_alloc(st, &g->smooth, g->n_pad));
-        PF_TRY(dev_alloc(st, &g->slice_ptr, g->n_slices + 1));
-
-        PF_HIP(hipMemsetAsync(zeroed, 0, sizeof(int32_t) * (size_t)(3 * zstride + 8), st));
-        PF_HIP(hipMemsetAsync(g->deg, 0, sizeof(double) * 3 * g->n_pad, st));
-        if (sid == 0) PF_HIP(hipEventRecord(ctx->ev0, st));
-
         const bool face_bound = vpf == 3 && n_faces > 0;
-        if (face_bound) PF_TRY(scratch(&pmin, 1));
-        if (n_edges) {
-            k_count_edges<<<nblk(n_edges), PF_BLOCK, 0, st>>>(d_faces, n_edges, vpf, n, cnt, flags, reinterpret_cast<double*>(pmin));
-            PF_HIP(hipGetLastError());
+        if (k == 0) {  // storage, the edge list counted and scattered
+            // (the counters that start from zero share one block, and so do deg / g / sg: two memsets instead of seven launches)
+            int32_t* zeroed = nullptr;
+            const int64_t zstride = (n + 1 + 7) & ~(int64_t)7;
+            PF_TRY(scratch(&zeroed, 3 * zstride + 8));
+            b_cnt = zeroed, b_cursor = zeroed + zstride, b_ucnt = zeroed + 2 * zstride, b_flags = zeroed + 3 * zstride;
+            PF_TRY(scratch(&b_start, n + 1));
+            PF_TRY(scratch(&b_rcol, n_edges));
+            PF_TRY(scratch(&b_rw, n_edges));
+            PF_TRY(dev_alloc(st, &g->rowptr, n + 1));
+            PF_TRY(dev_alloc(st, &g->deg, 3 * g->n_pad));  // deg, g, sg: one allocation (g->g and g->sg point into it)
+            g->g = g->deg + g->n_pad;
+            g->sg = g->deg + 2 * g->n_pad;
+            g->deg_block = true;
+            PF_TRY(dev_alloc(st, &g->diag, g->n_pad));
+            PF_TRY(dev_alloc(st, &g->label, g->n_pad));
+            PF_TRY(dev_alloc(st, &g->perm, g->n_pad));
+            PF_TRY(dev_alloc(st, &g->iperm, g->n_pad));
+            PF_TRY(dev_alloc(st, &g->smooth, g->n_pad));
+            PF_TRY(dev_alloc(st, &g->slice_ptr, g->n_slices + 1));
+
+            PF_HIP(hipMemsetAsync(zeroed, 0, sizeof(int32_t) * (size_t)(3 * zstride + 8), st));
+            PF_HIP(hipMemsetAsync(g->deg, 0, sizeof(double) * 3 * g->n_pad, st));
+            if (sid == 0) PF_HIP(hipEventRecord(ctx->ev0, st));
+
+            if (face_bound) PF_TRY(scratch(&pmin, 1));
+            if (n_edges) {
+                k_count_edges<<<nblk(n_edges), PF_BLOCK, 0, st>>>(d_faces, n_edges, vpf, n, b_cnt, b_flags, reinterpret_cast<double*>(pmin));
+                PF_HIP(hipGetLastError());
+            }
+            // No read-back on the way: faces the counting kernel flags (index out of range, repeated vertex) are skipped by
+            // the kernels behind it, col / w are sized by their upper bound (one entry per face edge; duplicates only shrink
+            // it), and the flags, the entry count and everything the second half needs come back in ONE synchronisation
+            // (each one costs ~30 us of idle device: 8 per mesh at first, 2 now).
+            PF_TRY(pf_exclusive_scan_i32(st, b_cnt, b_start, n + 1));
+            if (n_edges) {
+                k_scatter_edges<<<nblk(n_edges), PF_BLOCK, 0, st>>>(d_faces, d_pts, n_edges, vpf, n, b_start, b_cursor, b_rcol, b_rw, b_flags);
+                PF_HIP(hipGetLastError());
+            }
+            return PF_OK;
         }
-        // No read-back on the way: faces the counting kernel flags (index out of range, repeated vertex) are skipped by the
-        // kernels behind it, col / w are sized by their upper bound (one entry per face edge; duplicates only shrink it),
-        // and the flags, the entry count and everything the second half needs come back in ONE synchronisation (each one
-        // costs ~30 us of idle device: 8 per mesh at first, 2 now).
-        PF_TRY(pf_exclusive_scan_i32(st, cnt, start, n + 1));
-        if (n_edges) {
-            k_scatter_edges<<<nblk(n_edges), PF_BLOCK, 0, st>>>(d_faces, d_pts, n_edges, vpf, n, start, cursor, rcol, rw, flags);
+        if (k == 1) {  // CSR(W), degrees, the face bound
+            k_sort_unique_rows<<<nblk(n), PF_BLOCK, 0, st>>>(b_start, n, b_rcol, b_rw, b_ucnt);
             PF_HIP(hipGetLastError());
-        }
-        k_sort_unique_rows<<<nblk(n), PF_BLOCK, 0, st>>>(start, n, rcol, rw, ucnt);
-        PF_HIP(hipGetLastError());
-        PF_TRY(pf_exclusive_scan_i32(st, ucnt, g->rowptr, n + 1));
-        PF_TRY(dev_alloc(st, &g->col, n_edges));
-        PF_TRY(dev_alloc(st, &g->w, n_edges));
-        k_compact_rows<<<nblk(n), PF_BLOCK, 0, st>>>(start, g->rowptr, n, rcol, rw, g->col, g->w, g->deg, g->g, g->sg);
-        PF_HIP(hipGetLastError());
-        // the face-by-face bound of the spectrum (k_face_bound); it holds if every undirected edge lies in exactly two
-        // triangles: W symmetric and no directed edge listed twice - both known after the read-back
-        if (face_bound) {
-            k_face_bound<<<nblk(n_faces), PF_BLOCK, 0, st>>>(d_faces, d_pts, n_faces, n, pmin);
+            PF_TRY(pf_exclusive_scan_i32(st, b_ucnt, g->rowptr, n + 1));
+            PF_TRY(dev_alloc(st, &g->col, n_edges));
+            PF_TRY(dev_alloc(st, &g->w, n_edges));
+            k_compact_rows<<<nblk(n), PF_BLOCK, 0, st>>>(b_start, g->rowptr, n, b_rcol, b_rw, g->col, g->w, g->deg, g->g, g->sg);
             PF_HIP(hipGetLastError());
+            // the face-by-face bound of the spectrum (k_face_bound); it holds if every undirected edge lies in exactly two
+            // triangles: W symmetric and no directed edge listed twice - both known after the read-back
+            if (face_bound) {
+                k_face_bound<<<nblk(n_faces), PF_BLOCK, 0, st>>>(d_faces, d_pts, n_faces, n, pmin);
+                PF_HIP(hipGetLastError());
+            }
+            fin.g = g, fin.d_pts = d_pts, fin.numeric_symmetry = false, fin.d_extra = b_flags, fin.h_extra = h_flags;
+            fin.nnz_from_rowptr = true, fin.d_pmin = pmin, fin.h_pmin = &h_pmin, fin.sid = sid;
+            return PF_OK;
         }
-        fin.g = g, fin.d_pts = d_pts, fin.numeric_symmetry = false, fin.d_extra = flags, fin.h_extra = h_flags;
-        fin.nnz_from_rowptr = true, fin.d_pmin = pmin, fin.h_pmin = &h_pmin, fin.sid = sid;
-        return fin.begin();
+        if (k == 2) return fin.begin_stats_and_labels();
+        return fin.queue_order(false);
     }
 
     int end() {
@@ -1023,36 +1051,58 @@ int pf_graph_build_device2(pf_mesh* mesh_a, pf_mesh* mesh_b, pf_graph** out_a, p
         MeshBuild a, b;
         rc = pf_streams_join(ctx, 1);  // the second stream sees the uploads and may reuse what the first has released
         if (rc == PF_OK) {
-            // the first halves are ~75 launches each, ~4 us of host time apiece: queued from two threads, or the second
-            // mesh would only start when the first one's kernels are nearly through (the ctx keeps ONE worker thread for
-            // this: a new thread's first HIP call costs ~0.3 ms)
-            int rc_b = PF_OK;
-            std::string err_b;
+            // The first halves are ~55 launches each, ~4 us of host time apiece.  Queued one build after the other, the
+            // second mesh would start when the first one's kernels are half through; queued from two threads (rounds 2-3)
+            // they start together - until the host's scheduler leaves the second thread waiting for a core for 3-9 ms,
+            // which it did in one step of six in about one process of twelve on this pool's loaded hosts (PF_DEBUG_BUILD:
+            // "worker began 3045 us after the call", "ended 9344").  So: ONE thread, the two builds phase by phase (four
+            // phases of ~15 launches): the second stream is never more than one phase behind, 0.45 ms of launching against
+            // 0.97 ms of device time.  PF_BUILD_THREAD=1: the two-thread form.
             static const bool dbg = getenv("PF_DEBUG_BUILD") != nullptr;
+            static const bool threaded = [] { const char* e = getenv("PF_BUILD_THREAD"); return e && e[0] == '1'; }();
             using clk = std::chrono::steady_clock;
             const clk::time_point t0 = clk::now();
-            clk::time_point tb0 = t0, tb1 = t0;
-            pf_worker_run(ctx, [&] {
-                tb0 = clk::now();
-                rc_b = b.begin(mesh_b, 1);
-                tb1 = clk::now();
-                if (rc_b != PF_OK) err_b = pf_last_error();  // (the message is thread-local)
-            });
-            rc = a.begin(mesh_a, 0);
-            const clk::time_point ta1 = clk::now();
-            pf_worker_wait(ctx);
-            if (dbg) {
-                auto us = [&](clk::time_point t) { return std::chrono::duration<double, std::micro>(t - t0).count(); };
-                fprintf(stderr, "pf_build2: worker began %.0f us after the call, ended %.0f; main thread's half ended %.0f; joined %.0f\n", us(tb0),
-                        us(tb1), us(ta1), us(clk::now()));
-            }
-            if (rc == PF_OK && rc_b != PF_OK) {
-                rc = rc_b;
-                pf_set_error("%s", err_b.c_str());
+            if (threaded) {
+                int rc_b = PF_OK;
+                std::string err_b;
+                clk::time_point tb0 = t0, tb1 = t0;
+                pf_worker_run(ctx, [&] {
+                    tb0 = clk::now();
+                    rc_b = b.begin(mesh_b, 1);
+                    tb1 = clk::now();
+                    if (rc_b != PF_OK) err_b = pf_last_error();  // (the message is thread-local)
+                });
+                rc = a.begin(mesh_a, 0);
+                const clk::time_point ta1 = clk::now();
+                pf_worker_wait(ctx);
+                if (dbg) {
+                    auto us = [&](clk::time_point t) { return std::chrono::duration<double, std::micro>(t - t0).count(); };
+                    fprintf(stderr, "pf_build2: worker began %.0f us after the call, ended %.0f; main thread's half ended %.0f; joined %.0f\n", us(tb0),
+                            us(tb1), us(ta1), us(clk::now()));
+                }
+                if (rc == PF_OK && rc_b != PF_OK) {
+                    rc = rc_b;
+                    pf_set_error("%s", err_b.c_str());
+                }
+            } else {
+                rc = a.prepare(mesh_a, 0);
+                if (rc == PF_OK) rc = b.prepare(mesh_b, 1);
+                for (int k = 0; k < MeshBuild::N_PHASES && rc == PF_OK; ++k) {
+                    rc = a.phase(k);
+                    if (rc == PF_OK) rc = b.phase(k);
+                }
+                if (dbg) fprintf(stderr, "pf_build2: first halves queued in %.0f us (one thread, phase by phase)\n",
+                                 std::chrono::duration<double, std::micro>(clk::now() - t0).count());
             }
         }
+        const auto tq0 = std::chrono::steady_clock::now();
         if (rc == PF_OK) rc = a.end();
+        const auto tq1 = std::chrono::steady_clock::now();
         if (rc == PF_OK) rc = b.end();
+        const auto tq2 = std::chrono::steady_clock::now();
+        if (getenv("PF_DEBUG_BUILD"))
+            fprintf(stderr, "pf_build2: second halves (wait for the read-back, SELL fill queued): first mesh %.0f us, second %.0f us\n",
+                    std::chrono::duration<double, std::micro>(tq1 - tq0).count(), std::chrono::duration<double, std::micro>(tq2 - tq1).count());
         // the temporaries go back before the join, so that the first stream may have the second one's from now on (a
         // block is visible across streams only if it was released before the join)
         a.release();
@@ -1067,6 +1117,9 @@ int pf_graph_build_device2(pf_mesh* mesh_a, pf_mesh* mesh_b, pf_graph** out_a, p
             float ms = 0.f;
             if (e1 == hipSuccess && e2 == hipSuccess && hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) == hipSuccess) ctx->build_ms = ms;
             else rc = PF_E_HIP, pf_set_error("pf_graph_build_device2: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
+            if (getenv("PF_DEBUG_BUILD"))
+                fprintf(stderr, "pf_build2: device time of the pair build %.3f ms (events on the ctx stream); the last wait began %.0f us after the second halves\n", ms,
+                        std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tq2).count());
         }
         if (rc == PF_OK) {
             a.g->build_stream = b.g->build_stream = nullptr;
