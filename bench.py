@@ -433,8 +433,10 @@ def main():
         _hip.persist_clock(c, reset=True)
     barrier()
     t0 = time.perf_counter()
+    step_ends = []
     for _ in range(args.steps):
         idx, max_res, nnz, coords = hot_path_step(ctxs, mesh_t, mesh_s, args.k, args.samples, timers)
+        step_ends.append(time.perf_counter())
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -617,6 +619,8 @@ def main():
                                       for key in ("assembly", "eigensolve", "eigsort", "knn")},
             **({"assembly_detail_ms_per_step": {k2: 1e3 * v2 / args.steps for k2, v2 in timers["assembly_detail"].items()}}
                if "assembly_detail" in timers else {}),
+            **({"ms_of_each_step": [round(1e3 * (b - a), 3) for a, b in zip([t0] + step_ends[:-1], step_ends)]}
+               if os.environ.get("PF_BENCH_DETAIL") == "1" else {}),
             "matvecs_per_step": timers["matvecs"] / args.steps,
             # eigenpairs/s of the eigensolve alone (Laplacian on the device -> normalised eigenpairs in
             # host memory), and the algorithmic bytes the operator kernel moved per step (sum over its launches)
