@@ -146,14 +146,16 @@ __device__ __forceinline__ unsigned spread16(unsigned v) {
 // morton = 0: row-major cell id (references); 1: Morton code of the cell (queries)
 __global__ __launch_bounds__(PF_BLOCK) void k_cell_keys(const double* __restrict__ pts, int64_t n, int d,
                                                         const KnnGrid* __restrict__ gp, int morton, unsigned* __restrict__ keys,
-                                                        int32_t* __restrict__ vals) {
+                                                        int32_t* __restrict__ vals, int32_t* __restrict__ hist) {
     const int64_t i = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
     if (i >= n) return;
     const KnnGrid g = *gp;
     const int cx = cell_of(pts[i * d + g.a0], g.lo0, g.s0, g.r0);
     const int cy = cell_of(pts[i * d + g.a1], g.lo1, g.s1, g.r1);
-    keys[i] = morton ? (spread16((unsigned)cx) | (spread16((unsigned)cy) << 1)) : (unsigned)(cy * g.r0 + cx);
-    vals[i] = (int32_t)i;
+    const unsigned key = morton ? (spread16((unsigned)cx) | (spread16((unsigned)cy) << 1)) : (unsigned)(cy * g.r0 + cx);
+    keys[i] = key;
+    if (hist) atomicAdd(&hist[key], 1);  // the counting sort's histogram, taken while the key is at hand
+    else vals[i] = (int32_t)i;           // the radix sort's payload
 }
 
 __global__ __launch_bounds__(PF_BLOCK) void k_gather_rows(const double* __restrict__ pts, const int32_t* __restrict__ order,
@@ -718,23 +720,22 @@ int grow(hipStream_t st, T** p, int64_t* cap, int64_t need) {
 // counting sort by cell key (keys < n_buckets): histogram, exclusive scan, scatter through per-bucket cursors.  The
 // order inside a bucket is whatever the atomics make it: the search does not care (the minimum of (distance, original
 // index) does not depend on the order candidates or queries are visited in).
-__global__ __launch_bounds__(PF_BLOCK) void k_bucket_count(const unsigned* __restrict__ keys, int64_t n, int32_t* __restrict__ hist) {
-    const int64_t i = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
-    if (i < n) atomicAdd(&hist[keys[i]], 1);
-}
+// (the histogram is taken by k_cell_keys; the scatter carries the point's row along, so no gather pass follows)
 __global__ __launch_bounds__(PF_BLOCK) void k_bucket_scatter(const unsigned* __restrict__ keys, int64_t n, const int32_t* __restrict__ start,
                                                              int32_t* __restrict__ cursor, unsigned* __restrict__ key_out,
-                                                             int32_t* __restrict__ orig_out) {
+                                                             int32_t* __restrict__ orig_out, const double* __restrict__ pts, int d,
+                                                             double* __restrict__ rows_out) {
     const int64_t i = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
     if (i >= n) return;
     const unsigned k = keys[i];
-    const int32_t pos = start[k] + atomicAdd(&cursor[k], 1);
+    const int64_t pos = start[k] + atomicAdd(&cursor[k], 1);
     key_out[pos] = k;
     orig_out[pos] = (int32_t)i;
+    for (int c = 0; c < d; ++c) rows_out[pos * d + c] = pts[i * d + c];
 }
 
-// sort one point set by grid cell: sorted keys, original indices, gathered rows.  250k points: 5 small launches (~40 us)
-// where hipCUB's radix sort dispatches a merge sort of 17 launches (~107 us) for arrays below 1M items.
+// sort one point set by grid cell: sorted keys, original indices, gathered rows.  250k points: a memset and 4 small
+// launches where hipCUB's radix sort dispatches a merge sort of 17 launches (~107 us) for arrays below 1M items.
 int sort_points(pf_ctx* c, const double* pts, int64_t n, int d, int morton, int key_bits, unsigned* key_out, int32_t* orig_out,
                 double* rows_out) {
     hipStream_t st = c->stream;
@@ -744,11 +745,6 @@ int sort_points(pf_ctx* c, const double* pts, int64_t n, int d, int morton, int 
     size_t bytes = 0;
     int rc = PF_OK;
     hipError_t e = pf_malloc(st, (void**)&k0, sizeof(unsigned) * n);
-    if (e == hipSuccess) e = pf_malloc(st, (void**)&v0, sizeof(int32_t) * n);
-    if (e == hipSuccess) {
-        k_cell_keys<<<nblk(n), PF_BLOCK, 0, st>>>(pts, n, d, (const KnnGrid*)c->knn_grid, morton, k0, v0);
-        e = hipGetLastError();
-    }
     // keys are cell ids (row-major: < res^2) or Morton codes of cells (< 4^ceil(log2 res))
     int64_t n_buckets = 1;
     {
@@ -769,22 +765,27 @@ int sort_points(pf_ctx* c, const double* pts, int64_t n, int d, int morton, int 
         if (e == hipSuccess) {
             int32_t* start = hist + n_buckets + 1;
             int32_t* cursor = start + n_buckets + 1;
-            k_bucket_count<<<nblk(n), PF_BLOCK, 0, st>>>(k0, n, hist);
+            k_cell_keys<<<nblk(n), PF_BLOCK, 0, st>>>(pts, n, d, (const KnnGrid*)c->knn_grid, morton, k0, nullptr, hist);
             e = hipGetLastError();
             if (e == hipSuccess && pf_exclusive_scan_i32(st, hist, start, n_buckets + 1) != PF_OK) e = hipErrorUnknown;
             if (e == hipSuccess) {
-                k_bucket_scatter<<<nblk(n), PF_BLOCK, 0, st>>>(k0, n, start, cursor, key_out, orig_out);
+                k_bucket_scatter<<<nblk(n), PF_BLOCK, 0, st>>>(k0, n, start, cursor, key_out, orig_out, pts, d, rows_out);
                 e = hipGetLastError();
             }
         }
     } else {
+        if (e == hipSuccess) e = pf_malloc(st, (void**)&v0, sizeof(int32_t) * n);
+        if (e == hipSuccess) {
+            k_cell_keys<<<nblk(n), PF_BLOCK, 0, st>>>(pts, n, d, (const KnnGrid*)c->knn_grid, morton, k0, v0, nullptr);
+            e = hipGetLastError();
+        }
         if (e == hipSuccess) e = hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, k0, key_out, v0, orig_out, (int)n, 0, key_bits, st);
         if (e == hipSuccess) e = pf_malloc(st, &tmp, bytes);
         if (e == hipSuccess) e = hipcub::DeviceRadixSort::SortPairs(tmp, bytes, k0, key_out, v0, orig_out, (int)n, 0, key_bits, st);
-    }
-    if (e == hipSuccess) {
-        k_gather_rows<<<nblk(n), PF_BLOCK, 0, st>>>(pts, orig_out, n, d, rows_out);
-        e = hipGetLastError();
+        if (e == hipSuccess) {
+            k_gather_rows<<<nblk(n), PF_BLOCK, 0, st>>>(pts, orig_out, n, d, rows_out);
+            e = hipGetLastError();
+        }
     }
     if (e != hipSuccess) {
         pf_set_error("pf_knn: %s", hipGetErrorString(e));
