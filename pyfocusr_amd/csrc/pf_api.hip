@@ -5,6 +5,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <mutex>
 
 #include "pf_internal.h"
@@ -163,7 +164,12 @@ hipError_t pf_malloc(hipStream_t st, void** p, size_t bytes) {
     }
     if (!*p) {
         c->alloc_misses += 1;
+        static const bool dbg_alloc = getenv("PF_DEBUG_ALLOC") != nullptr;
+        const auto t_miss = std::chrono::steady_clock::now();
         hipError_t e = hipMalloc(p, bytes);
+        if (dbg_alloc)
+            fprintf(stderr, "libpyfocusr_hip: allocation %lld of ctx %p went to the driver: %zu bytes, stream %d, %.0f us\n", (long long)c->alloc_misses,
+                    (void*)c, bytes, sid, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_miss).count());
         if (e != hipSuccess) {  // give cached blocks back to the driver and retry once
             (void)hipStreamSynchronize(c->stream);
             if (c->stream_b) (void)hipStreamSynchronize(c->stream_b);
