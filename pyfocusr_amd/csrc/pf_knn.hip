@@ -757,7 +757,11 @@ int sort_points(pf_ctx* c, const double* pts, int64_t n, int d, int morton, int 
             n_buckets = d == 1 ? res : (int64_t)res * res;
         }
     }
-    if (e == hipSuccess && n_buckets <= ((int64_t)1 << 22)) {
+    // (PF_KNN_BUCKET_MAX, read per call: the tests send small inputs down the radix-sort path that only point sets of more
+    // than 16M points take by themselves)
+    int64_t bucket_max = (int64_t)1 << 22;
+    if (const char* ev = getenv("PF_KNN_BUCKET_MAX")) bucket_max = atoll(ev);
+    if (e == hipSuccess && n_buckets <= bucket_max) {
         int32_t* hist = nullptr;  // [n_buckets + 1] counts, [n_buckets + 1] starts, [n_buckets] cursors
         e = pf_malloc(st, (void**)&hist, sizeof(int32_t) * (size_t)(3 * n_buckets + 2));
         tmp = hist;

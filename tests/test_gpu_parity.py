@@ -828,6 +828,27 @@ def test_knn_bit_exact(ctx, d, n_ref, n_qry):
         ctx.knn_mode(0)
 
 
+def test_knn_radix_sorted_cells(ctx, monkeypatch):
+    """The point sort of the grid search by hipCUB's radix sort (what sets of more than 16M points take; forced here by
+    PF_KNN_BUCKET_MAX): same indices and distances as the counting sort's path and as brute force."""
+    rng = np.random.default_rng(77)
+    for n_ref, n_qry, d in ((40000, 40000, 5), (70000, 20000, 3), (20000, 50000, 2)):
+        ref = rng.uniform(-0.5, 0.5, size=(n_ref, d))
+        qry = ref[rng.integers(0, n_ref, n_qry)] + 0.01 * rng.standard_normal((n_qry, d))
+        ctx.knn_mode(1)
+        try:
+            idx0, d0 = ctx.knn1(ref, qry, return_d2=True)
+            monkeypatch.setenv("PF_KNN_BUCKET_MAX", "1")
+            idx1, d1 = ctx.knn1(ref, qry, return_d2=True)
+            monkeypatch.delenv("PF_KNN_BUCKET_MAX")
+        finally:
+            ctx.knn_mode(0)
+        assert np.array_equal(idx0, idx1) and np.array_equal(d0, d1)
+        rows = rng.integers(0, n_qry, 300)
+        bidx, bd2 = orc.knn1_bruteforce(ref, qry[rows])
+        assert np.array_equal(idx1[rows], bidx) and np.array_equal(d1[rows], bd2)
+
+
 def test_knn_box_hierarchy(ctx):
     """pf_knn_tree.hip (the default for d >= 7) where its pruning is stressed: embedded 2-manifolds at sizes with several
     supers, exact ties on a lattice, duplicated references, queries that ARE references, clouds far apart (nothing
