@@ -59,14 +59,6 @@ __device__ __forceinline__ int cell_of(double x, double lo, double scale, int r)
     return t > 0.0 ? (t >= (double)r ? r - 1 : (int)t) : 0;
 }
 
-template <int D>
-__device__ __forceinline__ double pick(const double (&q)[D], int axis) {
-    double v = q[0];
-#pragma unroll
-    for (int c = 1; c < D; ++c) v = (c == axis) ? q[c] : v;
-    return v;
-}
-
 // per-axis [min, max] of the reference set (order-preserving integer encoding + 64-bit atomics)
 __global__ __launch_bounds__(PF_BLOCK) void k_extent(const double* __restrict__ pts, int64_t n, int d, unsigned long long* ext /* [2][16] */) {
     __shared__ unsigned long long part[PF_BLOCK / PF_WAVE][32];
@@ -251,7 +243,8 @@ __global__ __launch_bounds__(BS) void k_knn_grid(const double* __restrict__ ref_
     double q[D];
 #pragma unroll
     for (int c = 0; c < D; ++c) q[c] = qry_s[qq * D + c];
-    const double qx = pick<D>(q, g.a0), qy = pick<D>(q, g.a1);
+    // (read by their run-time axis from memory: picked out of q[] the compiler makes them indexed reads of a scratch copy)
+    const double qx = qry_s[qq * D + g.a0], qy = qry_s[qq * D + g.a1];
     const int cx = cell_of(qx, g.lo0, g.s0, g.r0), cy = cell_of(qy, g.lo1, g.s1, g.r1);
 
     // ---- phase 1: upper bound from the cells around the query (grow the ring until K candidates are found)
@@ -467,6 +460,10 @@ __global__ __launch_bounds__(PF_BLOCK) void k_knn_coop(const double* __restrict_
     if (q0 >= n_qry) return;  // (wave-uniform)
     const int nq = n_qry - q0 < G ? (int)(n_qry - q0) : G;
     double q[G][D];  // wave-uniform (a short group replays its last query)
+    // the two grid coordinates of each query once more, read by their (run-time) axis: picking them out of q[][] the
+    // compiler turns into an indexed read of a copy of q in SCRATCH memory - 176 bytes per lane stored by every wave at its
+    // start, 656 MB of writes per 250k x 250k search by the counters, and the scratch set-up of every wave launch
+    double qx[G], qy[G];
     double best[G];
     int32_t bidx[G];
     int ux0 = 0x7fffffff, ux1 = -1, uy0 = 0x7fffffff, uy1 = -1;  // the cells of the group's queries
@@ -475,7 +472,9 @@ __global__ __launch_bounds__(PF_BLOCK) void k_knn_coop(const double* __restrict_
         const int64_t qi = q0 + (i < nq ? i : nq - 1);
 #pragma unroll
         for (int c = 0; c < D; ++c) q[i][c] = qry_s[qi * D + c];
-        const int cx = cell_of(pick<D>(q[i], g.a0), g.lo0, g.s0, g.r0), cy = cell_of(pick<D>(q[i], g.a1), g.lo1, g.s1, g.r1);
+        qx[i] = qry_s[qi * D + g.a0];
+        qy[i] = qry_s[qi * D + g.a1];
+        const int cx = cell_of(qx[i], g.lo0, g.s0, g.r0), cy = cell_of(qy[i], g.lo1, g.s1, g.r1);
         ux0 = min(ux0, cx), ux1 = max(ux1, cx);
         uy0 = min(uy0, cy), uy1 = max(uy1, cy);
         best[i] = INFINITY;
@@ -544,9 +543,8 @@ __global__ __launch_bounds__(PF_BLOCK) void k_knn_coop(const double* __restrict_
         for (int i = 0; i < G; ++i) {
             wave_argmin(best[i], bidx[i]);
             all = all && best[i] < INFINITY;
-            const double qx = pick<D>(q[i], g.a0), qy = pick<D>(q[i], g.a1);
             const double rad = sqrt(best[i]) * (1.0 + 1e-9) + 1e-300;  // inflated against the rounding of sqrt / the subtractions
-            double xl = qx - rad, xh = qx + rad, yl = qy - rad, yh = qy + rad;
+            double xl = qx[i] - rad, xh = qx[i] + rad, yl = qy[i] - rad, yh = qy[i] + rad;
             xl -= fabs(xl) * 1e-15;
             xh += fabs(xh) * 1e-15;
             yl -= fabs(yl) * 1e-15;

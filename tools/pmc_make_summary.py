@@ -82,9 +82,27 @@ for label, needle, fdir, wdir in (("k_cheb_resident<2, 1, 8, true>", "k_cheb_res
                           "the launch's steps; hand-off accesses are 8-byte agent-scope loads / stores (outside the guide's "
                           "calibration of FETCH_SIZE, which is for wide streaming reads)")
     kernels[label] = entry
+# the other kernels of the step, from the same two passes: average traffic per dispatch, for comparison with their
+# algorithmic bytes
+others = {}
+if args.fetch and args.write:
+    ftab, wtab = counter_avg(args.fetch, "FETCH_SIZE"), counter_avg(args.write, "WRITE_SIZE")
+    for needle in ("k_orth_dots", "k_orth_project", "k_knn_coop", "k_count_edges", "k_scatter_edges", "k_vec_apply", "k_combine",
+                   "k_fill_sell_entries"):
+        fname, (fcalls, fkb) = pick(ftab, needle)
+        wname, (wcalls, wkb) = pick(wtab, needle)
+        if fname is None or wname is None:
+            continue
+        e = dict(dispatches_counted_fetch=fcalls, dispatches_counted_write=wcalls, hbm_read_bytes_per_launch=2.0 * fkb * 1024.0,
+                 hbm_write_bytes_per_launch=wkb * 1024.0)
+        st = next((v for k, v in stats.items() if needle in k), None)
+        if st:
+            e.update(kernel_trace_calls=st["calls"], kernel_trace_avg_ns=st["avg_ns"],
+                     GBps_of_counter_traffic=(e["hbm_read_bytes_per_launch"] + e["hbm_write_bytes_per_launch"]) / st["avg_ns"])
+        others[needle] = e
 out = dict(source="rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) -- python3 bench.py --steps 2 --warmup 1 "
                   "--no-extras --no-cpu-baseline (250k-vertex pair, k=5); streaming kernel: the same with PF_PERSIST=0",
-           kernels=kernels)
+           kernels=kernels, other_kernels_average_per_dispatch=others)
 with open(args.out, "w") as fh:
     json.dump(out, fh, indent=1)
 print(json.dumps(out, indent=1))
