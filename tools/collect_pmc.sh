@@ -16,4 +16,5 @@ PF_PERSIST=0 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $o
 cd $root
 python3 tools/pmc_make_summary.py --fetch $out/pmc_fetch --write $out/pmc_write --fetch-stream $out/pmc_fetch_stream --write-stream $out/pmc_write_stream \
     --stats profiles/${tag}_kernel_stats.csv --bench profiles/${tag}_bench_under_rocprof.json --out $out/pmc_summary.json > /dev/null
+python3 tools/pmc_list_all.py $out/pmc_fetch $out/pmc_write profiles/${tag}_kernel_stats.csv > $out/all_kernels.md
 rm -rf $out/pmc_fetch $out/pmc_write $out/pmc_fetch_stream $out/pmc_write_stream
