@@ -27,7 +27,8 @@ namespace {
 
 __global__ __launch_bounds__(PF_BLOCK) void k_count_edges(const int32_t* __restrict__ faces, int64_t n_edges,
                                                           int32_t vpf, int64_t n, int32_t* __restrict__ cnt,
-                                                          int32_t* __restrict__ flags, double* __restrict__ quarter) {
+                                                          int32_t* __restrict__ rank, int32_t* __restrict__ flags,
+                                                          double* __restrict__ quarter) {
     const int64_t e = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
     if (e == 0 && quarter) *quarter = 0.25;  // k_face_bound's running minimum starts there (instead of two fills of its own)
     if (e >= n_edges) return;
@@ -43,13 +44,15 @@ __global__ __launch_bounds__(PF_BLOCK) void k_count_edges(const int32_t* __restr
         atomicOr(flags, 2);
         return;
     }
-    atomicAdd(&cnt[src], 1);
+    // the edge's place in its vertex's list is what the count was when it arrived: k_scatter_edges needs no atomic of its
+    // own (1.5 M atomics on scattered addresses per 250k mesh and pass - the two meshes of a pair queue for the same units)
+    rank[e] = atomicAdd(&cnt[src], 1);
 }
 
 __global__ __launch_bounds__(PF_BLOCK) void k_scatter_edges(const int32_t* __restrict__ faces,
                                                             const double* __restrict__ pts, int64_t n_edges,
                                                             int32_t vpf, int64_t n, const int32_t* __restrict__ start,
-                                                            int32_t* __restrict__ cursor, int32_t* __restrict__ rcol,
+                                                            const int32_t* __restrict__ rank, int32_t* __restrict__ rcol,
                                                             double* __restrict__ rw, int32_t* __restrict__ flags) {
     const int64_t e = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
     if (e >= n_edges) return;
@@ -64,7 +67,7 @@ __global__ __launch_bounds__(PF_BLOCK) void k_scatter_edges(const int32_t* __res
     const double d2 = (dx * dx + dy * dy) + dz * dz;  // np.sum(np.square(.)): left to right
     const double wv = 1.0 / sqrt(d2);                 // graph.py:177-178
     if (!isfinite(wv)) atomicOr(flags, 4);            // coincident or non-finite vertices: the reference stores inf / nan
-    const int32_t slot = start[src] + atomicAdd(&cursor[src], 1);
+    const int32_t slot = start[src] + rank[e];
     rcol[slot] = dst;
     rw[slot] = wv;
 }
@@ -784,7 +787,7 @@ struct MeshBuild {
     // The first half in four phases (a pair's two builds are queued phase by phase from ONE thread, see
     // pf_graph_build_device2); begin() runs them in a row.
     static constexpr int N_PHASES = 4;
-    int32_t *b_cnt = nullptr, *b_start = nullptr, *b_cursor = nullptr, *b_rcol = nullptr, *b_ucnt = nullptr, *b_flags = nullptr;
+    int32_t *b_cnt = nullptr, *b_start = nullptr, *b_rank = nullptr, *b_rcol = nullptr, *b_ucnt = nullptr, *b_flags = nullptr;
     double* b_rw = nullptr;
 
     int begin(pf_mesh* m, int stream_id) {
@@ -825,8 +828,9 @@ struct MeshBuild {
             // (the counters that start from zero share one block, and so do deg / g / sg: two memsets instead of seven launches)
             int32_t* zeroed = nullptr;
             const int64_t zstride = (n + 1 + 7) & ~(int64_t)7;
-            PF_TRY(scratch(&zeroed, 3 * zstride + 8));
-            b_cnt = zeroed, b_cursor = zeroed + zstride, b_ucnt = zeroed + 2 * zstride, b_flags = zeroed + 3 * zstride;
+            PF_TRY(scratch(&zeroed, 2 * zstride + 8));
+            b_cnt = zeroed, b_ucnt = zeroed + zstride, b_flags = zeroed + 2 * zstride;
+            PF_TRY(scratch(&b_rank, n_edges));
             PF_TRY(scratch(&b_start, n + 1));
             PF_TRY(scratch(&b_rcol, n_edges));
             PF_TRY(scratch(&b_rw, n_edges));
@@ -842,13 +846,13 @@ struct MeshBuild {
             PF_TRY(dev_alloc(st, &g->smooth, g->n_pad));
             PF_TRY(dev_alloc(st, &g->slice_ptr, g->n_slices + 1));
 
-            PF_HIP(hipMemsetAsync(zeroed, 0, sizeof(int32_t) * (size_t)(3 * zstride + 8), st));
+            PF_HIP(hipMemsetAsync(zeroed, 0, sizeof(int32_t) * (size_t)(2 * zstride + 8), st));
             PF_HIP(hipMemsetAsync(g->deg, 0, sizeof(double) * 3 * g->n_pad, st));
             if (sid == 0) PF_HIP(hipEventRecord(ctx->ev0, st));
 
             if (face_bound) PF_TRY(scratch(&pmin, 1));
             if (n_edges) {
-                k_count_edges<<<nblk(n_edges), PF_BLOCK, 0, st>>>(d_faces, n_edges, vpf, n, b_cnt, b_flags, reinterpret_cast<double*>(pmin));
+                k_count_edges<<<nblk(n_edges), PF_BLOCK, 0, st>>>(d_faces, n_edges, vpf, n, b_cnt, b_rank, b_flags, reinterpret_cast<double*>(pmin));
                 PF_HIP(hipGetLastError());
             }
             // No read-back on the way: faces the counting kernel flags (index out of range, repeated vertex) are skipped by
@@ -857,7 +861,7 @@ struct MeshBuild {
             // (each one costs ~30 us of idle device: 8 per mesh at first, 2 now).
             PF_TRY(pf_exclusive_scan_i32(st, b_cnt, b_start, n + 1));
             if (n_edges) {
-                k_scatter_edges<<<nblk(n_edges), PF_BLOCK, 0, st>>>(d_faces, d_pts, n_edges, vpf, n, b_start, b_cursor, b_rcol, b_rw, b_flags);
+                k_scatter_edges<<<nblk(n_edges), PF_BLOCK, 0, st>>>(d_faces, d_pts, n_edges, vpf, n, b_start, b_rank, b_rcol, b_rw, b_flags);
                 PF_HIP(hipGetLastError());
             }
             return PF_OK;
