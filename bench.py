@@ -187,9 +187,70 @@ def bundled_15k_pair(ctx, k=5, reps=3):
             err = max(err, float(np.max(np.abs(g.eig_vals[:len(gv)] / gv - 1.0))))
         if best is None or dt < best[0]:
             best = (dt, timers)
-    return dict(workload="C2: data/target_mesh_15k.vtk + data/source_mesh_15k.vtk (14998 / 14996 vertices), k=5",
-                ms=1e3 * best[0], eigenpairs_per_s=2 * k / best[0], matvecs=best[1]["matvecs"],
+    return dict(workload="C2: data/target_mesh_15k.vtk + data/source_mesh_15k.vtk (14998 / 14996 vertices), k=5; asymmetric W "
+                         "(one-way edges): restarted Arnoldi on L, both graphs in shared launches",
+                ms=1e3 * best[0], eigenpairs_per_s=2 * k / best[0],
+                breakdown_ms={key: 1e3 * best[1][key] for key in ("assembly", "eigensolve", "eigsort", "knn")},
+                matvecs=best[1]["matvecs"], solver_modes=[int(getattr(g.eigs_stats, "mode", -1)) for g in graphs],
                 max_rel_eigenvalue_error_vs_reference=err)
+
+
+def messy_250k_pair(ctx, n=250000, k=5, samples=5000, reps=3, check_cpu=True):
+    """The headline pair with the defect classes of the reference's scanned meshes (`meshgen.messy_blob_mesh`:
+    ten small holes, stranded vertices, reversed and duplicated faces: ~50 one-way edges per mesh): W asymmetric
+    (graph.py:178), three extra null eigenvalues for the widen-and-retry rule (graph.py:374-379).  Untimed extra: stage
+    times of the best of `reps` passes, the eigenvalue error of one mesh against the oracle's `recursive_eig` (scipy
+    eigs), 96 correspondence rows against a brute-force scan."""
+    from pyfocusr_amd import _hip
+    from pyfocusr_amd.meshgen import messy_blob_mesh
+
+    meshes = [messy_blob_mesh(n, seed=s) for s in (0, 1)]
+    for m in meshes:
+        m._pf_device_mesh = _hip.DeviceMesh(m.points, m.faces, ctx=ctx)
+    best = None
+    for _ in range(reps + 1):
+        timers = dict(assembly=0.0, eigensolve=0.0, eigsort=0.0, knn=0.0, matvecs=0)
+        t0 = time.perf_counter()
+        graphs = hot_path_step([ctx, ctx], meshes[0], meshes[1], k, samples, timers, keep_graphs=True)
+        dt = time.perf_counter() - t0
+        if best is None or dt < best[0]:
+            best = (dt, timers, graphs)
+    gt, gs = best[2]
+    out = dict(workload="the C3 pair (%d vertices, k=%d) with scan defects: per mesh 7 triangular + 3 hexagonal holes, 3 stranded "
+                        "vertices, 2 reversed faces, 2 edges in three faces" % (n, k),
+               ms=1e3 * best[0], eigenpairs_per_s=2 * k / best[0],
+               breakdown_ms={key: 1e3 * best[1][key] for key in ("assembly", "eigensolve", "eigsort", "knn")},
+               matvecs=best[1]["matvecs"], columns=[int(len(g.eig_vals)) for g in (gt, gs)],
+               solver_modes=[int(getattr(g.eigs_stats, "mode", -1)) for g in (gt, gs)],
+               outer_steps=[int(g.eigs_stats.outer_steps) for g in (gt, gs)],
+               max_eig_residual=float(max(g.eigs_stats.residuals.max() for g in (gt, gs))))
+    # correspondences of 96 source rows against a brute force over all target rows (the coordinates the search used)
+    np.random.seed(4321)
+    timers = dict(assembly=0.0, eigensolve=0.0, eigsort=0.0, knn=0.0, matvecs=0)
+    idx, _, _, (vt, vs, w, vals_t, vals_s) = hot_path_step([ctx, ctx], meshes[0], meshes[1], k, samples, timers)
+    tgt, src = vt[:, :k] * w[None, :], vs[:, :k] * w[None, :]
+    rows = np.linspace(0, n - 1, 96).astype(np.int64)
+    bad = 0
+    for r in rows:
+        d2 = np.zeros(n)
+        for c in range(k):
+            d2 += (src[r, c] - tgt[:, c]) ** 2
+        bad += int(np.argmin(d2) != idx[r])
+    out["knn_rows_checked_bruteforce"], out["knn_index_mismatches"] = int(len(rows)), bad
+    if check_cpu:
+        from oracle import reference_port as orc
+
+        t0 = time.perf_counter()
+        W, deg, d_inv, L = orc.graph_matrices(meshes[0].points, meshes[0].faces)
+        ref_vals, _ = orc.recursive_eig(L, k + 1, k)
+        ref_vals = np.sort(ref_vals)
+        out["cpu_oracle_seconds_one_mesh"] = time.perf_counter() - t0
+        m = min(len(ref_vals), len(vals_t))
+        out["columns_of_the_oracle"] = int(len(ref_vals))
+        out["max_rel_eigenvalue_error_vs_oracle"] = float(np.max(np.abs(np.asarray(vals_t)[:m] / ref_vals[:m] - 1.0)))
+    for m_ in meshes:
+        del m_._pf_device_mesh
+    return out
 
 
 def c5_1m_k10(ctx, n=1000000, k=10, samples=5000, reps=2):
@@ -324,6 +385,34 @@ def split_pair_step(ctx, dist, torch, tdev, rank, mesh, k, n_samples):
     return np.concatenate([p[:, 0] for p in parts]).astype(np.int64)
 
 
+def free_port():
+    import socket
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        return sock.getsockname()[1]
+
+
+def spawn_command(n_gpus, argv, port):
+    """The launcher line of the contract for N ranks on one node (what the driver itself runs for N > 1)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus), "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def spawn_ranks(n_gpus, argv=None):
+    """Run this script's ranks as children of a process that has not touched the GPU; returns the exit status to pass on
+    (the launcher's: non-zero if any rank failed; rank 0's JSON line goes to stdout as it is printed)."""
+    import subprocess
+
+    cmd = spawn_command(n_gpus, sys.argv[1:] if argv is None else argv, free_port())
+    if os.environ.get("PF_BENCH_SPAWN_DRYRUN") == "1":  # (tests: the command only)
+        print(json.dumps(cmd))
+        return 0
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # (dmabuf IPC: what RCCL needs on this pool's hosts)
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -360,8 +449,13 @@ def main():
     if args.k < 2:
         raise SystemExit("bench.py: --k must be >= 2 (with a single eigenmap the reference's eigenvalue-gap cost, "
                          "eigsort.py:149-158, is the mean of an empty difference: NaN)")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # a plain `python bench.py --gpus N`: start the N ranks ourselves, as fresh child processes (one per GPU over
+        # torch.distributed.run), BEFORE this process has made any GPU call - it never will: it relays the ranks' output
+        # and exits with their status
+        raise SystemExit(spawn_ranks(args.gpus))
     if world != args.gpus:
-        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
 
     import torch
 
@@ -656,6 +750,12 @@ def main():
             except Exception as exc:  # noqa: BLE001
                 out["single_graph_solve"] = dict(error="%s: %s" % (type(exc).__name__, exc))
                 failed.append("single_graph_solve")
+            try:
+                out["messy_250k_pair"] = messy_250k_pair(ctx, n=args.n, k=args.k, samples=args.samples, check_cpu=not args.no_cpu_baseline)
+                out["messy_250k_pair"]["ratio_to_clean_pair"] = out["messy_250k_pair"]["ms"] / out["ms_per_step"]
+            except Exception as exc:  # noqa: BLE001
+                out["messy_250k_pair"] = dict(error="%s: %s" % (type(exc).__name__, exc))
+                failed.append("messy_250k_pair")
             try:
                 out["c5_1m_k10"] = c5_1m_k10(ctx)
             except Exception as exc:  # noqa: BLE001 - an extra: recorded, and the exit status says so

@@ -219,7 +219,7 @@ int pf_orth_begin2(pf_graph* ga, int32_t w_a, int32_t first_a, int32_t count_a, 
  * does not wait for the host between the two).  orth[8] = {w, first, count, normalize} of a, then of b; cheb_i[8] =
  * {op, src, dst, degree} of a, then of b; cheb_d[6] = {c, e, rho} of a, then of b. */
 int pf_orth_cheb2(pf_graph* ga, pf_graph* gb, const int32_t* orth, const int32_t* cheb_i, const double* cheb_d);
-/* 1 if the last pf_orth_end found that the first Gram-Schmidt pass had cancelled digits (|w'| < 0.3 |w|) and ran the
+/* 1 (2: see pf_orth_device_passes) if the last pf_orth_end found that the first Gram-Schmidt pass had cancelled digits (|w'| < 0.3 |w|) and ran the
  * second pass itself, after everything queued behind pf_orth_begin: work queued in between that READ slot w (the next
  * filter application of a pipelined driver) saw the un-refined, un-normalised vector and has to be repeated.  Rare:
  * never on the 250k blobs, a few times per solve right after a restart on small graphs. */
@@ -228,6 +228,13 @@ int pf_orth_redone(pf_graph* g);
  * iterations that come close to exhausting a small space (unfiltered solves of tiny graphs), where the loose criterion
  * loses orthogonality.  Per graph; off by default. */
 int pf_orth_strict(pf_graph* g, int32_t on);
+/* on != 0: pf_orth_begin / pf_orth_begin2 / pf_orth_cheb2 queue the second pass together with the first; it runs on the
+ * device's own verdict (two launches that return at once when the first pass was fine) and reports h1 + h2 itself, so
+ * work queued behind the step never reads a stale w: pf_orth_redone then returns 2 ("two passes, nothing to repeat")
+ * instead of 1.  For iterations whose steps often cancel digits - restarted Arnoldi with strongly amplified outliers in
+ * the basis (asymmetric W): a repeated filter application costs more than the ~5 us of the two idle launches.  Per graph;
+ * off by default. */
+int pf_orth_device_passes(pf_graph* g, int32_t on);
 int pf_scale(pf_graph* g, int32_t slot, double alpha);
 /* slots [dst_first, dst_first+k) = slots [src_first, src_first+m) * Y, Y row-major m x k; ranges must not overlap */
 int pf_combine(pf_graph* g, int32_t src_first, int32_t m, const double* Y, int32_t k, int32_t dst_first);
@@ -261,6 +268,10 @@ int pf_final_remap_begin(pf_graph* g, const int32_t* col, const double* sign, in
 /* Pinned (page-locked) host memory for results that should arrive by one DMA; independent of any ctx. */
 int pf_host_alloc(size_t bytes, void** out);
 int pf_host_free(void* p);
+/* Before a pinned block is reused without being freed (a caller-side pool): forget any eigenvector download the library
+ * still owes to it (held back by pf_finalize_vectors_begin; left behind by a call that failed) and wait for one in flight.
+ * pf_host_free does the same before it unmaps the block. */
+int pf_host_detach(void* p);
 /* The block written by the last pf_finalize_vectors stays resident in HBM.  out[t][c] = that block's row rows[t]
  * (n_rows x count, row-major): the sampled eigenvector rows of Graph.get_rand_eig_vecs (graph.py:266-267) without
  * touching the host copy. */
@@ -331,9 +342,13 @@ int pf_knn_download(pf_ctx* ctx, int64_t* idx_out, double* d2_out);
  * [n][*n_out] row-major, unit 2-norm, sign fixed (largest-|entry| positive), min-max normalised to [-0.5, 0.5] when
  * minmax != 0 (graph.py:254-257).  The reference's widen-and-retry rule (graph.py:369-384) only changes HOW MANY pairs
  * it asks for: a caller that wants its column count asks for k_final - #nulls, with #nulls = n_components +
- * n_isolated of pf_graph_get_info.  Covers symmetric W (no one-way edges) and graphs of at least ~100 vertices;
- * PF_E_STATE otherwise — pyfocusr_amd/_krylov.py is the general driver (asymmetric W, complex spectra, two graphs per
- * launch).  vals needs room for n_wanted values, vecs for n * n_wanted. */
+ * n_isolated of pf_graph_get_info.  Symmetric W: thick-restart Lanczos on S = G^1/2 (D - W) G^1/2.  Asymmetric W
+ * (one-way edges, graph.py:178: both bundled 15k meshes): restarted Arnoldi on L itself - the complex eigenvalues of
+ * the non-normal L are carried as dominant Ritz values of the interval filter, or, when the low eigenvalues are complex
+ * themselves (open surfaces), enclosed by the ellipse filter; real parts are returned as the reference does
+ * (graph.py:386-389), a conjugate pair as a repeated value with a fixed phase.  Graphs of fewer than ~100 vertices and
+ * operators whose wanted eigenvalues are no corner of the spectrum are refused with PF_E_STATE (pyfocusr_amd/_krylov.py
+ * keeps the unfiltered mode for them).  vals needs room for n_wanted values, vecs for n * n_wanted. */
 typedef struct pf_eigs_stats {
     int64_t matvecs;      /* SpMV-equivalent launches */
     int32_t outer_steps;  /* Lanczos steps */
@@ -344,11 +359,16 @@ typedef struct pf_eigs_stats {
     double cut;           /* lower end of the damped interval */
     double max_residual;  /* max ||S x - lambda x||_2 of the returned pairs */
     int32_t second_passes; /* outer steps whose Gram-Schmidt projection cancelled digits (second pass run) */
-    int32_t reserved;
+    int32_t mode;          /* 0: symmetric W (Lanczos on S); 1: asymmetric W, interval filter (Arnoldi on L, complex outliers carried); 2: ellipse filter */
 } pf_eigs_stats;
 int pf_eigs_smallest(pf_graph* g, int32_t n_wanted, int32_t minmax, double* vals, double* vecs, int32_t* n_out,
                      pf_eigs_stats* stats);
-/* The two graphs of a pair (target and source mesh of focusr.py:134-170; one ctx, both symmetric) solved TOGETHER: the
+/* The same with the options of the pair call: residuals (nullable) = ||A x - lambda x||_2 per returned pair;
+ * async_download = 1: the call returns with the eigenvector download still in flight into vecs (pinned: pf_host_alloc) -
+ * pf_finalize_vectors_end(g) before reading it. */
+int pf_eigs_smallest_ex(pf_graph* g, int32_t n_wanted, int32_t minmax, int32_t async_download, double* vals, double* vecs,
+                        double* residuals, int32_t* n_out, pf_eigs_stats* stats);
+/* The two graphs of a pair (target and source mesh of focusr.py:134-170; one ctx; symmetric or not, each by its own) solved TOGETHER: the
  * two iterations advance in lockstep, every Gram-Schmidt step and filter application that both have pending runs in
  * launches the graphs share (pf_orth_cheb2: one library call and three launches per outer step of the pair), one graph
  * finishes alone once its partner has converged.  res_a / res_b (nullable): ||S x - lambda x||_2 per returned pair.

@@ -43,7 +43,7 @@ class GraphInfo(C.Structure):
 class EigsStats(C.Structure):
     _fields_ = [("matvecs", C.c_int64), ("outer_steps", C.c_int32), ("restarts", C.c_int32), ("filter_resets", C.c_int32),
                 ("degree", C.c_int32), ("n_null", C.c_int32), ("cut", C.c_double), ("max_residual", C.c_double),
-                ("second_passes", C.c_int32), ("reserved", C.c_int32)]
+                ("second_passes", C.c_int32), ("mode", C.c_int32)]
 
 
 class Timing(C.Structure):
@@ -128,6 +128,10 @@ SIGNATURES = {
     "pf_knn_run": (C.c_int, [C.c_void_p]),
     "pf_knn_download": (C.c_int, [C.c_void_p, _i64p, _f64p]),
     "pf_eigs_smallest": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _f64p, _f64p, C.POINTER(C.c_int32), C.POINTER(EigsStats)]),
+    "pf_host_detach": (C.c_int, [C.c_void_p]),
+    "pf_orth_device_passes": (C.c_int, [C.c_void_p, C.c_int32]),
+    "pf_eigs_smallest_ex": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, _f64p, _f64p, _f64p, C.POINTER(C.c_int32),
+                                      C.POINTER(EigsStats)]),
     "pf_eigs_smallest2": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                     _f64p, _f64p, _f64p, C.POINTER(C.c_int32), C.POINTER(EigsStats),
                                     _f64p, _f64p, _f64p, C.POINTER(C.c_int32), C.POINTER(EigsStats)]),
@@ -217,16 +221,32 @@ class _PinnedBlock(object):
 
 _pinned_free = {}  # nbytes -> [ptr]: blocks of collected arrays, reused by the next result of the same size
 _pinned_cached = [0]
-_PINNED_CACHE_BYTES = 1 << 30
+_pinned_lock = threading.Lock()  # (compute_spectra runs one host thread per context; arrays are collected on any thread)
+_PINNED_CACHE_BYTES = 256 << 20  # page-locked memory kept for reuse: four 250k x 5 result pairs and their remapped images
 
 
 def _pinned_release(ptr, nbytes):
     if _pinned_free is None or _lib is None:
         return
-    if _pinned_cached[0] + nbytes <= _PINNED_CACHE_BYTES:
-        _pinned_free.setdefault(nbytes, []).append(ptr)
-        _pinned_cached[0] += nbytes
-    else:
+    # a download the library still OWES to this block (pf_finalize_vectors_begin holds downloads back; a failed call may
+    # have left one behind) must never be queued once the block can be handed out again; one in flight is waited for
+    _lib.pf_host_detach(C.c_void_p(ptr))
+    with _pinned_lock:
+        keep = _pinned_cached[0] + nbytes <= _PINNED_CACHE_BYTES
+        if keep:
+            _pinned_free.setdefault(nbytes, []).append(ptr)
+            _pinned_cached[0] += nbytes
+    if not keep:
+        _lib.pf_host_free(C.c_void_p(ptr))
+
+
+def pinned_trim():
+    """Give the cached page-locked blocks back to the system (they are kept for reuse otherwise, up to 256 MiB)."""
+    with _pinned_lock:
+        blocks = [p for ptrs in _pinned_free.values() for p in ptrs]
+        _pinned_free.clear()
+        _pinned_cached[0] = 0
+    for ptr in blocks:
         _lib.pf_host_free(C.c_void_p(ptr))
 
 
@@ -239,11 +259,13 @@ def pinned_empty(shape, dtype=np.float64):
     count = int(np.prod(shape)) if len(shape) else 1
     nbytes = max(count * dtype.itemsize, 1)
     nbytes = (nbytes + 4095) & ~4095
-    free = _pinned_free.get(nbytes)
-    if free:
-        ptr = free.pop()
-        _pinned_cached[0] -= nbytes
-    else:
+    ptr = None
+    with _pinned_lock:
+        free = _pinned_free.get(nbytes)
+        if free:
+            ptr = free.pop()
+            _pinned_cached[0] -= nbytes
+    if ptr is None:
         p = C.c_void_p()
         _check(lib.pf_host_alloc(C.c_size_t(nbytes), C.byref(p)))
         ptr = int(p.value)
@@ -826,12 +848,19 @@ class DeviceLaplacian(object):
         """Second Gram-Schmidt pass at the classical threshold (|w'| < 0.71 |w|) instead of the loose one (0.3)."""
         _check(self._lib.pf_orth_strict(self._h, int(bool(on))))
 
+    def orth_device_passes(self, on):
+        """The second Gram-Schmidt pass queued with the first, run on the device's own verdict (`pf_orth_device_passes`):
+        nothing queued behind a step ever reads a stale vector (`orth_redone` stays False, `orth_twice` tells)."""
+        _check(self._lib.pf_orth_device_passes(self._h, int(bool(on))))
+
     def orth_end(self):
         h = np.empty(max(self._orth_count, 1), dtype=np.float64)
         nrm = C.c_double()
         _check(self._lib.pf_orth_end(self._h, _f64(h), C.byref(nrm)))
         # the step needed its second Gram-Schmidt pass, run only now: anything queued since orth_begin that read w is stale
-        self.orth_redone = self._lib.pf_orth_redone(self._h) == 1
+        r = self._lib.pf_orth_redone(self._h)
+        self.orth_redone = r == 1
+        self.orth_twice = r == 2  # (both passes ran on the device, before anything queued behind them)
         return h[: self._orth_count], float(nrm.value)
 
     def orth_abandon(self):
@@ -935,19 +964,29 @@ class DeviceLaplacian(object):
         _check(self._lib.pf_spmv_host(self._h, self.op if op is None else int(op), _f64(x), _f64(y)))
         return y
 
-    def eigs_smallest(self, n_wanted, minmax=False):
-        """`pf_eigs_smallest`: the eigensolve as ONE C call (symmetric W only) -> (vals, vecs (n, m), stats dict)."""
-        vals = np.empty(int(n_wanted))
-        vecs = np.empty((self.n, int(n_wanted)))
-        n_out, st = C.c_int32(), EigsStats()
-        _check(self._lib.pf_eigs_smallest(self._h, int(n_wanted), int(bool(minmax)), _f64(vals), _f64(vecs), C.byref(n_out),
-                                          C.byref(st)))
-        m = n_out.value
-        out = np.ascontiguousarray(vecs.reshape(-1)[: self.n * m].reshape(self.n, m))
-        return vals[:m].copy(), out, {f: getattr(st, f) for f, _ in EigsStats._fields_}
+    def eigs_smallest(self, n_wanted, minmax=False, wait=True):
+        """`pf_eigs_smallest_ex`: the eigensolve as ONE C call -> (vals, vecs (n, m) in pinned memory, stats dict with a
+        `residuals` array).  `wait=False`: the eigenvector download is still in flight (`finalize_wait()`)."""
+        m = int(n_wanted)
+        vals, vecs, resid, n_out, st = np.empty(m), pinned_empty((self.n, m)), np.zeros(m), C.c_int32(), EigsStats()
+        _check(self._lib.pf_eigs_smallest_ex(self._h, m, int(bool(minmax)), 0 if wait else 1, _f64(vals), _f64(vecs), _f64(resid),
+                                             C.byref(n_out), C.byref(st)))
+        return self._eigs_result(vals, vecs, resid, n_out.value, st, wait)
+
+    def _eigs_result(self, vals, vecs, resid, m, st, wait):
+        self._final_count = m
+        self._final_pending = (not wait) and m > 0
+        self._final_out = vecs if self._final_pending else None  # (kept alive until the download has been collected)
+        if m != vecs.shape[1]:  # fewer pairs than asked for: the library wrote an (n, m) block
+            if self._final_pending:
+                self.finalize_wait()
+            vecs = np.ascontiguousarray(vecs.reshape(-1)[: self.n * m].reshape(self.n, m))
+        stats = {f: getattr(st, f) for f, _ in EigsStats._fields_}
+        stats["residuals"] = resid[:m].copy()
+        return vals[:m].copy(), vecs, stats
 
     def eigs_smallest2(self, other, n_wanted, n_wanted_other, minmax=False, wait=True):
-        """`pf_eigs_smallest2`: this graph and `other` (same ctx, both with symmetric W) solved together in ONE C call -
+        """`pf_eigs_smallest2`: this graph and `other` (same ctx) solved together in ONE C call -
         the pipelined pair driver in C++.  Returns two tuples (vals, vecs (n, m) in pinned memory, stats dict with a
         `residuals` array).  `wait=False`: the eigenvector downloads are still in flight (`finalize_wait()` on each)."""
         outs = []
@@ -957,20 +996,7 @@ class DeviceLaplacian(object):
         _check(self._lib.pf_eigs_smallest2(self._h, other._h, int(n_wanted), int(n_wanted_other), int(bool(minmax)), 0 if wait else 1,
                                            _f64(va), _f64(xa), _f64(ra), C.byref(na), C.byref(sa),
                                            _f64(vb), _f64(xb), _f64(rb), C.byref(nb), C.byref(sb)))
-        res = []
-        for dev, (vals, vecs, resid, n_out, st) in zip((self, other), outs):
-            m = n_out.value
-            dev._final_count = m
-            dev._final_pending = (not wait) and m > 0
-            dev._final_out = vecs if dev._final_pending else None  # (kept alive until the download has been collected)
-            if m != vecs.shape[1]:  # fewer pairs than asked for: the library wrote an (n, m) block
-                if dev._final_pending:
-                    dev.finalize_wait()
-                vecs = np.ascontiguousarray(vecs.reshape(-1)[: dev.n * m].reshape(dev.n, m))
-            stats = {f: getattr(st, f) for f, _ in EigsStats._fields_ if f != "reserved"}
-            stats["residuals"] = resid[:m].copy()
-            res.append((vals[:m].copy(), vecs, stats))
-        return res[0], res[1]
+        return tuple(dev._eigs_result(vals, vecs, resid, n_out.value, st, wait) for dev, (vals, vecs, resid, n_out, st) in zip((self, other), outs))
 
     # ---- primitives of the row-partitioned solve (pyfocusr_amd/rowpart.py)
     def op_step(self, x, prev, out, alpha, c, beta, op=None):

@@ -236,13 +236,14 @@ int pf_host_alloc(size_t bytes, void** out) {
     return PF_OK;
 }
 
-int pf_host_free(void* p) {
+// a download that is still OWED to this block (pf_finalize_vectors_begin holds it back) must never be queued: the device
+// would write into memory that is about to be unmapped or handed to somebody else; one that is in flight is waited for
+int pf_host_detach(void* p) {
     if (!p) return PF_OK;
-    // a download that is still OWED to this block (pf_finalize_vectors_begin holds it back) must never be queued: the
-    // device would write into unmapped memory; one that is in flight is waited for
-    {
-        std::lock_guard<std::mutex> lk(g_ctx_mutex);
-        for (pf_ctx* c : g_ctxs) {
+    std::lock_guard<std::mutex> lk(g_ctx_mutex);
+    for (pf_ctx* c : g_ctxs) {
+        {
+            std::lock_guard<std::mutex> lk2(c->deferred_mutex);
             for (size_t i = 0; i < c->deferred.size();) {
                 pf_graph* g = c->deferred[i];
                 if (g->dl_src && g->dl_dst == p) {
@@ -252,9 +253,15 @@ int pf_host_free(void* p) {
                     ++i;
                 }
             }
-            if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
         }
+        if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
     }
+    return PF_OK;
+}
+
+int pf_host_free(void* p) {
+    if (!p) return PF_OK;
+    PF_TRY(pf_host_detach(p));
     PF_HIP(hipHostFree(p));
     return PF_OK;
 }

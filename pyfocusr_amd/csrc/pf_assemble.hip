@@ -923,6 +923,7 @@ void pf_graph_free(pf_graph* g) {
     hipStream_t st = g->ctx->stream;
     (void)pf_finalize_vectors_end(g);  // a download still in flight reads final_vecs
     {
+        std::lock_guard<std::mutex> lk(g->ctx->deferred_mutex);
         auto& dq = g->ctx->deferred;
         dq.erase(std::remove(dq.begin(), dq.end(), g), dq.end());
     }

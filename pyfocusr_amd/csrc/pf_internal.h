@@ -150,7 +150,8 @@ struct pf_ctx {
     std::function<void()> worker_task;
     bool worker_busy = false, worker_stop = false;
     hipEvent_t join_ev = nullptr;
-    std::vector<pf_graph*> deferred;  // graphs with a download that is not queued yet
+    std::vector<pf_graph*> deferred;  // graphs with a download that is not queued yet ...
+    std::mutex deferred_mutex;        // ... guarded: pf_host_free / pf_host_detach walk every ctx's list from whatever thread collects an array
     int64_t alloc_misses = 0;  // allocations the cache could not serve (hipMalloc: 0.1-1 ms each)
     uint64_t alloc_epoch = 1;
     uint64_t visible[2] = {0, 0};  // stream sid may take the OTHER stream's blocks released before this epoch
@@ -255,6 +256,8 @@ struct pf_graph {
     double orth_serial = 0.0;    // tickets handed to the fused Gram-Schmidt kernels so far
     double orth_ticket = 0.0;    // ticket of the step in flight (0: that step reports through orth_ev instead)
     double orth_thresh = 0.09;   // second pass when |w'|^2 < orth_thresh |w|^2 (0.5: strict, pf_orth_strict)
+    int32_t orth_device_passes = 0;  // 1: the second Gram-Schmidt pass is queued with the first and runs on the device's own verdict
+    int32_t orth_twice = 0;          // the last collected step took both passes on the device
     // the last pf_finalize_vectors result stays in HBM (mesh order, [n][final_count] row-major) for pf_final_rows and
     // pf_knn1_graphs: the spectral coordinates never have to come back from the host
     double* final_vecs = nullptr;
@@ -291,6 +294,7 @@ int pf_pinned_scratch(pf_ctx* c, size_t bytes, void** out, int sid = 0);  // sid
 // sizes rounded up to 8 bytes
 int pf_copy_by_kernel(hipStream_t st, const void* src, void* dst, size_t bytes);
 int pf_downloads_release(pf_ctx* c);  // queue every download of the ctx that was held back (behind what the ctx stream holds now)
+int pf_download_cancel(pf_graph* g);  // forget the image owed to the caller's buffer / wait for the one in flight (a call is about to fail)
 // `waiter_sid` (0: stream, 1: stream_b) waits for everything queued on the other stream so far; afterwards it may reuse
 // the blocks the other stream has released, and use what the other stream has written
 int pf_streams_join(pf_ctx* c, int waiter_sid);

@@ -227,6 +227,12 @@ struct OrthArgs {
     double* host_out;  // pinned: h, |w'|^2, redo, then the ticket (written last: the host polls it)
     double thresh;     // second pass when |w'|^2 < thresh |w|^2
     double ticket;     // this step's number (> 0)
+    // The second pass ON THE DEVICE (pf_orth_device_passes): the two kernels are queued twice; pass 1 leaves its verdict in
+    // device memory and reports to the host only if it was fine, pass 2 returns at once unless the verdict asks for it and
+    // reports h1 + h2 and the norm itself.  Whatever is queued behind (the next filter application of a pipelined driver)
+    // then always reads the final vector - no pf_orth_redone, no repeated application.
+    int32_t pass;      // 0: one pass, a raised verdict is the host's business (pf_orth_end); 1 / 2: first / second of two; -1: not this graph
+    double* verdict;   // device copy of pass 1's verdict
 };
 struct OrthArgs2 {
     OrthArgs g[2];
@@ -239,7 +245,8 @@ __global__ __launch_bounds__(PF_BLOCK) void k_orth_dots(OrthArgs2 a2) {
     const OrthArgs& a = a2.g[blockIdx.z];
     const int b = blockIdx.y;
     const int64_t chunk = blockIdx.x;
-    if (b > a.count || chunk >= a.n_chunks) return;  // (block-uniform: the grid is sized for the larger graph of a pair)
+    if (a.pass < 0 || b > a.count || chunk >= a.n_chunks) return;  // (block-uniform: the grid is sized for the larger graph of a pair)
+    if (a.pass == 2 && *a.verdict == 0.0) return;                  // (the first pass was fine)
     const double* v = a.ws + (int64_t)(b == a.count ? a.wslot : a.first + b) * a.n_pad;
     const double* w = a.ws + (int64_t)a.wslot * a.n_pad;
     const int64_t lo = chunk * PF_DOT_CHUNK;
@@ -262,7 +269,8 @@ __global__ __launch_bounds__(PF_BLOCK) void k_orth_project(OrthArgs2 a2) {
     __shared__ double hs[PF_ORTH_MAX + 1];
     __shared__ double s_scale, s_after, s_redo;
     const OrthArgs& a = a2.g[blockIdx.z];
-    if (2 * (int64_t)blockIdx.x * PF_BLOCK >= a.n_pad) return;  // (block-uniform)
+    if (a.pass < 0 || 2 * (int64_t)blockIdx.x * PF_BLOCK >= a.n_pad) return;  // (block-uniform)
+    if (a.pass == 2 && *a.verdict == 0.0) return;
     const int lane = threadIdx.x & (PF_WAVE - 1);
     const int32_t count = a.count;
     for (int b = threadIdx.x / PF_WAVE; b < count + 1; b += PF_BLOCK / PF_WAVE) {
@@ -277,28 +285,35 @@ __global__ __launch_bounds__(PF_BLOCK) void k_orth_project(OrthArgs2 a2) {
         double sum = 0.0;
         for (int b = 0; b < count; ++b) sum += hs[b] * hs[b];
         const double before = hs[count], after = before - sum;
-        const bool fine = after >= a.thresh * before;  // (false for NaN and for a vanished vector: take the second pass)
-        s_redo = fine ? 0.0 : 1.0;
+        // (false for NaN and for a vanished vector: take the second pass.  The second pass itself is final - "twice is
+        // enough" - unless it produced no number at all: verdict 1 then hands the step to pf_orth_end's own passes)
+        const bool fine = a.pass == 2 ? (after == after) : after >= a.thresh * before;
+        s_redo = fine ? (a.pass == 2 ? 2.0 : 0.0) : 1.0;
         s_after = after;
         s_scale = (fine && a.normalize && after > 1e-280) ? 1.0 / sqrt(after) : 1.0;
     }
     __syncthreads();
     if (blockIdx.x == 0) {
+        const bool report = !(a.pass == 1 && s_redo != 0.0);  // (a first pass that asks for the second leaves the report to it)
         for (int b = threadIdx.x; b < count; b += PF_BLOCK) {
-            a.hsum[b] = hs[b];
-            a.host_out[b] = hs[b];
+            const double hb = a.pass == 2 ? a.hsum[b] + hs[b] : hs[b];
+            a.hsum[b] = hb;
+            if (report) a.host_out[b] = hb;
         }
         if (threadIdx.x == 0) {
+            if (a.pass == 1) *a.verdict = s_redo;
             *a.nrm2 = s_after;
-            a.host_out[count] = s_after;
-            a.host_out[count + 1] = s_redo;
+            if (report) {
+                a.host_out[count] = s_after;
+                a.host_out[count + 1] = s_redo;
+            }
         }
         // the ticket goes out behind everything else (system-scope fences + the block's barrier): the host polls it
         // instead of waiting for an event behind the kernel - the coefficients are known long before the projection
         // below has finished, and an event record would cost ~5 us of device time per step
         __threadfence_system();
         __syncthreads();
-        if (threadIdx.x == 0) {
+        if (threadIdx.x == 0 && report) {
             __hip_atomic_store(a.host_out + count + 2, a.ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
@@ -1242,6 +1257,8 @@ static OrthArgs orth_args(pf_graph* g, int32_t w, int32_t first, int32_t count, 
     g->orth_serial += 1.0;
     a.ticket = g->orth_serial;
     g->orth_ticket = a.ticket;  // pf_orth_end polls for it
+    a.pass = g->orth_device_passes ? 1 : 0;
+    a.verdict = g->coef + 3 * g->coef_cap;
     return a;
 }
 
@@ -1261,6 +1278,13 @@ int pf_orth_begin(pf_graph* g, int32_t w, int32_t first, int32_t count, int32_t 
         PF_HIP(hipGetLastError());
         k_orth_project<<<dim3(nblk(g->n_pad / 2), 1u, 1u), PF_BLOCK, 0, st>>>(a2);
         PF_HIP(hipGetLastError());
+        if (a2.g[0].pass == 1) {  // the second pass, on the device's own verdict
+            a2.g[0].pass = 2;
+            k_orth_dots<<<dim3((unsigned)g->n_chunks, (unsigned)(count + 1), 1u), PF_BLOCK, 0, st>>>(a2);
+            PF_HIP(hipGetLastError());
+            k_orth_project<<<dim3(nblk(g->n_pad / 2), 1u, 1u), PF_BLOCK, 0, st>>>(a2);
+            PF_HIP(hipGetLastError());
+        }
     } else if (count == 0) {
         k_dot_partial<<<dim3((unsigned)g->n_chunks, 1u), PF_BLOCK, 0, st>>>(g->ws, g->n_pad, w, w, g->n_chunks, g->partials);
         PF_HIP(hipGetLastError());
@@ -1306,6 +1330,13 @@ int pf_orth_begin2(pf_graph* ga, int32_t w_a, int32_t first_a, int32_t count_a, 
     PF_HIP(hipGetLastError());
     k_orth_project<<<dim3(nblk(std::max(ga->n_pad, gb->n_pad) / 2), 1u, 2u), PF_BLOCK, 0, st>>>(a2);
     PF_HIP(hipGetLastError());
+    if (a2.g[0].pass == 1 || a2.g[1].pass == 1) {  // the second pass of the graph(s) that asked for it, on the device's own verdict
+        for (int q = 0; q < 2; ++q) a2.g[q].pass = a2.g[q].pass == 1 ? 2 : -1;
+        k_orth_dots<<<dim3((unsigned)std::max(ga->n_chunks, gb->n_chunks), (unsigned)(std::max(count_a, count_b) + 1), 2u), PF_BLOCK, 0, st>>>(a2);
+        PF_HIP(hipGetLastError());
+        k_orth_project<<<dim3(nblk(std::max(ga->n_pad, gb->n_pad) / 2), 1u, 2u), PF_BLOCK, 0, st>>>(a2);
+        PF_HIP(hipGetLastError());
+    }
     // (no event: both results carry tickets, pf_orth_end polls for them)
     ga->orth_wait = ga->orth_ev;
     gb->orth_wait = gb->orth_ev;
@@ -1356,7 +1387,8 @@ int pf_orth_end(pf_graph* g, double* h, double* nrm) {
     g->orth_pending = -1;
     g->orth_redone = 0;
     PF_TRY(pf_persist_check(g->ctx));
-    if (g->orth_host[count + 1] != 0.0) {
+    g->orth_twice = g->orth_host[count + 1] == 2.0 ? 1 : 0;  // (both passes ran on the device: nothing behind them read a stale w)
+    if (g->orth_host[count + 1] == 1.0) {
         // the first pass cancelled digits (or w vanished): second pass, exact norm, normalisation - synchronously.
         // Whatever was queued behind pf_orth_begin read a w that is only now final: pf_orth_redone tells the caller.
         hipStream_t st = g->ctx->stream;
@@ -1393,9 +1425,15 @@ int pf_orth_strict(pf_graph* g, int32_t on) {
     return PF_OK;
 }
 
+int pf_orth_device_passes(pf_graph* g, int32_t on) {
+    PF_CHECK(g != nullptr, PF_E_ARG, "pf_orth_device_passes: NULL graph");
+    g->orth_device_passes = on ? 1 : 0;
+    return PF_OK;
+}
+
 int pf_orth_redone(pf_graph* g) {
     PF_CHECK(g != nullptr, PF_E_ARG, "pf_orth_redone: NULL graph");
-    return g->orth_redone;
+    return g->orth_redone ? 1 : (g->orth_twice ? 2 : 0);
 }
 
 int pf_orth(pf_graph* g, int32_t w, int32_t first, int32_t count, double* h, double* nrm) {
@@ -1536,11 +1574,15 @@ static bool downloads_deferred() {
 // the owed image of g goes onto the copy stream, behind everything the ctx stream holds at this moment
 static int queue_download(pf_graph* g) {
     pf_ctx* ctx = g->ctx;
-    auto it = std::find(ctx->deferred.begin(), ctx->deferred.end(), g);
-    if (it != ctx->deferred.end()) ctx->deferred.erase(it);
-    if (!g->dl_src) return PF_OK;
-    const double* src = g->dl_src;
-    g->dl_src = nullptr;
+    const double* src = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(ctx->deferred_mutex);
+        auto it = std::find(ctx->deferred.begin(), ctx->deferred.end(), g);
+        if (it != ctx->deferred.end()) ctx->deferred.erase(it);
+        src = g->dl_src;
+        g->dl_src = nullptr;
+    }
+    if (!src) return PF_OK;
     PF_HIP(hipEventRecord(g->final_ready, ctx->stream));
     PF_HIP(hipStreamWaitEvent(ctx->copy_stream, g->final_ready, 0));
     // (the runtime's copy: a download kernel of our own with a few blocks, at the copy stream's low priority, only got CUs
@@ -1550,8 +1592,40 @@ static int queue_download(pf_graph* g) {
     return PF_OK;
 }
 
+// forget the image owed to the caller's buffer (never queued: nothing will be written), or wait for the one in flight;
+// the resident block on the device stays usable.  For callers that are about to report a failure.
+extern "C++" int pf_download_cancel(pf_graph* g) {
+    pf_ctx* ctx = g->ctx;
+    bool owed = false;
+    {
+        std::lock_guard<std::mutex> lk(ctx->deferred_mutex);
+        auto it = std::find(ctx->deferred.begin(), ctx->deferred.end(), g);
+        if (it != ctx->deferred.end()) ctx->deferred.erase(it);
+        owed = g->dl_src != nullptr;
+        g->dl_src = nullptr;
+    }
+    if (g->final_pending != 0) {
+        g->final_pending = 0;
+        g->final_check = 0;
+        if (!owed) (void)hipEventSynchronize(g->final_done);
+        pf_free(ctx->stream, g->final_params);
+        g->final_params = nullptr;
+        pf_free(ctx->stream, g->final_tmp);
+        g->final_tmp = nullptr;
+    }
+    return PF_OK;
+}
+
 extern "C++" int pf_downloads_release(pf_ctx* c) {
-    while (!c->deferred.empty()) PF_TRY(queue_download(c->deferred.back()));
+    for (;;) {
+        pf_graph* g = nullptr;
+        {
+            std::lock_guard<std::mutex> lk(c->deferred_mutex);
+            if (c->deferred.empty()) break;
+            g = c->deferred.back();
+        }
+        PF_TRY(queue_download(g));
+    }
     return PF_OK;
 }
 
@@ -1638,6 +1712,7 @@ int pf_finalize_vectors_begin(pf_graph* g, int32_t first, int32_t count, int32_t
     g->dl_dst = out;
     g->dl_bytes = sizeof(double) * (size_t)g->n * count;
     if (downloads_deferred()) {
+        std::lock_guard<std::mutex> lk(ctx->deferred_mutex);
         if (std::find(ctx->deferred.begin(), ctx->deferred.end(), g) == ctx->deferred.end()) ctx->deferred.push_back(g);
     } else {
         PF_TRY(queue_download(g));
@@ -1730,6 +1805,7 @@ int pf_final_remap_begin(pf_graph* g, const int32_t* col, const double* sign, in
     g->dl_bytes = sizeof(double) * (size_t)g->n * count;
     g->final_pending = count;
     if (downloads_deferred()) {
+        std::lock_guard<std::mutex> lk(ctx->deferred_mutex);
         if (std::find(ctx->deferred.begin(), ctx->deferred.end(), g) == ctx->deferred.end()) ctx->deferred.push_back(g);
     } else {
         PF_TRY(queue_download(g));

@@ -59,7 +59,15 @@ namespace {
 
 // Two resident kernels in flight on different streams could each be given part of the CUs and wait for the rest until
 // the bounded waits give up: only one ctx of the process uses this path at a time.
-std::atomic<pf_ctx*> g_owner{nullptr};
+// who may have resident kernels in flight, per device; `m` is held from the decision to launch until the launch's
+// completion event has been recorded, so that a second ctx can never judge the path free in between
+struct DeviceOwner {
+    std::mutex m;
+    pf_ctx* owner = nullptr;
+};
+constexpr int PF_MAX_DEVICES = 64;
+DeviceOwner g_owners[PF_MAX_DEVICES];
+DeviceOwner& owner_of(const pf_ctx* ctx) { return g_owners[(unsigned)ctx->device % PF_MAX_DEVICES]; }
 std::atomic<int> g_persist{-1};            // -1 undecided (environment PF_PERSIST=0 disables), 0 off, 1 on
 std::atomic<uint64_t> g_abort_epoch{1};    // bumped when a launch aborted: every graph's ring is refilled before reuse
 std::atomic<int> g_test_aborts{0};         // pf_persist_test_hook: launches that start with the abort flag raised
@@ -942,26 +950,32 @@ bool persist_available(bool first_try) {
     return false;
 }
 
-// Only one ctx may have resident kernels in flight (two grids would each get part of the CUs and wait for the rest).  The
-// path belongs to the ctx that used it last; another ctx takes it over when the owner's last resident launch has
-// completed, and runs this application one step per launch otherwise - it does not wait.
-bool persist_acquire(pf_ctx* ctx) {
-    pf_ctx* owner = g_owner.load();
-    if (owner == ctx) return true;
-    if (owner == nullptr) {
-        pf_ctx* expected = nullptr;
-        return g_owner.compare_exchange_strong(expected, ctx) || expected == ctx;
+// Only one ctx per DEVICE may have resident kernels in flight (two grids would each get part of the CUs and wait for the
+// rest).  The path belongs to the ctx that used it last; another ctx of the same device takes it over when the owner's
+// last resident launch has completed, and runs this application one step per launch otherwise - it does not wait.
+// The guard holds the device's lock until it goes out of scope - behind the launch and the record of its completion
+// event - so that "the owner's last launch has completed" cannot be judged between another thread's decision to launch
+// and its launch (round 3's check-then-act: two resident grids, each waiting for the other's CUs until the spin limit).
+struct OwnerGuard {
+    std::unique_lock<std::mutex> lk;
+    bool ok = false;
+    explicit OwnerGuard(pf_ctx* ctx) : lk(owner_of(ctx).m) {
+        DeviceOwner& d = owner_of(ctx);
+        if (d.owner == ctx) {
+            ok = true;
+        } else if (d.owner == nullptr) {
+            d.owner = ctx;
+            ok = true;
+        } else if (d.owner->persist_done_ev == nullptr || hipEventQuery(d.owner->persist_done_ev) == hipSuccess) {
+            // (no event: the owner took the path and its launch failed before it could record one - nothing in flight)
+            d.owner = ctx;
+            g_owner_switches.fetch_add(1);
+            ok = true;
+        } else {
+            (void)hipGetLastError();  // still running (or queued)
+        }
     }
-    if (owner->persist_done_ev && hipEventQuery(owner->persist_done_ev) != hipSuccess) {
-        (void)hipGetLastError();
-        return false;  // still running (or queued)
-    }
-    if (g_owner.compare_exchange_strong(owner, ctx)) {
-        g_owner_switches.fetch_add(1);
-        return true;
-    }
-    return false;
-}
+};
 
 int persist_launched(pf_ctx* ctx) {  // the mark the next would-be owner looks at
     if (!ctx->persist_done_ev) PF_HIP(hipEventCreateWithFlags(&ctx->persist_done_ev, hipEventDisableTiming));
@@ -1094,7 +1108,8 @@ int persist_cheb2(const pf_persist_args* a, const pf_persist_args* b, int64_t gr
     }
     const int64_t need = ga->lds_need2_value;
     if (need < 0 || (size_t)need > RX_LDS_LIMIT) return PF_OK;
-    if (!persist_acquire(ctx)) return PF_OK;
+    OwnerGuard own(ctx);
+    if (!own.ok) return PF_OK;
     hipStream_t st = ctx->stream;
     if (!ctx->persist_sync) {
         PF_HIP(pf_malloc(st, (void**)&ctx->persist_sync, sizeof(uint32_t) * 32));
@@ -1236,7 +1251,11 @@ extern "C" int pf_persist_pair_halves(int on) {
 
 extern "C" int pf_persist_state(pf_ctx* ctx, pf_persist_info* out) {
     PF_CHECK(out != nullptr, PF_E_ARG, "pf_persist_state: NULL argument");
-    pf_ctx* owner = g_owner.load();
+    pf_ctx* owner = nullptr;
+    if (ctx) {
+        std::lock_guard<std::mutex> lk(owner_of(ctx).m);
+        owner = owner_of(ctx).owner;
+    }
     out->enabled = persist_enabled() ? 1 : 0;
     out->two_step = two_step_level();
     out->owner = owner == nullptr ? 0 : (owner == ctx ? 1 : -1);
@@ -1287,7 +1306,7 @@ int hold_ticks(int ng, int nw, bool halves, int windows) {
 // keeps the fastest.  Results do not depend on the hold-back (test_resident_kernel_bit_identical), so the trial launches
 // are ordinary filter applications.  PF_PERSIST_CAL=0 keeps the table.
 struct HoldCalibration {
-    static constexpr int SLOTS = 16, MAX_CAND = 7, STEP = 4, REACH = 12, SAMPLES = 2;
+    static constexpr int SLOTS = 16, MAX_CAND = 7, STEP = 4, REACH = 12, SAMPLES = 3;
     struct State {
         int table = 0, n_cand = 0, next = 0, chosen = -1;
         int cand[MAX_CAND];
@@ -1341,8 +1360,16 @@ struct HoldCalibration {
         } else if (s.n_cand < MAX_CAND && b == lo && b - STEP >= std::max(s.table - REACH, 1)) {
             add(s, b - STEP);
         } else {
-            s.chosen = b;
+            // a neighbour of the table's value has to beat it by more than the noise of three launches (a first launch
+            // beside another tenant, clocks still ramping); otherwise the table stands
+            s.chosen = (b != s.table && s.best_us[best] > 0.99 * s.best_us[0]) ? s.table : b;
         }
+    }
+    void release(int slot) {  // the launch that was to report into `slot` was never queued
+        if (slot < 0 || slot >= SLOTS || meta[slot].id == 0) return;
+        auto it = states.find(meta[slot].key);
+        if (it != states.end() && meta[slot].cand < it->second.n_cand && it->second.asked[meta[slot].cand] > 0) --it->second.asked[meta[slot].cand];
+        meta[slot].id = 0;
     }
     // the hold-back of the launch that is about to be queued; *slot / *id: where and as what it reports (-1: it does not)
     int pick(uint64_t key, int table, int32_t steps, int* slot, unsigned long long* id) {
@@ -1472,7 +1499,8 @@ int pf_persist_cheb(const pf_persist_args* a, const pf_persist_args* b, int* don
     }
     const int64_t need = ga->lds_need_value;
     if (need < 0 || (size_t)need > RX_LDS_LIMIT) return PF_OK;
-    if (!persist_acquire(ctx)) return PF_OK;  // another ctx has resident kernels in flight
+    OwnerGuard own(ctx);
+    if (!own.ok) return PF_OK;  // another ctx has resident kernels in flight
     if (ng == 2 && nw == 1 && pair_halves_enabled()) {  // each half of a block fetches one graph's outside rows: they must fit
         int32_t most = 0;
         for (int32_t c : ga->h_px_gh_cnt) most = std::max(most, c);
@@ -1547,6 +1575,10 @@ int pf_persist_cheb(const pf_persist_args* a, const pf_persist_args* b, int* don
     kernel<<<dim3((unsigned)grid), dim3(RX_THREADS), (size_t)need, st>>>(args);
     const hipError_t err = hipGetLastError();
     if (err != hipSuccess) {
+        if (args.report && ctx->persist_cal) {
+            auto* cal = static_cast<HoldCalibration*>(ctx->persist_cal);
+            cal->release((int)((args.report - cal->ring) / 2));
+        }
         g_persist.store(0);  // the classic path from now on
         (void)hipGetLastError();
         return PF_OK;
@@ -1565,8 +1597,10 @@ int pf_persist_cheb(const pf_persist_args* a, const pf_persist_args* b, int* don
 }
 
 void pf_persist_release(pf_ctx* ctx) {
-    pf_ctx* expected = ctx;
-    g_owner.compare_exchange_strong(expected, nullptr);
+    {
+        std::lock_guard<std::mutex> lk(owner_of(ctx).m);
+        if (owner_of(ctx).owner == ctx) owner_of(ctx).owner = nullptr;
+    }
     if (ctx->persist_cal) {  // (pf_destroy has synchronised the stream: no launch is left to report)
         auto* cal = static_cast<HoldCalibration*>(ctx->persist_cal);
         if (cal->ring) (void)hipHostFree(cal->ring);
@@ -1583,7 +1617,7 @@ int pf_persist_check(pf_ctx* ctx) {
     if (ctx->persist_abort && *ctx->persist_abort) {
         (void)hipStreamSynchronize(ctx->stream);
         *ctx->persist_abort = 0;
-        (void)hipMemsetAsync(ctx->persist_sync, 0, sizeof(uint32_t) * 32, ctx->stream);
+        (void)hipMemsetAsync(ctx->persist_sync, 0, sizeof(uint32_t) * 8, ctx->stream);  // (the abort words; the clock counters behind them stay)
         (void)hipStreamSynchronize(ctx->stream);
         (void)hipGetLastError();
         g_abort_epoch.fetch_add(1);

@@ -127,8 +127,16 @@ class Graph(object):
     @property
     def eig_vecs(self):
         if self._eig_pending:  # the download the eigensolve queued is collected by the first reader
+            try:
+                self._device.finalize_wait()
+            except Exception:
+                # the image never arrived (a non-finite norm, a HIP error): no later reader may mistake the unfilled
+                # pinned array for eigenvectors
+                self._eig_pending = False
+                self._eig_vecs = None
+                self._final_map = None
+                raise
             self._eig_pending = False
-            self._device.finalize_wait()
         return self._eig_vecs
 
     @eig_vecs.setter
@@ -276,6 +284,12 @@ class Graph(object):
         dev = self.device
         if self.verbose:
             print("Beginning Eigen Decomposition")
+        if PAIR_DRIVER == "c" and _spectra_c([self]):
+            if self.verbose:
+                print("All final eigenvalues are: \n{}".format(self.eig_vals))
+                print("-" * 72)
+                print("Final eigenvalues of interest are: \n{}".format(self.eig_vals))
+            return
         self._set_spectrum(*_device_eigs(
             dev,
             k=self.n_spectral_features + 1,
@@ -411,51 +425,66 @@ def build_devices(graphs):
     return [g.device for g in graphs]
 
 
-PAIR_DRIVER = os.environ.get("PF_PAIR_DRIVER", "c")  # "c": pf_eigs_smallest2 where it applies; "python": always _krylov.drive_pair
+PAIR_DRIVER = os.environ.get("PF_PAIR_DRIVER", "c")  # "c": pf_eigs_smallest / pf_eigs_smallest2 where they apply; "python": always the generators of _krylov.py
 
 
-def _paired_spectra_c(ga, gb):
-    """The paired solve behind ONE library call (`pf_eigs_smallest2`: the pair driver restated in C++, symmetric W only):
-    no interpreter between the launches of an outer step.  Returns False when the call does not cover the pair (an
-    asymmetric W, a graph too small for the filtered iteration, null vectors the component count did not predict, fewer
-    eigenpairs than the reference's widen-and-retry loop ends with): the Python driver then does the whole solve."""
+def _c_plan(g, dev):
+    """How many eigenpairs the C driver has to return for `g`: the column count the reference's widen-and-retry loop
+    ends with (graph.py:374-379), given the null eigenvalues the assembler already knows."""
+    n_null = dev.n_components + dev.n_isolated
+    k_final, retries = _widened_k(g.n_spectral_features + 1, g.n_spectral_features, 1, n_null, dev.n)
+    return max(min(k_final - n_null, dev.n - n_null), 0), retries
+
+
+def _c_accept(g, dev, plan, result):
+    """Store what the C driver returned for `g` (see `_spectra_c`)."""
     from ._krylov import EigsStats
 
-    da, db = ga.device, gb.device
-    if (not hasattr(da, "eigs_smallest2") or da.ctx is not db.ctx or not (da.symmetric and db.symmetric)
-            or (ga.norm_eig_vecs is True) != (gb.norm_eig_vecs is True)
-            or not (getattr(da, "lock_nulls", True) and getattr(db, "lock_nulls", True))):
+    (m_out, retries), (vals, vecs, st) = plan, result
+    if g.verbose:
+        print("Starting!")
+        for _ in range(retries):
+            print("Not enough eigenvalues found, trying again with more eigenvalues!")
+            print("Starting!")
+    stats = EigsStats()
+    for key in ("matvecs", "outer_steps", "restarts", "filter_resets", "degree", "cut", "n_null", "second_passes", "mode"):
+        setattr(stats, key, st[key])
+    stats.residuals = st["residuals"]
+    g._set_spectrum(vals, vecs, stats)
+
+
+def _spectra_c(graphs):
+    """The eigensolve of one graph, or of the two graphs of a pair, behind ONE library call (`pf_eigs_smallest` /
+    `pf_eigs_smallest2`: the Krylov driver restated in C++ - Lanczos for symmetric W, Arnoldi with carried outliers or
+    the ellipse filter for asymmetric W): no interpreter between the launches of an outer step.  Returns False when the
+    call does not cover the graphs (too small for the filtered iteration, a general matrix without analytic null
+    vectors, null vectors the component count did not predict, fewer eigenpairs than the reference's widen-and-retry
+    loop ends with): the Python driver then does the whole solve."""
+    devs = [g.device for g in graphs]
+    if not all(hasattr(d, "eigs_smallest2") and getattr(d, "lock_nulls", True) for d in devs):
         return False
-    plans = []
-    for g, dev in ((ga, da), (gb, db)):
-        n_null = dev.n_components + dev.n_isolated
-        k_final, retries = _widened_k(g.n_spectral_features + 1, g.n_spectral_features, 1, n_null, dev.n)
-        m_out = max(min(k_final - n_null, dev.n - n_null), 0)
-        if m_out == 0:
-            return False
-        plans.append((m_out, retries))
+    if len(graphs) == 2 and (devs[0].ctx is not devs[1].ctx or (graphs[0].norm_eig_vecs is True) != (graphs[1].norm_eig_vecs is True)):
+        return False
+    plans = [_c_plan(g, d) for g, d in zip(graphs, devs)]
+    if any(m_out == 0 for m_out, _ in plans):
+        return False
+    minmax = graphs[0].norm_eig_vecs is True
     try:
-        ra, rb = da.eigs_smallest2(db, plans[0][0], plans[1][0], minmax=ga.norm_eig_vecs is True, wait=False)
+        if len(graphs) == 2:
+            results = devs[0].eigs_smallest2(devs[1], plans[0][0], plans[1][0], minmax=minmax, wait=False)
+        else:
+            results = (devs[0].eigs_smallest(plans[0][0], minmax=minmax),)
     except _hip.PfError as exc:
         if getattr(exc, "code", None) in (_hip.PF_E_STATE, _hip.PF_E_DEGENERATE):
             return False
         raise
-    for dev, (m_out, _), (vals, vecs, st) in zip((da, db), plans, (ra, rb)):
+    for dev, (m_out, _), (vals, vecs, st) in zip(devs, plans, results):
         if len(vals) != m_out or st["n_null"] != dev.n_components:
-            da.finalize_wait()
-            db.finalize_wait()
+            for d in devs:
+                d.finalize_wait()
             return False
-    for g, (m_out, retries), (vals, vecs, st) in zip((ga, gb), plans, (ra, rb)):
-        if g.verbose:
-            print("Starting!")
-            for _ in range(retries):
-                print("Not enough eigenvalues found, trying again with more eigenvalues!")
-                print("Starting!")
-        stats = EigsStats()
-        for key in ("matvecs", "outer_steps", "restarts", "filter_resets", "degree", "cut", "n_null", "second_passes"):
-            setattr(stats, key, st[key])
-        stats.residuals = st["residuals"]
-        g._set_spectrum(vals, vecs, stats)
+    for g, dev, plan, result in zip(graphs, devs, plans, results):
+        _c_accept(g, dev, plan, result)
     return True
 
 
@@ -466,7 +495,7 @@ def _paired_spectra(ga, gb):
     for g in (ga, gb):
         if g.verbose:
             print("Beginning Eigen Decomposition")
-    if PAIR_DRIVER == "c" and _paired_spectra_c(ga, gb):
+    if PAIR_DRIVER == "c" and _spectra_c([ga, gb]):
         for g in (ga, gb):
             if g.verbose:
                 print("All final eigenvalues are: \n{}".format(g.eig_vals))

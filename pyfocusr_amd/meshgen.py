@@ -45,3 +45,27 @@ def blob_mesh(n_points, seed=0, permute=True):
         pts = new_pts
         faces = perm[faces]
     return PolyMesh(pts, faces.astype(np.int32))
+
+
+def messy_blob_mesh(n_points, seed=0, n_single=7, n_star=3, n_flip=2, n_fin=2):
+    """`blob_mesh` with the defect classes of the reference's own scanned meshes (`source_mesh_15k` has
+    duplicated directed edges, edges in three faces, one-way edges, unreferenced points) at the density of a cleaned-up
+    scan: `n_single` faces deleted (a triangular hole each: three one-way edges), the faces around `n_star` vertices
+    deleted (a hexagonal hole and a stranded vertex each), `n_flip` faces with reversed orientation (three directed
+    edges listed twice, their reverses missing), `n_fin` extra faces on an existing edge (an edge in three faces).  With
+    the defaults ~50 one-way entries: W is asymmetric (graph.py:178), L non-normal, `n_star` isolated vertices add to
+    the null eigenvalues the reference's widen-and-retry loop (graph.py:374-379) has to step over."""
+    m = blob_mesh(n_points, seed=seed)
+    pts, faces = m.points, m.faces.copy()
+    rng = np.random.default_rng(1000 + seed)
+    n_faces = len(faces)
+    pick = rng.choice(n_faces, size=n_single + n_flip + n_fin, replace=False)
+    single, flip, fin = pick[:n_single], pick[n_single:n_single + n_flip], pick[n_single + n_flip:]
+    faces[flip] = faces[flip][:, [0, 2, 1]]
+    extra = [[faces[f][0], faces[f][1], faces[(f + n_faces // 2) % n_faces][0]] for f in fin]
+    stars = rng.choice(n_points, size=n_star, replace=False)
+    keep = np.ones(n_faces, dtype=bool)
+    keep[single] = False
+    keep &= ~np.isin(faces, stars).any(axis=1)
+    faces = np.concatenate([faces[keep], np.asarray(extra, dtype=faces.dtype).reshape(-1, 3)])
+    return PolyMesh(pts, faces.astype(np.int32))

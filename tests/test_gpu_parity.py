@@ -373,6 +373,50 @@ def test_orth_one_pass_with_second_pass_on_demand(golden, devices):
             np.testing.assert_allclose(got, r * scale, rtol=0, atol=(1e-13 if not expect_redo else 1e-8) * np.linalg.norm(r * scale), err_msg=label)
             if normalize:
                 np.testing.assert_allclose(np.linalg.norm(got), 1.0, rtol=1e-13)
+    # the second pass queued with the first and run on the device's own verdict (pf_orth_device_passes; round 4: what the
+    # Arnoldi driver of asymmetric graphs uses): same numbers, and what was queued BEHIND the step read the final vector
+    dev.orth_device_passes(True)
+    try:
+        for label, w, twice in (("random", rng.standard_normal(n), False),
+                                ("cancelling", 3.0 * Qb[:, 0] - 2.0 * Qb[:, 4] + 1e-7 * noise, True),
+                                ("inside the span", Qb @ np.arange(1.0, 7.0), True)):
+            dev.upload(8, w)
+            dev.orth_begin(8, 0, 6, normalize=True)
+            dev.copy(8, 9, 1)  # queued behind the step, before its result is collected: the pipelined driver's next application
+            h, nrm = dev.orth_end()
+            assert not dev.orth_redone and dev.orth_twice == twice, label
+            r = w - Qb @ (Qb.T @ w)
+            r = r - Qb @ (Qb.T @ r)
+            np.testing.assert_allclose(h, Qb.T @ w, rtol=1e-12, atol=1e-12, err_msg=label)
+            got = dev.download_slots(8, 2)
+            assert np.array_equal(got[:, 0], got[:, 1]), label  # the copy saw the refined, normalised vector
+            if label == "inside the span":
+                assert nrm < 1e-13 * np.linalg.norm(w)
+                continue
+            np.testing.assert_allclose(nrm, np.linalg.norm(r), rtol=1e-13 if not twice else 1e-8, err_msg=label)
+            assert np.max(np.abs(Qb.T @ got[:, 0])) < 1e-13 * (np.linalg.norm(w) / nrm if not twice else 1.0)
+            np.testing.assert_allclose(np.linalg.norm(got[:, 0]), 1.0, rtol=1e-13)
+        # a pair: one graph with the device passes, its partner without (the partner's blocks sit the second launches out)
+        other = devices("target_mesh_15k")
+        other.ws_ensure(12)
+        Qo, _ = np.linalg.qr(rng.standard_normal((other.n, 4)))
+        for b in range(4):
+            other.upload(b, Qo[:, b])
+        wo = Qo @ np.array([2.0, -1.0, 0.5, 0.25]) + 1e-6 * rng.standard_normal(other.n)
+        w = 3.0 * Qb[:, 0] - 2.0 * Qb[:, 4] + 1e-7 * noise
+        dev.upload(8, w)
+        other.upload(8, wo)
+        dev.orth_begin2((8, 0, 6, True), other, (8, 0, 4, True))
+        h, nrm = dev.orth_end()
+        ho, nrmo = other.orth_end()
+        assert dev.orth_twice and not dev.orth_redone and other.orth_redone and not other.orth_twice
+        np.testing.assert_allclose(h, Qb.T @ w, rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(ho, Qo.T @ wo, rtol=1e-12, atol=1e-12)
+        for d_, Q_ in ((dev, Qb), (other, Qo)):
+            got = d_.download_slots(8, 1)[:, 0]
+            assert np.max(np.abs(Q_.T @ got)) < 1e-13 and abs(np.linalg.norm(got) - 1.0) < 1e-13
+    finally:
+        dev.orth_device_passes(False)
     # strict mode (pf_orth_strict: unfiltered / small solves): the classical threshold |w'| < 0.71 |w|
     w = Qb @ np.array([0.8, 0.0, 0.5, 0.0, 0.3, 0.0]) + 0.75 * noise / np.linalg.norm(noise)  # |w'| / |w| ~ 0.6
     for strict, expect_redo in ((False, False), (True, True), (False, False)):
@@ -771,18 +815,23 @@ def test_pair_driver_in_c(golden, hip, ctx):
     ref = orc.graph_spectrum(pts, faces, 4)
     assert gs[0].eig_vals.shape == ref["eig_vals"].shape
     np.testing.assert_allclose(gs[0].eig_vals, ref["eig_vals"], rtol=1e-8)
-    # what the call does not cover goes to the Python driver without a trace: an asymmetric partner, a tiny graph
+    # what the call does not cover goes to the Python driver without a trace: a tiny graph
     for n_small, covered in ((150, True), (40, False)):
         small = [Graph(blob_mesh(n_small, seed=6), n_spectral_features=3, n_rand_samples=10**9, ctx=ctx, verbose=False),
                  Graph(blob_mesh(9000, seed=7), n_spectral_features=3, n_rand_samples=10**9, ctx=ctx, verbose=False)]
-        assert graph_mod._paired_spectra_c(*small) == covered
+        assert graph_mod._spectra_c(small) == covered
         if not covered:
             graph_mod._paired_spectra(*small)
         for g, seed, n in zip(small, (6, 7), (n_small, 9000)):
             m = blob_mesh(n, seed=seed)
             np.testing.assert_allclose(g.eig_vals, orc.graph_spectrum(m.points, m.faces, 3)["eig_vals"], rtol=1e-8)
-    g15 = Graph(mesh_of(golden("source_mesh_15k")), n_spectral_features=5, n_rand_samples=10**9, ctx=ctx, verbose=False)
-    assert not graph_mod._paired_spectra_c(g15, Graph(blob_mesh(9000, seed=7), n_spectral_features=5, n_rand_samples=10**9, ctx=ctx, verbose=False))
+    # a symmetric and an asymmetric graph in one call: Lanczos for the one, Arnoldi for the other, launches shared
+    mixed = [Graph(mesh_of(golden("source_mesh_15k")), n_spectral_features=5, n_rand_samples=10**9, ctx=ctx, verbose=False),
+             Graph(blob_mesh(9000, seed=7), n_spectral_features=5, n_rand_samples=10**9, ctx=ctx, verbose=False)]
+    assert graph_mod._spectra_c(mixed) and [g.eigs_stats.mode for g in mixed] == [1, 0]
+    np.testing.assert_allclose(mixed[0].eig_vals[:5], golden("source_mesh_15k")["k5_eig_vals"][:5], rtol=1e-8)
+    m = blob_mesh(9000, seed=7)
+    np.testing.assert_allclose(mixed[1].eig_vals, orc.graph_spectrum(m.points, m.faces, 5)["eig_vals"], rtol=1e-8)
 
 
 def test_multi_component_and_recursive_eig(hip, ctx):
@@ -1694,6 +1743,16 @@ def test_resident_kernel_timeout_is_survived(hip, ctx):
         dev.close()
         return [vals]
 
+    rough = [np.delete(m.faces, [5, 900, 4000, 4001, 20000], axis=0) for m in meshes]  # a few one-way edges: Arnoldi on L
+
+    def c_pair_asymmetric():
+        da, db = (hip.DeviceLaplacian(m.points, f, ctx=ctx) for m, f in zip(meshes, rough))
+        (va, _, sa), (vb, _, sb) = da.eigs_smallest2(db, 4, 4)
+        assert sa["mode"] == 1 and sb["mode"] == 1
+        da.close()
+        db.close()
+        return [va, vb]
+
     def python_pair():
         from pyfocusr_amd import graph as graph_mod
 
@@ -1712,7 +1771,7 @@ def test_resident_kernel_timeout_is_survived(hip, ctx):
         return out, n
 
     try:
-        for fn in (pair, python_pair, single, plain_matrix, c_call):  # (pair: pf_eigs_smallest2)
+        for fn in (pair, python_pair, single, plain_matrix, c_call, c_pair_asymmetric):  # (pair: pf_eigs_smallest2)
             hip.persist_enable(True)
             good, n_good = resident_launches(fn)
             assert n_good > 0, fn.__name__  # the resident kernel is what normally runs here
@@ -1786,7 +1845,7 @@ def test_resident_kernel_timeout_is_survived(hip, ctx):
 
 
 def test_eigs_smallest_single_c_call(golden, hip, ctx):
-    """`pf_eigs_smallest` (the eigensolve as ONE C call, symmetric W) against the golden eigenpairs of the reference,
+    """`pf_eigs_smallest` (the eigensolve as ONE C call; symmetric W here) against the golden eigenpairs of the reference,
     the oracle on synthetic and multi-component meshes, and its documented refusals."""
     from pyfocusr_amd import PolyMesh  # noqa: F401
     from pyfocusr_amd.meshgen import blob_mesh
@@ -1835,17 +1894,95 @@ def test_eigs_smallest_single_c_call(golden, hip, ctx):
         off = gram - np.diag(np.diag(gram))
         assert np.max(np.abs(off)) < 1e-9 * np.max(np.abs(np.diag(gram)))
         dev.close()
-    # refusals: one-way edges, tiny graphs
-    g15 = golden("source_mesh_15k")
-    dev = hip.DeviceLaplacian(g15["points"], g15["faces"], ctx=ctx)
-    with pytest.raises(hip.PfError):
-        dev.eigs_smallest(5)
-    dev.close()
+    # refusal: graphs too small for the filtered iteration (the Python driver's unfiltered mode covers them)
     t = blob_mesh(40, seed=1)
     dev = hip.DeviceLaplacian(t.points, t.faces, ctx=ctx)
-    with pytest.raises(hip.PfError):
+    with pytest.raises(hip.PfError) as err:
         dev.eigs_smallest(5)
+    assert err.value.code == hip.PF_E_STATE
     dev.close()
+
+
+def test_eigs_c_call_asymmetric_w(golden, hip, ctx):
+    """The general branch of the C driver (round 4: restarted Arnoldi in pf_krylov.h, what both bundled 15k meshes take -
+    graph.py:178 writes directed entries, their scans have one-way edges): `pf_eigs_smallest_ex` against the reference's
+    golden eigenpairs, the pair call against two single calls and against the Python generators, an open surface
+    (complex low eigenvalues: ellipse filter), a messy closed blob (interval filter, ~50 outliers' worth of one-way
+    edges), and the public path on top of it."""
+    from pyfocusr_amd import Graph, PolyMesh
+    from pyfocusr_amd import graph as graph_mod
+    from pyfocusr_amd.graph import compute_spectra
+    from pyfocusr_amd.meshgen import messy_blob_mesh
+
+    devs = {}
+    for name, m_out in (("target_mesh_15k", 5), ("source_mesh_15k", 9)):  # (source: 3 nulls -> the widen rule ends with 9 columns)
+        g = golden(name)
+        dev = devs[name] = hip.DeviceLaplacian(g["points"], g["faces"], ctx=ctx)
+        assert not dev.symmetric and 0 < dev.n_oneway <= 32
+        vals, vecs, st = dev.eigs_smallest(m_out, minmax=True)
+        m = min(m_out, len(g["k5_eig_vals"]))
+        assert st["mode"] == 1 and len(vals) == m_out and st["n_null"] == dev.n_components and st["degree"] <= 128
+        np.testing.assert_allclose(vals[:m], g["k5_eig_vals"][:m], rtol=1e-8)
+        assert np.max(np.abs(vecs[:, :m] - g["k5_eig_vecs"][:, :m])) < 5e-7
+        assert st["residuals"].max() < 1e-9 and st["max_residual"] == st["residuals"].max()
+    # the two of them in shared launches, downloads left in flight: what two single calls return
+    dt, ds = devs["target_mesh_15k"], devs["source_mesh_15k"]
+    before = hip.persist_state(ctx)["launches"]
+    (vt, xt, stt), (vs, xs, sts) = dt.eigs_smallest2(ds, 5, 9, minmax=True, wait=False)
+    assert hip.persist_state(ctx)["launches"] > before  # the resident filter kernel serves L = G (D - W) too
+    dt.finalize_wait()
+    ds.finalize_wait()
+    for dev, vals, vecs, m_out in ((dt, vt, xt, 5), (ds, vs, xs, 9)):
+        v1, x1, s1 = dev.eigs_smallest(m_out, minmax=True)
+        np.testing.assert_allclose(vals, v1, rtol=1e-12)
+        assert np.max(np.abs(vecs - x1)) < 1e-9
+    for dev in devs.values():
+        dev.close()
+    # the public path takes the C driver for them (and the Python generators agree)
+    results = {}
+    for driver in ("c", "python"):
+        graph_mod.PAIR_DRIVER = driver
+        try:
+            gs = [Graph(mesh_of(golden(n)), n_spectral_features=5, n_rand_samples=10**9, ctx=ctx, verbose=False)
+                  for n in ("target_mesh_15k", "source_mesh_15k")]
+            compute_spectra(gs)
+            results[driver] = [(g.eig_vals.copy(), g.eig_vecs.copy(), g.eigs_stats) for g in gs]
+            for g in gs:
+                g.device.close()
+        finally:
+            graph_mod.PAIR_DRIVER = "c"
+    for (vc, xc, sc), (vp, xp, sp) in zip(results["c"], results["python"]):
+        assert getattr(sc, "mode", None) == 1 and xc.shape == xp.shape
+        np.testing.assert_allclose(vc, vp, rtol=1e-9)
+        assert np.max(np.abs(xc - xp)) < 5e-7
+    # an open surface: 712 one-way boundary edges, complex low eigenvalues -> ellipse filter inside the C call
+    nx, ny = 100, 80
+    r = np.random.default_rng(0)
+    x, y = np.meshgrid(np.arange(nx, dtype=float), np.arange(ny, dtype=float), indexing="ij")
+    pts = np.stack([x, y, 0.3 * np.sin(x / 5) + 0.2 * np.cos(y / 7)], -1).reshape(-1, 3) + 0.05 * r.normal(size=(nx * ny, 3))
+    idx = np.arange(nx * ny).reshape(nx, ny)
+    a, b, c, d = idx[:-1, :-1].ravel(), idx[1:, :-1].ravel(), idx[1:, 1:].ravel(), idx[:-1, 1:].ravel()
+    faces = np.concatenate([np.stack([a, b, c], 1), np.stack([a, c, d], 1)])
+    ref = orc.graph_spectrum(pts, faces, 5)
+    dev = hip.DeviceLaplacian(pts, faces, ctx=ctx)
+    vals, vecs, st = dev.eigs_smallest(6)
+    assert st["mode"] == 2 and len(vals) >= 5
+    m = min(len(vals), len(ref["eig_vals"]))
+    np.testing.assert_allclose(vals[:m], ref["eig_vals"][:m], rtol=1e-7)
+    assert np.isclose(vals[0], vals[1], rtol=1e-9)
+    dev.close()
+    # a closed blob with the defect classes of the scans: interval filter, the outliers carried
+    mesh = messy_blob_mesh(30000, seed=2)
+    ref = orc.graph_spectrum(mesh.points, mesh.faces, 5)
+    gr = Graph(mesh, n_spectral_features=5, n_rand_samples=10**9, ctx=ctx, verbose=False)
+    gr.get_graph_spectrum()
+    assert gr.device.n_isolated == 3 and gr.device.n_oneway > 32 and gr.eigs_stats.mode == 1
+    assert gr.eig_vals.shape == ref["eig_vals"].shape
+    np.testing.assert_allclose(gr.eig_vals, ref["eig_vals"], rtol=1e-8)
+    L = ref["L"]
+    raw = gr.device.eigs_smallest(len(gr.eig_vals))[1]
+    assert np.max(np.linalg.norm(L @ raw - raw * gr.eig_vals[None, :], axis=0)) < 1e-9
+    gr.device.close()
 
 
 def test_large_hole_needs_taller_ellipse(ctx):

@@ -1,0 +1,18 @@
+#!/bin/bash
+# round 4, first collection: (1) kernel stats / gaps / timeline of the C5 step (1M-vertex pair, k = 10) on one GPU,
+# (2) where the bundled 15k pair (asymmetric W) spends its time before the general driver moves into C++
+root=${GRAFT_REPO_ROOT:-/root/repo}
+out=$root/gpurun_out/r04_a
+rm -rf $out && mkdir -p $out
+cd /tmp && export TMPDIR=/tmp
+python3 $root/tools/profile_15k.py > $out/profile_15k.txt 2>&1
+echo "15k done" > $out/progress.txt
+args="--vertices 1000000 --k 10 --steps 2 --warmup 1 --no-extras --no-cpu-baseline"
+timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 $root/bench.py $args > $out/c5_bench_under_rocprof.json 2> $out/rocprof.err
+cp $(ls $out/stats/*/*kernel_stats.csv | tail -1) $out/c5_kernel_stats.csv
+python3 $root/tools/trace_gaps.py $(ls $out/stats/*/*kernel_trace.csv | tail -1) 0.6 > $out/c5_gaps.txt
+python3 $root/tools/trace_timeline.py $(ls $out/stats/*/*kernel_trace.csv | tail -1) > $out/c5_timeline_last_step.txt
+rm -rf $out/stats
+echo "c5 done" >> $out/progress.txt
+python3 $root/bench.py $args > $out/c5_bench.json 2> $out/c5_bench.err
+echo "all done" >> $out/progress.txt
