@@ -35,7 +35,8 @@ METRIC = "lowest-k eigenpairs/sec + KNN-correspondence wall-clock, 250k-vertex m
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md, HBM)
 # LDS peak (MI355X_MICROARCH.md, LDS table): ds_read_b64 conflict-free = 256 B per clock and CU; 256 CUs; 2.4 GHz
 LDS_PEAK_GBS = 256.0 * 256 * 2.4
-PMC_SUMMARY = os.path.join("profiles", "r03_pmc_summary.json")
+PMC_SUMMARY = os.path.join("profiles", "r04_pmc_summary.json")
+FP64_VALU_PEAK_TFLOPS = 78.6  # MI355X FP64 vector peak (MI355X_MICROARCH.md; SURVEY 8d: what bounds the exact KNN)
 TIMING_STRIDE = 4  # filter applications per HIP event pair
 
 
@@ -136,7 +137,8 @@ def cpu_baseline(meshes, k, coords, gpu_vals, gpu_idx, eigs_runs=3):
     t_pair_mt = sum(t_asm) + sum(t_eigs) + t_tree + t_query_mt
     best_effort = dict(value=2 * k / t_pair_mt, unit="eigenpairs/s", cores=os.cpu_count(), pair_seconds=t_pair_mt,
                        sample="as above with KDTree.query(workers=-1): %.3fs for all %d queries" % (t_query_mt, n))
-    base = dict(best_effort_all_cores=best_effort, value=2 * k / t_pair, unit="eigenpairs/s", cores=1, kind="port",
+    base = dict(best_effort_all_cores=best_effort, value=2 * k / t_pair, unit="eigenpairs/s", cores=1, cpu_model=cpu_model(),
+                host_threads=os.cpu_count(), kind="port",
                 sample="the whole step, measured: both meshes - vectorised assembly %s s, scipy eigs(sigma=1e-10, ncv=4(k+1)) "
                        "%s s (median of %d runs each after one warm-up solve); KDTree build %.2fs + query of all %d source "
                        "points %.2fs; pair: %.1fs"
@@ -147,6 +149,20 @@ def cpu_baseline(meshes, k, coords, gpu_vals, gpu_idx, eigs_runs=3):
                   note="device eigenvalues of BOTH meshes of the last timed step against scipy eigs on the oracle's L; "
                        "every device 1-NN index of the last timed step against KDTree.query")
     return base, parity
+
+
+def cpu_model():
+    """The host CPU's model string (stated next to the core count of the CPU baseline)."""
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+
+    return platform.processor() or "unknown"
 
 
 def device_copy_gbs(torch, dev, n_bytes=1 << 30, reps=10):
@@ -733,6 +749,47 @@ def main():
             "max_eig_residual": float(max_res),
             "roofline": roofline,
         }
+        # every stage against the roofline that bounds it.  Assembly: SURVEY 8d's algorithmic bytes
+        # (144 n per mesh: points and faces in, CSR(W) / L values, degrees out) over the stage's wall time against the HBM
+        # peak - the stage is ~110 small dependent launches, bound by their number and latency, not by bytes; `traffic` =
+        # what its kernels really moved (PMC passes of this command, committed).  1-NN: floating-point operations of the
+        # squared distances the search evaluates (3 d per candidate-query pair, pairs counted by one extra untimed search
+        # with the counting instantiation) over the kernel's time against the FP64 vector peak.
+        stage_pmc = {}
+        if os.path.exists(os.path.join(REPO, PMC_SUMMARY)):
+            with open(os.path.join(REPO, PMC_SUMMARY)) as fh:
+                stage_pmc = json.load(fh).get("stages", {})
+        asm_bytes = 2 * 144.0 * n
+        asm_s = timers["assembly"] / args.steps
+        asm_traffic = stage_pmc.get("assembly", {}).get("hbm_bytes_per_step")
+        out["roofline_assembly"] = {
+            "bound": "hbm", "achieved": asm_bytes / asm_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": asm_bytes / asm_s / 1e9 / HBM_PEAK_GBS,
+            "algorithmic_bytes_per_step": asm_bytes, "ms_per_step": 1e3 * asm_s, "traffic": asm_traffic,
+            "traffic_over_algorithmic": None if asm_traffic is None else asm_traffic / asm_bytes,
+            "dispatches_per_step": stage_pmc.get("assembly", {}).get("dispatches_per_step"),
+            "traffic_source": PMC_SUMMARY if asm_traffic is not None else None,
+            "note": "both meshes of the pair; wall time of the stage (the two builds run side by side on two streams)"}
+        try:
+            ctx.knn_count(True)
+            np.random.seed(99)
+            extra = dict(assembly=0.0, eigensolve=0.0, eigsort=0.0, knn=0.0, matvecs=0)
+            hot_path_step(ctxs, mesh_t, mesh_s, args.k, args.samples, extra)
+            pairs = ctx.knn_count(False)
+            knn_ms = tm["knn_ms"] if tm["knn_ms"] > 0 else None  # (the search of the last timed step, by HIP events)
+            flops = 3.0 * args.k * pairs
+            out["roofline_knn"] = {
+                "bound": "fp64 valu", "kernel": "k_knn_coop<%d> (exact 1-NN of every source row, grid over two axes, 64 candidates per wave step)" % args.k,
+                "achieved": None if not knn_ms else flops / (knn_ms * 1e-3) / 1e12, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": None if not knn_ms else flops / (knn_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS,
+                "candidate_query_pairs": pairs, "candidates_per_query": pairs / float(n), "flops_per_pair": 3 * args.k,
+                "brute_force_pairs": float(n) * n, "pruned_to_fraction": pairs / (float(n) * n), "kernel_ms": knn_ms,
+                "traffic": stage_pmc.get("knn", {}).get("hbm_bytes_per_step"),
+                "note": "pairs counted in one extra untimed step (same meshes, another eigsort sample: the count moves a few per cent "
+                        "with the sampled weights); kernel_ms: HIP events around the search of the timed steps; the kernel is bound by "
+                        "the latency of its per-chunk loads, not by the FP64 rate (DESIGN.md section 5)"}
+        except Exception as exc:  # noqa: BLE001
+            out["roofline_knn"] = dict(error="%s: %s" % (type(exc).__name__, exc))
+            failed.append("roofline_knn")
         if args.trace_calls:
             out["host_call_ms_per_step"] = {k: v / args.steps for k, v in call_ms.items()}
         if roofline_stream is not None:

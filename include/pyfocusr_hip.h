@@ -302,6 +302,9 @@ int pf_knn_mode(pf_ctx* ctx, int32_t mode);
 /* Visits of the last hierarchy search, summed over the waves (counted only while enable_counting was 1 for that search;
  * the call also sets the switch for the searches to come). */
 int pf_knn_tree_stats(pf_ctx* ctx, int32_t enable_counting, int64_t* leaves_scanned, int64_t* supers_opened);
+/* The same for the grid search (k = 1, d <= 9): candidate-query pairs whose squared distance the last counted search
+ * evaluated (3 d floating-point operations each): the work behind the 1-NN stage's roofline entry in bench.py. */
+int pf_knn_count(pf_ctx* ctx, int32_t enable_counting, int64_t* pairs);
 /* k nearest neighbours (1 <= k <= 4, d <= 4), ascending by (distance, index): the 3-NN of
  * Focusr.get_weighted_final_node_locations (focusr.py:409-412).  idx_out / d2_out: n_qry x k row-major. */
 int pf_knn(pf_ctx* ctx, const double* ref, int64_t n_ref, const double* qry, int64_t n_qry, int32_t d, int32_t k,

@@ -128,6 +128,7 @@ SIGNATURES = {
     "pf_knn_run": (C.c_int, [C.c_void_p]),
     "pf_knn_download": (C.c_int, [C.c_void_p, _i64p, _f64p]),
     "pf_eigs_smallest": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, _f64p, _f64p, C.POINTER(C.c_int32), C.POINTER(EigsStats)]),
+    "pf_knn_count": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int64)]),
     "pf_host_detach": (C.c_int, [C.c_void_p]),
     "pf_orth_device_passes": (C.c_int, [C.c_void_p, C.c_int32]),
     "pf_eigs_smallest_ex": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, _f64p, _f64p, _f64p, C.POINTER(C.c_int32),
@@ -388,6 +389,12 @@ class Context(object):
         """How 1-NN searches prune: 0 by depth (grid for d <= 6, box hierarchy for d >= 7), 1 always the grid, 2 always
         the hierarchy.  The results are the same bits."""
         _check(self._lib.pf_knn_mode(self._h, int(mode)))
+
+    def knn_count(self, enable_counting=False):
+        """Candidate-query pairs evaluated by the last counted grid search (`pf_knn_count`); sets the switch for the next."""
+        pairs = C.c_int64()
+        _check(self._lib.pf_knn_count(self._h, int(bool(enable_counting)), C.byref(pairs)))
+        return int(pairs.value)
 
     def knn_tree_stats(self, enable_counting=False):
         """(leaves scanned, supers opened) of the last box-hierarchy search, if counting was on for it; sets the switch."""

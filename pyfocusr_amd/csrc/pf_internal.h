@@ -112,6 +112,8 @@ struct pf_ctx {
     double* knn_d2 = nullptr;   // [n_qry]
     bool knn_ready = false, knn_done = false;
     pf_knn_tree knn_tree;
+    bool knn_count_on = false;              // pf_knn_count: the counting instantiation of k_knn_coop
+    unsigned long long* knn_visited = nullptr;
     int32_t knn_mode = 0;  // 0: by depth (box hierarchy for k = 1, d >= PF_KNN_TREE_MIN_D = 7), 1: always the grid, 2: always the hierarchy
     // operator timing: event pairs recorded around filter applications, resolved lazily in pf_timing_get so
     // that timing never blocks the host (the solver queues the next application while this one runs)
@@ -183,8 +185,18 @@ struct pf_graph {
     int32_t* label = nullptr; // component root per vertex
     // solver-internal renumbering (pf_reorder.hip): operator storage and workspace vectors live in
     // "new" order; everything that crosses the C-ABI is in the mesh's own ("old") order.
-    int32_t* perm = nullptr;  // [n_pad] new -> old, -1 on padding rows
-    int32_t* iperm = nullptr; // [n]     old -> new
+    // Three vertex numberings.  ORIGINAL: the caller's (everything that crosses the C-ABI).  M-SPACE (round 4; mesh graphs
+    // only): the Morton rank of the vertex position - the assembler renumbers points and faces FIRST and builds CSR(W), deg,
+    // labels ... in that space, so that every per-row gather of the build hits lines its neighbours share (the synthetic
+    // meshes shuffle their vertices on purpose).  SOLVER: m-space rows permuted inside windows (boundary rows first, then
+    // by degree).  morder == nullptr (a graph handed in as a matrix): m-space is the original numbering.
+    int32_t* morder = nullptr; // [n]     m -> original
+    int32_t* mrank = nullptr;  // [n]     original -> m
+    int32_t* perm_m = nullptr; // [n_pad] solver row -> m (-1 on padding rows); == perm when morder == nullptr
+    int32_t* iperm_m = nullptr; // [n]    m -> solver row;                        == iperm when morder == nullptr
+    int32_t* perm = nullptr;  // [n_pad] solver row -> original vertex, -1 on padding rows
+    int32_t* iperm = nullptr; // [n]     original vertex -> solver row
+    unsigned long long* order_bbox = nullptr;  // (during a build) the bounding box of the points, encoded (pf_reorder.hip)
     double* smooth = nullptr; // [n_pad] solver order: low-order polynomial of the vertex position (Krylov start vector)
     double* stage = nullptr;  // [stage_cap] staging for permuted uploads/downloads
     int64_t stage_cap = 0;
@@ -328,6 +340,9 @@ int pf_reduce_ensure(pf_graph* g, int32_t count);
 // d_overflow (device int, nullable): the Morton order by counting (pf_reorder.hip); set to 1 when a cell holds too many
 // vertices for that - the caller then repeats the call with nullptr (the general sort)
 int pf_compute_order(pf_graph* g, const double* d_pts, int32_t* d_overflow = nullptr);
+// the Morton order of the mesh's points, before anything else of a build: fills g->morder / g->mrank (allocated here) and
+// g->order_bbox; d_overflow (nullable: general sort) is raised when the counting sort met a pile of vertices in one cell
+int pf_morton_order(pf_graph* g, const double* d_pts, int32_t* d_overflow);
 
 // Rows per window of the resident Chebyshev kernel: one window per block, at most 256 blocks.
 static inline int32_t pf_window_rows(int64_t n_pad) { return n_pad <= 262144 ? 1024 : (n_pad <= 524288 ? 2048 : 4096); }

@@ -446,13 +446,16 @@ __device__ __forceinline__ void wave_argmin(double& s, int32_t& o) {
     }
 }
 
-template <int D>
+// COUNT (pf_knn_count; a separate instantiation, the search itself never pays for it): the candidate-query pairs whose
+// distance the search evaluates, summed into *visited - the work figure behind the roofline entry of the 1-NN stage.
+template <int D, bool COUNT = false>
 __global__ __launch_bounds__(PF_BLOCK) void k_knn_coop(const double* __restrict__ soa, int64_t ld, const int32_t* __restrict__ ref_orig,
                                                        const int32_t* __restrict__ cell_start, const double* __restrict__ qry_s,
                                                        const int32_t* __restrict__ qry_orig, int64_t n_qry,
                                                        const KnnGrid* __restrict__ gp, int64_t* __restrict__ idx_out,
-                                                       double* __restrict__ d2_out) {
+                                                       double* __restrict__ d2_out, unsigned long long* __restrict__ visited = nullptr) {
     constexpr int G = knn_group(D);
+    unsigned long long seen = 0;  // (wave-uniform)
     const KnnGrid g = *gp;
     const int lane = threadIdx.x & (PF_WAVE - 1);
     const int64_t group = (int64_t)blockIdx.x * (PF_BLOCK / PF_WAVE) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x / PF_WAVE));
@@ -501,6 +504,7 @@ __global__ __launch_bounds__(PF_BLOCK) void k_knn_coop(const double* __restrict_
             const int row = (int)__popcll(__ballot(inc <= j));  // lanes whose rows end before chunk j
             const int32_t first = row > 0 ? __builtin_amdgcn_readlane(inc, row - 1) : 0;
             const int32_t r = __builtin_amdgcn_readlane(b_l, row) + (j - first) * PF_WAVE + lane;
+            if constexpr (COUNT) seen += (unsigned long long)__popcll(__ballot(r < __builtin_amdgcn_readlane(e_l, row)));
             if (r < __builtin_amdgcn_readlane(e_l, row)) {
                 double x[D];
 #pragma unroll
@@ -591,6 +595,9 @@ __global__ __launch_bounds__(PF_BLOCK) void k_knn_coop(const double* __restrict_
             d2_out[dst] = best[i];
         }
     }
+    if constexpr (COUNT) {
+        if (lane == 0 && visited) atomicAdd(visited, seen * (unsigned long long)nq);
+    }
 }
 
 // ---- small problems (both sets <= PF_KNN_SMALL points, k = 1): the exhaustive scan in ONE launch -----------------------------
@@ -680,9 +687,17 @@ int launch_knn_k(pf_ctx* c) {
     // coordinates and best lists in LDS instead was slower still: d = 10: 78 ms, d = 12: 139)
     if constexpr (K == 1 && D <= 9) {
         const int64_t waves = (c->knn_nqry + knn_group(D) - 1) / knn_group(D);
-        k_knn_coop<D><<<(unsigned)((waves + PF_BLOCK / PF_WAVE - 1) / (PF_BLOCK / PF_WAVE)), PF_BLOCK, 0, c->stream>>>(
-            c->knn_ref_soa, c->knn_ref_ld, c->knn_ref_orig, c->knn_cell_start, c->knn_qry_s, c->knn_qry_orig, c->knn_nqry,
-            (const KnnGrid*)c->knn_grid, c->knn_idx, c->knn_d2);
+        if (c->knn_count_on) {
+            if (!c->knn_visited) PF_HIP(pf_malloc(c->stream, (void**)&c->knn_visited, sizeof(unsigned long long)));
+            PF_HIP(hipMemsetAsync(c->knn_visited, 0, sizeof(unsigned long long), c->stream));
+            k_knn_coop<D, true><<<(unsigned)((waves + PF_BLOCK / PF_WAVE - 1) / (PF_BLOCK / PF_WAVE)), PF_BLOCK, 0, c->stream>>>(
+                c->knn_ref_soa, c->knn_ref_ld, c->knn_ref_orig, c->knn_cell_start, c->knn_qry_s, c->knn_qry_orig, c->knn_nqry,
+                (const KnnGrid*)c->knn_grid, c->knn_idx, c->knn_d2, c->knn_visited);
+        } else {
+            k_knn_coop<D><<<(unsigned)((waves + PF_BLOCK / PF_WAVE - 1) / (PF_BLOCK / PF_WAVE)), PF_BLOCK, 0, c->stream>>>(
+                c->knn_ref_soa, c->knn_ref_ld, c->knn_ref_orig, c->knn_cell_start, c->knn_qry_s, c->knn_qry_orig, c->knn_nqry,
+                (const KnnGrid*)c->knn_grid, c->knn_idx, c->knn_d2);
+        }
     } else {
         k_knn_grid<D, K, BS, 512><<<(unsigned)((c->knn_nqry + BS - 1) / BS), BS, 0, c->stream>>>(
             c->knn_ref_s, c->knn_ref_orig, c->knn_cell_start, c->knn_nref, c->knn_qry_s, c->knn_qry_orig, c->knn_nqry,
@@ -955,6 +970,20 @@ int pf_knn_run(pf_ctx* c) {
     PF_HIP(hipEventElapsedTime(&ms, c->ev0, c->ev1));
     c->knn_ms = ms;
     c->knn_done = true;
+    return PF_OK;
+}
+
+/* Candidate-query pairs the grid search (k = 1, d <= 9) evaluated in the last search run with counting on; the call also
+ * sets the switch for the searches to come (a separate kernel instantiation: the default search does not count). */
+int pf_knn_count(pf_ctx* c, int32_t enable_counting, int64_t* pairs) {
+    PF_CHECK(c != nullptr, PF_E_ARG, "pf_knn_count: ctx is NULL");
+    unsigned long long h = 0ull;
+    if (c->knn_visited) {
+        PF_HIP(hipMemcpyAsync(&h, c->knn_visited, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+        PF_HIP(hipStreamSynchronize(c->stream));
+    }
+    if (pairs) *pairs = (int64_t)h;
+    c->knn_count_on = enable_counting != 0;
     return PF_OK;
 }
 

@@ -113,11 +113,11 @@ __global__ __launch_bounds__(PF_BLOCK) void k_boundary_flags(const int32_t* __re
                                                              int64_t n, int32_t win_rows, unsigned* __restrict__ flag) {
     const int64_t r = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
     if (r >= n) return;
-    const int32_t old = order[r];
+    const int32_t old = order ? order[r] : (int32_t)r;  // (order == pos == nullptr: the rows stand in their base order already)
     const int32_t w = (int32_t)(r / win_rows);
     bool mine = false;
     for (int32_t a = rowptr[old]; a < rowptr[old + 1]; ++a) {
-        const int32_t rj = pos[col[a]];
+        const int32_t rj = pos ? pos[col[a]] : col[a];
         if (rj / win_rows != w) {
             mine = true;
             flag[rj] = 1u;  // (plain stores of the same value: a benign race)
@@ -134,11 +134,11 @@ __global__ __launch_bounds__(PF_BLOCK) void k_second_ring_flags(const int32_t* _
                                                                 int64_t n, unsigned* __restrict__ flag) {
     const int64_t r = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
     if (r >= n) return;
-    const int32_t old = order[r];
+    const int32_t old = order ? order[r] : (int32_t)r;
     const bool boundary = flag[r] == 1u;
     bool near = false;
     for (int32_t a = rowptr[old]; a < rowptr[old + 1]; ++a) {
-        const int32_t rj = pos[col[a]];
+        const int32_t rj = pos ? pos[col[a]] : col[a];
         const unsigned f = flag[rj];  // (0 may turn into 2 meanwhile; 1 never changes in this kernel)
         if (boundary && f == 0u) flag[rj] = 2u;
         near |= f == 1u;
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(PF_BLOCK) void k_degree_keys(const int32_t* __restr
                                                           unsigned* __restrict__ keys) {
     const int64_t r = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
     if (r >= n) return;
-    const int32_t old = order[r];
+    const int32_t old = order ? order[r] : (int32_t)r;
     int32_t d = rowptr[old + 1] - rowptr[old];
     d = d > 1023 ? 1023 : d;
     const unsigned f = flag[r];
@@ -189,7 +189,7 @@ __global__ __launch_bounds__(1024) void k_sort_windows(const unsigned* __restric
     }
     for (int i = threadIdx.x; i < win_rows; i += 1024) {
         const int64_t r = r0 + i;
-        if (r < n) out[r] = vals[r0 + (int64_t)(wbuf[i] & 0xffffffffull)];
+        if (r < n) out[r] = vals ? vals[r0 + (int64_t)(wbuf[i] & 0xffffffffull)] : (int32_t)(r0 + (int64_t)(wbuf[i] & 0xffffffffull));
     }
 }
 
@@ -204,6 +204,17 @@ __global__ __launch_bounds__(PF_BLOCK) void k_finish_perm(int32_t* __restrict__ 
     if (r >= n_pad) return;
     if (r < n) iperm[perm[r]] = (int32_t)r;
     else perm[r] = -1;
+}
+
+// perm[r] = morder[perm_m[r]] (-1 on padding rows), iperm[original] = r: what the C-ABI side of the library maps with
+__global__ __launch_bounds__(PF_BLOCK) void k_compose_perm(const int32_t* __restrict__ perm_m, const int32_t* __restrict__ morder,
+                                                           int64_t n_pad, int32_t* __restrict__ perm, int32_t* __restrict__ iperm) {
+    const int64_t r = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
+    if (r >= n_pad) return;
+    const int32_t m = perm_m[r];
+    const int32_t o = m >= 0 ? morder[m] : -1;
+    perm[r] = o;
+    if (o >= 0) iperm[o] = (int32_t)r;
 }
 
 // Krylov start vector, part 1: a low-order polynomial of the vertex position (coordinates mapped to
@@ -283,8 +294,134 @@ __global__ __launch_bounds__(PF_BLOCK) void k_order_rank(const unsigned* __restr
 
 }  // namespace
 
-// Fills g->perm [n_pad], g->iperm [n] and g->smooth [n_pad] (all already allocated).
+// The Morton order of a mesh's points, computed BEFORE the mesh is assembled (round 4): g->morder[m] = original vertex,
+// g->mrank[original] = m, g->order_bbox.  The assembler renumbers points and faces with it and builds everything in that
+// space; pf_compute_order then only refines the order inside windows.
+int pf_morton_order(pf_graph* g, const double* d_pts, int32_t* d_overflow) {
+    hipStream_t st = g->build_stream ? g->build_stream : g->ctx->stream;
+    const int64_t n = g->n;
+    const int in = (int)n;
+    unsigned *k0 = nullptr, *k1 = nullptr;
+    int32_t* v0 = nullptr;
+    void* tmp = nullptr;
+    int32_t *hist = nullptr, *bstart = nullptr;
+    int rc = PF_OK;
+    auto fail = [&](hipError_t e) {
+        if (e != hipSuccess && rc == PF_OK) {
+            pf_set_error("pf_morton_order: %s", hipGetErrorString(e));
+            rc = PF_E_HIP;
+        }
+        return e != hipSuccess;
+    };
+    do {
+        if (fail(pf_malloc(st, (void**)&g->order_bbox, 6 * sizeof(unsigned long long)))) break;
+        if (fail(pf_malloc(st, (void**)&g->morder, sizeof(int32_t) * std::max<int64_t>(n, 1)))) break;
+        if (fail(pf_malloc(st, (void**)&g->mrank, sizeof(int32_t) * std::max<int64_t>(n, 1)))) break;
+        if (fail(pf_malloc(st, (void**)&k0, sizeof(unsigned) * std::max<int64_t>(n, 1))) ||
+            fail(pf_malloc(st, (void**)&k1, sizeof(unsigned) * std::max<int64_t>(n, 1))) ||
+            fail(pf_malloc(st, (void**)&v0, sizeof(int32_t) * std::max<int64_t>(n, 1))))
+            break;
+        if (fail(hipMemsetAsync(g->order_bbox, 0, 6 * sizeof(unsigned long long), st))) break;
+        if (n == 0) break;
+        k_bbox<<<256, PF_BLOCK, 0, st>>>(d_pts, n, g->order_bbox);
+        k_morton_keys<<<nblk(n), PF_BLOCK, 0, st>>>(d_pts, n, g->order_bbox, k0, v0);
+        if (fail(hipGetLastError())) break;
+        const bool counting = d_overflow != nullptr && n >= 4096;  // (else: the general sort)
+        if (counting) {
+            int bits = 12;
+            while (bits < 22 && ((int64_t)1 << bits) < 2 * n) ++bits;  // ~2 buckets per vertex, 4 M at most
+            const int shift = 30 - bits;
+            const int64_t nb = (int64_t)1 << bits;
+            if (fail(pf_malloc(st, (void**)&hist, sizeof(int32_t) * (size_t)(2 * nb + 2)))) break;  // [nb + 1] counts, then [nb] cursors
+            if (fail(pf_malloc(st, (void**)&bstart, sizeof(int32_t) * (size_t)(nb + 1)))) break;
+            if (fail(hipMemsetAsync(hist, 0, sizeof(int32_t) * (size_t)(2 * nb + 2), st))) break;
+            k_order_hist<<<nblk(n), PF_BLOCK, 0, st>>>(k0, n, shift, hist);
+            if (fail(hipGetLastError())) break;
+            if (pf_exclusive_scan_i32(st, hist, bstart, nb + 1) != PF_OK) {
+                rc = PF_E_HIP;
+                break;
+            }
+            // k1 / v0: the bucketed keys and vertices (v0's identity is not needed any more: the index is the thread's own)
+            k_order_scatter<<<nblk(n), PF_BLOCK, 0, st>>>(k0, n, shift, bstart, hist + nb + 1, k1, v0);
+            k_order_rank<<<nblk(n), PF_BLOCK, 0, st>>>(k1, v0, n, shift, bstart, g->morder, d_overflow);
+            if (fail(hipGetLastError())) break;
+        } else {
+            size_t need = 0;
+            if (fail(hipcub::DeviceRadixSort::SortPairs(nullptr, need, k0, k1, v0, g->morder, in, 0, 30, st))) break;
+            if (fail(pf_malloc(st, &tmp, need))) break;
+            if (fail(hipcub::DeviceRadixSort::SortPairs(tmp, need, k0, k1, v0, g->morder, in, 0, 30, st))) break;
+        }
+        k_scatter_pos<<<nblk(n), PF_BLOCK, 0, st>>>(g->morder, n, g->mrank);
+        if (fail(hipGetLastError())) break;
+    } while (0);
+    pf_free(st, k0);
+    pf_free(st, k1);
+    pf_free(st, v0);
+    pf_free(st, tmp);
+    pf_free(st, hist);
+    pf_free(st, bstart);
+    return rc;
+}
+
+// The order inside windows for a graph whose rows stand in Morton order already (g->morder set: a mesh assembled in
+// m-space; d_pts: the points in that order): boundary rows first, then by degree; g->perm_m / g->iperm_m (solver <-> m),
+// their compositions with morder in g->perm / g->iperm (solver <-> original), g->smooth.
+static int order_in_windows(pf_graph* g, const double* d_pts) {
+    hipStream_t st = g->build_stream ? g->build_stream : g->ctx->stream;
+    const int64_t n = g->n;
+    const int32_t win_rows = g->win_rows;
+    unsigned *bflag = nullptr, *k0 = nullptr, *k1 = nullptr;
+    int32_t* v1 = nullptr;
+    void* tmp = nullptr;
+    int rc = PF_OK;
+    auto fail = [&](hipError_t e) {
+        if (e != hipSuccess && rc == PF_OK) {
+            pf_set_error("pf_compute_order: %s", hipGetErrorString(e));
+            rc = PF_E_HIP;
+        }
+        return e != hipSuccess;
+    };
+    do {
+        if (fail(pf_malloc(st, (void**)&bflag, sizeof(unsigned) * std::max<int64_t>(n, 1)))) break;
+        if (fail(pf_malloc(st, (void**)&k0, sizeof(unsigned) * std::max<int64_t>(n, 1)))) break;
+        if (fail(hipMemsetAsync(bflag, 0, sizeof(unsigned) * std::max<int64_t>(n, 1), st))) break;
+        k_boundary_flags<<<nblk(n), PF_BLOCK, 0, st>>>(nullptr, g->rowptr, g->col, nullptr, n, win_rows, bflag);
+        k_second_ring_flags<<<nblk(n), PF_BLOCK, 0, st>>>(nullptr, g->rowptr, g->col, nullptr, n, bflag);
+        k_degree_keys<<<nblk(n), PF_BLOCK, 0, st>>>(nullptr, g->rowptr, bflag, n, win_rows, k0);
+        if (fail(hipGetLastError())) break;
+        if (win_rows <= 4096) {
+            int32_t n_pow2 = 2;
+            while (n_pow2 < win_rows) n_pow2 <<= 1;
+            k_sort_windows<<<(unsigned)((n + win_rows - 1) / win_rows), 1024, sizeof(unsigned long long) * (size_t)n_pow2, st>>>(
+                k0, nullptr, n, win_rows, n_pow2, g->perm_m);
+            if (fail(hipGetLastError())) break;
+        } else {
+            int bits2 = 12;
+            for (int64_t w = (n + win_rows - 1) / win_rows; w > 0; w >>= 1) ++bits2;
+            if (fail(pf_malloc(st, (void**)&k1, sizeof(unsigned) * n)) || fail(pf_malloc(st, (void**)&v1, sizeof(int32_t) * n))) break;
+            k_iota<<<nblk(n), PF_BLOCK, 0, st>>>(v1, n);
+            size_t need = 0;
+            if (fail(hipcub::DeviceRadixSort::SortPairs(nullptr, need, k0, k1, v1, g->perm_m, (int)n, 0, bits2, st))) break;
+            if (fail(pf_malloc(st, &tmp, need))) break;
+            if (fail(hipcub::DeviceRadixSort::SortPairs(tmp, need, k0, k1, v1, g->perm_m, (int)n, 0, bits2, st))) break;
+        }
+        k_finish_perm<<<nblk(g->n_pad), PF_BLOCK, 0, st>>>(g->perm_m, g->iperm_m, n, g->n_pad);
+        k_compose_perm<<<nblk(g->n_pad), PF_BLOCK, 0, st>>>(g->perm_m, g->morder, g->n_pad, g->perm, g->iperm);
+        k_smooth_start<<<nblk(g->n_pad), PF_BLOCK, 0, st>>>(d_pts, g->perm_m, g->order_bbox, g->n_pad, g->smooth);
+        if (fail(hipGetLastError())) break;
+    } while (0);
+    pf_free(st, bflag);
+    pf_free(st, k0);
+    pf_free(st, k1);
+    pf_free(st, v1);
+    pf_free(st, tmp);
+    return rc;
+}
+
+// Fills g->perm [n_pad], g->iperm [n] and g->smooth [n_pad] (all already allocated) - and g->perm_m / g->iperm_m for a
+// mesh assembled in m-space.
 int pf_compute_order(pf_graph* g, const double* d_pts, int32_t* d_overflow) {
+    if (g->morder) return order_in_windows(g, d_pts);
     hipStream_t st = g->build_stream ? g->build_stream : g->ctx->stream;
     const int64_t n = g->n;
     const int in = (int)n;

@@ -100,9 +100,46 @@ if args.fetch and args.write:
             e.update(kernel_trace_calls=st["calls"], kernel_trace_avg_ns=st["avg_ns"],
                      GBps_of_counter_traffic=(e["hbm_read_bytes_per_launch"] + e["hbm_write_bytes_per_launch"]) / st["avg_ns"])
         others[needle] = e
+# per stage of a step: counter traffic of every kernel that belongs to the stage's source files, summed over the run and
+# divided by the steps the profiled command ran (timed + warm-up) - what bench.py's `roofline_assembly` / `roofline_knn`
+# entries quote as `traffic`
+import re
+
+repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def kernels_of(*files):
+    names = set()
+    for f in files:
+        with open(os.path.join(repo, "pyfocusr_amd", "csrc", f)) as fh:
+            names.update(re.findall(r"__global__[^;{]*?void\s+(\w+)\s*\(", fh.read()))
+    return names
+
+
+stage_files = dict(assembly=("pf_assemble.hip", "pf_reorder.hip", "pf_scan.hip"), knn=("pf_knn.hip", "pf_knn_tree.hip"))
+stages = {}
+if args.fetch and args.write:
+    ftab, wtab = counter_avg(args.fetch, "FETCH_SIZE"), counter_avg(args.write, "WRITE_SIZE")
+    n_steps = max(int(bench.get("steps", 2)) + int(bench.get("warmup", 1)), 1)
+    for stage, files in stage_files.items():
+        names = kernels_of(*files)
+        rd = wr = 0.0
+        n_disp = 0
+        for kname, (calls, kb) in ftab.items():
+            m = re.search(r"(\w+)(<[^(]*>)?\(", kname.replace("(anonymous namespace)::", ""))
+            if m and m.group(1) in names:
+                rd += 2.0 * kb * 1024.0 * calls
+                n_disp += calls
+        for kname, (calls, kb) in wtab.items():
+            m = re.search(r"(\w+)(<[^(]*>)?\(", kname.replace("(anonymous namespace)::", ""))
+            if m and m.group(1) in names:
+                wr += kb * 1024.0 * calls
+        stages[stage] = dict(hbm_read_bytes_per_step=rd / n_steps, hbm_write_bytes_per_step=wr / n_steps,
+                             hbm_bytes_per_step=(rd + wr) / n_steps, dispatches_per_step=n_disp / n_steps, steps_counted=n_steps,
+                             kernels_from=list(files))
 out = dict(source="rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) -- python3 bench.py --steps 2 --warmup 1 "
                   "--no-extras --no-cpu-baseline (250k-vertex pair, k=5); streaming kernel: the same with PF_PERSIST=0",
-           kernels=kernels, other_kernels_average_per_dispatch=others)
+           kernels=kernels, other_kernels_average_per_dispatch=others, stages=stages)
 with open(args.out, "w") as fh:
     json.dump(out, fh, indent=1)
 print(json.dumps(out, indent=1))

@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """Size sweep of the hot path: per mesh size, GPU assembly / eigensolve / KNN times,
-SpMV launch time and roofline fraction, and the reference's scipy `eigs` call timed on the host for
-comparison.  python tools/sweep.py [--cpu-max 250000] n1 n2 ...   -> markdown table on stdout."""
+the filter kernels' time per step - the resident kernel (operators in registers: an EFFECTIVE rate, not a roofline
+fraction) and, from one extra solve with the resident path off, the streaming kernel against the HBM roofline - and the
+reference's scipy `eigs` call timed on the host for comparison (north_star: "eigenpairs/sec on synthetic meshes of
+10k-1M ... as fraction of HBM roofline, next to the reference scipy path").
+python tools/sweep.py [--cpu-max 100000] n1 n2 ...   -> markdown table on stdout."""
 import argparse
 import os
 import sys
@@ -18,15 +21,16 @@ from pyfocusr_amd.meshgen import blob_mesh  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("sizes", type=int, nargs="*", default=[10000, 30000, 100000, 250000, 500000, 1000000])
-ap.add_argument("--cpu-max", type=int, default=250000)
+ap.add_argument("--cpu-max", type=int, default=100000, help="largest size whose scipy eigs column is measured here (250k: bench.py's cpu_baseline leg)")
 ap.add_argument("--k", type=int, default=5)
 args = ap.parse_args()
 
 ctx = _hip.default_context()
 ctx.timing_enable(True)
-print("| n | k | assembly ms (pair) | eigensolve ms (pair) | matvecs/mesh | us per step of the pair | filter kernel | effective GB/s (algorithmic bytes / time) | eigsort ms | KNN ms | "
-      "eigenpairs/s (pair, all stages) | scipy eigs s/mesh | max residual |")
-print("|---|---|---|---|---|---|---|---|---|---|---|---|---|")
+print("| n | k | assembly ms (pair) | eigensolve ms (pair) | matvecs/mesh | us per step of the pair | filter kernel | effective GB/s (algorithmic bytes / time) | "
+      "streaming kernel: us per launch (both graphs) | streaming kernel: algorithmic GB/s | fraction of the 8 TB/s HBM peak | eigsort ms | KNN ms | "
+      "eigenpairs/s (pair, all stages) | scipy eigs s/mesh (1 thread) | eigensolve speed-up vs scipy (pair) | max residual |")
+print("|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|")
 for n in args.sizes:
     k = args.k if n < 1000000 else 10  # BASELINE config C5: k = 10 at 1M
     meshes = [blob_mesh(n, seed=s) for s in (0, 1)]
@@ -62,7 +66,21 @@ for n in args.sizes:
             g.device.close()
         if best is None or row["eig"] < best["eig"]:
             best = row
-    cpu = ""
+    # the kernel that does stream the operators through HBM: one extra solve with the resident path off
+    _hip.persist_enable(False)
+    try:
+        ctx.timing(reset=True)
+        gs = [Graph(m, n_spectral_features=k, n_rand_samples=5000, ctx=ctx, verbose=False) for m in meshes]
+        compute_spectra(gs)
+        for g in gs:
+            _ = g.eig_vecs
+            g.device.close()
+        tm = ctx.timing()
+        s_us = 1e3 * tm["op_ms"] / max(tm["op_launches"], 1)
+        s_gbs = tm["op_bytes"] / max(tm["op_ms"], 1e-9) / 1e6
+    finally:
+        _hip.persist_enable(True)
+    cpu, cpu_s = "", None
     if n <= args.cpu_max:
         dev = _hip.DeviceLaplacian(meshes[0].points, meshes[0].faces, ctx=ctx)
         d = dev.download()
@@ -71,14 +89,16 @@ for n in args.sizes:
         L = (sparse.diags(1.0 / (d["deg"] + 1e-8)) @ (sparse.diags(d["deg"]) - W)).tocsr()
         t0 = time.perf_counter()
         eigs(L, k=k + 1, sigma=1e-10, which="LM", ncv=4 * (k + 1))
-        cpu = "%.2f" % (time.perf_counter() - t0)
+        cpu_s = time.perf_counter() - t0
+        cpu = "%.2f" % cpu_s
     total = best["asm"] + best["eig"] + best["sort"] + best["knn"]
     kind = "one step per launch"
     if best["persist"]:
         kind = "resident, one launch per graph" if best["split"] else "resident, both graphs per launch"
-    print("| %d | %d | %.2f | %.2f | %d | %.2f | %s | %.0f | %.2f | %.2f | %.1f | %s | %.1e |" % (
-        n, k, 1e3 * best["asm"], 1e3 * best["eig"], best["mv"], best["us"], kind, best["gbs"],
-        1e3 * best["sort"], 1e3 * best["knn"], 2 * k / total, cpu, best["res"]), flush=True)
+    print("| %d | %d | %.2f | %.2f | %d | %.2f | %s | %.0f | %.2f | %.0f | %.2f | %.2f | %.2f | %.1f | %s | %s | %.1e |" % (
+        n, k, 1e3 * best["asm"], 1e3 * best["eig"], best["mv"], best["us"], kind, best["gbs"], s_us, s_gbs, s_gbs / 8000.0,
+        1e3 * best["sort"], 1e3 * best["knn"], 2 * k / total, cpu, "" if cpu_s is None else "%.0f x" % (2 * cpu_s / best["eig"]),
+        best["res"]), flush=True)
     for m in meshes:
         m._pf_device_mesh.close()
 
