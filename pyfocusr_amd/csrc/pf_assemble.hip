@@ -117,6 +117,23 @@ __global__ __launch_bounds__(PF_BLOCK) void k_face_bound(const int32_t* __restri
     }
 }
 
+// ---- m-space (round 4): the mesh renumbered by the Morton rank of its points before anything is assembled ----------------
+// pts_m[m] = pts[morder[m]]; faces_m[e] = mrank[faces[e]] (an index out of range stays out of range: k_count_edges flags it)
+__global__ __launch_bounds__(PF_BLOCK) void k_renumber_points(const double* __restrict__ pts, const int32_t* __restrict__ morder,
+                                                              int64_t n, double* __restrict__ out) {
+    const int64_t t = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
+    if (t >= 3 * n) return;
+    const int64_t m = t / 3;
+    out[t] = pts[3 * (int64_t)morder[m] + (t - 3 * m)];
+}
+__global__ __launch_bounds__(PF_BLOCK) void k_renumber_faces(const int32_t* __restrict__ faces, const int32_t* __restrict__ mrank,
+                                                             int64_t n_edges, int64_t n, int32_t* __restrict__ out) {
+    const int64_t e = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
+    if (e >= n_edges) return;
+    const int32_t v = faces[e];
+    out[e] = (v >= 0 && v < n) ? mrank[v] : (v < 0 ? v : (int32_t)n);
+}
+
 // one thread per vertex: insertion-sort its (col, w) segment by column, drop duplicate columns
 // (a directed edge listed by two faces carries the same weight), report the unique count.
 // The segments of a block's 256 vertices are one contiguous piece of rcol / rw (~3000 entries): it is staged in LDS by
@@ -124,13 +141,17 @@ __global__ __launch_bounds__(PF_BLOCK) void k_face_bound(const int32_t* __restri
 // sort's ~40 dependent moves per row are LDS accesses instead of global ones (89 -> ~25 us at 250k vertices).  A block
 // whose piece does not fit (very high degrees) sorts in place in global memory, as before.
 constexpr int PF_SORT_CAP = 4096;  // entries staged per block: 48 KB
+// `key` (nullable): the ORIGINAL vertex number of an m-space column - a row's entries stand in the order of the caller's
+// numbering whatever space they are stored in: the degree is their sum from left to right (lil_matrix.sum, graph.py:217)
+// and the boundary format is CSR with sorted original columns.
 template <typename C, typename W>
-__device__ __forceinline__ int32_t sort_unique_segment(C* c, W* v, int32_t b, int32_t e) {
+__device__ __forceinline__ int32_t sort_unique_segment(C* c, W* v, int32_t b, int32_t e, const int32_t* __restrict__ key = nullptr) {
     for (int32_t a = b + 1; a < e; ++a) {
         const int32_t cc = c[a];
         const double vv = v[a];
+        const int32_t kc = key ? key[cc] : cc;
         int32_t p = a - 1;
-        while (p >= b && c[p] > cc) {
+        while (p >= b && (key ? key[c[p]] : c[p]) > kc) {
             c[p + 1] = c[p];
             v[p + 1] = v[p];
             --p;
@@ -151,7 +172,7 @@ __device__ __forceinline__ int32_t sort_unique_segment(C* c, W* v, int32_t b, in
 
 __global__ __launch_bounds__(PF_BLOCK) void k_sort_unique_rows(const int32_t* __restrict__ start, int64_t n,
                                                                int32_t* __restrict__ rcol, double* __restrict__ rw,
-                                                               int32_t* __restrict__ ucnt) {
+                                                               int32_t* __restrict__ ucnt, const int32_t* __restrict__ key) {
     __shared__ int32_t s_c[PF_SORT_CAP];
     __shared__ double s_v[PF_SORT_CAP];
     const int64_t i0 = (int64_t)blockIdx.x * PF_BLOCK;
@@ -159,7 +180,7 @@ __global__ __launch_bounds__(PF_BLOCK) void k_sort_unique_rows(const int32_t* __
     const int64_t i1 = i0 + PF_BLOCK < n ? i0 + PF_BLOCK : n;
     const int32_t lo = start[i0], hi = start[i1];  // (block-uniform)
     if (hi - lo > PF_SORT_CAP) {
-        if (i < n) ucnt[i] = sort_unique_segment(rcol, rw, start[i], start[i + 1]);
+        if (i < n) ucnt[i] = sort_unique_segment(rcol, rw, start[i], start[i + 1], key);
         return;
     }
     for (int32_t a = threadIdx.x; a < hi - lo; a += PF_BLOCK) {
@@ -167,7 +188,7 @@ __global__ __launch_bounds__(PF_BLOCK) void k_sort_unique_rows(const int32_t* __
         s_v[a] = rw[lo + a];
     }
     __syncthreads();
-    if (i < n) ucnt[i] = sort_unique_segment(s_c, s_v, start[i] - lo, start[i + 1] - lo);
+    if (i < n) ucnt[i] = sort_unique_segment(s_c, s_v, start[i] - lo, start[i + 1] - lo, key);
     __syncthreads();
     for (int32_t a = threadIdx.x; a < hi - lo; a += PF_BLOCK) {
         rcol[lo + a] = s_c[a];
@@ -229,7 +250,7 @@ __global__ __launch_bounds__(PF_BLOCK) void k_row_stats(const int32_t* __restric
 __global__ __launch_bounds__(PF_BLOCK) void k_symmetry_probe(const int32_t* __restrict__ rowptr,
                                                              const int32_t* __restrict__ col,
                                                              const double* __restrict__ values, int64_t n,
-                                                             int32_t* __restrict__ asym) {
+                                                             int32_t* __restrict__ asym, const int32_t* __restrict__ key = nullptr) {
     // eight threads per row, each with every eighth entry: the binary searches of a row (three dependent gathers each, in
     // rows that lie anywhere) are in flight together instead of one after the other (50 -> ~15 us at 250k vertices)
     const int64_t t = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
@@ -239,6 +260,7 @@ __global__ __launch_bounds__(PF_BLOCK) void k_symmetry_probe(const int32_t* __re
         const int32_t j = col[a];
         int32_t lo = rowptr[j], hi = rowptr[j + 1] - 1;
         bool found = false;
+        const int32_t ki = key ? key[i] : (int32_t)i;  // (rows are sorted by the original number of their columns)
         while (lo <= hi) {
             const int32_t mid = (lo + hi) >> 1;
             const int32_t c = col[mid];
@@ -246,7 +268,7 @@ __global__ __launch_bounds__(PF_BLOCK) void k_symmetry_probe(const int32_t* __re
                 found = values == nullptr || values[mid] == values[a];
                 break;
             }
-            if (c < (int32_t)i) lo = mid + 1; else hi = mid - 1;
+            if ((key ? key[c] : c) < ki) lo = mid + 1; else hi = mid - 1;
         }
         if (!found) atomicAdd(asym, 1);  // one-way (or numerically unequal) entry
     }
@@ -476,6 +498,47 @@ __global__ __launch_bounds__(PF_BLOCK) void k_l_diag(const double* __restrict__ 
     if (i < n) out[i] = g[i] * deg[i];
 }
 
+// ---- the boundary format of a graph assembled in m-space: CSR(W), deg, labels in the caller's vertex order, made on demand
+// (pf_graph_download: reference-style views, tests; never on the timed path)
+__global__ __launch_bounds__(PF_BLOCK) void k_len_original(const int32_t* __restrict__ rowptr_m, const int32_t* __restrict__ mrank,
+                                                           int64_t n, int32_t* __restrict__ len) {
+    const int64_t i = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
+    if (i > n) return;
+    len[i] = i < n ? rowptr_m[mrank[i] + 1] - rowptr_m[mrank[i]] : 0;
+}
+// one thread per original row: its entries stand in the order of their original columns already (k_sort_unique_rows' key)
+__global__ __launch_bounds__(PF_BLOCK) void k_rows_original(const int32_t* __restrict__ rowptr_m, const int32_t* __restrict__ col_m,
+                                                            const double* __restrict__ w_m, const double* __restrict__ g_m,
+                                                            const double* __restrict__ deg_m, const int32_t* __restrict__ mrank,
+                                                            const int32_t* __restrict__ morder, const int32_t* __restrict__ rowptr_o,
+                                                            int64_t n, int32_t* __restrict__ col_o, double* __restrict__ w_o,
+                                                            double* __restrict__ loff_o, double* __restrict__ deg_o,
+                                                            double* __restrict__ ldiag_o) {
+    const int64_t i = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const int32_t m = mrank[i];
+    const double gi = g_m[m];
+    if (deg_o) deg_o[i] = deg_m[m];
+    if (ldiag_o) ldiag_o[i] = gi * deg_m[m];
+    const int32_t b = rowptr_m[m], cnt = rowptr_m[m + 1] - b, dst = rowptr_o[i];
+    for (int32_t a = 0; a < cnt; ++a) {
+        if (col_o) col_o[dst + a] = morder[col_m[b + a]];
+        if (w_o) w_o[dst + a] = w_m[b + a];
+        if (loff_o) loff_o[dst + a] = -(gi * w_m[b + a]);
+    }
+}
+// component labels as the reference-side tests know them: the SMALLEST original vertex number of the component
+__global__ __launch_bounds__(PF_BLOCK) void k_label_min_original(const int32_t* __restrict__ label_m, const int32_t* __restrict__ morder,
+                                                                 int64_t n, int32_t* __restrict__ smallest) {
+    const int64_t m = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
+    if (m < n) atomicMin(&smallest[label_m[m]], morder[m]);
+}
+__global__ __launch_bounds__(PF_BLOCK) void k_label_original(const int32_t* __restrict__ label_m, const int32_t* __restrict__ mrank,
+                                                             const int32_t* __restrict__ smallest, int64_t n, int32_t* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
+    if (i < n) out[i] = smallest[label_m[mrank[i]]];
+}
+
 inline unsigned nblk(int64_t n) { return (unsigned)((n + PF_BLOCK - 1) / PF_BLOCK); }
 
 template <typename T>
@@ -599,7 +662,7 @@ struct FinishJob {
         stats = flags + 2;  // [0] isolated, [1] max degree, [2] asym, [3] changed, [4] n_roots
         k_row_stats<<<nblk(n), PF_BLOCK, 0, st>>>(g->rowptr, n, stats);
         PF_HIP(hipGetLastError());
-        k_symmetry_probe<<<nblk(8 * n), PF_BLOCK, 0, st>>>(g->rowptr, g->col, numeric_symmetry ? g->w : nullptr, n, stats + 2);
+        k_symmetry_probe<<<nblk(8 * n), PF_BLOCK, 0, st>>>(g->rowptr, g->col, numeric_symmetry ? g->w : nullptr, n, stats + 2, g->morder);
         PF_HIP(hipGetLastError());
 
         // components
@@ -628,7 +691,8 @@ struct FinishJob {
         const int64_t n = g->n;
         PF_TRY(pf_compute_order(g, d_pts, robust ? nullptr : flags));  // (flags[0]: free for this; the statistics start at flags + 2)
         if (robust) PF_HIP(hipMemsetAsync(flags, 0, sizeof(int32_t), st));
-        k_slice_widths<<<nblk(g->n_pad), PF_BLOCK, 0, st>>>(g->rowptr, g->perm, n, g->n_slices, width64);
+        if (!g->perm_m) g->perm_m = g->perm, g->iperm_m = g->iperm;  // (no m-space: a graph handed in as a matrix)
+        k_slice_widths<<<nblk(g->n_pad), PF_BLOCK, 0, st>>>(g->rowptr, g->perm_m, n, g->n_slices, width64);
         PF_HIP(hipGetLastError());
         PF_TRY(pf_exclusive_scan_i64(st, width64, g->slice_ptr, g->n_slices + 1));
         if (!report) {
@@ -716,10 +780,10 @@ struct FinishJob {
         if (g->is_symmetric) PF_TRY(dev_alloc(st, &g->sval_sym, g->sell_entries));
         static const bool by_rows = [] { const char* e = getenv("PF_FILL_SELL_ROWS"); return e && e[0] == '1'; }();  // (A/B: a thread per row)
         if (by_rows)
-            k_fill_sell<<<nblk(g->n_pad), PF_BLOCK, 0, st>>>(g->rowptr, g->col, g->w, g->deg, g->g, g->sg, g->perm, g->iperm, n, g->n_pad,
+            k_fill_sell<<<nblk(g->n_pad), PF_BLOCK, 0, st>>>(g->rowptr, g->col, g->w, g->deg, g->g, g->sg, g->perm_m, g->iperm_m, n, g->n_pad,
                                                              g->slice_ptr, g->scol, g->sval_rw, g->sval_sym, g->diag);
         else
-            k_fill_sell_entries<<<(unsigned)g->n_slices, PF_BLOCK, 0, st>>>(g->rowptr, g->col, g->w, g->deg, g->g, g->sg, g->perm, g->iperm, n,
+            k_fill_sell_entries<<<(unsigned)g->n_slices, PF_BLOCK, 0, st>>>(g->rowptr, g->col, g->w, g->deg, g->g, g->sg, g->perm_m, g->iperm_m, n,
                                                                             g->slice_ptr, g->scol, g->sval_rw, g->sval_sym, g->diag);
         PF_HIP(hipGetLastError());
         return PF_OK;
@@ -789,6 +853,10 @@ struct MeshBuild {
     static constexpr int N_PHASES = 4;
     int32_t *b_cnt = nullptr, *b_start = nullptr, *b_rank = nullptr, *b_rcol = nullptr, *b_ucnt = nullptr, *b_flags = nullptr;
     double* b_rw = nullptr;
+    double* pts_m = nullptr;     // the points and ...
+    int32_t* faces_m = nullptr;  // ... faces renumbered by the Morton rank of the points (m-space)
+    bool robust = false;         // the Morton order by the general sort (second attempt: vertices piled into one cell)
+    bool needs_robust = false;   // end(): the counting sort gave up - build once more with robust = true
 
     int begin(pf_mesh* m, int stream_id) {
         PF_TRY(prepare(m, stream_id));
@@ -821,10 +889,11 @@ struct MeshBuild {
         pf_ctx* ctx = mesh->ctx;
         const int64_t n = mesh->n, n_faces = mesh->n_faces;
         const int32_t vpf = mesh->vpf;
-        const double* d_pts = mesh->pts;
-        const int32_t* d_faces = mesh->faces;
+        // from phase 0 on everything reads the mesh in m-space
+        const double* d_pts = pts_m;
+        const int32_t* d_faces = faces_m;
         const bool face_bound = vpf == 3 && n_faces > 0;
-        if (k == 0) {  // storage, the edge list counted and scattered
+        if (k == 0) {  // storage, the Morton order and the renumbered mesh, the edge list counted and scattered
             // (the counters that start from zero share one block, and so do deg / g / sg: two memsets instead of seven launches)
             int32_t* zeroed = nullptr;
             const int64_t zstride = (n + 1 + 7) & ~(int64_t)7;
@@ -846,9 +915,28 @@ struct MeshBuild {
             PF_TRY(dev_alloc(st, &g->smooth, g->n_pad));
             PF_TRY(dev_alloc(st, &g->slice_ptr, g->n_slices + 1));
 
+            PF_TRY(dev_alloc(st, &g->perm_m, g->n_pad));
+            PF_TRY(dev_alloc(st, &g->iperm_m, g->n_pad));
             PF_HIP(hipMemsetAsync(zeroed, 0, sizeof(int32_t) * (size_t)(2 * zstride + 8), st));
             PF_HIP(hipMemsetAsync(g->deg, 0, sizeof(double) * 3 * g->n_pad, st));
             if (sid == 0) PF_HIP(hipEventRecord(ctx->ev0, st));
+            // m-space first: the Morton rank of every point (positions only), points and faces renumbered by it.  Every
+            // gather of the build from here on - edge ends, reverse edges, neighbours' degrees, window flags - lands in
+            // lines that the neighbouring threads share, whatever order the caller's vertices came in (round 3: ~35 x
+            // the algorithmic bytes in counter traffic on the shuffled synthetic meshes).  b_flags[1]: the counting
+            // sort's overflow flag (piled vertices), read back with everything else.
+            PF_TRY(pf_morton_order(g, mesh->pts, robust ? nullptr : b_flags + 1));
+            PF_TRY(scratch(&pts_m, 3 * n));
+            PF_TRY(scratch(&faces_m, n_edges));
+            d_pts = pts_m, d_faces = faces_m;
+            if (n) {
+                k_renumber_points<<<nblk(3 * n), PF_BLOCK, 0, st>>>(mesh->pts, g->morder, n, pts_m);
+                PF_HIP(hipGetLastError());
+            }
+            if (n_edges) {
+                k_renumber_faces<<<nblk(n_edges), PF_BLOCK, 0, st>>>(mesh->faces, g->mrank, n_edges, n, faces_m);
+                PF_HIP(hipGetLastError());
+            }
 
             if (face_bound) PF_TRY(scratch(&pmin, 1));
             if (n_edges) {
@@ -867,7 +955,7 @@ struct MeshBuild {
             return PF_OK;
         }
         if (k == 1) {  // CSR(W), degrees, the face bound
-            k_sort_unique_rows<<<nblk(n), PF_BLOCK, 0, st>>>(b_start, n, b_rcol, b_rw, b_ucnt);
+            k_sort_unique_rows<<<nblk(n), PF_BLOCK, 0, st>>>(b_start, n, b_rcol, b_rw, b_ucnt, g->morder);
             PF_HIP(hipGetLastError());
             PF_TRY(pf_exclusive_scan_i32(st, b_ucnt, g->rowptr, n + 1));
             PF_TRY(dev_alloc(st, &g->col, n_edges));
@@ -891,6 +979,10 @@ struct MeshBuild {
     int end() {
         const int64_t n = mesh->n;
         PF_TRY(fin.end());
+        if (h_flags[1] != 0 && !(h_flags[0] & 7)) {  // vertices piled into one cell of the Morton grid: the whole build once more,
+            needs_robust = true;                      // with the general sort (the order the atomics left is not reproducible)
+            return PF_OK;
+        }
         PF_CHECK(!(h_flags[0] & 1), PF_E_ARG, "pf_graph_build: face index out of range [0,%lld)", (long long)n);
         PF_CHECK(!(h_flags[0] & 2), PF_E_DEGENERATE, "pf_graph_build: a face repeats a vertex on one edge");
         PF_CHECK(!(h_flags[0] & 4), PF_E_DEGENERATE,
@@ -944,6 +1036,11 @@ void pf_graph_free(pf_graph* g) {
         pf_free(st, g->sg);
     }
     pf_free(st, g->label);
+    if (g->perm_m != g->perm) pf_free(st, g->perm_m);
+    if (g->iperm_m != g->iperm) pf_free(st, g->iperm_m);
+    pf_free(st, g->morder);
+    pf_free(st, g->mrank);
+    pf_free(st, g->order_bbox);
     pf_free(st, g->perm);
     pf_free(st, g->iperm);
     pf_free(st, g->smooth);
@@ -1021,6 +1118,18 @@ int pf_graph_build_device(pf_mesh* mesh, pf_graph** out) {
     MeshBuild job;
     PF_TRY(job.begin(mesh, 0));
     PF_TRY(job.end());
+    if (job.needs_robust) {
+        if (getenv("PF_DEBUG_WINDOWS")) fprintf(stderr, "pyfocusr_hip: renumbering by counting gave up, building again with the general sort\n");
+        MeshBuild again;
+        again.robust = true;
+        PF_TRY(again.begin(mesh, 0));
+        PF_TRY(again.end());
+        PF_HIP(hipStreamSynchronize(ctx->stream));
+        again.g->build_stream = nullptr;
+        again.ok = true;
+        *out = again.g;
+        return PF_OK;
+    }
     PF_HIP(hipEventRecord(ctx->ev1, ctx->stream));
     PF_HIP(hipStreamSynchronize(ctx->stream));
     float ms = 0.f;
@@ -1052,6 +1161,7 @@ int pf_graph_build_device2(pf_mesh* mesh_a, pf_mesh* mesh_b, pf_graph** out_a, p
         return r;
     }
     int rc = PF_OK;
+    bool redo = false;
     {
         MeshBuild a, b;
         rc = pf_streams_join(ctx, 1);  // the second stream sees the uploads and may reuse what the first has released
@@ -1126,7 +1236,9 @@ int pf_graph_build_device2(pf_mesh* mesh_a, pf_mesh* mesh_b, pf_graph** out_a, p
                 fprintf(stderr, "pf_build2: device time of the pair build %.3f ms (events on the ctx stream); the last wait began %.0f us after the second halves\n", ms,
                         std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tq2).count());
         }
-        if (rc == PF_OK) {
+        if (rc == PF_OK && (a.needs_robust || b.needs_robust)) {
+            redo = true;  // (a pile of vertices in one Morton cell: the two builds once more, one after the other; below)
+        } else if (rc == PF_OK) {
             a.g->build_stream = b.g->build_stream = nullptr;
             a.ok = b.ok = true;
             *out_a = a.g;
@@ -1135,6 +1247,17 @@ int pf_graph_build_device2(pf_mesh* mesh_a, pf_mesh* mesh_b, pf_graph** out_a, p
             (void)hipStreamSynchronize(ctx->stream_b);
             (void)hipStreamSynchronize(ctx->stream);
         }
+    }
+    if (redo) {
+        (void)hipStreamSynchronize(ctx->stream_b);
+        (void)hipStreamSynchronize(ctx->stream);
+        PF_TRY(pf_graph_build_device(mesh_a, out_a));
+        const int r = pf_graph_build_device(mesh_b, out_b);
+        if (r != PF_OK) {
+            pf_graph_free(*out_a);
+            *out_a = nullptr;
+        }
+        return r;
     }
     return rc;
 }
@@ -1245,6 +1368,53 @@ int pf_graph_download(pf_graph* g, int32_t* rowptr, int32_t* colidx, double* w, 
     PF_CHECK(g, PF_E_ARG, "pf_graph_download: graph is NULL");
     PF_HIP(hipSetDevice(g->ctx->device));
     hipStream_t st = g->ctx->stream;
+    if (g->morder) {  // assembled in m-space: the caller's order is made here
+        const int64_t n = g->n, nnz = g->nnz_w;
+        int32_t *len = nullptr, *rp = nullptr, *co = nullptr, *lab = nullptr, *small = nullptr;
+        double *wo = nullptr, *lo = nullptr, *dg = nullptr, *ld = nullptr;
+        int rc = PF_OK;
+        auto bad = [&](hipError_t e) {
+            if (e != hipSuccess && rc == PF_OK) {
+                pf_set_error("pf_graph_download: %s", hipGetErrorString(e));
+                rc = PF_E_HIP;
+            }
+            return e != hipSuccess;
+        };
+        do {
+            if (bad(pf_malloc(st, (void**)&len, sizeof(int32_t) * (size_t)(n + 1))) || bad(pf_malloc(st, (void**)&rp, sizeof(int32_t) * (size_t)(n + 1)))) break;
+            k_len_original<<<nblk(n + 1), PF_BLOCK, 0, st>>>(g->rowptr, g->mrank, n, len);
+            if (bad(hipGetLastError())) break;
+            if (pf_exclusive_scan_i32(st, len, rp, n + 1) != PF_OK) {
+                rc = PF_E_HIP;
+                break;
+            }
+            const size_t ne = (size_t)std::max<int64_t>(nnz, 1);
+            if (colidx && bad(pf_malloc(st, (void**)&co, sizeof(int32_t) * ne))) break;
+            if (w && bad(pf_malloc(st, (void**)&wo, sizeof(double) * ne))) break;
+            if (l_offdiag && bad(pf_malloc(st, (void**)&lo, sizeof(double) * ne))) break;
+            if (deg && bad(pf_malloc(st, (void**)&dg, sizeof(double) * (size_t)n))) break;
+            if (l_diag && bad(pf_malloc(st, (void**)&ld, sizeof(double) * (size_t)n))) break;
+            k_rows_original<<<nblk(n), PF_BLOCK, 0, st>>>(g->rowptr, g->col, g->w, g->g, g->deg, g->mrank, g->morder, rp, n, co, wo, lo, dg, ld);
+            if (bad(hipGetLastError())) break;
+            if (component_label) {
+                if (bad(pf_malloc(st, (void**)&lab, sizeof(int32_t) * (size_t)n)) || bad(pf_malloc(st, (void**)&small, sizeof(int32_t) * (size_t)n))) break;
+                if (bad(hipMemsetAsync(small, 0x7f, sizeof(int32_t) * (size_t)n, st))) break;
+                k_label_min_original<<<nblk(n), PF_BLOCK, 0, st>>>(g->label, g->morder, n, small);
+                k_label_original<<<nblk(n), PF_BLOCK, 0, st>>>(g->label, g->mrank, small, n, lab);
+                if (bad(hipGetLastError())) break;
+                if (bad(hipMemcpyAsync(component_label, lab, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, st))) break;
+            }
+            if (rowptr && bad(hipMemcpyAsync(rowptr, rp, sizeof(int32_t) * (size_t)(n + 1), hipMemcpyDeviceToHost, st))) break;
+            if (colidx && nnz && bad(hipMemcpyAsync(colidx, co, sizeof(int32_t) * (size_t)nnz, hipMemcpyDeviceToHost, st))) break;
+            if (w && nnz && bad(hipMemcpyAsync(w, wo, sizeof(double) * (size_t)nnz, hipMemcpyDeviceToHost, st))) break;
+            if (l_offdiag && nnz && bad(hipMemcpyAsync(l_offdiag, lo, sizeof(double) * (size_t)nnz, hipMemcpyDeviceToHost, st))) break;
+            if (deg && bad(hipMemcpyAsync(deg, dg, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, st))) break;
+            if (l_diag && bad(hipMemcpyAsync(l_diag, ld, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, st))) break;
+        } while (0);
+        bad(hipStreamSynchronize(st));
+        for (void* q : {(void*)len, (void*)rp, (void*)co, (void*)lab, (void*)small, (void*)wo, (void*)lo, (void*)dg, (void*)ld}) pf_free(st, q);
+        return rc;
+    }
     double* tmp = nullptr;
     if (rowptr) PF_HIP(hipMemcpyAsync(rowptr, g->rowptr, sizeof(int32_t) * (g->n + 1), hipMemcpyDeviceToHost, st));
     if (colidx && g->nnz_w) PF_HIP(hipMemcpyAsync(colidx, g->col, sizeof(int32_t) * g->nnz_w, hipMemcpyDeviceToHost, st));

@@ -380,13 +380,15 @@ __global__ __launch_bounds__(PF_BLOCK) void k_mask_isolated(double* __restrict__
 // Krylov start vector, part 2: smooth part + counter-based noise (splitmix64 of (seed, vertex)), zero
 // on isolated vertices and padding.  Noise keeps every eigenmode present whatever the geometry.
 __global__ __launch_bounds__(PF_BLOCK) void k_start_vector(double* __restrict__ x, const double* __restrict__ smooth,
-                                                           const int32_t* __restrict__ perm, const int32_t* __restrict__ rowptr,
+                                                           const int32_t* __restrict__ perm, const int32_t* __restrict__ perm_m,
+                                                           const int32_t* __restrict__ rowptr,
                                                            int64_t n_pad, unsigned long long seed, double noise) {
     const int64_t r = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
     if (r >= n_pad) return;
-    const int32_t i = perm[r];
+    const int32_t i = perm[r];    // the caller's vertex number: what the noise is keyed by, whatever the internal order
+    const int32_t m = perm_m[r];  // the row of CSR(W)
     double v = 0.0;
-    if (i >= 0 && rowptr[i + 1] > rowptr[i]) {
+    if (i >= 0 && rowptr[m + 1] > rowptr[m]) {
         unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (unsigned long long)(i + 1);
         z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
         z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
@@ -551,8 +553,8 @@ __device__ __forceinline__ VecStats stats_shfl(const VecStats& v, int off) {
 
 __global__ __launch_bounds__(PF_BLOCK) void k_vec_stats_partial(const double* __restrict__ ws, int64_t n_pad, int64_t n,
                                                                 int32_t first, const double* __restrict__ sg,
-                                                                const int32_t* __restrict__ perm, int32_t from_sym,
-                                                                int64_t n_chunks, VecStats* __restrict__ partial) {
+                                                                const int32_t* __restrict__ perm, const int32_t* __restrict__ perm_m,
+                                                                int32_t from_sym, int64_t n_chunks, VecStats* __restrict__ partial) {
     __shared__ VecStats red[PF_BLOCK / PF_WAVE];
     const int b = blockIdx.y;
     const double* x = ws + (int64_t)(first + b) * n_pad;
@@ -563,7 +565,7 @@ __global__ __launch_bounds__(PF_BLOCK) void k_vec_stats_partial(const double* __
     for (int64_t r = lo + threadIdx.x; r < hi; r += PF_BLOCK) {
         const int64_t i = perm[r];  // mesh-order index: the tie-break key of the sign convention
         double v = x[r];
-        if (from_sym) v *= sg[i];
+        if (from_sym) v *= sg[perm_m[r]];  // (per-vertex arrays live in m-space)
         VecStats e{v * v, v, v, fabs(v), v, i};
         stats_merge(st, e);
     }
@@ -615,12 +617,12 @@ __global__ void k_vec_params(const VecStats* __restrict__ fin, int32_t count, in
 // out[i][c] = (x_c[i] * scale_c - off_c) * inv_c - half_c       (row-major n x count)
 __global__ __launch_bounds__(PF_BLOCK) void k_vec_apply(const double* __restrict__ ws, int64_t n_pad, int64_t n,
                                                         int32_t first, int32_t count, const double* __restrict__ sg,
-                                                        const int32_t* __restrict__ iperm, int32_t from_sym,
-                                                        const double* __restrict__ params, double* __restrict__ out) {
+                                                        const int32_t* __restrict__ iperm, const int32_t* __restrict__ mrank,
+                                                        int32_t from_sym, const double* __restrict__ params, double* __restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
     if (i >= n) return;
     const int64_t r = iperm[i];
-    const double s = from_sym ? sg[i] : 1.0;
+    const double s = from_sym ? sg[mrank ? mrank[i] : i] : 1.0;
     for (int c = 0; c < count; ++c) {
         const double scale = params[4 * c + 0], off = params[4 * c + 1], ptp = params[4 * c + 2], half = params[4 * c + 3];
         double v = (ws[(int64_t)(first + c) * n_pad + r] * s) * scale;
@@ -646,7 +648,8 @@ __global__ __launch_bounds__(PF_BLOCK) void k_final_rows(const double* __restric
 __global__ __launch_bounds__(PF_BLOCK) void k_fill_mean_filter(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                                                                const double* __restrict__ w, const double* __restrict__ deg,
                                                                const int32_t* __restrict__ perm, const int32_t* __restrict__ iperm,
-                                                               int64_t n_pad, const int64_t* __restrict__ slice_ptr,
+                                                               const int32_t* __restrict__ key, int64_t n_pad,
+                                                               const int64_t* __restrict__ slice_ptr,
                                                                int32_t* __restrict__ mf_col, double* __restrict__ mf_val) {
     const int64_t row = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
     if (row >= n_pad) return;
@@ -659,9 +662,10 @@ __global__ __launch_bounds__(PF_BLOCK) void k_fill_mean_filter(const int32_t* __
     if (i >= 0) {
         const double dinv = 1.0 / (1.0 + deg[i]);
         bool diag_done = false;
+        const int32_t ki = key ? key[i] : i;  // (scipy's order is that of the caller's vertex numbers; perm / iperm / col: m-space)
         for (int32_t a = rowptr[i + 1] - 1; a >= rowptr[i]; --a) {
             const int32_t j = col[a];
-            if (!diag_done && j < i) {
+            if (!diag_done && (key ? key[j] : j) < ki) {
                 mf_col[base + (int64_t)PF_WAVE * e + lane] = (int32_t)row;
                 mf_val[base + (int64_t)PF_WAVE * e + lane] = dinv;
                 ++e;
@@ -1013,14 +1017,14 @@ int pf_ws_copy(pf_graph* g, int32_t src, int32_t dst, int32_t count) {
 int pf_mask_isolated(pf_graph* g, int32_t slot) {
     PF_TRY(check_slots(g, slot, 1, "pf_mask_isolated"));
     if (g->n_isolated == 0) return PF_OK;
-    k_mask_isolated<<<nblk(g->n), PF_BLOCK, 0, g->ctx->stream>>>(pf_slot(g, slot), g->rowptr, g->perm, g->n);
+    k_mask_isolated<<<nblk(g->n), PF_BLOCK, 0, g->ctx->stream>>>(pf_slot(g, slot), g->rowptr, g->perm_m, g->n);
     PF_HIP(hipGetLastError());
     return PF_OK;
 }
 
 int pf_start_vector(pf_graph* g, int32_t slot, uint64_t seed) {
     PF_TRY(check_slots(g, slot, 1, "pf_start_vector"));
-    k_start_vector<<<nblk(g->n_pad), PF_BLOCK, 0, g->ctx->stream>>>(pf_slot(g, slot), g->smooth, g->perm, g->rowptr, g->n_pad,
+    k_start_vector<<<nblk(g->n_pad), PF_BLOCK, 0, g->ctx->stream>>>(pf_slot(g, slot), g->smooth, g->perm, g->perm_m, g->rowptr, g->n_pad,
                                                                     (unsigned long long)seed, 0.5);
     PF_HIP(hipGetLastError());
     return PF_OK;
@@ -1036,7 +1040,7 @@ int pf_lock_null_vectors(pf_graph* g, int32_t op, int32_t* n_locked) {
     hipStream_t st = g->ctx->stream;
     PF_TRY(pf_reduce_ensure(g, 1));
     for (int32_t c = 0; c < nc; ++c) {
-        k_null_vector<<<nblk(g->n_pad), PF_BLOCK, 0, st>>>(pf_slot(g, c), g->label, g->rowptr, g->deg, g->perm, g->n_pad,
+        k_null_vector<<<nblk(g->n_pad), PF_BLOCK, 0, st>>>(pf_slot(g, c), g->label, g->rowptr, g->deg, g->perm_m, g->n_pad,
                                                           g->roots[c], op == PF_OP_SYM && !g->unit_g);
         PF_HIP(hipGetLastError());
         // normalised with the norm still on the device (the same 1 / sqrt as on the host: the same bits; a component has at
@@ -1669,7 +1673,7 @@ int pf_finalize_vectors_begin(pf_graph* g, int32_t first, int32_t count, int32_t
     VecStats* part = reinterpret_cast<VecStats*>(g->partials);
     VecStats* fin = part + (size_t)count * g->n_chunks;
     dim3 grid((unsigned)g->n_chunks, (unsigned)count);
-    k_vec_stats_partial<<<grid, PF_BLOCK, 0, st>>>(g->ws, g->n_pad, g->n, first, g->sg, g->perm, from_sym, g->n_chunks, part);
+    k_vec_stats_partial<<<grid, PF_BLOCK, 0, st>>>(g->ws, g->n_pad, g->n, first, g->sg, g->perm, g->perm_m, from_sym, g->n_chunks, part);
     PF_HIP(hipGetLastError());
     k_vec_stats_finish<<<(unsigned)count, PF_WAVE, 0, st>>>(part, g->n_chunks, fin);
     PF_HIP(hipGetLastError());
@@ -1685,7 +1689,7 @@ int pf_finalize_vectors_begin(pf_graph* g, int32_t first, int32_t count, int32_t
     hipError_t e = pf_malloc(st, (void**)&d_out, sizeof(double) * (size_t)g->n * count);
     if (e == hipSuccess) {
         k_vec_params<<<1, PF_WAVE, 0, st>>>(fin, count, minmax, d_params);
-        k_vec_apply<<<nblk(g->n), PF_BLOCK, 0, st>>>(g->ws, g->n_pad, g->n, first, count, g->sg, g->iperm, from_sym, d_params, d_out);
+        k_vec_apply<<<nblk(g->n), PF_BLOCK, 0, st>>>(g->ws, g->n_pad, g->n, first, count, g->sg, g->iperm, g->mrank, from_sym, d_params, d_out);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(d_stats, fin, sizeof(VecStats) * count, hipMemcpyDeviceToDevice, st);
@@ -1870,7 +1874,7 @@ int pf_mean_filter(pf_graph* g, const double* values, int32_t ncols, int32_t ite
         const size_t entries = (size_t)(g->sell_entries + g->n_pad);
         PF_HIP(pf_malloc(st, (void**)&g->mf_col, sizeof(int32_t) * entries));
         PF_HIP(pf_malloc(st, (void**)&g->mf_val, sizeof(double) * entries));
-        k_fill_mean_filter<<<nblk(g->n_pad), PF_BLOCK, 0, st>>>(g->rowptr, g->col, g->w, g->deg, g->perm, g->iperm, g->n_pad,
+        k_fill_mean_filter<<<nblk(g->n_pad), PF_BLOCK, 0, st>>>(g->rowptr, g->col, g->w, g->deg, g->perm_m, g->iperm_m, g->morder, g->n_pad,
                                                                 g->slice_ptr, g->mf_col, g->mf_val);
         PF_HIP(hipGetLastError());
     }
