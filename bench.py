@@ -770,6 +770,8 @@ def main():
             "traffic_source": PMC_SUMMARY if asm_traffic is not None else None,
             "note": "both meshes of the pair; wall time of the stage (the two builds run side by side on two streams)"}
         try:
+            if args.no_extras:
+                raise LookupError("skipped with --no-extras (one extra untimed step)")
             ctx.knn_count(True)
             np.random.seed(99)
             extra = dict(assembly=0.0, eigensolve=0.0, eigsort=0.0, knn=0.0, matvecs=0)
@@ -787,6 +789,8 @@ def main():
                 "note": "pairs counted in one extra untimed step (same meshes, another eigsort sample: the count moves a few per cent "
                         "with the sampled weights); kernel_ms: HIP events around the search of the timed steps; the kernel is bound by "
                         "the latency of its per-chunk loads, not by the FP64 rate (DESIGN.md section 5)"}
+        except LookupError as exc:
+            out["roofline_knn"] = dict(skipped=str(exc))
         except Exception as exc:  # noqa: BLE001
             out["roofline_knn"] = dict(error="%s: %s" % (type(exc).__name__, exc))
             failed.append("roofline_knn")

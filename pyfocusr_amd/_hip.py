@@ -908,11 +908,6 @@ class DeviceLaplacian(object):
         """Normalised eigenvectors of `count` slots -> (n, count) array in PINNED host memory (one DMA on the ctx's copy
         stream).  `wait=False`: the array is returned while the download is still in flight - `finalize_wait()` before
         anybody reads it (`Graph.eig_vecs` does); the device-resident twin of the block is usable at once."""
-        if os.environ.get("PF_FINAL_PAGEABLE") == "1":  # comparison switch: pageable destination, synchronous (the round-2 form)
-            out = np.empty((self.n, int(count)), dtype=np.float64)
-            _check(self._lib.pf_finalize_vectors(self._h, int(first), int(count), int(self.op == PF_OP_SYM), int(bool(minmax)), _f64(out)))
-            self._final_count = int(count)
-            return out
         out = pinned_empty((self.n, int(count)))
         _check(self._lib.pf_finalize_vectors_begin(self._h, int(first), int(count), int(self.op == PF_OP_SYM), int(bool(minmax)),
                                                    _f64(out)))

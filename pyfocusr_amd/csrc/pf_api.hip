@@ -74,8 +74,7 @@ int pf_pinned_scratch(pf_ctx* c, size_t bytes, void** out, int sid) {
 hipError_t pf_create_side_stream(hipStream_t* s, bool low) {
     int least = 0, greatest = 0;
     if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least) {
-        static const bool all_high = [] { const char* e = getenv("PF_SIDE_STREAMS_HIGH"); return e && e[0] == '1'; }();  // (A/B)
-        return hipStreamCreateWithPriority(s, hipStreamNonBlocking, (low && !all_high) ? least : greatest);
+        return hipStreamCreateWithPriority(s, hipStreamNonBlocking, low ? least : greatest);
     }
     (void)hipGetLastError();
     return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
@@ -85,10 +84,8 @@ hipStream_t pf_stream_b(pf_ctx* c) {
     if (!c->stream_b) {
         hipStream_t s = nullptr;
         // (the least priority, like the copy stream - they are never busy together: the first mesh's kernels, at the main
-        // stream's normal priority, keep their pace and the second's fill the gaps: pair assembly 1.17 -> 1.14 ms;
-        // PF_STREAM_B_LOW=0: the greatest priority, as until the end of round 3)
-        static const bool b_low = [] { const char* e = getenv("PF_STREAM_B_LOW"); return !(e && e[0] == '0'); }();
-        if (pf_create_side_stream(&s, b_low) != hipSuccess ||
+        // stream's normal priority, keep their pace and the second's fill the gaps: pair assembly 1.17 -> 1.14 ms)
+        if (pf_create_side_stream(&s, true) != hipSuccess ||
             hipEventCreateWithFlags(&c->join_ev, hipEventDisableTiming) != hipSuccess) {
             (void)hipGetLastError();
             if (s) (void)hipStreamDestroy(s);

@@ -293,15 +293,26 @@ __device__ __forceinline__ int32_t uf_find(const int32_t* label, int32_t x) {
     return x;
 }
 
+// `key` (nullable: the vertex number itself): the ORDER the forest is built on.  In m-space the vertex numbers follow a
+// space-filling curve, and trees that always hook towards the smaller number grow along the curve - long chains, slow
+// rounds (13.8 us against 9.1 per round at 250k, measured); ordered by the caller's (unrelated) vertex numbers the forest
+// is the one of round 3, its gathers are still m-space local, and the surviving root of a component is the vertex with
+// the smallest ORIGINAL number - the label the boundary format hands out.
 __global__ __launch_bounds__(PF_BLOCK) void k_label_init(const int32_t* __restrict__ rowptr,
                                                          const int32_t* __restrict__ col, int64_t n, int64_t n_pad,
-                                                         int32_t* __restrict__ label) {
+                                                         int32_t* __restrict__ label, const int32_t* __restrict__ key) {
     const int64_t i = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
     if (i >= n_pad) return;
     int32_t m = (int32_t)i;
-    if (i < n)
-        for (int32_t a = rowptr[i]; a < rowptr[i + 1]; ++a) m = min(m, col[a]);
-    label[i] = m;  // parent <= child, equality for roots only: a forest
+    if (i < n) {
+        int32_t km = key ? key[i] : (int32_t)i;
+        for (int32_t a = rowptr[i]; a < rowptr[i + 1]; ++a) {
+            const int32_t c = col[a];
+            const int32_t kc = key ? key[c] : c;
+            if (kc < km) m = c, km = kc;
+        }
+    }
+    label[i] = m;  // parent <= child in the key's order, equality for roots only: a forest
 }
 
 __global__ __launch_bounds__(PF_BLOCK) void k_label_compress(int32_t* label, int64_t n, const int32_t* prev = nullptr) {
@@ -320,7 +331,8 @@ __global__ __launch_bounds__(PF_BLOCK) void k_label_compress(int32_t* label, int
 #define PF_CC_SWEEPS 1
 #endif
 __global__ __launch_bounds__(PF_BLOCK) void k_label_round(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, int64_t n,
-                                                          int32_t* label, int32_t* differing, const int32_t* prev) {
+                                                          int32_t* label, int32_t* differing, const int32_t* prev,
+                                                          const int32_t* __restrict__ key) {
     if (prev && *prev == 0) return;  // the previous round changed nothing: converged (rounds are queued ahead, unasked)
     const int64_t i = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
     bool any = false;
@@ -337,7 +349,8 @@ __global__ __launch_bounds__(PF_BLOCK) void k_label_round(const int32_t* __restr
             for (int32_t a = b; a < e; ++a) {
                 const int32_t fv = uf_find(label, col[a]);
                 if (fu != fv) {
-                    const int32_t lo = fu < fv ? fu : fv, hi = fu < fv ? fv : fu;
+                    const bool u_first = key ? key[fu] < key[fv] : fu < fv;
+                    const int32_t lo = u_first ? fu : fv, hi = u_first ? fv : fu;
                     label[hi] = lo;
                     fu = lo;
                     again = true;
@@ -376,48 +389,6 @@ __global__ __launch_bounds__(PF_BLOCK) void k_slice_widths(const int32_t* __rest
     const int64_t s = row / PF_WAVE;
     if ((threadIdx.x & (PF_WAVE - 1)) == 0 && s < n_slices) width64[s] = (int64_t)c * PF_WAVE;
     if (row == 0) width64[n_slices] = 0;  // (the scan's extra element: no fill of its own)
-}
-
-__global__ __launch_bounds__(PF_BLOCK) void k_fill_sell(const int32_t* __restrict__ rowptr,
-                                                        const int32_t* __restrict__ col, const double* __restrict__ w,
-                                                        const double* __restrict__ deg, const double* __restrict__ g,
-                                                        const double* __restrict__ sg, const int32_t* __restrict__ perm,
-                                                        const int32_t* __restrict__ iperm, int64_t n, int64_t n_pad,
-                                                        const int64_t* __restrict__ slice_ptr, int32_t* __restrict__ scol,
-                                                        double* __restrict__ sval_rw, double* __restrict__ sval_sym,
-                                                        double* __restrict__ diag) {
-    const int64_t row = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
-    if (row >= n_pad) return;
-    const int64_t s = row / PF_WAVE;
-    const int lane = (int)(row & (PF_WAVE - 1));
-    const int64_t base = slice_ptr[s];
-    const int32_t width = (int32_t)((slice_ptr[s + 1] - base) / PF_WAVE);
-    int32_t b = 0, cnt = 0;
-    double gi = 0.0, si = 0.0;
-    if (row < n) {
-        const int32_t old = perm[row];
-        b = rowptr[old];
-        cnt = rowptr[old + 1] - b;
-        gi = g[old];
-        si = sg[old];
-        diag[row] = gi * deg[old];  // L_ii = g_i deg_i  (graph.py:226)
-    } else {
-        diag[row] = 0.0;
-    }
-    for (int32_t j = 0; j < width; ++j) {
-        const int64_t idx = pf_sell_index(base, width, j, lane);
-        if (j < cnt) {
-            const int32_t c = col[b + j];
-            const double wv = w[b + j];
-            scol[idx] = iperm[c];
-            sval_rw[idx] = -(gi * wv);  // L_ij = g_i * (0 - W_ij)
-            if (sval_sym) sval_sym[idx] = -(wv * (si * sg[c]));
-        } else {
-            scol[idx] = (int32_t)row;  // padding: zero weight on the row's own (in-window) column
-            sval_rw[idx] = 0.0;
-            if (sval_sym) sval_sym[idx] = 0.0;
-        }
-    }
 }
 
 // The same storage, one block per slice and one thread per stored ENTRY (round 3).  k_fill_sell walks a row's entries one
@@ -666,13 +637,13 @@ struct FinishJob {
         PF_HIP(hipGetLastError());
 
         // components
-        k_label_init<<<nblk(g->n_pad), PF_BLOCK, 0, st>>>(g->rowptr, g->col, n, g->n_pad, g->label);
+        k_label_init<<<nblk(g->n_pad), PF_BLOCK, 0, st>>>(g->rowptr, g->col, n, g->n_pad, g->label, g->morder);
         PF_HIP(hipGetLastError());
         // PF_CC_FIRST rounds are queued without asking: a round that follows a round without changes returns at once
         // (~2 us instead of ~15), and whether the last one still changed something is read back with everything else below
         for (round = 0; round < PF_CC_FIRST; ++round) {
             const int32_t* prev = round ? round_flags + round - 1 : nullptr;
-            k_label_round<<<nblk(n), PF_BLOCK, 0, st>>>(g->rowptr, g->col, n, g->label, round_flags + round, prev);
+            k_label_round<<<nblk(n), PF_BLOCK, 0, st>>>(g->rowptr, g->col, n, g->label, round_flags + round, prev, g->morder);
             PF_HIP(hipGetLastError());
         }
         k_label_compress<<<nblk(n), PF_BLOCK, 0, st>>>(g->label, n);
@@ -744,7 +715,7 @@ struct FinishJob {
             for (;;) {
                 PF_CHECK(round + 3 <= PF_CC_ROUNDS, PF_E_HIP, "pf_graph_build: component labelling did not converge");
                 for (int b = 0; b < 3; ++b, ++round) {
-                    k_label_round<<<nblk(n), PF_BLOCK, 0, st>>>(g->rowptr, g->col, n, g->label, round_flags + round, nullptr);
+                    k_label_round<<<nblk(n), PF_BLOCK, 0, st>>>(g->rowptr, g->col, n, g->label, round_flags + round, nullptr, g->morder);
                     PF_HIP(hipGetLastError());
                 }
                 k_label_compress<<<nblk(n), PF_BLOCK, 0, st>>>(g->label, n);
@@ -778,13 +749,8 @@ struct FinishJob {
         PF_TRY(dev_alloc(st, &g->scol, g->sell_entries));
         PF_TRY(dev_alloc(st, &g->sval_rw, g->sell_entries));
         if (g->is_symmetric) PF_TRY(dev_alloc(st, &g->sval_sym, g->sell_entries));
-        static const bool by_rows = [] { const char* e = getenv("PF_FILL_SELL_ROWS"); return e && e[0] == '1'; }();  // (A/B: a thread per row)
-        if (by_rows)
-            k_fill_sell<<<nblk(g->n_pad), PF_BLOCK, 0, st>>>(g->rowptr, g->col, g->w, g->deg, g->g, g->sg, g->perm_m, g->iperm_m, n, g->n_pad,
-                                                             g->slice_ptr, g->scol, g->sval_rw, g->sval_sym, g->diag);
-        else
-            k_fill_sell_entries<<<(unsigned)g->n_slices, PF_BLOCK, 0, st>>>(g->rowptr, g->col, g->w, g->deg, g->g, g->sg, g->perm_m, g->iperm_m, n,
-                                                                            g->slice_ptr, g->scol, g->sval_rw, g->sval_sym, g->diag);
+        k_fill_sell_entries<<<(unsigned)g->n_slices, PF_BLOCK, 0, st>>>(g->rowptr, g->col, g->w, g->deg, g->g, g->sg, g->perm_m, g->iperm_m, n,
+                                                                        g->slice_ptr, g->scol, g->sval_rw, g->sval_sym, g->diag);
         PF_HIP(hipGetLastError());
         return PF_OK;
     }
@@ -1172,43 +1138,18 @@ int pf_graph_build_device2(pf_mesh* mesh_a, pf_mesh* mesh_b, pf_graph** out_a, p
             // which it did in one step of six in about one process of twelve on this pool's loaded hosts (PF_DEBUG_BUILD:
             // "worker began 3045 us after the call", "ended 9344").  So: ONE thread, the two builds phase by phase (four
             // phases of ~15 launches): the second stream is never more than one phase behind, 0.45 ms of launching against
-            // 0.97 ms of device time.  PF_BUILD_THREAD=1: the two-thread form.
+            // 0.97 ms of device time.
             static const bool dbg = getenv("PF_DEBUG_BUILD") != nullptr;
-            static const bool threaded = [] { const char* e = getenv("PF_BUILD_THREAD"); return e && e[0] == '1'; }();
             using clk = std::chrono::steady_clock;
             const clk::time_point t0 = clk::now();
-            if (threaded) {
-                int rc_b = PF_OK;
-                std::string err_b;
-                clk::time_point tb0 = t0, tb1 = t0;
-                pf_worker_run(ctx, [&] {
-                    tb0 = clk::now();
-                    rc_b = b.begin(mesh_b, 1);
-                    tb1 = clk::now();
-                    if (rc_b != PF_OK) err_b = pf_last_error();  // (the message is thread-local)
-                });
-                rc = a.begin(mesh_a, 0);
-                const clk::time_point ta1 = clk::now();
-                pf_worker_wait(ctx);
-                if (dbg) {
-                    auto us = [&](clk::time_point t) { return std::chrono::duration<double, std::micro>(t - t0).count(); };
-                    fprintf(stderr, "pf_build2: worker began %.0f us after the call, ended %.0f; main thread's half ended %.0f; joined %.0f\n", us(tb0),
-                            us(tb1), us(ta1), us(clk::now()));
-                }
-                if (rc == PF_OK && rc_b != PF_OK) {
-                    rc = rc_b;
-                    pf_set_error("%s", err_b.c_str());
-                }
-            } else {
-                rc = a.prepare(mesh_a, 0);
-                if (rc == PF_OK) rc = b.prepare(mesh_b, 1);
-                for (int k = 0; k < MeshBuild::N_PHASES && rc == PF_OK; ++k) {
-                    rc = a.phase(k);
-                    if (rc == PF_OK) rc = b.phase(k);
-                }
-                if (dbg) fprintf(stderr, "pf_build2: first halves queued in %.0f us (one thread, phase by phase)\n",
-                                 std::chrono::duration<double, std::micro>(clk::now() - t0).count());
+            rc = a.prepare(mesh_a, 0);
+            if (rc == PF_OK) rc = b.prepare(mesh_b, 1);
+            for (int k = 0; k < MeshBuild::N_PHASES && rc == PF_OK; ++k) {
+                rc = a.phase(k);
+                if (rc == PF_OK) rc = b.phase(k);
             }
+            if (dbg) fprintf(stderr, "pf_build2: first halves queued in %.0f us (one thread, phase by phase)\n",
+                             std::chrono::duration<double, std::micro>(clk::now() - t0).count());
         }
         const auto tq0 = std::chrono::steady_clock::now();
         if (rc == PF_OK) rc = a.end();

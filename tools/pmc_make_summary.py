@@ -120,7 +120,9 @@ stage_files = dict(assembly=("pf_assemble.hip", "pf_reorder.hip", "pf_scan.hip")
 stages = {}
 if args.fetch and args.write:
     ftab, wtab = counter_avg(args.fetch, "FETCH_SIZE"), counter_avg(args.write, "WRITE_SIZE")
-    n_steps = max(int(bench.get("steps", 2)) + int(bench.get("warmup", 1)), 1)
+    # steps the PROFILED command ran (timed + warm-up + any extra untimed step): every step assembles two meshes
+    ce = [calls for kname, (calls, kb) in ftab.items() if "k_count_edges" in kname]
+    n_steps = max(sum(ce) // 2, 1) if ce else max(int(bench.get("steps", 2)) + int(bench.get("warmup", 1)), 1)
     for stage, files in stage_files.items():
         names = kernels_of(*files)
         rd = wr = 0.0
