@@ -263,8 +263,9 @@ struct Solver {
         // small ones it can lose orthogonality.  The setting is sticky per graph: set here either way.
         PFK_TRY(ops->orth_strict(n_active < 4096));
         // Arnoldi with strongly amplified outliers in the basis cancels digits in every sixth step or so (15k bundled meshes;
-        // nearly every step at higher degree): the second pass rides with the first instead of costing a repeated application
-        PFK_TRY(ops->orth_device_passes(!sym));
+        // nearly every step at higher degree): the second pass rides with the first instead of costing a repeated application.
+        // Lanczos: only the first two steps of a solve (see step(): the first product with the start vector always cancels).
+        PFK_TRY(ops->orth_device_passes(true));
         c0 = ops->n_components();
         want = (int)std::min<int64_t>(n_wanted, std::max<int64_t>(n_active - c0, 0));
         st.mode = sym ? 0 : 1;
@@ -560,6 +561,12 @@ struct Solver {
                         }
                     }
                     st.outer_steps += 1;
+                    // Symmetric graphs: B v0 lies mostly along v0 and the locked null vectors - the first Gram-Schmidt step of
+                    // every solve (250k blobs: always; the second sometimes) cancels digits, and its second pass, run by
+                    // orth_end AFTER the speculative application had read the vector, cost that application (200 us of a
+                    // 10.7 ms step, both graphs).  The first two steps take the device's own second pass; later steps (ratios
+                    // 0.35-0.78) the single pass without the two idle launches.
+                    if (sym) PFK_TRY(ops->orth_device_passes(j <= c0 + 1));
                     // the Gram-Schmidt step and - to keep the device busy - the NEXT filter application, queued before this
                     // step's coefficients are read (a speculative application after the last step would be wasted)
                     spec = j + 1 < m_max && !near_conv;
