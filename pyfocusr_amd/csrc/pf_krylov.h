@@ -290,6 +290,9 @@ struct Solver {
         // loses: at 15 windows a recurrence step still costs 1.6 us, and the more the outliers are amplified the more
         // Gram-Schmidt steps cancel digits; placement as _krylov._solve_gen)
         if (!sym) strength = 2.0;
+        // (a stronger filter for the graph of a pair that wants more columns - 9 against 5 for the bundled 15k pair - evens the
+        // two step counts out, 44 / 48 instead of 48 / 53 on the messy 250k pair, at more recurrence steps per shared launch:
+        // measured neutral, 12.94 against 12.95 ms and 5.11 against 5.15; not kept)
         cut0 = (sym ? 8.0 : 12.0) * (want + 1) / (double)std::max<int64_t>(n_active, 1);
         if (const char* ev = getenv("PF_EIGS_CUT")) cut0 *= atof(ev) / (sym ? 8.0 : 12.0);  // (experiments: the filter's placement ...
         if (const char* ev = getenv("PF_EIGS_STRENGTH")) strength = atof(ev);  // ... and strength; results agree to tol)

@@ -240,36 +240,63 @@ struct OrthArgs2 {
 
 // partial[b][chunk] = <slot first+b, slot wslot> over the chunk, b < count; partial[count][chunk] = |w|^2 over the chunk
 // (k_dot_partial's sums, in its order)
+// VB: basis vectors per block.  1: the shape tuned for bases that live in the Infinity Cache (250k pairs: 6 TB/s).  4 (bases
+// beyond it: 1M rows x 50 vectors = 400 MB): the chunk of w is loaded ONCE for four vectors - with one vector per block it
+// came back from HBM once per vector, half of the kernel's traffic - and four vectors' 32 KB pieces are in flight per block.
+// Per (vector, chunk) the sums are formed by the same threads in the same order either way: the same bits.
+template <int VB>
 __global__ __launch_bounds__(PF_BLOCK) void k_orth_dots(OrthArgs2 a2) {
-    __shared__ double red[PF_BLOCK / PF_WAVE];
+    __shared__ double red[VB][PF_BLOCK / PF_WAVE];
     const OrthArgs& a = a2.g[blockIdx.z];
-    const int b = blockIdx.y;
+    const int b0 = blockIdx.y * VB;
     const int64_t chunk = blockIdx.x;
-    if (a.pass < 0 || b > a.count || chunk >= a.n_chunks) return;  // (block-uniform: the grid is sized for the larger graph of a pair)
-    if (a.pass == 2 && *a.verdict == 0.0) return;                  // (the first pass was fine)
-    const double* v = a.ws + (int64_t)(b == a.count ? a.wslot : a.first + b) * a.n_pad;
+    if (a.pass < 0 || b0 > a.count || chunk >= a.n_chunks) return;  // (block-uniform: the grid is sized for the larger graph of a pair)
+    if (a.pass == 2 && *a.verdict == 0.0) return;                   // (the first pass was fine)
     const double* w = a.ws + (int64_t)a.wslot * a.n_pad;
     const int64_t lo = chunk * PF_DOT_CHUNK;
-    const int64_t hi = lo + PF_DOT_CHUNK < a.n_pad ? lo + PF_DOT_CHUNK : a.n_pad;
-    double s = 0.0;
-    for (int64_t i = lo + 2 * threadIdx.x; i < hi; i += 2 * PF_BLOCK) {
-        const double2 x = *reinterpret_cast<const double2*>(v + i);
-        const double2 c = *reinterpret_cast<const double2*>(w + i);
-        s += x.x * c.x;
-        s += x.y * c.y;
+    // n_pad is a multiple of the chunk: every chunk is whole, every thread has PF_DOT_CHUNK / (2 PF_BLOCK) = 8 pairs, all
+    // of whose loads are issued before the first product waits for one (the sums keep their order)
+    constexpr int PAIRS = PF_DOT_CHUNK / (2 * PF_BLOCK);
+    double2 cs[PAIRS], xs[VB][PAIRS];
+#pragma unroll
+    for (int it = 0; it < PAIRS; ++it) cs[it] = *reinterpret_cast<const double2*>(w + lo + 2 * threadIdx.x + (int64_t)it * (2 * PF_BLOCK));
+#pragma unroll
+    for (int u = 0; u < VB; ++u) {
+        const int b = b0 + u;
+        if (b > a.count) continue;
+        const double* v = a.ws + (int64_t)(b == a.count ? a.wslot : a.first + b) * a.n_pad;
+#pragma unroll
+        for (int it = 0; it < PAIRS; ++it) xs[u][it] = *reinterpret_cast<const double2*>(v + lo + 2 * threadIdx.x + (int64_t)it * (2 * PF_BLOCK));
     }
 #pragma unroll
-    for (int off = PF_WAVE / 2; off > 0; off >>= 1) s += __shfl_down(s, off, PF_WAVE);
-    if ((threadIdx.x & (PF_WAVE - 1)) == 0) red[threadIdx.x / PF_WAVE] = s;
+    for (int u = 0; u < VB; ++u) {
+        if (b0 + u > a.count) continue;
+        double s = 0.0;
+#pragma unroll
+        for (int it = 0; it < PAIRS; ++it) {
+            s += xs[u][it].x * cs[it].x;
+            s += xs[u][it].y * cs[it].y;
+        }
+#pragma unroll
+        for (int off = PF_WAVE / 2; off > 0; off >>= 1) s += __shfl_down(s, off, PF_WAVE);
+        if ((threadIdx.x & (PF_WAVE - 1)) == 0) red[u][threadIdx.x / PF_WAVE] = s;
+    }
     __syncthreads();
-    if (threadIdx.x == 0) a.partial[(int64_t)b * a.n_chunks + chunk] = (red[0] + red[1]) + (red[2] + red[3]);
+    if (threadIdx.x < VB && b0 + (int)threadIdx.x <= a.count)
+        a.partial[(int64_t)(b0 + threadIdx.x) * a.n_chunks + chunk] =
+            (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
 }
 
+// P: pairs of rows per thread.  1: a block owns 512 rows (many blocks: what fills the chip at 250k rows).  8 (bases beyond the
+// Infinity Cache): a block owns a whole 4096-row chunk, so that it reads 32 KB of every basis vector in one piece instead of
+// 4 KB pieces of fifty streams (DRAM pages), and the sums of the partial dot products are redone by an eighth of the blocks.
+// Per row the subtractions are the same, in the same order.
+template <int P>
 __global__ __launch_bounds__(PF_BLOCK) void k_orth_project(OrthArgs2 a2) {
     __shared__ double hs[PF_ORTH_MAX + 1];
     __shared__ double s_scale, s_after, s_redo;
     const OrthArgs& a = a2.g[blockIdx.z];
-    if (a.pass < 0 || 2 * (int64_t)blockIdx.x * PF_BLOCK >= a.n_pad) return;  // (block-uniform)
+    if (a.pass < 0 || 2 * (int64_t)blockIdx.x * PF_BLOCK * P >= a.n_pad) return;  // (block-uniform)
     if (a.pass == 2 && *a.verdict == 0.0) return;
     const int lane = threadIdx.x & (PF_WAVE - 1);
     const int32_t count = a.count;
@@ -317,19 +344,77 @@ __global__ __launch_bounds__(PF_BLOCK) void k_orth_project(OrthArgs2 a2) {
             __hip_atomic_store(a.host_out + count + 2, a.ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
-    const int64_t i = 2 * ((int64_t)blockIdx.x * PF_BLOCK + threadIdx.x);
-    if (i >= a.n_pad) return;
-    double2 acc = *reinterpret_cast<double2*>(a.ws + (int64_t)a.wslot * a.n_pad + i);
-    for (int b = 0; b < count; ++b) {
-        const double hb = hs[b];
-        const double2 v = *reinterpret_cast<const double2*>(a.ws + (int64_t)(a.first + b) * a.n_pad + i);
-        acc.x -= hb * v.x;
-        acc.y -= hb * v.y;
-    }
     const double sc = s_scale;
-    acc.x *= sc;
-    acc.y *= sc;
-    *reinterpret_cast<double2*>(a.ws + (int64_t)a.wslot * a.n_pad + i) = acc;
+    if constexpr (P == 1) {
+        const int64_t i = 2 * ((int64_t)blockIdx.x * PF_BLOCK + threadIdx.x);
+        if (i >= a.n_pad) return;
+        double2 acc = *reinterpret_cast<double2*>(a.ws + (int64_t)a.wslot * a.n_pad + i);
+        // eight basis vectors' loads in flight per thread (the subtractions keep their order: the same bits)
+        int b = 0;
+        for (; b + 8 <= count; b += 8) {
+            double2 vv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) vv[u] = *reinterpret_cast<const double2*>(a.ws + (int64_t)(a.first + b + u) * a.n_pad + i);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const double hb = hs[b + u];
+                acc.x -= hb * vv[u].x;
+                acc.y -= hb * vv[u].y;
+            }
+        }
+        for (; b < count; ++b) {
+            const double hb = hs[b];
+            const double2 v = *reinterpret_cast<const double2*>(a.ws + (int64_t)(a.first + b) * a.n_pad + i);
+            acc.x -= hb * v.x;
+            acc.y -= hb * v.y;
+        }
+        acc.x *= sc;
+        acc.y *= sc;
+        *reinterpret_cast<double2*>(a.ws + (int64_t)a.wslot * a.n_pad + i) = acc;
+    } else {
+        const int64_t i0 = (int64_t)blockIdx.x * (2 * PF_BLOCK * P) + 2 * threadIdx.x;  // (n_pad is a multiple of 4096: whole blocks)
+        double2 acc[P];
+#pragma unroll
+        for (int it = 0; it < P; ++it) acc[it] = *reinterpret_cast<double2*>(a.ws + (int64_t)a.wslot * a.n_pad + i0 + (int64_t)it * (2 * PF_BLOCK));
+        // (one block per CU at this shape: two vectors' pieces - 2 x 8 x 16 bytes per thread - are requested before the
+        // first is used; the subtractions keep the order b, b + 1)
+        int b = 0;
+        for (; b + 2 <= count; b += 2) {
+            const double h0 = hs[b], h1 = hs[b + 1];
+            const double* v0 = a.ws + (int64_t)(a.first + b) * a.n_pad + i0;
+            const double* v1 = v0 + a.n_pad;
+            double2 x0[P], x1[P];
+#pragma unroll
+            for (int it = 0; it < P; ++it) x0[it] = *reinterpret_cast<const double2*>(v0 + (int64_t)it * (2 * PF_BLOCK));
+#pragma unroll
+            for (int it = 0; it < P; ++it) x1[it] = *reinterpret_cast<const double2*>(v1 + (int64_t)it * (2 * PF_BLOCK));
+#pragma unroll
+            for (int it = 0; it < P; ++it) {
+                acc[it].x -= h0 * x0[it].x;
+                acc[it].y -= h0 * x0[it].y;
+                acc[it].x -= h1 * x1[it].x;
+                acc[it].y -= h1 * x1[it].y;
+            }
+        }
+        for (; b < count; ++b) {
+            const double hb = hs[b];
+            const double* vb = a.ws + (int64_t)(a.first + b) * a.n_pad + i0;
+            double2 vv[P];
+#pragma unroll
+            for (int it = 0; it < P; ++it) vv[it] = *reinterpret_cast<const double2*>(vb + (int64_t)it * (2 * PF_BLOCK));
+#pragma unroll
+            for (int it = 0; it < P; ++it) {
+                acc[it].x -= hb * vv[it].x;
+                acc[it].y -= hb * vv[it].y;
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < P; ++it) {
+            acc[it].x *= sc;
+            acc[it].y *= sc;
+            *reinterpret_cast<double2*>(a.ws + (int64_t)a.wslot * a.n_pad + i0 + (int64_t)it * (2 * PF_BLOCK)) = acc[it];
+        }
+    }
 }
 __global__ __launch_bounds__(PF_BLOCK) void k_scale_finishing(double* __restrict__ x, int64_t n_pad, const double* __restrict__ partial,
                                                               int64_t n_chunks, int normalize, const double* __restrict__ hsum,
@@ -1203,6 +1288,22 @@ int pf_dots(pf_graph* g, int32_t w, int32_t first, int32_t count, double* out) {
     return small_to_host(g, g->coef, out, (size_t)count);
 }
 
+// the two launches of one Gram-Schmidt pass (of one graph, or of both graphs of a pair: ng = 2); bases beyond the Infinity
+// Cache (>= 400k rows: 1M x 50 vectors = 400 MB) take the shapes with several vectors / a whole chunk per block
+static int orth_launch_pass(const OrthArgs2& a2, int ng, int64_t n_chunks, int64_t n_pad, int32_t count, hipStream_t st) {
+    if (n_pad >= 400000) {
+        k_orth_dots<4><<<dim3((unsigned)n_chunks, (unsigned)((count + 1 + 3) / 4), (unsigned)ng), PF_BLOCK, 0, st>>>(a2);
+        PF_HIP(hipGetLastError());
+        k_orth_project<8><<<dim3((unsigned)(n_pad / (2 * PF_BLOCK * 8)), 1u, (unsigned)ng), PF_BLOCK, 0, st>>>(a2);
+    } else {
+        k_orth_dots<1><<<dim3((unsigned)n_chunks, (unsigned)(count + 1), (unsigned)ng), PF_BLOCK, 0, st>>>(a2);
+        PF_HIP(hipGetLastError());
+        k_orth_project<1><<<dim3(nblk(n_pad / 2), 1u, (unsigned)ng), PF_BLOCK, 0, st>>>(a2);
+    }
+    PF_HIP(hipGetLastError());
+    return PF_OK;
+}
+
 // checks, pinned result buffer, event: everything of pf_orth_begin that comes before the launches
 static int orth_prepare(pf_graph* g, int32_t w, int32_t first, int32_t count, int32_t normalize) {
     PF_TRY(check_slots(g, w, 1, "pf_orth_begin"));
@@ -1278,16 +1379,10 @@ int pf_orth_begin(pf_graph* g, int32_t w, int32_t first, int32_t count, int32_t 
         // dot products; the second Gram-Schmidt pass is pf_orth_end's business in the rare step that needs it
         OrthArgs2 a2{};
         a2.g[0] = orth_args(g, w, first, count, normalize);
-        k_orth_dots<<<dim3((unsigned)g->n_chunks, (unsigned)(count + 1), 1u), PF_BLOCK, 0, st>>>(a2);
-        PF_HIP(hipGetLastError());
-        k_orth_project<<<dim3(nblk(g->n_pad / 2), 1u, 1u), PF_BLOCK, 0, st>>>(a2);
-        PF_HIP(hipGetLastError());
+        PF_TRY(orth_launch_pass(a2, 1, g->n_chunks, g->n_pad, count, st));
         if (a2.g[0].pass == 1) {  // the second pass, on the device's own verdict
             a2.g[0].pass = 2;
-            k_orth_dots<<<dim3((unsigned)g->n_chunks, (unsigned)(count + 1), 1u), PF_BLOCK, 0, st>>>(a2);
-            PF_HIP(hipGetLastError());
-            k_orth_project<<<dim3(nblk(g->n_pad / 2), 1u, 1u), PF_BLOCK, 0, st>>>(a2);
-            PF_HIP(hipGetLastError());
+            PF_TRY(orth_launch_pass(a2, 1, g->n_chunks, g->n_pad, count, st));
         }
     } else if (count == 0) {
         k_dot_partial<<<dim3((unsigned)g->n_chunks, 1u), PF_BLOCK, 0, st>>>(g->ws, g->n_pad, w, w, g->n_chunks, g->partials);
@@ -1330,16 +1425,12 @@ int pf_orth_begin2(pf_graph* ga, int32_t w_a, int32_t first_a, int32_t count_a, 
     OrthArgs2 a2{};
     a2.g[0] = orth_args(ga, w_a, first_a, count_a, normalize_a);
     a2.g[1] = orth_args(gb, w_b, first_b, count_b, normalize_b);
-    k_orth_dots<<<dim3((unsigned)std::max(ga->n_chunks, gb->n_chunks), (unsigned)(std::max(count_a, count_b) + 1), 2u), PF_BLOCK, 0, st>>>(a2);
-    PF_HIP(hipGetLastError());
-    k_orth_project<<<dim3(nblk(std::max(ga->n_pad, gb->n_pad) / 2), 1u, 2u), PF_BLOCK, 0, st>>>(a2);
-    PF_HIP(hipGetLastError());
+    const int64_t chunks2 = std::max(ga->n_chunks, gb->n_chunks), pad2 = std::max(ga->n_pad, gb->n_pad);
+    const int32_t count2 = std::max(count_a, count_b);
+    PF_TRY(orth_launch_pass(a2, 2, chunks2, pad2, count2, st));
     if (a2.g[0].pass == 1 || a2.g[1].pass == 1) {  // the second pass of the graph(s) that asked for it, on the device's own verdict
         for (int q = 0; q < 2; ++q) a2.g[q].pass = a2.g[q].pass == 1 ? 2 : -1;
-        k_orth_dots<<<dim3((unsigned)std::max(ga->n_chunks, gb->n_chunks), (unsigned)(std::max(count_a, count_b) + 1), 2u), PF_BLOCK, 0, st>>>(a2);
-        PF_HIP(hipGetLastError());
-        k_orth_project<<<dim3(nblk(std::max(ga->n_pad, gb->n_pad) / 2), 1u, 2u), PF_BLOCK, 0, st>>>(a2);
-        PF_HIP(hipGetLastError());
+        PF_TRY(orth_launch_pass(a2, 2, chunks2, pad2, count2, st));
     }
     // (no event: both results carry tickets, pf_orth_end polls for them)
     ga->orth_wait = ga->orth_ev;
