@@ -286,15 +286,27 @@ struct Solver {
         reg = std::max(m_max + 1, 2 * (q_target + out_cap) + 2);
         PFK_TRY(ops->ws_ensure(2 * reg));
         A0 = 0, B0 = reg;
-        // (asymmetric graphs: a stronger filter - fewer, longer applications - was measured on the bundled 15k pair and
-        // loses: at 15 windows a recurrence step still costs 1.6 us, and the more the outliers are amplified the more
-        // Gram-Schmidt steps cancel digits; placement as _krylov._solve_gen)
-        if (!sym) strength = 2.0;
+        // Asymmetric graphs: placement 12 (want + 1) / n and strength 2.0 where that gives a degree of 64 or more (the messy 250k
+        // pair: 15.4 ms; 16.0-16.3 with stronger filters, which only run into the degree cap).  Small graphs gain from
+        // fewer, longer applications - an outer step costs ~46 us besides its recurrence (launch preamble, Gram-Schmidt with
+        // its device-side second pass) and the step count has a floor, the carried outliers: bundled 15k pair 6.85 ms at
+        // (12, 2.0) with degrees 29 / 23, 6.1-6.2 anywhere in (6..8, 2.5..3.0) with degrees ~52 / 40 - so placement and
+        // strength move towards (7, 2.75) as the degree at (12, 2.0) falls from 64 to 32.
+        double cut_factor = sym ? 8.0 : 12.0;
+        if (!sym) {
+            strength = 2.0;
+            double c_, e_;
+            int p0 = 0;
+            choose_filter(cut_factor * (want + 1) / (double)std::max<int64_t>(n_active, 1), hi, strength, 128, &c_, &e_, &p0);
+            const double f = std::min(std::max((64.0 - p0) / 32.0, 0.0), 1.0);
+            cut_factor -= 5.0 * f;
+            strength += 0.75 * f;
+        }
         // (a stronger filter for the graph of a pair that wants more columns - 9 against 5 for the bundled 15k pair - evens the
         // two step counts out, 44 / 48 instead of 48 / 53 on the messy 250k pair, at more recurrence steps per shared launch:
         // measured neutral, 12.94 against 12.95 ms and 5.11 against 5.15; not kept)
-        cut0 = (sym ? 8.0 : 12.0) * (want + 1) / (double)std::max<int64_t>(n_active, 1);
-        if (const char* ev = getenv("PF_EIGS_CUT")) cut0 *= atof(ev) / (sym ? 8.0 : 12.0);  // (experiments: the filter's placement ...
+        cut0 = cut_factor * (want + 1) / (double)std::max<int64_t>(n_active, 1);
+        if (const char* ev = getenv("PF_EIGS_CUT")) cut0 *= atof(ev) / cut_factor;  // (experiments: the filter's placement ...
         if (const char* ev = getenv("PF_EIGS_STRENGTH")) strength = atof(ev);  // ... and strength; results agree to tol)
         H.assign((size_t)m_max * m_max, 0.0);
         b.assign((size_t)m_max, 0.0);

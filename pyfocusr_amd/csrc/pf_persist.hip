@@ -400,6 +400,15 @@ __global__ __launch_bounds__(RX_THREADS) void k_cheb_resident(RxArgs a) {
 #endif
         if (early) __builtin_amdgcn_s_setprio(3);
         const unsigned step_top = (unsigned)__builtin_amdgcn_s_memrealtime();
+        // (threads with four rows: the row number is "new" in every step, so that the compiler forms a row's LDS and memory
+        // addresses where it uses them instead of keeping ~6 registers per row alive across the whole recurrence, and
+        // spilling; 1M-row pair, k = 10: eigensolves 73.0 -> 69.8 ms)
+        int32_t rtk[NG];
+#pragma unroll
+        for (int q = 0; q < NG; ++q) {
+            rtk[q] = rt[q];
+            if (NG * NW >= 4) asm volatile("" : "+v"(rtk[q]));
+        }
 #pragma unroll
         for (int w = 0; w < NW; ++w) {
 #pragma unroll
@@ -408,11 +417,25 @@ __global__ __launch_bounds__(RX_THREADS) void k_cheb_resident(RxArgs a) {
                 if (!have[q] || k > g.degree) continue;  // (wave-uniform) a graph whose recurrence is over sits the step out
                 const double* x = xb[q] + (size_t)cur * xlen[q];
                 double* xn = xb[q] + (size_t)(cur ^ 1) * xlen[q];
-                const int32_t lr = w * RX_THREADS + rt[q];
+                const int32_t lr = w * RX_THREADS + rtk[q];
                 const int32_t wd = width[q][w];
                 const double xi = xc[q][w];  // the row's own x: last step's result, still in its register
                 double acc = rx_row_dispatch<JR>(__builtin_amdgcn_readfirstlane(wd < JR ? wd : JR), x, dg[q][w], xi, v[q][w], slp[q][w]);
-                for (int j = JR; j < wd; ++j) {
+#ifndef RX_OV_PAIRS
+#define RX_OV_PAIRS 1
+#endif
+                int j = JR;
+#if RX_OV_PAIRS
+                for (; j + 1 < wd; j += 2) {  // (two entries' value, slot and x reads in flight together; fmas in entry order)
+                    const int32_t o = ovoff[q][w] + (j - JR) * PF_WAVE + lane;
+                    const double a0 = ov_val[o], a1 = ov_val[o + PF_WAVE];
+                    const unsigned s0 = ov_slot[o], s1 = ov_slot[o + PF_WAVE];
+                    const double x0 = x[s0], x1 = x[s1];
+                    acc = __builtin_fma(a0, x0, acc);
+                    acc = __builtin_fma(a1, x1, acc);
+                }
+#endif
+                for (; j < wd; ++j) {
                     const int32_t o = ovoff[q][w] + (j - JR) * PF_WAVE + lane;
                     acc = __builtin_fma(ov_val[o], x[ov_slot[o]], acc);
                 }
