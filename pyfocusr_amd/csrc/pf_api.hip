@@ -9,6 +9,7 @@
 #include <mutex>
 
 #include "pf_internal.h"
+#include "pf_launch.h"
 
 static thread_local char g_err[1024] = "";
 static std::mutex g_ctx_mutex;
@@ -182,6 +183,10 @@ hipError_t pf_malloc(hipStream_t st, void** p, size_t bytes) {
 
 void pf_free(hipStream_t st, void* p) {
     if (!p) return;
+    if (pfl::tl_rec) {  // launches of this thread are being recorded: the block stays taken until they have been queued
+        pfl::tl_rec->frees.emplace_back(st, p);
+        return;
+    }
     int sid = 0;
     pf_ctx* c = ctx_of_stream(st, &sid);
     if (!c) return;
@@ -191,6 +196,60 @@ void pf_free(hipStream_t st, void* p) {
     c->free_blocks.emplace(it->second, pf_ctx::FreeBlock{p, sid, c->alloc_epoch});
     c->live_blocks.erase(it);
 }
+
+namespace pfl {
+
+void flush(Recorder& a, Recorder* b, hipStream_t st) {
+    Recorder* const saved = tl_rec;
+    tl_rec = nullptr;  // what runs now is launched, and frees are frees
+    size_t i = 0, j = 0;
+    const size_t na = a.ops.size(), nb = b ? b->ops.size() : 0;
+    while (i < na && j < nb) {
+        const Op& x = a.ops[i];
+        const Op& y = b->ops[j];
+        if (x.key != y.key) {
+            // a copy or an event record that only one mesh has (the first one records the build's start): it runs alone
+            if (!x.key) {
+                x.call(st);
+                ++i;
+                continue;
+            }
+            if (!y.key) {
+                y.call(st);
+                ++j;
+                continue;
+            }
+            break;  // different kernels: the two host codes took different turns - the rest one after the other
+        }
+        if (x.key && x.block.x == y.block.x && x.block.y == y.block.y && x.block.z == y.block.z) {
+            x.run2(x, y, st);
+        } else if (x.key) {
+            x.run1(x, st);
+            y.run1(y, st);
+        } else {
+            x.call(st);
+            y.call(st);
+        }
+        ++i, ++j;
+    }
+    for (; i < na; ++i) a.ops[i].key ? a.ops[i].run1(a.ops[i], st) : a.ops[i].call(st);
+    for (; j < nb; ++j) b->ops[j].key ? b->ops[j].run1(b->ops[j], st) : b->ops[j].call(st);
+    a.ops.clear();
+    for (auto& f : a.frees) pf_free(f.first, f.second);
+    a.frees.clear();
+    if (b) {
+        b->ops.clear();
+        for (auto& f : b->frees) pf_free(f.first, f.second);
+        b->frees.clear();
+    }
+    tl_rec = saved;
+}
+
+void flush_self(hipStream_t st) {
+    if (tl_rec) flush(*tl_rec, nullptr, st);
+}
+
+}  // namespace pfl
 
 void pf_set_error(const char* fmt, ...) {
     va_list ap;
@@ -374,6 +433,12 @@ int pf_timing_enable(pf_ctx* c, int on) {
 int pf_timing_get(pf_ctx* c, pf_timing* out, int reset) {
     PF_CHECK(c != nullptr && out != nullptr, PF_E_ARG, "pf_timing_get: NULL argument");
     PF_TRY(pf_timing_collect(c));
+    if (c->build_pending) {
+        c->build_pending = false;
+        float ms = 0.f;
+        if (hipEventSynchronize(c->ev1) == hipSuccess && hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) c->build_ms = ms;
+        else (void)hipGetLastError();
+    }
     out->op_ms = c->op_ms;
     out->op_launches = c->op_launches;
     out->op_bytes = c->op_bytes;

@@ -22,10 +22,13 @@
 #include <thread>
 
 #include "pf_internal.h"
+#include "pf_launch.h"
 
 namespace {
 
-__global__ __launch_bounds__(PF_BLOCK) void k_count_edges(const int32_t* __restrict__ faces, int64_t n_edges,
+struct k_count_edges {
+    static constexpr int BOUNDS = PF_BLOCK;
+    static __device__ __forceinline__ void run(const int32_t* __restrict__ faces, int64_t n_edges,
                                                           int32_t vpf, int64_t n, int32_t* __restrict__ cnt,
                                                           int32_t* __restrict__ rank, int32_t* __restrict__ flags,
                                                           double* __restrict__ quarter) {
@@ -48,8 +51,11 @@ __global__ __launch_bounds__(PF_BLOCK) void k_count_edges(const int32_t* __restr
     // own (1.5 M atomics on scattered addresses per 250k mesh and pass - the two meshes of a pair queue for the same units)
     rank[e] = atomicAdd(&cnt[src], 1);
 }
+};
 
-__global__ __launch_bounds__(PF_BLOCK) void k_scatter_edges(const int32_t* __restrict__ faces,
+struct k_scatter_edges {
+    static constexpr int BOUNDS = PF_BLOCK;
+    static __device__ __forceinline__ void run(const int32_t* __restrict__ faces,
                                                             const double* __restrict__ pts, int64_t n_edges,
                                                             int32_t vpf, int64_t n, const int32_t* __restrict__ start,
                                                             const int32_t* __restrict__ rank, int32_t* __restrict__ rcol,
@@ -71,6 +77,7 @@ __global__ __launch_bounds__(PF_BLOCK) void k_scatter_edges(const int32_t* __res
     rcol[slot] = dst;
     rw[slot] = wv;
 }
+};
 
 // A rigorous upper bound for the spectrum of the normalised Laplacian of a closed triangle mesh, face by face.
 // If every undirected edge lies in exactly two triangles, W = sum over triangles t of A_t, the triangle's own adjacency
@@ -82,7 +89,9 @@ __global__ __launch_bounds__(PF_BLOCK) void k_scatter_edges(const int32_t* __res
 // against the generic bound 2: 1.69 for the 250k blobs, 1.60 for the bundled 5k mesh (their lambda_max: 1.58, 1.49).  The
 // Chebyshev filter's degree scales with the square root of the interval it has to damp.  P is homogeneous of degree 0: the
 // weights themselves (1 / edge length) serve.  out: bits of min P (positive doubles order like their bit patterns).
-__global__ __launch_bounds__(PF_BLOCK) void k_face_bound(const int32_t* __restrict__ faces, const double* __restrict__ pts,
+struct k_face_bound {
+    static constexpr int BOUNDS = PF_BLOCK;
+    static __device__ __forceinline__ void run(const int32_t* __restrict__ faces, const double* __restrict__ pts,
                                                          int64_t n_faces, int64_t n, unsigned long long* __restrict__ out) {
     __shared__ double red[PF_BLOCK / PF_WAVE];
     const int64_t f = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
@@ -116,23 +125,30 @@ __global__ __launch_bounds__(PF_BLOCK) void k_face_bound(const int32_t* __restri
         atomicMin(out, (unsigned long long)__double_as_longlong(m));
     }
 }
+};
 
 // ---- m-space (round 4): the mesh renumbered by the Morton rank of its points before anything is assembled ----------------
 // pts_m[m] = pts[morder[m]]; faces_m[e] = mrank[faces[e]] (an index out of range stays out of range: k_count_edges flags it)
-__global__ __launch_bounds__(PF_BLOCK) void k_renumber_points(const double* __restrict__ pts, const int32_t* __restrict__ morder,
+struct k_renumber_points {
+    static constexpr int BOUNDS = PF_BLOCK;
+    static __device__ __forceinline__ void run(const double* __restrict__ pts, const int32_t* __restrict__ morder,
                                                               int64_t n, double* __restrict__ out) {
     const int64_t t = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
     if (t >= 3 * n) return;
     const int64_t m = t / 3;
     out[t] = pts[3 * (int64_t)morder[m] + (t - 3 * m)];
 }
-__global__ __launch_bounds__(PF_BLOCK) void k_renumber_faces(const int32_t* __restrict__ faces, const int32_t* __restrict__ mrank,
+};
+struct k_renumber_faces {
+    static constexpr int BOUNDS = PF_BLOCK;
+    static __device__ __forceinline__ void run(const int32_t* __restrict__ faces, const int32_t* __restrict__ mrank,
                                                              int64_t n_edges, int64_t n, int32_t* __restrict__ out) {
     const int64_t e = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
     if (e >= n_edges) return;
     const int32_t v = faces[e];
     out[e] = (v >= 0 && v < n) ? mrank[v] : (v < 0 ? v : (int32_t)n);
 }
+};
 
 // one thread per vertex: insertion-sort its (col, w) segment by column, drop duplicate columns
 // (a directed edge listed by two faces carries the same weight), report the unique count.
@@ -170,7 +186,9 @@ __device__ __forceinline__ int32_t sort_unique_segment(C* c, W* v, int32_t b, in
     return u;
 }
 
-__global__ __launch_bounds__(PF_BLOCK) void k_sort_unique_rows(const int32_t* __restrict__ start, int64_t n,
+struct k_sort_unique_rows {
+    static constexpr int BOUNDS = PF_BLOCK;
+    static __device__ __forceinline__ void run(const int32_t* __restrict__ start, int64_t n,
                                                                int32_t* __restrict__ rcol, double* __restrict__ rw,
                                                                int32_t* __restrict__ ucnt, const int32_t* __restrict__ key) {
     __shared__ int32_t s_c[PF_SORT_CAP];
@@ -195,8 +213,11 @@ __global__ __launch_bounds__(PF_BLOCK) void k_sort_unique_rows(const int32_t* __
         rw[lo + a] = s_v[a];
     }
 }
+};
 
-__global__ __launch_bounds__(PF_BLOCK) void k_compact_rows(const int32_t* __restrict__ start,
+struct k_compact_rows {
+    static constexpr int BOUNDS = PF_BLOCK;
+    static __device__ __forceinline__ void run(const int32_t* __restrict__ start,
                                                            const int32_t* __restrict__ rowptr, int64_t n,
                                                            const int32_t* __restrict__ rcol,
                                                            const double* __restrict__ rw, int32_t* __restrict__ col,
@@ -218,8 +239,11 @@ __global__ __launch_bounds__(PF_BLOCK) void k_compact_rows(const int32_t* __rest
     g[i] = gi;
     sg[i] = sqrt(gi);
 }
+};
 
-__global__ __launch_bounds__(PF_BLOCK) void k_row_stats(const int32_t* __restrict__ rowptr, int64_t n,
+struct k_row_stats {
+    static constexpr int BOUNDS = PF_BLOCK;
+    static __device__ __forceinline__ void run(const int32_t* __restrict__ rowptr, int64_t n,
                                                         int32_t* __restrict__ stats /* [0]=n_isolated [1]=max_degree */) {
     const int64_t i = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
     const int32_t c = i < n ? rowptr[i + 1] - rowptr[i] : -1;
@@ -244,10 +268,13 @@ __global__ __launch_bounds__(PF_BLOCK) void k_row_stats(const int32_t* __restric
         if (s_iso) atomicAdd(&stats[0], s_iso);
     }
 }
+};
 
 // values == nullptr: structural symmetry (mesh graphs: W_ij and W_ji are then equal bit for bit);
 // otherwise the values must agree as well (general Laplacians handed in as CSR).
-__global__ __launch_bounds__(PF_BLOCK) void k_symmetry_probe(const int32_t* __restrict__ rowptr,
+struct k_symmetry_probe {
+    static constexpr int BOUNDS = PF_BLOCK;
+    static __device__ __forceinline__ void run(const int32_t* __restrict__ rowptr,
                                                              const int32_t* __restrict__ col,
                                                              const double* __restrict__ values, int64_t n,
                                                              int32_t* __restrict__ asym, const int32_t* __restrict__ key = nullptr) {
@@ -273,6 +300,7 @@ __global__ __launch_bounds__(PF_BLOCK) void k_symmetry_probe(const int32_t* __re
         if (!found) atomicAdd(asym, 1);  // one-way (or numerically unequal) entry
     }
 }
+};
 
 // ---- weakly connected components -----------------------------------------------------------------------------
 // Atomics on one address serialise at ~10 ns each on this part (measured: 4 k atomicMax on one word = 41 us), and every
@@ -298,7 +326,9 @@ __device__ __forceinline__ int32_t uf_find(const int32_t* label, int32_t x) {
 // rounds (13.8 us against 9.1 per round at 250k, measured); ordered by the caller's (unrelated) vertex numbers the forest
 // is the one of round 3, its gathers are still m-space local, and the surviving root of a component is the vertex with
 // the smallest ORIGINAL number - the label the boundary format hands out.
-__global__ __launch_bounds__(PF_BLOCK) void k_label_init(const int32_t* __restrict__ rowptr,
+struct k_label_init {
+    static constexpr int BOUNDS = PF_BLOCK;
+    static __device__ __forceinline__ void run(const int32_t* __restrict__ rowptr,
                                                          const int32_t* __restrict__ col, int64_t n, int64_t n_pad,
                                                          int32_t* __restrict__ label, const int32_t* __restrict__ key) {
     const int64_t i = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
@@ -314,12 +344,16 @@ __global__ __launch_bounds__(PF_BLOCK) void k_label_init(const int32_t* __restri
     }
     label[i] = m;  // parent <= child in the key's order, equality for roots only: a forest
 }
+};
 
-__global__ __launch_bounds__(PF_BLOCK) void k_label_compress(int32_t* label, int64_t n, const int32_t* prev = nullptr) {
+struct k_label_compress {
+    static constexpr int BOUNDS = PF_BLOCK;
+    static __device__ __forceinline__ void run(int32_t* label, int64_t n, const int32_t* prev = nullptr) {
     if (prev && *prev == 0) return;
     const int64_t i = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
     if (i < n) label[i] = uf_find(label, (int32_t)i);
 }
+};
 
 // One ROUND in one launch (round 3): a vertex first points itself at its current root (the flattening that used to be a
 // launch of its own), then hooks across its edges between ROOTS found by walking the pointers as they are at that moment.
@@ -330,7 +364,9 @@ __global__ __launch_bounds__(PF_BLOCK) void k_label_compress(int32_t* label, int
 #ifndef PF_CC_SWEEPS
 #define PF_CC_SWEEPS 1
 #endif
-__global__ __launch_bounds__(PF_BLOCK) void k_label_round(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, int64_t n,
+struct k_label_round {
+    static constexpr int BOUNDS = PF_BLOCK;
+    static __device__ __forceinline__ void run(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col, int64_t n,
                                                           int32_t* label, int32_t* differing, const int32_t* prev,
                                                           const int32_t* __restrict__ key) {
     if (prev && *prev == 0) return;  // the previous round changed nothing: converged (rounds are queued ahead, unasked)
@@ -362,8 +398,11 @@ __global__ __launch_bounds__(PF_BLOCK) void k_label_round(const int32_t* __restr
     }
     if (__any(any) && (threadIdx.x & (PF_WAVE - 1)) == 0) *differing = 1;
 }
+};
 
-__global__ __launch_bounds__(PF_BLOCK) void k_collect_roots(const int32_t* __restrict__ label,
+struct k_collect_roots {
+    static constexpr int BOUNDS = PF_BLOCK;
+    static __device__ __forceinline__ void run(const int32_t* __restrict__ label,
                                                             const int32_t* __restrict__ rowptr, int64_t n,
                                                             int32_t* __restrict__ roots, int32_t* __restrict__ n_roots) {
     const int64_t i = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
@@ -373,9 +412,12 @@ __global__ __launch_bounds__(PF_BLOCK) void k_collect_roots(const int32_t* __res
         if (k < PF_MAX_ROOTS) roots[k] = (int32_t)i;
     }
 }
+};
 
 // ---- SELL-64 ----------------------------------------------------------------------------------
-__global__ __launch_bounds__(PF_BLOCK) void k_slice_widths(const int32_t* __restrict__ rowptr,
+struct k_slice_widths {
+    static constexpr int BOUNDS = PF_BLOCK;
+    static __device__ __forceinline__ void run(const int32_t* __restrict__ rowptr,
                                                            const int32_t* __restrict__ perm, int64_t n,
                                                            int64_t n_slices, int64_t* __restrict__ width64) {
     const int64_t row = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;  // renumbered row
@@ -390,13 +432,16 @@ __global__ __launch_bounds__(PF_BLOCK) void k_slice_widths(const int32_t* __rest
     if ((threadIdx.x & (PF_WAVE - 1)) == 0 && s < n_slices) width64[s] = (int64_t)c * PF_WAVE;
     if (row == 0) width64[n_slices] = 0;  // (the scan's extra element: no fill of its own)
 }
+};
 
 // The same storage, one block per slice and one thread per stored ENTRY (round 3).  k_fill_sell walks a row's entries one
 // after the other - two dependent gathers each (the entry, then iperm / sg of its column), seven times in a row per
 // lane: 110-150 us for a 250k-vertex mesh whose vertices come in no particular order.  Here every entry of the slice is
 // its own thread: the row's facts sit in LDS, entry q of the slice is written by thread q (coalesced, the layout of
 // pf_sell_index inverted), and all gathers of a slice are in flight together.
-__global__ __launch_bounds__(PF_BLOCK) void k_fill_sell_entries(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+struct k_fill_sell_entries {
+    static constexpr int BOUNDS = PF_BLOCK;
+    static __device__ __forceinline__ void run(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                                                                 const double* __restrict__ w, const double* __restrict__ deg,
                                                                 const double* __restrict__ g, const double* __restrict__ sg,
                                                                 const int32_t* __restrict__ perm, const int32_t* __restrict__ iperm,
@@ -454,31 +499,43 @@ __global__ __launch_bounds__(PF_BLOCK) void k_fill_sell_entries(const int32_t* _
         }
     }
 }
+};
 
-__global__ __launch_bounds__(PF_BLOCK) void k_l_offdiag(const int32_t* __restrict__ rowptr, const double* __restrict__ w,
+struct k_l_offdiag {
+    static constexpr int BOUNDS = PF_BLOCK;
+    static __device__ __forceinline__ void run(const int32_t* __restrict__ rowptr, const double* __restrict__ w,
                                                         const double* __restrict__ g, int64_t n, double* __restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
     if (i >= n) return;
     const double gi = g[i];
     for (int32_t a = rowptr[i]; a < rowptr[i + 1]; ++a) out[a] = -(gi * w[a]);
 }
+};
 
-__global__ __launch_bounds__(PF_BLOCK) void k_l_diag(const double* __restrict__ deg, const double* __restrict__ g, int64_t n,
+struct k_l_diag {
+    static constexpr int BOUNDS = PF_BLOCK;
+    static __device__ __forceinline__ void run(const double* __restrict__ deg, const double* __restrict__ g, int64_t n,
                                                      double* __restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
     if (i < n) out[i] = g[i] * deg[i];
 }
+};
 
 // ---- the boundary format of a graph assembled in m-space: CSR(W), deg, labels in the caller's vertex order, made on demand
 // (pf_graph_download: reference-style views, tests; never on the timed path)
-__global__ __launch_bounds__(PF_BLOCK) void k_len_original(const int32_t* __restrict__ rowptr_m, const int32_t* __restrict__ mrank,
+struct k_len_original {
+    static constexpr int BOUNDS = PF_BLOCK;
+    static __device__ __forceinline__ void run(const int32_t* __restrict__ rowptr_m, const int32_t* __restrict__ mrank,
                                                            int64_t n, int32_t* __restrict__ len) {
     const int64_t i = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
     if (i > n) return;
     len[i] = i < n ? rowptr_m[mrank[i] + 1] - rowptr_m[mrank[i]] : 0;
 }
+};
 // one thread per original row: its entries stand in the order of their original columns already (k_sort_unique_rows' key)
-__global__ __launch_bounds__(PF_BLOCK) void k_rows_original(const int32_t* __restrict__ rowptr_m, const int32_t* __restrict__ col_m,
+struct k_rows_original {
+    static constexpr int BOUNDS = PF_BLOCK;
+    static __device__ __forceinline__ void run(const int32_t* __restrict__ rowptr_m, const int32_t* __restrict__ col_m,
                                                             const double* __restrict__ w_m, const double* __restrict__ g_m,
                                                             const double* __restrict__ deg_m, const int32_t* __restrict__ mrank,
                                                             const int32_t* __restrict__ morder, const int32_t* __restrict__ rowptr_o,
@@ -498,17 +555,24 @@ __global__ __launch_bounds__(PF_BLOCK) void k_rows_original(const int32_t* __res
         if (loff_o) loff_o[dst + a] = -(gi * w_m[b + a]);
     }
 }
+};
 // component labels as the reference-side tests know them: the SMALLEST original vertex number of the component
-__global__ __launch_bounds__(PF_BLOCK) void k_label_min_original(const int32_t* __restrict__ label_m, const int32_t* __restrict__ morder,
+struct k_label_min_original {
+    static constexpr int BOUNDS = PF_BLOCK;
+    static __device__ __forceinline__ void run(const int32_t* __restrict__ label_m, const int32_t* __restrict__ morder,
                                                                  int64_t n, int32_t* __restrict__ smallest) {
     const int64_t m = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
     if (m < n) atomicMin(&smallest[label_m[m]], morder[m]);
 }
-__global__ __launch_bounds__(PF_BLOCK) void k_label_original(const int32_t* __restrict__ label_m, const int32_t* __restrict__ mrank,
+};
+struct k_label_original {
+    static constexpr int BOUNDS = PF_BLOCK;
+    static __device__ __forceinline__ void run(const int32_t* __restrict__ label_m, const int32_t* __restrict__ mrank,
                                                              const int32_t* __restrict__ smallest, int64_t n, int32_t* __restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
     if (i < n) out[i] = smallest[label_m[mrank[i]]];
 }
+};
 
 inline unsigned nblk(int64_t n) { return (unsigned)((n + PF_BLOCK - 1) / PF_BLOCK); }
 
@@ -524,7 +588,9 @@ namespace {
 
 // split a general CSR matrix into its diagonal and off-diagonals: w = -A_ij, deg = A_ii, g = sg = 1, so that the
 // operator storage (-g_i w) reproduces A_ij and the dense diagonal g_i deg_i reproduces A_ii.
-__global__ __launch_bounds__(PF_BLOCK) void k_csr_count_offdiag(const int32_t* __restrict__ rp, const int32_t* __restrict__ ci,
+struct k_csr_count_offdiag {
+    static constexpr int BOUNDS = PF_BLOCK;
+    static __device__ __forceinline__ void run(const int32_t* __restrict__ rp, const int32_t* __restrict__ ci,
                                                                 int64_t n, int32_t* __restrict__ cnt, int32_t* __restrict__ flags) {
     const int64_t i = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
     if (i >= n) return;
@@ -537,8 +603,11 @@ __global__ __launch_bounds__(PF_BLOCK) void k_csr_count_offdiag(const int32_t* _
     }
     cnt[i] = c;
 }
+};
 
-__global__ __launch_bounds__(PF_BLOCK) void k_csr_split(const int32_t* __restrict__ rp, const int32_t* __restrict__ ci,
+struct k_csr_split {
+    static constexpr int BOUNDS = PF_BLOCK;
+    static __device__ __forceinline__ void run(const int32_t* __restrict__ rp, const int32_t* __restrict__ ci,
                                                         const double* __restrict__ va, const int32_t* __restrict__ rowptr,
                                                         int64_t n, int32_t* __restrict__ col, double* __restrict__ w,
                                                         double* __restrict__ deg, double* __restrict__ g, double* __restrict__ sg) {
@@ -559,6 +628,7 @@ __global__ __launch_bounds__(PF_BLOCK) void k_csr_split(const int32_t* __restric
     g[i] = 1.0;
     sg[i] = 1.0;
 }
+};
 
 // Common tail of the builders: CSR(W) (or the off-diagonals of a general Laplacian), deg, g, sg are in
 // place; derive symmetry, statistics, components, the solver renumbering and the SELL-64 storage.
@@ -567,7 +637,9 @@ __global__ __launch_bounds__(PF_BLOCK) void k_csr_split(const int32_t* __restric
 // [16..16 + PF_ROOTS_AHEAD) the first component roots
 constexpr int PF_ROOTS_AHEAD = 16;
 constexpr int PF_REPORT_INTS = 16 + PF_ROOTS_AHEAD + 2;  // (+ the 64 bits of the face bound's P_min)
-__global__ void k_report(const int32_t* __restrict__ stats, const int32_t* __restrict__ last_round, const int32_t* __restrict__ rowptr_n,
+struct k_report {
+    static constexpr int BOUNDS = 1024;
+    static __device__ __forceinline__ void run(const int32_t* __restrict__ stats, const int32_t* __restrict__ last_round, const int32_t* __restrict__ rowptr_n,
                          const int32_t* __restrict__ extra, const int32_t* __restrict__ roots, const int32_t* __restrict__ pmin_bits,
                          const int32_t* __restrict__ order_overflow, int32_t* __restrict__ out) {
     const int t = threadIdx.x;
@@ -579,6 +651,7 @@ __global__ void k_report(const int32_t* __restrict__ stats, const int32_t* __res
     if (t >= 16 && t < 16 + PF_ROOTS_AHEAD) out[t] = roots[t - 16];
     if (t >= 16 + PF_ROOTS_AHEAD && t < PF_REPORT_INTS) out[t] = pmin_bits ? pmin_bits[t - 16 - PF_ROOTS_AHEAD] : 0;
 }
+};
 
 // `d_extra` / `h_extra` (8 ints, optional): device flags of the caller that ride in this job's one read-back; when
 // any is set end() returns at once (PF_OK, extra_hit = true) and the caller reports ITS error.  `nnz_from_rowptr`:
@@ -629,26 +702,26 @@ struct FinishJob {
         tmp.push_back(width64);
         PF_TRY(dev_alloc(st, &d_roots, PF_MAX_ROOTS));
         tmp.push_back(d_roots);
-        PF_HIP(hipMemsetAsync(flags, 0, sizeof(int32_t) * (8 + PF_CC_ROUNDS), st));
+        PF_HIP(pfl::memset_words(st, flags, 0, sizeof(int32_t) * (8 + PF_CC_ROUNDS)));
         stats = flags + 2;  // [0] isolated, [1] max degree, [2] asym, [3] changed, [4] n_roots
-        k_row_stats<<<nblk(n), PF_BLOCK, 0, st>>>(g->rowptr, n, stats);
+        pfl::launch<k_row_stats>(dim3(nblk(n)), dim3(PF_BLOCK), 0, st, g->rowptr, n, stats);
         PF_HIP(hipGetLastError());
-        k_symmetry_probe<<<nblk(8 * n), PF_BLOCK, 0, st>>>(g->rowptr, g->col, numeric_symmetry ? g->w : nullptr, n, stats + 2, g->morder);
+        pfl::launch<k_symmetry_probe>(dim3(nblk(8 * n)), dim3(PF_BLOCK), 0, st, g->rowptr, g->col, numeric_symmetry ? g->w : nullptr, n, stats + 2, g->morder);
         PF_HIP(hipGetLastError());
 
         // components
-        k_label_init<<<nblk(g->n_pad), PF_BLOCK, 0, st>>>(g->rowptr, g->col, n, g->n_pad, g->label, g->morder);
+        pfl::launch<k_label_init>(dim3(nblk(g->n_pad)), dim3(PF_BLOCK), 0, st, g->rowptr, g->col, n, g->n_pad, g->label, g->morder);
         PF_HIP(hipGetLastError());
         // PF_CC_FIRST rounds are queued without asking: a round that follows a round without changes returns at once
         // (~2 us instead of ~15), and whether the last one still changed something is read back with everything else below
         for (round = 0; round < PF_CC_FIRST; ++round) {
             const int32_t* prev = round ? round_flags + round - 1 : nullptr;
-            k_label_round<<<nblk(n), PF_BLOCK, 0, st>>>(g->rowptr, g->col, n, g->label, round_flags + round, prev, g->morder);
+            pfl::launch<k_label_round>(dim3(nblk(n)), dim3(PF_BLOCK), 0, st, g->rowptr, g->col, n, g->label, round_flags + round, prev, g->morder);
             PF_HIP(hipGetLastError());
         }
-        k_label_compress<<<nblk(n), PF_BLOCK, 0, st>>>(g->label, n);
+        pfl::launch<k_label_compress>(dim3(nblk(n)), dim3(PF_BLOCK), 0, st, g->label, n, nullptr);
         PF_HIP(hipGetLastError());
-        k_collect_roots<<<nblk(n), PF_BLOCK, 0, st>>>(g->label, g->rowptr, n, d_roots, stats + 4);
+        pfl::launch<k_collect_roots>(dim3(nblk(n)), dim3(PF_BLOCK), 0, st, g->label, g->rowptr, n, d_roots, stats + 4);
         PF_HIP(hipGetLastError());
         return PF_OK;
     }
@@ -661,33 +734,33 @@ struct FinishJob {
     int queue_order(bool robust) {
         const int64_t n = g->n;
         PF_TRY(pf_compute_order(g, d_pts, robust ? nullptr : flags));  // (flags[0]: free for this; the statistics start at flags + 2)
-        if (robust) PF_HIP(hipMemsetAsync(flags, 0, sizeof(int32_t), st));
+        if (robust) PF_HIP(pfl::memset_words(st, flags, 0, sizeof(int32_t)));
         if (!g->perm_m) g->perm_m = g->perm, g->iperm_m = g->iperm;  // (no m-space: a graph handed in as a matrix)
-        k_slice_widths<<<nblk(g->n_pad), PF_BLOCK, 0, st>>>(g->rowptr, g->perm_m, n, g->n_slices, width64);
+        pfl::launch<k_slice_widths>(dim3(nblk(g->n_pad)), dim3(PF_BLOCK), 0, st, g->rowptr, g->perm_m, n, g->n_slices, width64);
         PF_HIP(hipGetLastError());
         PF_TRY(pf_exclusive_scan_i64(st, width64, g->slice_ptr, g->n_slices + 1));
         if (!report) {
             PF_TRY(dev_alloc(st, &report, PF_REPORT_INTS));
             tmp.push_back(report);
         }
-        k_report<<<1, PF_WAVE, 0, st>>>(stats, round_flags + PF_CC_FIRST - 1, nnz_from_rowptr ? g->rowptr + n : nullptr, d_extra, d_roots,
+        pfl::launch<k_report>(dim3(1), dim3(PF_WAVE), 0, st, stats, round_flags + PF_CC_FIRST - 1, nnz_from_rowptr ? g->rowptr + n : nullptr, d_extra, d_roots,
                                         reinterpret_cast<const int32_t*>(d_pmin), flags, report);
         PF_HIP(hipGetLastError());
         slice_bytes = sizeof(int64_t) * (size_t)(g->n_slices + 1);
         PF_TRY(pf_pinned_scratch(g->ctx, slice_bytes + sizeof(int32_t) * PF_REPORT_INTS, &pin, sid));
         h_report = reinterpret_cast<int32_t*>(static_cast<unsigned char*>(pin) + slice_bytes);
-        PF_HIP(hipMemcpyAsync(pin, g->slice_ptr, slice_bytes, hipMemcpyDeviceToHost, st));
-        PF_HIP(hipMemcpyAsync(h_report, report, sizeof(int32_t) * PF_REPORT_INTS, hipMemcpyDeviceToHost, st));
+        PF_HIP(pfl::memcpy_async(st, pin, g->slice_ptr, slice_bytes, hipMemcpyDeviceToHost));
+        PF_HIP(pfl::memcpy_async(st, h_report, report, sizeof(int32_t) * PF_REPORT_INTS, hipMemcpyDeviceToHost));
         return PF_OK;
     }
 
     int end() {
         const int64_t n = g->n;
-        PF_HIP(hipStreamSynchronize(st));
+        PF_HIP(pfl::sync(st));
         if (h_report[7] != 0) {  // vertices piled into one cell of the Morton grid: once more, with the general sort
             if (getenv("PF_DEBUG_WINDOWS")) fprintf(stderr, "pyfocusr_hip: renumbering by counting gave up, repeating with the general sort\n");
             PF_TRY(queue_order(true));
-            PF_HIP(hipStreamSynchronize(st));
+            PF_HIP(pfl::sync(st));
         }
         g->h_slice_ptr.resize((size_t)g->n_slices + 1);  // the resident Chebyshev kernel sizes its LDS from this
         memcpy(g->h_slice_ptr.data(), pin, slice_bytes);
@@ -715,21 +788,21 @@ struct FinishJob {
             for (;;) {
                 PF_CHECK(round + 3 <= PF_CC_ROUNDS, PF_E_HIP, "pf_graph_build: component labelling did not converge");
                 for (int b = 0; b < 3; ++b, ++round) {
-                    k_label_round<<<nblk(n), PF_BLOCK, 0, st>>>(g->rowptr, g->col, n, g->label, round_flags + round, nullptr, g->morder);
+                    pfl::launch<k_label_round>(dim3(nblk(n)), dim3(PF_BLOCK), 0, st, g->rowptr, g->col, n, g->label, round_flags + round, nullptr, g->morder);
                     PF_HIP(hipGetLastError());
                 }
-                k_label_compress<<<nblk(n), PF_BLOCK, 0, st>>>(g->label, n);
+                pfl::launch<k_label_compress>(dim3(nblk(n)), dim3(PF_BLOCK), 0, st, g->label, n, nullptr);
                 PF_HIP(hipGetLastError());
-                PF_HIP(hipMemcpyAsync(&differing, round_flags + round - 1, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-                PF_HIP(hipStreamSynchronize(st));
+                PF_HIP(pfl::memcpy_async(st, &differing, round_flags + round - 1, sizeof(int32_t), hipMemcpyDeviceToHost));
+                PF_HIP(pfl::sync(st));
                 if (!differing) break;
             }
-            PF_HIP(hipMemsetAsync(stats + 4, 0, sizeof(int32_t), st));
-            k_collect_roots<<<nblk(n), PF_BLOCK, 0, st>>>(g->label, g->rowptr, n, d_roots, stats + 4);
+            PF_HIP(pfl::memset_words(st, stats + 4, 0, sizeof(int32_t)));
+            pfl::launch<k_collect_roots>(dim3(nblk(n)), dim3(PF_BLOCK), 0, st, g->label, g->rowptr, n, d_roots, stats + 4);
             PF_HIP(hipGetLastError());
-            PF_HIP(hipMemcpyAsync(&n_roots, stats + 4, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-            PF_HIP(hipMemcpyAsync(h_roots, d_roots, sizeof(h_roots), hipMemcpyDeviceToHost, st));
-            PF_HIP(hipStreamSynchronize(st));
+            PF_HIP(pfl::memcpy_async(st, &n_roots, stats + 4, sizeof(int32_t), hipMemcpyDeviceToHost));
+            PF_HIP(pfl::memcpy_async(st, h_roots, d_roots, sizeof(h_roots), hipMemcpyDeviceToHost));
+            PF_HIP(pfl::sync(st));
         }
         g->n_isolated = h_stats[0];
         g->max_degree = h_stats[1];
@@ -740,8 +813,8 @@ struct FinishJob {
         g->n_components = n_roots;
         g->roots.resize(n_roots);
         if (n_roots > PF_ROOTS_AHEAD) {
-            PF_HIP(hipMemcpyAsync(g->roots.data(), d_roots, sizeof(int32_t) * n_roots, hipMemcpyDeviceToHost, st));
-            PF_HIP(hipStreamSynchronize(st));
+            PF_HIP(pfl::memcpy_async(st, g->roots.data(), d_roots, sizeof(int32_t) * n_roots, hipMemcpyDeviceToHost));
+            PF_HIP(pfl::sync(st));
         } else {
             for (int32_t i = 0; i < n_roots; ++i) g->roots[(size_t)i] = h_roots[i];
         }
@@ -749,7 +822,7 @@ struct FinishJob {
         PF_TRY(dev_alloc(st, &g->scol, g->sell_entries));
         PF_TRY(dev_alloc(st, &g->sval_rw, g->sell_entries));
         if (g->is_symmetric) PF_TRY(dev_alloc(st, &g->sval_sym, g->sell_entries));
-        k_fill_sell_entries<<<(unsigned)g->n_slices, PF_BLOCK, 0, st>>>(g->rowptr, g->col, g->w, g->deg, g->g, g->sg, g->perm_m, g->iperm_m, n,
+        pfl::launch<k_fill_sell_entries>(dim3((unsigned)g->n_slices), dim3(PF_BLOCK), 0, st, g->rowptr, g->col, g->w, g->deg, g->g, g->sg, g->perm_m, g->iperm_m, n,
                                                                         g->slice_ptr, g->scol, g->sval_rw, g->sval_sym, g->diag);
         PF_HIP(hipGetLastError());
         return PF_OK;
@@ -830,11 +903,12 @@ struct MeshBuild {
         return PF_OK;
     }
 
-    int prepare(pf_mesh* m, int stream_id) {
+    // one_stream: the second mesh of a pair whose launches are shared (pf_launch.h) - everything on the ctx stream
+    int prepare(pf_mesh* m, int stream_id, bool one_stream = false) {
         mesh = m;
         sid = stream_id;
         pf_ctx* ctx = mesh->ctx;
-        st = sid ? ctx->stream_b : ctx->stream;
+        st = (sid && !one_stream) ? ctx->stream_b : ctx->stream;
         const int64_t n = mesh->n, n_faces = mesh->n_faces;
         const int32_t vpf = mesh->vpf;
         n_edges = n_faces * vpf;
@@ -883,9 +957,9 @@ struct MeshBuild {
 
             PF_TRY(dev_alloc(st, &g->perm_m, g->n_pad));
             PF_TRY(dev_alloc(st, &g->iperm_m, g->n_pad));
-            PF_HIP(hipMemsetAsync(zeroed, 0, sizeof(int32_t) * (size_t)(2 * zstride + 8), st));
-            PF_HIP(hipMemsetAsync(g->deg, 0, sizeof(double) * 3 * g->n_pad, st));
-            if (sid == 0) PF_HIP(hipEventRecord(ctx->ev0, st));
+            PF_HIP(pfl::memset_words(st, zeroed, 0, sizeof(int32_t) * (size_t)(2 * zstride + 8)));
+            PF_HIP(pfl::memset_words(st, g->deg, 0, sizeof(double) * 3 * g->n_pad));
+            if (sid == 0) PF_HIP(pfl::event_record(st, ctx->ev0));
             // m-space first: the Morton rank of every point (positions only), points and faces renumbered by it.  Every
             // gather of the build from here on - edge ends, reverse edges, neighbours' degrees, window flags - lands in
             // lines that the neighbouring threads share, whatever order the caller's vertices came in (round 3: ~35 x
@@ -896,17 +970,17 @@ struct MeshBuild {
             PF_TRY(scratch(&faces_m, n_edges));
             d_pts = pts_m, d_faces = faces_m;
             if (n) {
-                k_renumber_points<<<nblk(3 * n), PF_BLOCK, 0, st>>>(mesh->pts, g->morder, n, pts_m);
+                pfl::launch<k_renumber_points>(dim3(nblk(3 * n)), dim3(PF_BLOCK), 0, st, mesh->pts, g->morder, n, pts_m);
                 PF_HIP(hipGetLastError());
             }
             if (n_edges) {
-                k_renumber_faces<<<nblk(n_edges), PF_BLOCK, 0, st>>>(mesh->faces, g->mrank, n_edges, n, faces_m);
+                pfl::launch<k_renumber_faces>(dim3(nblk(n_edges)), dim3(PF_BLOCK), 0, st, mesh->faces, g->mrank, n_edges, n, faces_m);
                 PF_HIP(hipGetLastError());
             }
 
             if (face_bound) PF_TRY(scratch(&pmin, 1));
             if (n_edges) {
-                k_count_edges<<<nblk(n_edges), PF_BLOCK, 0, st>>>(d_faces, n_edges, vpf, n, b_cnt, b_rank, b_flags, reinterpret_cast<double*>(pmin));
+                pfl::launch<k_count_edges>(dim3(nblk(n_edges)), dim3(PF_BLOCK), 0, st, d_faces, n_edges, vpf, n, b_cnt, b_rank, b_flags, reinterpret_cast<double*>(pmin));
                 PF_HIP(hipGetLastError());
             }
             // No read-back on the way: faces the counting kernel flags (index out of range, repeated vertex) are skipped by
@@ -915,23 +989,23 @@ struct MeshBuild {
             // (each one costs ~30 us of idle device: 8 per mesh at first, 2 now).
             PF_TRY(pf_exclusive_scan_i32(st, b_cnt, b_start, n + 1));
             if (n_edges) {
-                k_scatter_edges<<<nblk(n_edges), PF_BLOCK, 0, st>>>(d_faces, d_pts, n_edges, vpf, n, b_start, b_rank, b_rcol, b_rw, b_flags);
+                pfl::launch<k_scatter_edges>(dim3(nblk(n_edges)), dim3(PF_BLOCK), 0, st, d_faces, d_pts, n_edges, vpf, n, b_start, b_rank, b_rcol, b_rw, b_flags);
                 PF_HIP(hipGetLastError());
             }
             return PF_OK;
         }
         if (k == 1) {  // CSR(W), degrees, the face bound
-            k_sort_unique_rows<<<nblk(n), PF_BLOCK, 0, st>>>(b_start, n, b_rcol, b_rw, b_ucnt, g->morder);
+            pfl::launch<k_sort_unique_rows>(dim3(nblk(n)), dim3(PF_BLOCK), 0, st, b_start, n, b_rcol, b_rw, b_ucnt, g->morder);
             PF_HIP(hipGetLastError());
             PF_TRY(pf_exclusive_scan_i32(st, b_ucnt, g->rowptr, n + 1));
             PF_TRY(dev_alloc(st, &g->col, n_edges));
             PF_TRY(dev_alloc(st, &g->w, n_edges));
-            k_compact_rows<<<nblk(n), PF_BLOCK, 0, st>>>(b_start, g->rowptr, n, b_rcol, b_rw, g->col, g->w, g->deg, g->g, g->sg);
+            pfl::launch<k_compact_rows>(dim3(nblk(n)), dim3(PF_BLOCK), 0, st, b_start, g->rowptr, n, b_rcol, b_rw, g->col, g->w, g->deg, g->g, g->sg);
             PF_HIP(hipGetLastError());
             // the face-by-face bound of the spectrum (k_face_bound); it holds if every undirected edge lies in exactly two
             // triangles: W symmetric and no directed edge listed twice - both known after the read-back
             if (face_bound) {
-                k_face_bound<<<nblk(n_faces), PF_BLOCK, 0, st>>>(d_faces, d_pts, n_faces, n, pmin);
+                pfl::launch<k_face_bound>(dim3(nblk(n_faces)), dim3(PF_BLOCK), 0, st, d_faces, d_pts, n_faces, n, pmin);
                 PF_HIP(hipGetLastError());
             }
             fin.g = g, fin.d_pts = d_pts, fin.numeric_symmetry = false, fin.d_extra = b_flags, fin.h_extra = h_flags;
@@ -962,7 +1036,7 @@ struct MeshBuild {
             g->spectral_bound = b < 2.0 ? b : 2.0;
         }
         PF_TRY(dev_alloc(st, &g->pts, 3 * n));  // kept for pf_point_rows (the mesh object may go away before the graph)
-        PF_HIP(hipMemcpyAsync(g->pts, mesh->pts, sizeof(double) * 3 * n, hipMemcpyDeviceToDevice, st));
+        PF_HIP(pfl::memcpy_async(st, g->pts, mesh->pts, sizeof(double) * 3 * n, hipMemcpyDeviceToDevice));
         return PF_OK;
     }
 };
@@ -1021,9 +1095,13 @@ void pf_graph_free(pf_graph* g) {
     pf_free(st, g->ws);
     pf_free(st, g->partials);
     pf_free(st, g->coef);
-    if (g->orth_pending >= 0) hipStreamSynchronize(st);  // an orthogonalisation nobody collected still writes the pinned buffer
+    if (g->orth_pending >= 0 || g->small_pending > 0 || g->px_state == -2) pfl::sync(st);  // a step or a result nobody collected still writes its pinned buffer
     if (g->orth_host) g->ctx->pinned_pool.emplace_back(g->orth_host_cap, g->orth_host);
     if (g->orth_ev) g->ctx->event_pool.push_back(g->orth_ev);
+    if (g->px_host) g->ctx->pinned_pool.emplace_back(g->px_host_cap, g->px_host);
+    if (g->px_ev) g->ctx->event_pool.push_back(g->px_ev);
+    if (g->small_host) g->ctx->pinned_pool.emplace_back(g->small_host_cap, g->small_host);
+    if (g->small_ev) g->ctx->event_pool.push_back(g->small_ev);
     delete g;
 }
 
@@ -1045,10 +1123,10 @@ int pf_mesh_upload(pf_ctx* ctx, const double* pts, int64_t n, const int32_t* fac
     int r = dev_alloc(st, &m->pts, 3 * n);
     if (r == PF_OK) r = dev_alloc(st, &m->faces, n_faces * vpf);
     hipError_t e = hipSuccess;
-    if (r == PF_OK) e = hipMemcpyAsync(m->pts, pts, sizeof(double) * 3 * n, hipMemcpyHostToDevice, ctx->stream);
+    if (r == PF_OK) e = pfl::memcpy_async(ctx->stream, m->pts, pts, sizeof(double) * 3 * n, hipMemcpyHostToDevice);
     if (r == PF_OK && e == hipSuccess && n_faces)
-        e = hipMemcpyAsync(m->faces, faces, sizeof(int32_t) * n_faces * vpf, hipMemcpyHostToDevice, ctx->stream);
-    if (r == PF_OK && e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        e = pfl::memcpy_async(ctx->stream, m->faces, faces, sizeof(int32_t) * n_faces * vpf, hipMemcpyHostToDevice);
+    if (r == PF_OK && e == hipSuccess) e = pfl::sync(ctx->stream);
     if (r != PF_OK || e != hipSuccess) {
         if (e != hipSuccess) pf_set_error("pf_mesh_upload: %s", hipGetErrorString(e));
         pf_mesh_free(m);
@@ -1090,17 +1168,15 @@ int pf_graph_build_device(pf_mesh* mesh, pf_graph** out) {
         again.robust = true;
         PF_TRY(again.begin(mesh, 0));
         PF_TRY(again.end());
-        PF_HIP(hipStreamSynchronize(ctx->stream));
+        PF_HIP(pfl::sync(ctx->stream));
         again.g->build_stream = nullptr;
         again.ok = true;
         *out = again.g;
         return PF_OK;
     }
-    PF_HIP(hipEventRecord(ctx->ev1, ctx->stream));
-    PF_HIP(hipStreamSynchronize(ctx->stream));
-    float ms = 0.f;
-    PF_HIP(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
-    ctx->build_ms = ms;
+    PF_HIP(pfl::event_record(ctx->stream, ctx->ev1));  // (no wait for the SELL fill: see pf_graph_build_device2)
+    ctx->build_pending = true;
+    if (pf_persist_enabled()) PF_TRY(pf_window_slots_begin(job.g));
     job.g->build_stream = nullptr;
     job.ok = true;
     *out = job.g;
@@ -1128,7 +1204,61 @@ int pf_graph_build_device2(pf_mesh* mesh_a, pf_mesh* mesh_b, pf_graph** out_a, p
     }
     int rc = PF_OK;
     bool redo = false;
-    {
+    static const bool two_streams = getenv("PF_PAIR_BUILD_STREAMS") != nullptr;  // (the form of rounds 2-4, for comparisons)
+    if (!two_streams) {
+        // SHARED LAUNCHES (pf_launch.h): the host code of every phase runs once per mesh, each into its own recorder, and
+        // what both meshes ask for goes out as one launch with the mesh in blockIdx.z - half the dispatches of the two-stream
+        // form, half the host time, one stream.
+        MeshBuild a, b;
+        pfl::Recorder ra, rb;
+        struct Unhook {
+            ~Unhook() { pfl::tl_rec = nullptr; }
+        } unhook;
+        hipStream_t st = ctx->stream;
+        rc = a.prepare(mesh_a, 0);
+        if (rc == PF_OK) rc = b.prepare(mesh_b, 1, true);
+        for (int k = 0; k < MeshBuild::N_PHASES && rc == PF_OK; ++k) {
+            pfl::tl_rec = &ra;
+            rc = a.phase(k);
+            pfl::tl_rec = &rb;
+            if (rc == PF_OK) rc = b.phase(k);
+            pfl::tl_rec = nullptr;
+            pfl::flush(ra, &rb, st);
+        }
+        // second halves: each waits for the read-back (one wait serves both: one stream), decides, and records its SELL fill
+        if (rc == PF_OK) {
+            pfl::tl_rec = &ra;
+            rc = a.end();
+            pfl::tl_rec = &rb;
+            if (rc == PF_OK) rc = b.end();
+            if (rc == PF_OK && !(a.needs_robust || b.needs_robust) && pf_persist_enabled()) {
+                // the window structures of the resident filter kernel, behind the fills (collected by the first application)
+                pfl::tl_rec = &ra;
+                rc = pf_window_slots_begin(a.g);
+                pfl::tl_rec = &rb;
+                if (rc == PF_OK) rc = pf_window_slots_begin(b.g);
+            }
+        }
+        pfl::tl_rec = nullptr;
+        pfl::flush(ra, &rb, st);  // (also after an error: the recorded launches are harmless, the held-back frees are due)
+        a.release();
+        b.release();
+        if (rc == PF_OK) {
+            const hipError_t e1 = hipEventRecord(ctx->ev1, st);  // (no wait for the fills: pf_timing_get reads the events)
+            if (e1 == hipSuccess) ctx->build_pending = true;
+            else rc = PF_E_HIP, pf_set_error("pf_graph_build_device2: %s", hipGetErrorString(e1));
+        }
+        if (rc == PF_OK && (a.needs_robust || b.needs_robust)) {
+            redo = true;  // (a pile of vertices in one Morton cell: the two builds once more, one after the other; below)
+        } else if (rc == PF_OK) {
+            a.g->build_stream = b.g->build_stream = nullptr;
+            a.ok = b.ok = true;
+            *out_a = a.g;
+            *out_b = b.g;
+        } else {
+            (void)hipStreamSynchronize(st);
+        }
+    } else {
         MeshBuild a, b;
         rc = pf_streams_join(ctx, 1);  // the second stream sees the uploads and may reuse what the first has released
         if (rc == PF_OK) {
@@ -1168,14 +1298,17 @@ int pf_graph_build_device2(pf_mesh* mesh_a, pf_mesh* mesh_b, pf_graph** out_a, p
         const int rj = pf_streams_join(ctx, 0);
         if (rc == PF_OK) rc = rj;
         if (rc == PF_OK) {
-            const hipError_t e1 = hipEventRecord(ctx->ev1, ctx->stream);
-            const hipError_t e2 = hipStreamSynchronize(ctx->stream);
-            float ms = 0.f;
-            if (e1 == hipSuccess && e2 == hipSuccess && hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) == hipSuccess) ctx->build_ms = ms;
-            else rc = PF_E_HIP, pf_set_error("pf_graph_build_device2: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
-            if (getenv("PF_DEBUG_BUILD"))
-                fprintf(stderr, "pf_build2: device time of the pair build %.3f ms (events on the ctx stream); the last wait began %.0f us after the second halves\n", ms,
-                        std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tq2).count());
+            // The call does NOT wait for the SELL fills it has queued: everything that reads the graphs is ordered behind
+            // them on the ctx stream, and the host fields came with the read-back.  The build's device time (pf_timing_get:
+            // build_ms) is taken from the events when somebody asks.
+            const hipError_t e1 = pfl::event_record(ctx->stream, ctx->ev1);
+            if (e1 == hipSuccess) ctx->build_pending = true;
+            else rc = PF_E_HIP, pf_set_error("pf_graph_build_device2: %s", hipGetErrorString(e1));
+        }
+        if (rc == PF_OK && !(a.needs_robust || b.needs_robust) && pf_persist_enabled()) {
+            // the window structures of the resident filter kernel, queued behind the fills (collected by the first application)
+            rc = pf_window_slots_begin(a.g);
+            if (rc == PF_OK) rc = pf_window_slots_begin(b.g);
         }
         if (rc == PF_OK && (a.needs_robust || b.needs_robust)) {
             redo = true;  // (a pile of vertices in one Morton cell: the two builds once more, one after the other; below)
@@ -1185,13 +1318,13 @@ int pf_graph_build_device2(pf_mesh* mesh_a, pf_mesh* mesh_b, pf_graph** out_a, p
             *out_a = a.g;
             *out_b = b.g;
         } else {
-            (void)hipStreamSynchronize(ctx->stream_b);
-            (void)hipStreamSynchronize(ctx->stream);
+            (void)pfl::sync(ctx->stream_b);
+            (void)pfl::sync(ctx->stream);
         }
     }
     if (redo) {
-        (void)hipStreamSynchronize(ctx->stream_b);
-        (void)hipStreamSynchronize(ctx->stream);
+        (void)pfl::sync(ctx->stream_b);
+        (void)pfl::sync(ctx->stream);
         PF_TRY(pf_graph_build_device(mesh_a, out_a));
         const int r = pf_graph_build_device(mesh_b, out_b);
         if (r != PF_OK) {
@@ -1252,33 +1385,33 @@ int pf_graph_from_matrix(pf_ctx* ctx, int64_t n, const int32_t* rowptr, const in
     PF_TRY(dev_alloc(st, &g->iperm, g->n_pad));
     PF_TRY(dev_alloc(st, &g->smooth, g->n_pad));
     PF_TRY(dev_alloc(st, &g->slice_ptr, g->n_slices + 1));
-    PF_HIP(hipMemcpyAsync(rp, rowptr, sizeof(int32_t) * (n + 1), hipMemcpyHostToDevice, st));
+    PF_HIP(pfl::memcpy_async(st, rp, rowptr, sizeof(int32_t) * (n + 1), hipMemcpyHostToDevice));
     if (nnz) {
-        PF_HIP(hipMemcpyAsync(ci, colidx, sizeof(int32_t) * nnz, hipMemcpyHostToDevice, st));
-        PF_HIP(hipMemcpyAsync(va, values, sizeof(double) * nnz, hipMemcpyHostToDevice, st));
+        PF_HIP(pfl::memcpy_async(st, ci, colidx, sizeof(int32_t) * nnz, hipMemcpyHostToDevice));
+        PF_HIP(pfl::memcpy_async(st, va, values, sizeof(double) * nnz, hipMemcpyHostToDevice));
     }
-    PF_HIP(hipMemsetAsync(cnt, 0, sizeof(int32_t) * (n + 1), st));
-    PF_HIP(hipMemsetAsync(flags, 0, sizeof(int32_t) * 8, st));
-    PF_HIP(hipMemsetAsync(g->deg, 0, sizeof(double) * g->n_pad, st));
-    PF_HIP(hipMemsetAsync(g->g, 0, sizeof(double) * g->n_pad, st));
-    PF_HIP(hipMemsetAsync(g->sg, 0, sizeof(double) * g->n_pad, st));
-    PF_HIP(hipEventRecord(ctx->ev0, st));
-    k_csr_count_offdiag<<<nblk(n), PF_BLOCK, 0, st>>>(rp, ci, n, cnt, flags);
+    PF_HIP(pfl::memset_words(st, cnt, 0, sizeof(int32_t) * (n + 1)));
+    PF_HIP(pfl::memset_words(st, flags, 0, sizeof(int32_t) * 8));
+    PF_HIP(pfl::memset_words(st, g->deg, 0, sizeof(double) * g->n_pad));
+    PF_HIP(pfl::memset_words(st, g->g, 0, sizeof(double) * g->n_pad));
+    PF_HIP(pfl::memset_words(st, g->sg, 0, sizeof(double) * g->n_pad));
+    PF_HIP(pfl::event_record(st, ctx->ev0));
+    pfl::launch<k_csr_count_offdiag>(dim3(nblk(n)), dim3(PF_BLOCK), 0, st, rp, ci, n, cnt, flags);
     PF_HIP(hipGetLastError());
     PF_TRY(pf_exclusive_scan_i32(st, cnt, g->rowptr, n + 1));
     int32_t h_flag = 0, nnz32 = 0;
-    PF_HIP(hipMemcpyAsync(&h_flag, flags, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    PF_HIP(hipMemcpyAsync(&nnz32, g->rowptr + n, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    PF_HIP(hipStreamSynchronize(st));
+    PF_HIP(pfl::memcpy_async(st, &h_flag, flags, sizeof(int32_t), hipMemcpyDeviceToHost));
+    PF_HIP(pfl::memcpy_async(st, &nnz32, g->rowptr + n, sizeof(int32_t), hipMemcpyDeviceToHost));
+    PF_HIP(pfl::sync(st));
     PF_CHECK(!h_flag, PF_E_ARG, "pf_graph_from_matrix: column indices must be in range, sorted and unique within each row");
     g->nnz_w = nnz32;
     PF_TRY(dev_alloc(st, &g->col, g->nnz_w));
     PF_TRY(dev_alloc(st, &g->w, g->nnz_w));
-    k_csr_split<<<nblk(n), PF_BLOCK, 0, st>>>(rp, ci, va, g->rowptr, n, g->col, g->w, g->deg, g->g, g->sg);
+    pfl::launch<k_csr_split>(dim3(nblk(n)), dim3(PF_BLOCK), 0, st, rp, ci, va, g->rowptr, n, g->col, g->w, g->deg, g->g, g->sg);
     PF_HIP(hipGetLastError());
     PF_TRY(finish_graph(g, nullptr, true));
-    PF_HIP(hipEventRecord(ctx->ev1, st));
-    PF_HIP(hipStreamSynchronize(st));
+    PF_HIP(pfl::event_record(st, ctx->ev1));
+    PF_HIP(pfl::sync(st));
     float ms = 0.f;
     PF_HIP(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
     ctx->build_ms = ms;
@@ -1323,7 +1456,7 @@ int pf_graph_download(pf_graph* g, int32_t* rowptr, int32_t* colidx, double* w, 
         };
         do {
             if (bad(pf_malloc(st, (void**)&len, sizeof(int32_t) * (size_t)(n + 1))) || bad(pf_malloc(st, (void**)&rp, sizeof(int32_t) * (size_t)(n + 1)))) break;
-            k_len_original<<<nblk(n + 1), PF_BLOCK, 0, st>>>(g->rowptr, g->mrank, n, len);
+            pfl::launch<k_len_original>(dim3(nblk(n + 1)), dim3(PF_BLOCK), 0, st, g->rowptr, g->mrank, n, len);
             if (bad(hipGetLastError())) break;
             if (pf_exclusive_scan_i32(st, len, rp, n + 1) != PF_OK) {
                 rc = PF_E_HIP;
@@ -1335,59 +1468,59 @@ int pf_graph_download(pf_graph* g, int32_t* rowptr, int32_t* colidx, double* w, 
             if (l_offdiag && bad(pf_malloc(st, (void**)&lo, sizeof(double) * ne))) break;
             if (deg && bad(pf_malloc(st, (void**)&dg, sizeof(double) * (size_t)n))) break;
             if (l_diag && bad(pf_malloc(st, (void**)&ld, sizeof(double) * (size_t)n))) break;
-            k_rows_original<<<nblk(n), PF_BLOCK, 0, st>>>(g->rowptr, g->col, g->w, g->g, g->deg, g->mrank, g->morder, rp, n, co, wo, lo, dg, ld);
+            pfl::launch<k_rows_original>(dim3(nblk(n)), dim3(PF_BLOCK), 0, st, g->rowptr, g->col, g->w, g->g, g->deg, g->mrank, g->morder, rp, n, co, wo, lo, dg, ld);
             if (bad(hipGetLastError())) break;
             if (component_label) {
                 if (bad(pf_malloc(st, (void**)&lab, sizeof(int32_t) * (size_t)n)) || bad(pf_malloc(st, (void**)&small, sizeof(int32_t) * (size_t)n))) break;
-                if (bad(hipMemsetAsync(small, 0x7f, sizeof(int32_t) * (size_t)n, st))) break;
-                k_label_min_original<<<nblk(n), PF_BLOCK, 0, st>>>(g->label, g->morder, n, small);
-                k_label_original<<<nblk(n), PF_BLOCK, 0, st>>>(g->label, g->mrank, small, n, lab);
+                if (bad(pfl::memset_words(st, small, 0x7f, sizeof(int32_t) * (size_t)n))) break;
+                pfl::launch<k_label_min_original>(dim3(nblk(n)), dim3(PF_BLOCK), 0, st, g->label, g->morder, n, small);
+                pfl::launch<k_label_original>(dim3(nblk(n)), dim3(PF_BLOCK), 0, st, g->label, g->mrank, small, n, lab);
                 if (bad(hipGetLastError())) break;
-                if (bad(hipMemcpyAsync(component_label, lab, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost, st))) break;
+                if (bad(pfl::memcpy_async(st, component_label, lab, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost))) break;
             }
-            if (rowptr && bad(hipMemcpyAsync(rowptr, rp, sizeof(int32_t) * (size_t)(n + 1), hipMemcpyDeviceToHost, st))) break;
-            if (colidx && nnz && bad(hipMemcpyAsync(colidx, co, sizeof(int32_t) * (size_t)nnz, hipMemcpyDeviceToHost, st))) break;
-            if (w && nnz && bad(hipMemcpyAsync(w, wo, sizeof(double) * (size_t)nnz, hipMemcpyDeviceToHost, st))) break;
-            if (l_offdiag && nnz && bad(hipMemcpyAsync(l_offdiag, lo, sizeof(double) * (size_t)nnz, hipMemcpyDeviceToHost, st))) break;
-            if (deg && bad(hipMemcpyAsync(deg, dg, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, st))) break;
-            if (l_diag && bad(hipMemcpyAsync(l_diag, ld, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, st))) break;
+            if (rowptr && bad(pfl::memcpy_async(st, rowptr, rp, sizeof(int32_t) * (size_t)(n + 1), hipMemcpyDeviceToHost))) break;
+            if (colidx && nnz && bad(pfl::memcpy_async(st, colidx, co, sizeof(int32_t) * (size_t)nnz, hipMemcpyDeviceToHost))) break;
+            if (w && nnz && bad(pfl::memcpy_async(st, w, wo, sizeof(double) * (size_t)nnz, hipMemcpyDeviceToHost))) break;
+            if (l_offdiag && nnz && bad(pfl::memcpy_async(st, l_offdiag, lo, sizeof(double) * (size_t)nnz, hipMemcpyDeviceToHost))) break;
+            if (deg && bad(pfl::memcpy_async(st, deg, dg, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost))) break;
+            if (l_diag && bad(pfl::memcpy_async(st, l_diag, ld, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost))) break;
         } while (0);
-        bad(hipStreamSynchronize(st));
+        bad(pfl::sync(st));
         for (void* q : {(void*)len, (void*)rp, (void*)co, (void*)lab, (void*)small, (void*)wo, (void*)lo, (void*)dg, (void*)ld}) pf_free(st, q);
         return rc;
     }
     double* tmp = nullptr;
-    if (rowptr) PF_HIP(hipMemcpyAsync(rowptr, g->rowptr, sizeof(int32_t) * (g->n + 1), hipMemcpyDeviceToHost, st));
-    if (colidx && g->nnz_w) PF_HIP(hipMemcpyAsync(colidx, g->col, sizeof(int32_t) * g->nnz_w, hipMemcpyDeviceToHost, st));
-    if (w && g->nnz_w) PF_HIP(hipMemcpyAsync(w, g->w, sizeof(double) * g->nnz_w, hipMemcpyDeviceToHost, st));
-    if (deg) PF_HIP(hipMemcpyAsync(deg, g->deg, sizeof(double) * g->n, hipMemcpyDeviceToHost, st));
+    if (rowptr) PF_HIP(pfl::memcpy_async(st, rowptr, g->rowptr, sizeof(int32_t) * (g->n + 1), hipMemcpyDeviceToHost));
+    if (colidx && g->nnz_w) PF_HIP(pfl::memcpy_async(st, colidx, g->col, sizeof(int32_t) * g->nnz_w, hipMemcpyDeviceToHost));
+    if (w && g->nnz_w) PF_HIP(pfl::memcpy_async(st, w, g->w, sizeof(double) * g->nnz_w, hipMemcpyDeviceToHost));
+    if (deg) PF_HIP(pfl::memcpy_async(st, deg, g->deg, sizeof(double) * g->n, hipMemcpyDeviceToHost));
     double* tmp_diag = nullptr;
     if (l_diag) {  // g->diag is stored in solver order: rebuild g_i deg_i in mesh order
         PF_HIP(pf_malloc(st, (void**)&tmp_diag, sizeof(double) * g->n));
-        k_l_diag<<<nblk(g->n), PF_BLOCK, 0, st>>>(g->deg, g->g, g->n, tmp_diag);
+        pfl::launch<k_l_diag>(dim3(nblk(g->n)), dim3(PF_BLOCK), 0, st, g->deg, g->g, g->n, tmp_diag);
         hipError_t ed = hipGetLastError();
-        if (ed == hipSuccess) ed = hipMemcpyAsync(l_diag, tmp_diag, sizeof(double) * g->n, hipMemcpyDeviceToHost, st);
+        if (ed == hipSuccess) ed = pfl::memcpy_async(st, l_diag, tmp_diag, sizeof(double) * g->n, hipMemcpyDeviceToHost);
         if (ed != hipSuccess) {
-            hipStreamSynchronize(st);
+            pfl::sync(st);
             pf_free(st, tmp_diag);
             pf_set_error("pf_graph_download: %s", hipGetErrorString(ed));
             return PF_E_HIP;
         }
     }
-    if (component_label) PF_HIP(hipMemcpyAsync(component_label, g->label, sizeof(int32_t) * g->n, hipMemcpyDeviceToHost, st));
+    if (component_label) PF_HIP(pfl::memcpy_async(st, component_label, g->label, sizeof(int32_t) * g->n, hipMemcpyDeviceToHost));
     if (l_offdiag && g->nnz_w) {
         PF_HIP(pf_malloc(st, (void**)&tmp, sizeof(double) * g->nnz_w));
-        k_l_offdiag<<<nblk(g->n), PF_BLOCK, 0, st>>>(g->rowptr, g->w, g->g, g->n, tmp);
+        pfl::launch<k_l_offdiag>(dim3(nblk(g->n)), dim3(PF_BLOCK), 0, st, g->rowptr, g->w, g->g, g->n, tmp);
         hipError_t e = hipGetLastError();
-        if (e == hipSuccess) e = hipMemcpyAsync(l_offdiag, tmp, sizeof(double) * g->nnz_w, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = pfl::memcpy_async(st, l_offdiag, tmp, sizeof(double) * g->nnz_w, hipMemcpyDeviceToHost);
         if (e != hipSuccess) {
-            hipStreamSynchronize(st);
+            pfl::sync(st);
             pf_free(st, tmp);
             pf_set_error("pf_graph_download: %s", hipGetErrorString(e));
             return PF_E_HIP;
         }
     }
-    hipError_t e = hipStreamSynchronize(st);
+    hipError_t e = pfl::sync(st);
     pf_free(st, tmp);
     pf_free(st, tmp_diag);
     PF_HIP(e);

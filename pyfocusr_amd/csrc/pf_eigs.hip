@@ -49,6 +49,9 @@ struct DeviceOps final : pfk::Ops {
     int combine(int32_t src_first, int32_t m, const double* Y, int32_t k, int32_t dst_first) override {
         return pf_combine(g, src_first, m, Y, k, dst_first);
     }
+    int combine2(int32_t src_first, int32_t m, const double* Y, int32_t k, int32_t dst_first, int32_t src_first2, int32_t dst_first2) override {
+        return pf_combine2(g, src_first, m, Y, k, dst_first, src_first2, dst_first2);
+    }
     int copy(int32_t src, int32_t dst, int32_t count) override { return pf_ws_copy(g, src, dst, count); }
     int spmv_multi(int32_t op, int32_t src_first, int32_t dst_first, int32_t count) override {
         return pf_spmv_multi(g, op, src_first, dst_first, count);
@@ -59,6 +62,14 @@ struct DeviceOps final : pfk::Ops {
     int resnorms(int32_t ax_first, int32_t x_first, const double* lam, int32_t count, double* out) override {
         return pf_resnorms(g, ax_first, x_first, lam, count, out);
     }
+    int gram_begin(int32_t first_a, int32_t count_a, int32_t first_b, int32_t count_b) override {
+        return pf_gram_begin(g, first_a, count_a, first_b, count_b);
+    }
+    int gram_end(double* out) override { return pf_small_end(g, out); }
+    int resnorms_begin(int32_t ax_first, int32_t x_first, const double* lam, int32_t count) override {
+        return pf_resnorms_begin(g, ax_first, x_first, lam, count);
+    }
+    int resnorms_end(double* out) override { return pf_small_end(g, out); }
     // the two graphs of a pair in shared launches (the partner is a DeviceOps of the same ctx: pf_eigs_smallest2 checks)
     int orth_begin_pair(pfk::Ops& other, const int32_t* o) override {
         return pf_orth_begin2(g, o[0], o[1], o[2], o[3], static_cast<DeviceOps&>(other).g, o[4], o[5], o[6], o[7]);
@@ -86,6 +97,10 @@ void give_up(pf_graph* g) {
         std::vector<double> h((size_t)g->orth_pending + 1);
         double nrm = 0.0;
         (void)pf_orth_end(g, h.data(), &nrm);
+    }
+    if (g->small_pending > 0) {  // an extraction was cut short between its halves
+        (void)hipEventSynchronize(g->small_ev);
+        g->small_pending = 0;
     }
     (void)pf_download_cancel(g);
 }

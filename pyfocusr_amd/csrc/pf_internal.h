@@ -87,6 +87,7 @@ struct pf_ctx {
     int64_t persist_launches = 0, persist_steps = 0;
     double knn_ms = 0.0;
     double build_ms = 0.0;
+    bool build_pending = false;  // ev0 / ev1 bracket a build whose device time has not been read yet
     // nearest-neighbour state (pf_knn_upload / run / download)
     double* knn_ref = nullptr;   // [n_ref][d] as uploaded
     double* knn_qry = nullptr;   // [n_qry][d]
@@ -215,7 +216,10 @@ struct pf_graph {
     // n_pad) consecutive solver-order rows, boundary rows first (pf_reorder.hip).  Built on first use (px_state).
     int32_t win_rows = 1024;
     std::vector<int64_t> h_slice_ptr;  // host copy of slice_ptr (LDS sizing)
-    int32_t px_state = -1;         // -1 not tried, 0 this graph is not covered, 1 ready
+    int32_t px_state = -1;         // -1 not tried, -2 in flight (pf_window_slots_begin), 0 this graph is not covered, 1 ready
+    double* px_host = nullptr;     // pinned: the per-window counts + the builder's flag on their way to the host
+    int32_t px_host_cap = 0;
+    hipEvent_t px_ev = nullptr;
     int32_t* px_slot = nullptr;    // [sell_entries] window-local slot of every SELL column: own row, or win_rows + index
                                    // into the window's sorted list of outside rows
     int32_t* px_gh_cnt = nullptr;  // [windows]
@@ -262,6 +266,11 @@ struct pf_graph {
     int32_t orth_host_cap = 0;
     int32_t orth_pending = -1;   // count of the orth in flight, -1 if none
     hipEvent_t orth_ev = nullptr;
+    // pf_gram_begin / pf_resnorms_begin -> pf_small_end: a few doubles on their way to the host
+    double* small_host = nullptr;  // [small_host_cap + 2] pinned
+    int32_t small_host_cap = 0, small_pending = 0;
+    bool small_root = false;       // pf_small_end returns square roots (residual norms)
+    hipEvent_t small_ev = nullptr;
     hipEvent_t orth_wait = nullptr;  // the event pf_orth_end waits on: orth_ev, or the partner graph's after pf_orth_begin2
     int32_t orth_w = 0, orth_first = 0, orth_normalize = 0;  // arguments of the orth in flight (pf_orth_end's second pass)
     int32_t orth_redone = 0;     // the last pf_orth_end ran the second Gram-Schmidt pass itself
@@ -352,6 +361,13 @@ static inline int32_t pf_window_rows(int64_t n_pad) { return n_pad <= 262144 ? 1
 // 1M pair, d = 10: 133 / 19.6 - profiles/r03_knn_hierarchy.md)
 constexpr int PF_KNN_TREE_MIN_D = 7;
 int pf_knn_tree_run(pf_ctx* c);
+extern "C" {
+int pf_gram_begin(pf_graph* g, int32_t first_a, int32_t count_a, int32_t first_b, int32_t count_b);
+int pf_resnorms_begin(pf_graph* g, int32_t ax_first, int32_t x_first, const double* lam, int32_t count);
+int pf_small_end(pf_graph* g, double* out);
+int pf_combine2(pf_graph* g, int32_t src_first, int32_t m, const double* Y, int32_t k, int32_t dst_first, int32_t src_first2,
+                int32_t dst_first2);
+}
 
 // pf_persist.hip: a whole recurrence T_degree((c - A)/e)/rho^degree src -> dst in ONE kernel (operator in registers,
 // x in LDS, neighbouring windows hand their boundary rows over through memory)
@@ -370,5 +386,7 @@ int pf_persist_set(int on);
 void pf_persist_release(pf_ctx* ctx);  // pf_destroy: another ctx may take the resident path over
 // pf_windows.hip
 int pf_window_slots_prepare(pf_graph* g);  // px_* of the graph (see pf_graph)
+int pf_window_slots_begin(pf_graph* g);    // ... queued only; _prepare collects
+bool pf_persist_enabled();
 int pf_window_rings_prepare(pf_graph* g);  // the second-ring structures on top of them (px2_state)
 void pf_window_slots_free(pf_graph* g);

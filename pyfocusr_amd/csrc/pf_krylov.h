@@ -78,10 +78,34 @@ struct Ops {
     virtual int orth_end(double* h, double* nrm, bool* redone) = 0;
     virtual int cheb(int32_t op, int32_t src, int32_t dst, int32_t degree, double c, double e, double rho) = 0;
     virtual int combine(int32_t src_first, int32_t m, const double* Y, int32_t k, int32_t dst_first) = 0;
+    // dst = src Y and dst2 = src2 Y (the same rotation of two blocks); default: two calls
+    virtual int combine2(int32_t src_first, int32_t m, const double* Y, int32_t k, int32_t dst_first, int32_t src_first2, int32_t dst_first2) {
+        const int rc = combine(src_first, m, Y, k, dst_first);
+        return rc ? rc : combine(src_first2, m, Y, k, dst_first2);
+    }
     virtual int copy(int32_t src, int32_t dst, int32_t count) = 0;
     virtual int spmv_multi(int32_t op, int32_t src_first, int32_t dst_first, int32_t count) = 0;
     virtual int gram(int32_t first_a, int32_t count_a, int32_t first_b, int32_t count_b, double* out) = 0;
     virtual int resnorms(int32_t ax_first, int32_t x_first, const double* lam, int32_t count, double* out) = 0;
+    // The same in two halves - queue, collect - so that the extractions of the two graphs of a pair overlap (one graph's
+    // host algebra and waits beside the other's launches).  Defaults: the synchronous call at the first half.
+    virtual int gram_begin(int32_t first_a, int32_t count_a, int32_t first_b, int32_t count_b) {
+        held.assign((size_t)count_a * count_b, 0.0);
+        return gram(first_a, count_a, first_b, count_b, held.data());
+    }
+    virtual int gram_end(double* out) {
+        std::copy(held.begin(), held.end(), out);
+        return 0;
+    }
+    virtual int resnorms_begin(int32_t ax_first, int32_t x_first, const double* lam, int32_t count) {
+        held.assign((size_t)count, 0.0);
+        return resnorms(ax_first, x_first, lam, count, held.data());
+    }
+    virtual int resnorms_end(double* out) {
+        std::copy(held.begin(), held.end(), out);
+        return 0;
+    }
+    std::vector<double> held;
     // launches that two graphs of a pair share; the defaults run them one after the other
     virtual int orth_begin_pair(Ops& other, const int32_t* orth /*[8]: w, first, count, normalize per graph*/) {
         PFK_TRY(orth_begin(orth[0], orth[1], orth[2]));
@@ -245,7 +269,13 @@ struct Solver {
     // then advance() continues); a single driver lets advance() run it in line
     bool analysis_due = false, inline_analysis = true, exhausted = false;
     int outcome = 0, analysis_rc = PF_OK;  // outcome: 1 converged, 2 the cut has to move, 3 complex outliers eat the dynamic range
-    enum { S_TOP, S_AFTER_CHEB, S_AFTER_ORTH, S_AFTER_ANALYSIS, S_DONE } state = S_TOP;
+    enum { S_TOP, S_AFTER_CHEB, S_AFTER_ORTH, S_AFTER_ANALYSIS, S_EXTRACT_B, S_EXTRACT_C, S_DONE } state = S_TOP;
+    // the extraction in three phases (queue Z, A Z and their Gram matrix | collect it, rotate, queue X, A X and the residual
+    // norms | collect them); stepwise_extract: advance() returns between the phases with no request (drive_pair alternates
+    // the two graphs' phases), `extracting` says so
+    bool stepwise_extract = false, extracting = false;
+    std::vector<double> ex_Rk;
+    int ex_nk = 0;
 
     // ellipse_hint: -1 by the number of one-way edges, 0 interval filter first, 1 ellipse filter at once
     int init(Ops* o, int32_t wanted, int ellipse_hint = -1) {
@@ -632,12 +662,12 @@ struct Solver {
                         pf_set_error("pf_eigs_smallest: the QR iteration of the projected %d x %d matrix failed", j, j);
                     if (analysis_rc != PF_OK) return analysis_rc;
                     if (outcome == 1) {
-                        const int rc = extract();
-                        if (rc != PF_OK) return rc;
-                        done = true;
-                        state = S_DONE;
+                        PFK_TRY(extract_a());
+                        extracting = true;
+                        state = S_EXTRACT_B;
                         req = Request{};
-                        return PF_OK;
+                        if (stepwise_extract) return PF_OK;
+                        break;
                     }
                     if (outcome == 2 || outcome == 3) {
                         if (resets >= 8) {
@@ -705,6 +735,23 @@ struct Solver {
                     begin_expand();
                     break;
                 }
+                case S_EXTRACT_B: {
+                    const int rc = extract_b();
+                    if (rc != PF_OK) {
+                        extracting = false;
+                        return rc;  // (NEED_ELLIPSE: advance() begins the other mode)
+                    }
+                    state = S_EXTRACT_C;
+                    if (stepwise_extract) return PF_OK;
+                    break;
+                }
+                case S_EXTRACT_C:
+                    PFK_TRY(extract_c());
+                    extracting = false;
+                    done = true;
+                    state = S_DONE;
+                    req = Request{};
+                    return PF_OK;
                 case S_DONE:
                     done = true;
                     req = Request{};
@@ -714,7 +761,7 @@ struct Solver {
     }
 
     // Rayleigh-Ritz on A itself over the converged Ritz / Schur vectors
-    int extract() {
+    int extract_a() {
         PFK_CHECK(2 * q + 1 <= reg, PF_E_STATE, "pf_eigs_smallest: workspace too small for the extraction (q = %d)", q);
         {
             std::vector<double> Y((size_t)j * q);
@@ -724,8 +771,13 @@ struct Solver {
         }
         PFK_TRY(ops->spmv_multi(op, B0, A0, q));  // A Z -> region A (the Krylov basis is no longer needed)
         st.matvecs += q;
-        std::vector<double> G((size_t)q * q), HA((size_t)q * q), lam, Rk;
-        PFK_TRY(ops->gram(A0, q, B0, q, G.data()));  // G[i][r] = <A z_i, z_r>
+        return ops->gram_begin(A0, q, B0, q);  // G[i][r] = <A z_i, z_r>
+    }
+
+    int extract_b() {
+        std::vector<double> G((size_t)q * q), HA((size_t)q * q), lam;
+        std::vector<double>& Rk = ex_Rk;
+        PFK_TRY(ops->gram_end(G.data()));
         int nk = 0;
         if (sym) {
             for (int a = 0; a < q; ++a)
@@ -810,13 +862,20 @@ struct Solver {
         PFK_CHECK(X0 + nk <= 2 * reg && AX0 + nk <= reg, PF_E_STATE, "pf_eigs_smallest: workspace too small for the extraction");
         n_out = nk;
         first_slot = X0;
+        ex_nk = nk;
         if (nk > 0) {
-            PFK_TRY(ops->combine(B0, q, Rk.data(), nk, X0));   // X = Z R
-            PFK_TRY(ops->combine(A0, q, Rk.data(), nk, AX0));  // A X = (A Z) R
+            PFK_TRY(ops->combine2(B0, q, Rk.data(), nk, X0, A0, AX0));  // X = Z R, A X = (A Z) R
             // (for a complex pair the real part alone is not an eigenvector: its "residual" is |Im lambda| |Im x|)
-            PFK_TRY(ops->resnorms(AX0, X0, vals.data(), nk, residuals.data()));
+            PFK_TRY(ops->resnorms_begin(AX0, X0, vals.data(), nk));
+        }
+        return PF_OK;
+    }
+
+    int extract_c() {
+        if (ex_nk > 0) {
+            PFK_TRY(ops->resnorms_end(residuals.data()));
             st.max_residual = 0.0;
-            for (int i = 0; i < nk; ++i) st.max_residual = std::max(st.max_residual, residuals[i]);
+            for (int i = 0; i < ex_nk; ++i) st.max_residual = std::max(st.max_residual, residuals[i]);
         }
         return PF_OK;
     }
@@ -909,6 +968,23 @@ inline int launch_request(Solver& s) {
 inline int advance_pair(Solver& a, Solver& b, bool do_a, bool do_b, AnalysisHelper* helper) {
     if (do_a) PFK_TRY(a.advance());
     if (do_b) PFK_TRY(b.advance());
+    // the phases of the extraction(s) in flight, the two graphs' alternating: each phase ends in launches, the next begins
+    // with the wait for them - which the partner's launches fill
+    auto extractions = [&]() -> int {
+        for (;;) {
+            bool any = false;
+            if (do_a && !a.done && a.extracting) {
+                PFK_TRY(a.advance());
+                any = true;
+            }
+            if (do_b && !b.done && b.extracting) {
+                PFK_TRY(b.advance());
+                any = true;
+            }
+            if (!any) return PF_OK;
+        }
+    };
+    PFK_TRY(extractions());
     for (;;) {
         const bool da = do_a && !a.done && a.analysis_due, db = do_b && !b.done && b.analysis_due;
         if (!da && !db) return PF_OK;
@@ -931,10 +1007,12 @@ inline int advance_pair(Solver& a, Solver& b, bool do_a, bool do_b, AnalysisHelp
                 other.req_launched = true;
             }
             PFK_TRY(ex.advance());
+            PFK_TRY(extractions());
             continue;
         }
         if (da) PFK_TRY(a.advance());
         if (db) PFK_TRY(b.advance());
+        PFK_TRY(extractions());
     }
 }
 
@@ -946,6 +1024,7 @@ inline int drive_pair(Solver& a, Solver& b) {
         if (!getenv("PF_EIGS_HELPER") || atoi(getenv("PF_EIGS_HELPER")) != 0) helper.reset(new AnalysisHelper());
     }
     a.inline_analysis = b.inline_analysis = false;
+    a.stepwise_extract = b.stepwise_extract = true;
     PFK_TRY(advance_pair(a, b, !a.done, !b.done, helper.get()));
     while (!a.done || !b.done) {
         if ((!a.done && a.req_launched) || (!b.done && b.req_launched)) {  // queued ahead of the partner's extraction: collect

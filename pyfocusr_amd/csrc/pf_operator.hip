@@ -518,11 +518,13 @@ __global__ __launch_bounds__(PF_BLOCK) void k_null_vector(double* __restrict__ x
 
 // dst_c = sum_b src_b Y[b][c] for up to 8 output columns per launch (Y row-major m x k, in device memory)
 constexpr int COMBINE_COLS = 8;
+// (blockIdx.y = 1: the same rotation of a second block of vectors, src_first2 -> dst_first2)
 __global__ __launch_bounds__(PF_BLOCK) void k_combine(double* __restrict__ ws, int64_t n_pad, int32_t src_first, int32_t m,
                                                       const double* __restrict__ Y, int32_t k, int32_t c0, int32_t ncols,
-                                                      int32_t dst_first) {
+                                                      int32_t dst_first, int32_t src_first2, int32_t dst_first2) {
     const int64_t i = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
     if (i >= n_pad) return;
+    if (blockIdx.y) src_first = src_first2, dst_first = dst_first2;
     double acc[COMBINE_COLS];
 #pragma unroll
     for (int c = 0; c < COMBINE_COLS; ++c) acc[c] = 0.0;
@@ -1545,10 +1547,24 @@ int pf_scale(pf_graph* g, int32_t slot, double alpha) {
 }
 
 int pf_combine(pf_graph* g, int32_t src_first, int32_t m, const double* Y, int32_t k, int32_t dst_first) {
+    return pf_combine2(g, src_first, m, Y, k, dst_first, -1, -1);
+}
+
+// dst = src Y and, when src_first2 >= 0, dst2 = src2 Y in the same launches (one upload of Y)
+int pf_combine2(pf_graph* g, int32_t src_first, int32_t m, const double* Y, int32_t k, int32_t dst_first, int32_t src_first2,
+                int32_t dst_first2) {
     PF_TRY(check_slots(g, src_first, m, "pf_combine"));
     PF_TRY(check_slots(g, dst_first, k, "pf_combine"));
     PF_CHECK(Y != nullptr && m > 0 && k > 0, PF_E_ARG, "pf_combine: bad argument");
     PF_CHECK(src_first + m <= dst_first || dst_first + k <= src_first, PF_E_ARG, "pf_combine: overlapping ranges");
+    const bool two = src_first2 >= 0;
+    if (two) {
+        PF_TRY(check_slots(g, src_first2, m, "pf_combine"));
+        PF_TRY(check_slots(g, dst_first2, k, "pf_combine"));
+        PF_CHECK((src_first2 + m <= dst_first2 || dst_first2 + k <= src_first2) && (dst_first + k <= dst_first2 || dst_first2 + k <= dst_first) &&
+                     (src_first + m <= dst_first2 || dst_first2 + k <= src_first) && (src_first2 + m <= dst_first || dst_first + k <= src_first2),
+                 PF_E_ARG, "pf_combine: overlapping ranges");
+    }
     pf_ctx* ctx = g->ctx;
     hipStream_t st = ctx->stream;
     double* dY = nullptr;
@@ -1593,7 +1609,8 @@ int pf_combine(pf_graph* g, int32_t src_first, int32_t m, const double* Y, int32
     hipError_t e = staged ? hipSuccess : hipMemcpyAsync(dY, Y, bytes, hipMemcpyHostToDevice, st);
     for (int32_t c0 = 0; c0 < k && e == hipSuccess; c0 += COMBINE_COLS) {
         const int32_t nc = std::min(COMBINE_COLS, k - c0);
-        k_combine<<<nblk(g->n_pad), PF_BLOCK, 0, st>>>(g->ws, g->n_pad, src_first, m, dY, k, c0, nc, dst_first);
+        k_combine<<<dim3(nblk(g->n_pad), two ? 2u : 1u), PF_BLOCK, 0, st>>>(g->ws, g->n_pad, src_first, m, dY, k, c0, nc, dst_first, src_first2,
+                                                                          dst_first2);
         e = hipGetLastError();
     }
     hipError_t e2 = staged ? hipSuccess : hipStreamSynchronize(st);  // (not staged: Y is the caller's host buffer)
@@ -1632,6 +1649,92 @@ int pf_gram(pf_graph* g, int32_t first_a, int32_t count_a, int32_t first_b, int3
     k_dot_finish<<<(unsigned)(count_a * count_b), PF_WAVE, 0, st>>>(g->partials, g->n_chunks, g->coef, nullptr, 0);
     PF_HIP(hipGetLastError());
     return small_to_host(g, g->coef, out, (size_t)count_a * count_b);
+}
+
+// pf_gram / pf_resnorms in two halves: _begin queues the kernels and a copy of the few results into a pinned block of the
+// graph's own, with an event behind it; pf_small_end waits for that event only - what the stream holds behind it (the
+// partner graph's extraction) keeps running.  One collection in flight per graph.
+static int small_begin(pf_graph* g, const double* d_src, size_t count, bool root) {
+    PF_CHECK(g->small_pending == 0, PF_E_STATE, "pf_gram_begin / pf_resnorms_begin: a previous result has not been collected");
+    pf_ctx* c = g->ctx;
+    hipStream_t st = c->stream;
+    if ((int64_t)count > g->small_host_cap || !g->small_host) {
+        if (g->small_host) {
+            PF_HIP(hipStreamSynchronize(st));
+            c->pinned_pool.emplace_back(g->small_host_cap, g->small_host);
+            g->small_host = nullptr;
+        }
+        const int32_t cap = std::max((int32_t)count, 64);
+        for (size_t i = 0; i < c->pinned_pool.size(); ++i)
+            if (c->pinned_pool[i].first >= cap) {
+                g->small_host_cap = c->pinned_pool[i].first;
+                g->small_host = c->pinned_pool[i].second;
+                c->pinned_pool.erase(c->pinned_pool.begin() + (long)i);
+                break;
+            }
+        if (!g->small_host) {
+            PF_HIP(hipHostMalloc((void**)&g->small_host, sizeof(double) * (size_t)(cap + 2), hipHostMallocDefault));
+            g->small_host_cap = cap;
+        }
+    }
+    if (!g->small_ev) {
+        if (!c->event_pool.empty()) {
+            g->small_ev = c->event_pool.back();
+            c->event_pool.pop_back();
+        } else {
+            PF_HIP(hipEventCreateWithFlags(&g->small_ev, hipEventDisableTiming));
+        }
+    }
+    PF_TRY(pf_copy_by_kernel(st, d_src, g->small_host, sizeof(double) * count));
+    PF_HIP(hipEventRecord(g->small_ev, st));
+    g->small_pending = (int32_t)count;
+    g->small_root = root;
+    return PF_OK;
+}
+
+int pf_small_end(pf_graph* g, double* out) {
+    PF_CHECK(g != nullptr && out != nullptr && g->small_pending > 0, PF_E_STATE, "pf_small_end: nothing to collect");
+    PF_HIP(hipEventSynchronize(g->small_ev));
+    const int32_t count = g->small_pending;
+    g->small_pending = 0;
+    for (int32_t i = 0; i < count; ++i) {
+        const double v = g->small_host[i];
+        out[i] = g->small_root ? sqrt(v > 0.0 ? v : 0.0) : v;
+    }
+    return PF_OK;
+}
+
+int pf_gram_begin(pf_graph* g, int32_t first_a, int32_t count_a, int32_t first_b, int32_t count_b) {
+    PF_TRY(check_slots(g, first_a, count_a, "pf_gram"));
+    PF_TRY(check_slots(g, first_b, count_b, "pf_gram"));
+    PF_CHECK(count_a > 0 && count_b > 0, PF_E_ARG, "pf_gram: bad argument");
+    PF_TRY(pf_reduce_ensure(g, count_a * count_b));  // partials: one column per pair
+    hipStream_t st = g->ctx->stream;
+    k_gram_partial<<<dim3((unsigned)g->n_chunks, (unsigned)(count_a * count_b)), PF_BLOCK, 0, st>>>(g->ws, g->n_pad, first_a, first_b, count_b,
+                                                                                                 g->n_chunks, g->partials);
+    PF_HIP(hipGetLastError());
+    k_dot_finish<<<(unsigned)(count_a * count_b), PF_WAVE, 0, st>>>(g->partials, g->n_chunks, g->coef, nullptr, 0);
+    PF_HIP(hipGetLastError());
+    return small_begin(g, g->coef, (size_t)count_a * count_b, false);
+}
+
+int pf_resnorms_begin(pf_graph* g, int32_t ax_first, int32_t x_first, const double* lam, int32_t count) {
+    PF_TRY(check_slots(g, ax_first, count, "pf_resnorms"));
+    PF_TRY(check_slots(g, x_first, count, "pf_resnorms"));
+    PF_CHECK(lam != nullptr && count > 0, PF_E_ARG, "pf_resnorms: bad argument");
+    hipStream_t st = g->ctx->stream;
+    PF_TRY(pf_reduce_ensure(g, count));
+    for (int32_t at = 0; at < count; at += PF_RESNORMS_MAX) {
+        const int32_t nb = std::min(count - at, PF_RESNORMS_MAX);
+        LamArgs la{};
+        for (int32_t i = 0; i < nb; ++i) la.lam[i] = lam[at + i];
+        k_resnorms_partial<<<dim3((unsigned)g->n_chunks, (unsigned)nb), PF_BLOCK, 0, st>>>(g->ws, g->n_pad, ax_first + at, x_first + at, la,
+                                                                                        g->n_chunks, g->partials);
+        PF_HIP(hipGetLastError());
+        k_dot_finish<<<(unsigned)nb, PF_WAVE, 0, st>>>(g->partials, g->n_chunks, g->coef + at, nullptr, 0);
+        PF_HIP(hipGetLastError());
+    }
+    return small_begin(g, g->coef, (size_t)count, true);
 }
 
 int pf_resnorms(pf_graph* g, int32_t ax_first, int32_t x_first, const double* lam, int32_t count, double* out) {

@@ -212,6 +212,7 @@ __global__ __launch_bounds__(RX_THREADS) void k_cheb_resident(RxArgs a) {
     const int tid = threadIdx.x;
     const int lane = tid & (PF_WAVE - 1);
     const int wave = tid >> 6;
+    (void)wave;  // (the stamps of the diagnostic build)
 
     // slot q of this wave is graph gq(q); its row of that graph's window is rt[q] (+ w * RX_THREADS)
     const int half = SW ? __builtin_amdgcn_readfirstlane(tid >> 9) : 0;
@@ -959,6 +960,10 @@ bool persist_enabled() {
     }
     return v >= 1;
 }
+
+}  // namespace
+bool pf_persist_enabled() { return persist_enabled(); }
+namespace {
 
 // a filter application is about to run: false while a suspension lasts (counted down here, once per application:
 // `first_try` is false for the further attempts pf_cheb2 makes for the same application)

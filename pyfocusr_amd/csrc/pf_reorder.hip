@@ -18,6 +18,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include "pf_internal.h"
+#include "pf_launch.h"
 
 namespace {
 
@@ -31,7 +32,9 @@ __device__ __forceinline__ double dec_f64(unsigned long long u) {
     return __longlong_as_double((long long)((u >> 63) ? (u & ~(1ull << 63)) : ~u));
 }
 
-__global__ __launch_bounds__(PF_BLOCK) void k_bbox(const double* __restrict__ pts, int64_t n, unsigned long long* bbox) {
+struct k_bbox {
+    static constexpr int BOUNDS = PF_BLOCK;
+    static __device__ __forceinline__ void run(const double* __restrict__ pts, int64_t n, unsigned long long* bbox) {
     unsigned long long lo[3] = {~0ull, ~0ull, ~0ull}, hi[3] = {0ull, 0ull, 0ull};
     for (int64_t i = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x; i < n; i += (int64_t)gridDim.x * PF_BLOCK) {
 #pragma unroll
@@ -72,6 +75,7 @@ __global__ __launch_bounds__(PF_BLOCK) void k_bbox(const double* __restrict__ pt
             atomicMax(&bbox[threadIdx.x], v);
     }
 }
+};
 
 __device__ __forceinline__ unsigned spread10(unsigned v) {  // 10 bits -> every third bit
     v &= 0x3ffu;
@@ -82,7 +86,9 @@ __device__ __forceinline__ unsigned spread10(unsigned v) {  // 10 bits -> every 
     return v;
 }
 
-__global__ __launch_bounds__(PF_BLOCK) void k_morton_keys(const double* __restrict__ pts, int64_t n,
+struct k_morton_keys {
+    static constexpr int BOUNDS = PF_BLOCK;
+    static __device__ __forceinline__ void run(const double* __restrict__ pts, int64_t n,
                                                           const unsigned long long* __restrict__ bbox,
                                                           unsigned* __restrict__ keys, int32_t* __restrict__ vals) {
     const int64_t i = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
@@ -100,15 +106,21 @@ __global__ __launch_bounds__(PF_BLOCK) void k_morton_keys(const double* __restri
     keys[i] = code;
     vals[i] = (int32_t)i;
 }
+};
 
-__global__ __launch_bounds__(PF_BLOCK) void k_scatter_pos(const int32_t* __restrict__ order, int64_t n, int32_t* __restrict__ pos) {
+struct k_scatter_pos {
+    static constexpr int BOUNDS = PF_BLOCK;
+    static __device__ __forceinline__ void run(const int32_t* __restrict__ order, int64_t n, int32_t* __restrict__ pos) {
     const int64_t r = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
     if (r < n) pos[order[r]] = (int32_t)r;
 }
+};
 
 // flag[r] = 1 for the Morton positions whose row has an entry in another window, and for the positions such an
 // entry points at (W may be asymmetric: a row can be read from outside without reading outside itself)
-__global__ __launch_bounds__(PF_BLOCK) void k_boundary_flags(const int32_t* __restrict__ order, const int32_t* __restrict__ rowptr,
+struct k_boundary_flags {
+    static constexpr int BOUNDS = PF_BLOCK;
+    static __device__ __forceinline__ void run(const int32_t* __restrict__ order, const int32_t* __restrict__ rowptr,
                                                              const int32_t* __restrict__ col, const int32_t* __restrict__ pos,
                                                              int64_t n, int32_t win_rows, unsigned* __restrict__ flag) {
     const int64_t r = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
@@ -125,11 +137,14 @@ __global__ __launch_bounds__(PF_BLOCK) void k_boundary_flags(const int32_t* __re
     }
     if (mine) flag[r] = 1u;
 }
+};
 
 // flag 2 for the positions one hop behind the boundary rows (rows a boundary row reads, or that read one): with two
 // recurrence steps per exchange (k_cheb_resident2) another window needs those as well, and a window publishes its leading
 // rows.  Only a sort heuristic: what is really published is derived from the windows' lists (pf_windows.hip).
-__global__ __launch_bounds__(PF_BLOCK) void k_second_ring_flags(const int32_t* __restrict__ order, const int32_t* __restrict__ rowptr,
+struct k_second_ring_flags {
+    static constexpr int BOUNDS = PF_BLOCK;
+    static __device__ __forceinline__ void run(const int32_t* __restrict__ order, const int32_t* __restrict__ rowptr,
                                                                 const int32_t* __restrict__ col, const int32_t* __restrict__ pos,
                                                                 int64_t n, unsigned* __restrict__ flag) {
     const int64_t r = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
@@ -145,10 +160,13 @@ __global__ __launch_bounds__(PF_BLOCK) void k_second_ring_flags(const int32_t* _
     }
     if (!boundary && near) flag[r] = 2u;
 }
+};
 
 // second key: window of win_rows Morton-consecutive rows, then boundary rows first, then the rows next to them, then
 // descending degree
-__global__ __launch_bounds__(PF_BLOCK) void k_degree_keys(const int32_t* __restrict__ order, const int32_t* __restrict__ rowptr,
+struct k_degree_keys {
+    static constexpr int BOUNDS = PF_BLOCK;
+    static __device__ __forceinline__ void run(const int32_t* __restrict__ order, const int32_t* __restrict__ rowptr,
                                                           const unsigned* __restrict__ flag, int64_t n, int32_t win_rows,
                                                           unsigned* __restrict__ keys) {
     const int64_t r = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
@@ -159,12 +177,15 @@ __global__ __launch_bounds__(PF_BLOCK) void k_degree_keys(const int32_t* __restr
     const unsigned f = flag[r];
     keys[r] = ((unsigned)(r / win_rows) << 12) | ((f == 1u ? 0u : (f == 2u ? 1u : 2u)) << 10) | (unsigned)(1023 - d);
 }
+};
 
 // The second sort is local: the key's high bits are the window, and the rows already stand in window order (Morton
 // position).  One block per window sorts (boundary flag | degree, position in the window) in LDS - the position makes the
 // keys unique, so the bitonic network gives exactly the stable sort by (flag, degree) a radix sort would (17 merge-sort
 // launches, ~107 us at 250k rows; this: one launch, ~10 us).
-__global__ __launch_bounds__(1024) void k_sort_windows(const unsigned* __restrict__ keys, const int32_t* __restrict__ vals, int64_t n,
+struct k_sort_windows {
+    static constexpr int BOUNDS = 1024;
+    static __device__ __forceinline__ void run(const unsigned* __restrict__ keys, const int32_t* __restrict__ vals, int64_t n,
                                                        int32_t win_rows, int32_t n_pow2, int32_t* __restrict__ out) {
     extern __shared__ unsigned long long wbuf[];
     const int64_t r0 = (int64_t)blockIdx.x * win_rows;
@@ -192,22 +213,31 @@ __global__ __launch_bounds__(1024) void k_sort_windows(const unsigned* __restric
         if (r < n) out[r] = vals ? vals[r0 + (int64_t)(wbuf[i] & 0xffffffffull)] : (int32_t)(r0 + (int64_t)(wbuf[i] & 0xffffffffull));
     }
 }
+};
 
-__global__ __launch_bounds__(PF_BLOCK) void k_iota(int32_t* __restrict__ v, int64_t n) {
+struct k_iota {
+    static constexpr int BOUNDS = PF_BLOCK;
+    static __device__ __forceinline__ void run(int32_t* __restrict__ v, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
     if (i < n) v[i] = (int32_t)i;
 }
+};
 
-__global__ __launch_bounds__(PF_BLOCK) void k_finish_perm(int32_t* __restrict__ perm, int32_t* __restrict__ iperm, int64_t n,
+struct k_finish_perm {
+    static constexpr int BOUNDS = PF_BLOCK;
+    static __device__ __forceinline__ void run(int32_t* __restrict__ perm, int32_t* __restrict__ iperm, int64_t n,
                                                           int64_t n_pad) {
     const int64_t r = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
     if (r >= n_pad) return;
     if (r < n) iperm[perm[r]] = (int32_t)r;
     else perm[r] = -1;
 }
+};
 
 // perm[r] = morder[perm_m[r]] (-1 on padding rows), iperm[original] = r: what the C-ABI side of the library maps with
-__global__ __launch_bounds__(PF_BLOCK) void k_compose_perm(const int32_t* __restrict__ perm_m, const int32_t* __restrict__ morder,
+struct k_compose_perm {
+    static constexpr int BOUNDS = PF_BLOCK;
+    static __device__ __forceinline__ void run(const int32_t* __restrict__ perm_m, const int32_t* __restrict__ morder,
                                                            int64_t n_pad, int32_t* __restrict__ perm, int32_t* __restrict__ iperm) {
     const int64_t r = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
     if (r >= n_pad) return;
@@ -216,11 +246,14 @@ __global__ __launch_bounds__(PF_BLOCK) void k_compose_perm(const int32_t* __rest
     perm[r] = o;
     if (o >= 0) iperm[o] = (int32_t)r;
 }
+};
 
 // Krylov start vector, part 1: a low-order polynomial of the vertex position (coordinates mapped to
 // [-1, 1] by the bounding box).  It is rich in the low eigenmodes the solver wants (a random vector
 // carries ~n^-1/2 of each), which saves about one outer step in twenty.  Stored in solver order.
-__global__ __launch_bounds__(PF_BLOCK) void k_smooth_start(const double* __restrict__ pts, const int32_t* __restrict__ perm,
+struct k_smooth_start {
+    static constexpr int BOUNDS = PF_BLOCK;
+    static __device__ __forceinline__ void run(const double* __restrict__ pts, const int32_t* __restrict__ perm,
                                                            const unsigned long long* __restrict__ bbox, int64_t n_pad,
                                                            double* __restrict__ out) {
     const int64_t r = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
@@ -240,6 +273,7 @@ __global__ __launch_bounds__(PF_BLOCK) void k_smooth_start(const double* __restr
     }
     out[r] = v;
 }
+};
 
 
 // ---- Morton order without a general sort (round 3) ------------------------------------------------------------------
@@ -251,12 +285,17 @@ __global__ __launch_bounds__(PF_BLOCK) void k_smooth_start(const double* __restr
 // build learns of it in its one read-back and repeats the ordering with the general sort.
 constexpr int32_t PF_ORDER_BUCKET_MAX = 1024;
 
-__global__ __launch_bounds__(PF_BLOCK) void k_order_hist(const unsigned* __restrict__ keys, int64_t n, int shift, int32_t* __restrict__ hist) {
+struct k_order_hist {
+    static constexpr int BOUNDS = PF_BLOCK;
+    static __device__ __forceinline__ void run(const unsigned* __restrict__ keys, int64_t n, int shift, int32_t* __restrict__ hist) {
     const int64_t i = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
     if (i < n) atomicAdd(&hist[keys[i] >> shift], 1);
 }
+};
 
-__global__ __launch_bounds__(PF_BLOCK) void k_order_scatter(const unsigned* __restrict__ keys, int64_t n, int shift,
+struct k_order_scatter {
+    static constexpr int BOUNDS = PF_BLOCK;
+    static __device__ __forceinline__ void run(const unsigned* __restrict__ keys, int64_t n, int shift,
                                                             const int32_t* __restrict__ start, int32_t* __restrict__ cursor,
                                                             unsigned* __restrict__ bkey, int32_t* __restrict__ bidx) {
     const int64_t i = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
@@ -267,8 +306,11 @@ __global__ __launch_bounds__(PF_BLOCK) void k_order_scatter(const unsigned* __re
     bkey[slot] = k;
     bidx[slot] = (int32_t)i;
 }
+};
 
-__global__ __launch_bounds__(PF_BLOCK) void k_order_rank(const unsigned* __restrict__ bkey, const int32_t* __restrict__ bidx, int64_t n,
+struct k_order_rank {
+    static constexpr int BOUNDS = PF_BLOCK;
+    static __device__ __forceinline__ void run(const unsigned* __restrict__ bkey, const int32_t* __restrict__ bidx, int64_t n,
                                                          int shift, const int32_t* __restrict__ start, int32_t* __restrict__ order,
                                                          int32_t* __restrict__ overflow) {
     const int64_t s = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
@@ -291,6 +333,7 @@ __global__ __launch_bounds__(PF_BLOCK) void k_order_rank(const unsigned* __restr
     }
     order[lo + before] = me;
 }
+};
 
 }  // namespace
 
@@ -321,10 +364,10 @@ int pf_morton_order(pf_graph* g, const double* d_pts, int32_t* d_overflow) {
             fail(pf_malloc(st, (void**)&k1, sizeof(unsigned) * std::max<int64_t>(n, 1))) ||
             fail(pf_malloc(st, (void**)&v0, sizeof(int32_t) * std::max<int64_t>(n, 1))))
             break;
-        if (fail(hipMemsetAsync(g->order_bbox, 0, 6 * sizeof(unsigned long long), st))) break;
+        if (fail(pfl::memset_words(st, g->order_bbox, 0, 6 * sizeof(unsigned long long)))) break;
         if (n == 0) break;
-        k_bbox<<<256, PF_BLOCK, 0, st>>>(d_pts, n, g->order_bbox);
-        k_morton_keys<<<nblk(n), PF_BLOCK, 0, st>>>(d_pts, n, g->order_bbox, k0, v0);
+        pfl::launch<k_bbox>(dim3(256), dim3(PF_BLOCK), 0, st, d_pts, n, g->order_bbox);
+        pfl::launch<k_morton_keys>(dim3(nblk(n)), dim3(PF_BLOCK), 0, st, d_pts, n, g->order_bbox, k0, v0);
         if (fail(hipGetLastError())) break;
         const bool counting = d_overflow != nullptr && n >= 4096;  // (else: the general sort)
         if (counting) {
@@ -334,24 +377,25 @@ int pf_morton_order(pf_graph* g, const double* d_pts, int32_t* d_overflow) {
             const int64_t nb = (int64_t)1 << bits;
             if (fail(pf_malloc(st, (void**)&hist, sizeof(int32_t) * (size_t)(2 * nb + 2)))) break;  // [nb + 1] counts, then [nb] cursors
             if (fail(pf_malloc(st, (void**)&bstart, sizeof(int32_t) * (size_t)(nb + 1)))) break;
-            if (fail(hipMemsetAsync(hist, 0, sizeof(int32_t) * (size_t)(2 * nb + 2), st))) break;
-            k_order_hist<<<nblk(n), PF_BLOCK, 0, st>>>(k0, n, shift, hist);
+            if (fail(pfl::memset_words(st, hist, 0, sizeof(int32_t) * (size_t)(2 * nb + 2)))) break;
+            pfl::launch<k_order_hist>(dim3(nblk(n)), dim3(PF_BLOCK), 0, st, k0, n, shift, hist);
             if (fail(hipGetLastError())) break;
             if (pf_exclusive_scan_i32(st, hist, bstart, nb + 1) != PF_OK) {
                 rc = PF_E_HIP;
                 break;
             }
             // k1 / v0: the bucketed keys and vertices (v0's identity is not needed any more: the index is the thread's own)
-            k_order_scatter<<<nblk(n), PF_BLOCK, 0, st>>>(k0, n, shift, bstart, hist + nb + 1, k1, v0);
-            k_order_rank<<<nblk(n), PF_BLOCK, 0, st>>>(k1, v0, n, shift, bstart, g->morder, d_overflow);
+            pfl::launch<k_order_scatter>(dim3(nblk(n)), dim3(PF_BLOCK), 0, st, k0, n, shift, bstart, hist + nb + 1, k1, v0);
+            pfl::launch<k_order_rank>(dim3(nblk(n)), dim3(PF_BLOCK), 0, st, k1, v0, n, shift, bstart, g->morder, d_overflow);
             if (fail(hipGetLastError())) break;
         } else {
             size_t need = 0;
+            pfl::flush_self(st);  // (a library sort launches at once: whatever this thread has recorded goes first)
             if (fail(hipcub::DeviceRadixSort::SortPairs(nullptr, need, k0, k1, v0, g->morder, in, 0, 30, st))) break;
             if (fail(pf_malloc(st, &tmp, need))) break;
             if (fail(hipcub::DeviceRadixSort::SortPairs(tmp, need, k0, k1, v0, g->morder, in, 0, 30, st))) break;
         }
-        k_scatter_pos<<<nblk(n), PF_BLOCK, 0, st>>>(g->morder, n, g->mrank);
+        pfl::launch<k_scatter_pos>(dim3(nblk(n)), dim3(PF_BLOCK), 0, st, g->morder, n, g->mrank);
         if (fail(hipGetLastError())) break;
     } while (0);
     pf_free(st, k0);
@@ -384,30 +428,30 @@ static int order_in_windows(pf_graph* g, const double* d_pts) {
     do {
         if (fail(pf_malloc(st, (void**)&bflag, sizeof(unsigned) * std::max<int64_t>(n, 1)))) break;
         if (fail(pf_malloc(st, (void**)&k0, sizeof(unsigned) * std::max<int64_t>(n, 1)))) break;
-        if (fail(hipMemsetAsync(bflag, 0, sizeof(unsigned) * std::max<int64_t>(n, 1), st))) break;
-        k_boundary_flags<<<nblk(n), PF_BLOCK, 0, st>>>(nullptr, g->rowptr, g->col, nullptr, n, win_rows, bflag);
-        k_second_ring_flags<<<nblk(n), PF_BLOCK, 0, st>>>(nullptr, g->rowptr, g->col, nullptr, n, bflag);
-        k_degree_keys<<<nblk(n), PF_BLOCK, 0, st>>>(nullptr, g->rowptr, bflag, n, win_rows, k0);
+        if (fail(pfl::memset_words(st, bflag, 0, sizeof(unsigned) * std::max<int64_t>(n, 1)))) break;
+        pfl::launch<k_boundary_flags>(dim3(nblk(n)), dim3(PF_BLOCK), 0, st, nullptr, g->rowptr, g->col, nullptr, n, win_rows, bflag);
+        pfl::launch<k_second_ring_flags>(dim3(nblk(n)), dim3(PF_BLOCK), 0, st, nullptr, g->rowptr, g->col, nullptr, n, bflag);
+        pfl::launch<k_degree_keys>(dim3(nblk(n)), dim3(PF_BLOCK), 0, st, nullptr, g->rowptr, bflag, n, win_rows, k0);
         if (fail(hipGetLastError())) break;
         if (win_rows <= 4096) {
             int32_t n_pow2 = 2;
             while (n_pow2 < win_rows) n_pow2 <<= 1;
-            k_sort_windows<<<(unsigned)((n + win_rows - 1) / win_rows), 1024, sizeof(unsigned long long) * (size_t)n_pow2, st>>>(
-                k0, nullptr, n, win_rows, n_pow2, g->perm_m);
+            pfl::launch<k_sort_windows>(dim3((unsigned)((n + win_rows - 1) / win_rows)), dim3(1024), sizeof(unsigned long long) * (size_t)n_pow2, st, k0, nullptr, n, win_rows, n_pow2, g->perm_m);
             if (fail(hipGetLastError())) break;
         } else {
             int bits2 = 12;
             for (int64_t w = (n + win_rows - 1) / win_rows; w > 0; w >>= 1) ++bits2;
             if (fail(pf_malloc(st, (void**)&k1, sizeof(unsigned) * n)) || fail(pf_malloc(st, (void**)&v1, sizeof(int32_t) * n))) break;
-            k_iota<<<nblk(n), PF_BLOCK, 0, st>>>(v1, n);
+            pfl::launch<k_iota>(dim3(nblk(n)), dim3(PF_BLOCK), 0, st, v1, n);
             size_t need = 0;
+            pfl::flush_self(st);  // (a library sort launches at once: whatever this thread has recorded goes first)
             if (fail(hipcub::DeviceRadixSort::SortPairs(nullptr, need, k0, k1, v1, g->perm_m, (int)n, 0, bits2, st))) break;
             if (fail(pf_malloc(st, &tmp, need))) break;
             if (fail(hipcub::DeviceRadixSort::SortPairs(tmp, need, k0, k1, v1, g->perm_m, (int)n, 0, bits2, st))) break;
         }
-        k_finish_perm<<<nblk(g->n_pad), PF_BLOCK, 0, st>>>(g->perm_m, g->iperm_m, n, g->n_pad);
-        k_compose_perm<<<nblk(g->n_pad), PF_BLOCK, 0, st>>>(g->perm_m, g->morder, g->n_pad, g->perm, g->iperm);
-        k_smooth_start<<<nblk(g->n_pad), PF_BLOCK, 0, st>>>(d_pts, g->perm_m, g->order_bbox, g->n_pad, g->smooth);
+        pfl::launch<k_finish_perm>(dim3(nblk(g->n_pad)), dim3(PF_BLOCK), 0, st, g->perm_m, g->iperm_m, n, g->n_pad);
+        pfl::launch<k_compose_perm>(dim3(nblk(g->n_pad)), dim3(PF_BLOCK), 0, st, g->perm_m, g->morder, g->n_pad, g->perm, g->iperm);
+        pfl::launch<k_smooth_start>(dim3(nblk(g->n_pad)), dim3(PF_BLOCK), 0, st, d_pts, g->perm_m, g->order_bbox, g->n_pad, g->smooth);
         if (fail(hipGetLastError())) break;
     } while (0);
     pf_free(st, bflag);
@@ -444,21 +488,23 @@ int pf_compute_order(pf_graph* g, const double* d_pts, int32_t* d_overflow) {
         unsigned* bflag = reinterpret_cast<unsigned*>(bbox + 6);
         if (fail(pf_malloc(st, (void**)&k0, sizeof(unsigned) * n)) || fail(pf_malloc(st, (void**)&k1, sizeof(unsigned) * n))) break;
         if (fail(pf_malloc(st, (void**)&v0, sizeof(int32_t) * n)) || fail(pf_malloc(st, (void**)&v1, sizeof(int32_t) * n))) break;
-        if (fail(hipMemsetAsync(bbox, 0, 6 * sizeof(unsigned long long) + sizeof(unsigned) * (size_t)n, st))) break;
+        if (fail(pfl::memset_words(st, bbox, 0, 6 * sizeof(unsigned long long) + sizeof(unsigned) * (size_t)n))) break;
         if (d_pts) {
-            k_bbox<<<256, PF_BLOCK, 0, st>>>(d_pts, n, bbox);
-            k_morton_keys<<<nblk(n), PF_BLOCK, 0, st>>>(d_pts, n, bbox, k0, v0);
+            pfl::launch<k_bbox>(dim3(256), dim3(PF_BLOCK), 0, st, d_pts, n, bbox);
+            pfl::launch<k_morton_keys>(dim3(nblk(n)), dim3(PF_BLOCK), 0, st, d_pts, n, bbox, k0, v0);
         } else {  // no geometry (graph handed in as a matrix): keep the caller's order, only sort degrees in windows
-            if (fail(hipMemsetAsync(k0, 0, sizeof(unsigned) * n, st))) break;
-            k_iota<<<nblk(n), PF_BLOCK, 0, st>>>(v0, n);
+            if (fail(pfl::memset_words(st, k0, 0, sizeof(unsigned) * n))) break;
+            pfl::launch<k_iota>(dim3(nblk(n)), dim3(PF_BLOCK), 0, st, v0, n);
         }
         if (fail(hipGetLastError())) break;
         const bool counting = d_pts != nullptr && d_overflow != nullptr && n >= 4096;  // (else: the general sort)
+        pfl::flush_self(st);  // (a library sort launches at once: whatever this thread has recorded goes first)
         if (fail(hipcub::DeviceRadixSort::SortPairs(nullptr, need, k0, k1, v0, v1, in, 0, 30, st))) break;
         tmp_bytes = need;
         const int32_t win_rows = g->win_rows;
         int bits2 = 12;
         for (int64_t w = (n + win_rows - 1) / win_rows; w > 0; w >>= 1) ++bits2;
+        pfl::flush_self(st);  // (a library sort launches at once: whatever this thread has recorded goes first)
         if (fail(hipcub::DeviceRadixSort::SortPairs(nullptr, need, k0, k1, v0, v1, in, 0, bits2, st))) break;
         tmp_bytes = need > tmp_bytes ? need : tmp_bytes;
         if (fail(pf_malloc(st, &tmp, tmp_bytes))) break;
@@ -475,15 +521,15 @@ int pf_compute_order(pf_graph* g, const double* d_pts, int32_t* d_overflow) {
                 pf_free(st, hist);
                 break;
             }
-            bool bad = fail(hipMemsetAsync(hist, 0, sizeof(int32_t) * (size_t)(2 * nb + 2), st));
+            bool bad = fail(pfl::memset_words(st, hist, 0, sizeof(int32_t) * (size_t)(2 * nb + 2)));
             if (!bad) {
-                k_order_hist<<<nblk(n), PF_BLOCK, 0, st>>>(k0, n, shift, hist);
+                pfl::launch<k_order_hist>(dim3(nblk(n)), dim3(PF_BLOCK), 0, st, k0, n, shift, hist);
                 bad = fail(hipGetLastError()) || pf_exclusive_scan_i32(st, hist, bstart, nb + 1) != PF_OK;
             }
             if (!bad) {
                 // k1 / v0: the bucketed keys and vertices (v0's identity is not needed any more: the index is the thread's own)
-                k_order_scatter<<<nblk(n), PF_BLOCK, 0, st>>>(k0, n, shift, bstart, hist + nb + 1, k1, v0);
-                k_order_rank<<<nblk(n), PF_BLOCK, 0, st>>>(k1, v0, n, shift, bstart, v1, d_overflow);
+                pfl::launch<k_order_scatter>(dim3(nblk(n)), dim3(PF_BLOCK), 0, st, k0, n, shift, bstart, hist + nb + 1, k1, v0);
+                pfl::launch<k_order_rank>(dim3(nblk(n)), dim3(PF_BLOCK), 0, st, k1, v0, n, shift, bstart, v1, d_overflow);
                 bad = fail(hipGetLastError());
             }
             pf_free(st, hist);
@@ -496,24 +542,23 @@ int pf_compute_order(pf_graph* g, const double* d_pts, int32_t* d_overflow) {
             break;
         }
         // v0 <- Morton position of every vertex (scratch until the second sort); the boundary flags in their zeroed block
-        k_scatter_pos<<<nblk(n), PF_BLOCK, 0, st>>>(v1, n, v0);
-        k_boundary_flags<<<nblk(n), PF_BLOCK, 0, st>>>(v1, g->rowptr, g->col, v0, n, win_rows, bflag);
-        k_second_ring_flags<<<nblk(n), PF_BLOCK, 0, st>>>(v1, g->rowptr, g->col, v0, n, bflag);
-        k_degree_keys<<<nblk(n), PF_BLOCK, 0, st>>>(v1, g->rowptr, bflag, n, win_rows, k0);
+        pfl::launch<k_scatter_pos>(dim3(nblk(n)), dim3(PF_BLOCK), 0, st, v1, n, v0);
+        pfl::launch<k_boundary_flags>(dim3(nblk(n)), dim3(PF_BLOCK), 0, st, v1, g->rowptr, g->col, v0, n, win_rows, bflag);
+        pfl::launch<k_second_ring_flags>(dim3(nblk(n)), dim3(PF_BLOCK), 0, st, v1, g->rowptr, g->col, v0, n, bflag);
+        pfl::launch<k_degree_keys>(dim3(nblk(n)), dim3(PF_BLOCK), 0, st, v1, g->rowptr, bflag, n, win_rows, k0);
         if (fail(hipGetLastError())) break;
         if (win_rows <= 4096) {
             int32_t n_pow2 = 2;
             while (n_pow2 < win_rows) n_pow2 <<= 1;
-            k_sort_windows<<<(unsigned)((n + win_rows - 1) / win_rows), 1024, sizeof(unsigned long long) * (size_t)n_pow2, st>>>(
-                k0, v1, n, win_rows, n_pow2, g->perm);
+            pfl::launch<k_sort_windows>(dim3((unsigned)((n + win_rows - 1) / win_rows)), dim3(1024), sizeof(unsigned long long) * (size_t)n_pow2, st, k0, v1, n, win_rows, n_pow2, g->perm);
             if (fail(hipGetLastError())) break;
         } else {
             need = tmp_bytes;
             if (fail(hipcub::DeviceRadixSort::SortPairs(tmp, need, k0, k1, v1, g->perm, in, 0, bits2, st))) break;
         }
-        k_finish_perm<<<nblk(g->n_pad), PF_BLOCK, 0, st>>>(g->perm, g->iperm, n, g->n_pad);
-        if (d_pts) k_smooth_start<<<nblk(g->n_pad), PF_BLOCK, 0, st>>>(d_pts, g->perm, bbox, g->n_pad, g->smooth);
-        else if (fail(hipMemsetAsync(g->smooth, 0, sizeof(double) * g->n_pad, st))) break;  // start vector = noise only
+        pfl::launch<k_finish_perm>(dim3(nblk(g->n_pad)), dim3(PF_BLOCK), 0, st, g->perm, g->iperm, n, g->n_pad);
+        if (d_pts) pfl::launch<k_smooth_start>(dim3(nblk(g->n_pad)), dim3(PF_BLOCK), 0, st, d_pts, g->perm, bbox, g->n_pad, g->smooth);
+        else if (fail(pfl::memset_words(st, g->smooth, 0, sizeof(double) * g->n_pad))) break;  // start vector = noise only
         if (fail(hipGetLastError())) break;
     } while (0);
     pf_free(st, bbox);

@@ -3,6 +3,7 @@
 // totals -> (recursive) scan of the totals -> per-block rescan with its offset.  Wave-level
 // scans use 64-lane shuffles; the four waves of a block meet through LDS.
 #include "pf_internal.h"
+#include "pf_launch.h"
 
 namespace {
 
@@ -41,7 +42,9 @@ __device__ __forceinline__ T block_exclusive_scan(T v, T* total) {
 }
 
 template <typename T>
-__global__ __launch_bounds__(PF_BLOCK) void scan_block_totals(const T* __restrict__ in, T* __restrict__ totals, int64_t n) {
+struct scan_block_totals {
+    static constexpr int BOUNDS = PF_BLOCK;
+    static __device__ __forceinline__ void run(const T* __restrict__ in, T* __restrict__ totals, int64_t n) {
     const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
     T s = 0;
 #pragma unroll
@@ -53,9 +56,12 @@ __global__ __launch_bounds__(PF_BLOCK) void scan_block_totals(const T* __restric
     (void)block_exclusive_scan(s, &total);
     if (threadIdx.x == 0) totals[blockIdx.x] = total;
 }
+};
 
 template <typename T>
-__global__ __launch_bounds__(PF_BLOCK) void scan_block_apply(const T* __restrict__ in, T* __restrict__ out,
+struct scan_block_apply {
+    static constexpr int BOUNDS = PF_BLOCK;
+    static __device__ __forceinline__ void run(const T* __restrict__ in, T* __restrict__ out,
                                                              const T* __restrict__ block_offset, int64_t n) {
     const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
     T v[SCAN_ITEMS];
@@ -75,13 +81,16 @@ __global__ __launch_bounds__(PF_BLOCK) void scan_block_apply(const T* __restrict
         run += v[k];
     }
 }
+};
 
 // the same, with the block's offset summed by the block itself from the (unscanned) totals of the blocks before it:
 // up to SCAN_DIRECT_BLOCKS totals are few enough to be re-read by every block (123 for 250k elements), which saves the
 // launch that scanned them
 constexpr int64_t SCAN_DIRECT_BLOCKS = 4096;
 template <typename T>
-__global__ __launch_bounds__(PF_BLOCK) void scan_block_apply_direct(const T* __restrict__ in, T* __restrict__ out,
+struct scan_block_apply_direct {
+    static constexpr int BOUNDS = PF_BLOCK;
+    static __device__ __forceinline__ void run(const T* __restrict__ in, T* __restrict__ out,
                                                                     const T* __restrict__ totals, int64_t n) {
     __shared__ T s_off;
     T mine = 0;
@@ -108,28 +117,29 @@ __global__ __launch_bounds__(PF_BLOCK) void scan_block_apply_direct(const T* __r
         run += v[k];
     }
 }
+};
 
 template <typename T>
 int exclusive_scan(hipStream_t st, const T* in, T* out, int64_t n) {
     if (n <= 0) return PF_OK;
     const int64_t blocks = (n + SCAN_TILE - 1) / SCAN_TILE;
     if (blocks == 1) {
-        scan_block_apply<T><<<1, PF_BLOCK, 0, st>>>(in, out, nullptr, n);
+        pfl::launch<scan_block_apply<T>>(dim3(1), dim3(PF_BLOCK), 0, st, in, out, nullptr, n);
         PF_HIP(hipGetLastError());
         return PF_OK;
     }
     T* totals = nullptr;
     PF_HIP(pf_malloc(st, (void**)&totals, sizeof(T) * blocks));
-    scan_block_totals<T><<<(unsigned)blocks, PF_BLOCK, 0, st>>>(in, totals, n);
+    pfl::launch<scan_block_totals<T>>(dim3((unsigned)blocks), dim3(PF_BLOCK), 0, st, in, totals, n);
     PF_HIP(hipGetLastError());
     int r = PF_OK;
     if (blocks <= SCAN_DIRECT_BLOCKS) {
-        scan_block_apply_direct<T><<<(unsigned)blocks, PF_BLOCK, 0, st>>>(in, out, totals, n);
+        pfl::launch<scan_block_apply_direct<T>>(dim3((unsigned)blocks), dim3(PF_BLOCK), 0, st, in, out, totals, n);
         if (hipGetLastError() != hipSuccess) r = PF_E_HIP;
     } else {
         r = exclusive_scan<T>(st, totals, totals, blocks);
         if (r == PF_OK) {
-            scan_block_apply<T><<<(unsigned)blocks, PF_BLOCK, 0, st>>>(in, out, totals, n);
+            pfl::launch<scan_block_apply<T>>(dim3((unsigned)blocks), dim3(PF_BLOCK), 0, st, in, out, totals, n);
             if (hipGetLastError() != hipSuccess) r = PF_E_HIP;
         }
     }

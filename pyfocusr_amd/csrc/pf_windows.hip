@@ -18,6 +18,7 @@
 #include <climits>
 
 #include "pf_internal.h"
+#include "pf_launch.h"
 
 namespace {
 
@@ -26,7 +27,9 @@ constexpr int WB_ADJ_WORDS = PF_WIN_MAX / 32;
 
 // pass 1: which windows read which (bit matrix), and the extent of each window's externally read rows.  A window's
 // outside entries hit a handful of neighbours: merged in LDS first (same-address atomics in memory serialise at ~10 ns)
-__global__ __launch_bounds__(PF_WIN_THREADS) void k_win_scan(const int64_t* __restrict__ slice_ptr, const int32_t* __restrict__ scol,
+struct k_win_scan {
+    static constexpr int BOUNDS = PF_WIN_THREADS;
+    static __device__ __forceinline__ void run(const int64_t* __restrict__ slice_ptr, const int32_t* __restrict__ scol,
                                                              int32_t win_rows, int32_t n_windows, uint32_t* __restrict__ adj,
                                                              int32_t* __restrict__ need) {
     __shared__ uint32_t l_adj[WB_ADJ_WORDS];
@@ -58,10 +61,13 @@ __global__ __launch_bounds__(PF_WIN_THREADS) void k_win_scan(const int64_t* __re
         if (l_need[B] > 0) atomicMax(&need[B], l_need[B]);
     if (tid == 0) atomicMax(&need[A], 1);  // row 0 of every window is always published (extra outside rows point at it)
 }
+};
 
 // pass 2: one block per window: sorted unique outside rows (+ row 0 of the windows that read this one without being
 // read by it), then the window-local slot of every entry
-__global__ __launch_bounds__(PF_WIN_THREADS) void k_win_build(const int64_t* __restrict__ slice_ptr, const int32_t* __restrict__ scol,
+struct k_win_build {
+    static constexpr int BOUNDS = PF_WIN_THREADS;
+    static __device__ __forceinline__ void run(const int64_t* __restrict__ slice_ptr, const int32_t* __restrict__ scol,
                                                               int32_t win_rows, int32_t n_windows, const uint32_t* __restrict__ adj,
                                                               int32_t* __restrict__ slot_out, int32_t* __restrict__ gh_cnt,
                                                               int32_t* __restrict__ gh_row, int32_t* __restrict__ flags) {
@@ -180,6 +186,7 @@ __global__ __launch_bounds__(PF_WIN_THREADS) void k_win_build(const int64_t* __r
         }
     }
 }
+};
 
 
 // ---- second ring (k_cheb_resident2: two recurrence steps per exchange)
@@ -189,7 +196,9 @@ __global__ __launch_bounds__(PF_WIN_THREADS) void k_win_build(const int64_t* __r
 // indices of its entries (padding included: the same operations in the same order as its owner's) and their
 // window-local slots (own row | win_rows + index in ring 1 | win_rows + |ring 1| + index in ring 2).  Which of a
 // window's leading rows some other window holds in either ring (need2), and who holds rows of whom (adj2).
-__global__ __launch_bounds__(PF_WIN_THREADS) void k_win_rings(const int64_t* __restrict__ slice_ptr, const int32_t* __restrict__ scol,
+struct k_win_rings {
+    static constexpr int BOUNDS = PF_WIN_THREADS;
+    static __device__ __forceinline__ void run(const int64_t* __restrict__ slice_ptr, const int32_t* __restrict__ scol,
                                                               int32_t win_rows, int32_t n_windows, const int32_t* __restrict__ gh_cnt,
                                                               int32_t* __restrict__ gh_row, int32_t* __restrict__ gh_cnt2,
                                                               int32_t* __restrict__ need2, uint32_t* __restrict__ adj2,
@@ -347,10 +356,13 @@ __global__ __launch_bounds__(PF_WIN_THREADS) void k_win_rings(const int64_t* __r
         if (l_need[B] > 0) atomicMax(&need2[B], l_need[B]);
     if (tid == 0) atomicMax(&need2[A], 1);
 }
+};
 
 // the hand-off protocol of the resident kernels needs "A holds rows of B" <=> "B holds rows of A" (see the header);
 // with a symmetric W it follows for both rings.  Anything else: this graph keeps one step per exchange.
-__global__ __launch_bounds__(PF_WIN_THREADS) void k_win_rings_check(const uint32_t* __restrict__ adj2, int32_t n_windows,
+struct k_win_rings_check {
+    static constexpr int BOUNDS = PF_WIN_THREADS;
+    static __device__ __forceinline__ void run(const uint32_t* __restrict__ adj2, int32_t n_windows,
                                                                     int32_t* __restrict__ flags) {
     for (int64_t p = (int64_t)blockIdx.x * PF_WIN_THREADS + threadIdx.x; p < (int64_t)n_windows * n_windows;
          p += (int64_t)gridDim.x * PF_WIN_THREADS) {
@@ -360,17 +372,48 @@ __global__ __launch_bounds__(PF_WIN_THREADS) void k_win_rings_check(const uint32
         if (ab != ba) atomicOr(flags, 2);
     }
 }
+};
 
 }  // namespace
 
 // g->px_state: -1 not tried, 0 this graph is not covered (the callers have other paths), 1 ready
-int pf_window_slots_prepare(pf_graph* g) {
-    if (g->px_state >= 0) return PF_OK;
+// The window structures in two halves: _begin queues the two kernels and the read-back of the per-window counts (pinned
+// block of the graph's own, event behind it) - the assembler calls it behind its SELL fill, so that the first filter
+// application of a solve finds them ready instead of building them with two synchronisations at its head (round 3:
+// ~70 us per graph) - and _prepare collects.  px_state: -1 not tried, -2 in flight, 0 not covered, 1 ready.
+int pf_window_slots_begin(pf_graph* g) {
+    if (g->px_state != -1) return PF_OK;
     g->px_state = 0;
     if (g->win_rows <= 0 || g->n_pad % g->win_rows != 0 || g->sell_entries <= 0) return PF_OK;
     const int64_t nw = g->n_pad / g->win_rows;
     if (nw > 256) return PF_OK;  // one window per block, one block per CU
-    hipStream_t st = g->ctx->stream;
+    pf_ctx* c = g->ctx;
+    hipStream_t st = c->stream;
+    const int64_t tail = (nw + 1) & ~(int64_t)1;  // (the builder's flag: 8-byte aligned behind the counts)
+    const size_t bytes = sizeof(int32_t) * (size_t)(tail + 2);
+    const int32_t need_doubles = (int32_t)((bytes + 7) / 8);
+    if (!g->px_host) {  // a pinned block: from the pool a freed graph left behind, or new
+        const int32_t cap = std::max(need_doubles, 64);
+        for (size_t i = 0; i < c->pinned_pool.size(); ++i)
+            if (c->pinned_pool[i].first >= cap) {
+                g->px_host_cap = c->pinned_pool[i].first;
+                g->px_host = c->pinned_pool[i].second;
+                c->pinned_pool.erase(c->pinned_pool.begin() + (long)i);
+                break;
+            }
+        if (!g->px_host) {
+            PF_HIP(hipHostMalloc((void**)&g->px_host, sizeof(double) * (size_t)(cap + 2), hipHostMallocDefault));
+            g->px_host_cap = cap;
+        }
+    }
+    if (!g->px_ev) {
+        if (!c->event_pool.empty()) {
+            g->px_ev = c->event_pool.back();
+            c->event_pool.pop_back();
+        } else {
+            PF_HIP(hipEventCreateWithFlags(&g->px_ev, hipEventDisableTiming));
+        }
+    }
     int32_t* flags = nullptr;
     uint32_t* adj = nullptr;
     hipError_t e = pf_malloc(st, (void**)&flags, sizeof(int32_t));
@@ -379,41 +422,49 @@ int pf_window_slots_prepare(pf_graph* g) {
     if (e == hipSuccess) e = pf_malloc(st, (void**)&g->px_gh_cnt, sizeof(int32_t) * (size_t)(nw + 4));  // [nw] counts, then the builder's flag
     if (e == hipSuccess) e = pf_malloc(st, (void**)&g->px_need, sizeof(int32_t) * nw);
     if (e == hipSuccess) e = pf_malloc(st, (void**)&g->px_gh_row, sizeof(int32_t) * nw * PF_WIN_GHOSTS);
-    if (e == hipSuccess) e = hipMemsetAsync(flags, 0, sizeof(int32_t), st);
-    if (e == hipSuccess) e = hipMemsetAsync(adj, 0, sizeof(uint32_t) * (size_t)nw * WB_ADJ_WORDS, st);
-    if (e == hipSuccess) e = hipMemsetAsync(g->px_gh_cnt, 0, sizeof(int32_t) * (size_t)(nw + 4), st);
-    if (e == hipSuccess) e = hipMemsetAsync(g->px_need, 0, sizeof(int32_t) * nw, st);
-    int32_t h_flag = 1;
-    g->h_px_gh_cnt.assign((size_t)nw, 0);
+    if (e == hipSuccess) e = pfl::memset_words(st, flags, 0, sizeof(int32_t));
+    if (e == hipSuccess) e = pfl::memset_words(st, adj, 0, sizeof(uint32_t) * (size_t)nw * WB_ADJ_WORDS);
+    if (e == hipSuccess) e = pfl::memset_words(st, g->px_gh_cnt, 0, sizeof(int32_t) * (size_t)(nw + 4));
+    if (e == hipSuccess) e = pfl::memset_words(st, g->px_need, 0, sizeof(int32_t) * nw);
     if (e == hipSuccess) {
-        k_win_scan<<<(unsigned)nw, PF_WIN_THREADS, 0, st>>>(g->slice_ptr, g->scol, g->win_rows, (int32_t)nw, adj, g->px_need);
-        k_win_build<<<(unsigned)nw, PF_WIN_THREADS, 0, st>>>(g->slice_ptr, g->scol, g->win_rows, (int32_t)nw, adj, g->px_slot,
+        pfl::launch<k_win_scan>(dim3((unsigned)nw), dim3(PF_WIN_THREADS), 0, st, g->slice_ptr, g->scol, g->win_rows, (int32_t)nw, adj, g->px_need);
+        pfl::launch<k_win_build>(dim3((unsigned)nw), dim3(PF_WIN_THREADS), 0, st, g->slice_ptr, g->scol, g->win_rows, (int32_t)nw, adj, g->px_slot,
                                                              g->px_gh_cnt, g->px_gh_row, flags);
         e = hipGetLastError();
     }
-    // the counts and the flag in ONE read-back through pinned memory and a copy kernel (two copies into pageable memory
-    // were two staged transfers with the host in between: ~60 us per graph at the head of a solve)
+    // the counts and the flag in ONE read-back through pinned memory and a copy kernel
+    if (e == hipSuccess) e = pfl::memcpy_async(st, g->px_gh_cnt + tail, flags, sizeof(int32_t), hipMemcpyDeviceToDevice);
     if (e == hipSuccess) {
-        const int64_t tail = (nw + 1) & ~(int64_t)1;  // (8-byte aligned behind the counts)
-        e = hipMemcpyAsync(g->px_gh_cnt + tail, flags, sizeof(int32_t), hipMemcpyDeviceToDevice, st);
-        void* pin = nullptr;
-        const size_t bytes = sizeof(int32_t) * (size_t)(tail + 2);
-        if (e == hipSuccess && pf_pinned_scratch(g->ctx, bytes, &pin) == PF_OK && pf_copy_by_kernel(st, g->px_gh_cnt, pin, bytes) == PF_OK) {
-            e = hipStreamSynchronize(st);
-            if (e == hipSuccess) {
-                memcpy(g->h_px_gh_cnt.data(), pin, sizeof(int32_t) * (size_t)nw);
-                h_flag = static_cast<const int32_t*>(pin)[tail];
-            }
-        } else if (e == hipSuccess) {
-            e = hipMemcpyAsync(&h_flag, flags, sizeof(int32_t), hipMemcpyDeviceToHost, st);
-            if (e == hipSuccess) e = hipMemcpyAsync(g->h_px_gh_cnt.data(), g->px_gh_cnt, sizeof(int32_t) * nw, hipMemcpyDeviceToHost, st);
-            if (e == hipSuccess) e = hipStreamSynchronize(st);
-        }
+        const int32_t* src = g->px_gh_cnt;
+        double* dst = g->px_host;
+        pfl::call(st, [=](hipStream_t s) { (void)pf_copy_by_kernel(s, src, dst, bytes); });
     }
+    if (e == hipSuccess) e = pfl::event_record(st, g->px_ev);
     pf_free(st, flags);
     pf_free(st, adj);
-    if (e != hipSuccess || h_flag) {
+    if (e != hipSuccess) {
         (void)hipGetLastError();
+        pf_window_slots_free(g);
+        return PF_OK;
+    }
+    g->px_state = -2;
+    return PF_OK;
+}
+
+int pf_window_slots_prepare(pf_graph* g) {
+    if (g->px_state == -1) PF_TRY(pf_window_slots_begin(g));
+    if (g->px_state != -2) return PF_OK;
+    g->px_state = 0;
+    const int64_t nw = g->n_pad / g->win_rows;
+    const int64_t tail = (nw + 1) & ~(int64_t)1;
+    if (hipEventSynchronize(g->px_ev) != hipSuccess) {
+        (void)hipGetLastError();
+        pf_window_slots_free(g);
+        return PF_OK;
+    }
+    const int32_t* pin = reinterpret_cast<const int32_t*>(g->px_host);
+    g->h_px_gh_cnt.assign(pin, pin + nw);
+    if (pin[tail]) {  // the builder's flag: a window reads more outside rows than the structures hold
         pf_window_slots_free(g);
         return PF_OK;
     }
@@ -464,31 +515,30 @@ int pf_window_rings_prepare(pf_graph* g) {
     if (e == hipSuccess) e = pf_malloc(st, (void**)&g->px_g1_w, (size_t)nw * PF_WIN_G1);
     if (e == hipSuccess) e = pf_malloc(st, (void**)&g->px_g1_pos, sizeof(int32_t) * (size_t)nw * PF_WIN_GW * PF_WIN_G1);
     if (e == hipSuccess) e = pf_malloc(st, (void**)&g->px_g1_slot, sizeof(uint16_t) * (size_t)nw * PF_WIN_GW * PF_WIN_G1);
-    if (e == hipSuccess) e = hipMemsetAsync(flags, 0, sizeof(int32_t), st);
-    if (e == hipSuccess) e = hipMemsetAsync(totals, 0, 2 * sizeof(unsigned long long), st);
-    if (e == hipSuccess) e = hipMemsetAsync(adj2, 0, sizeof(uint32_t) * (size_t)nw * WB_ADJ_WORDS, st);
-    if (e == hipSuccess) e = hipMemsetAsync(g->px_gh_cnt2, 0, sizeof(int32_t) * nw, st);
-    if (e == hipSuccess) e = hipMemsetAsync(g->px_need2, 0, sizeof(int32_t) * nw, st);
-    if (e == hipSuccess) e = hipMemsetAsync(g->px_g1_gw, 0, sizeof(int32_t) * nw, st);
+    if (e == hipSuccess) e = pfl::memset_words(st, flags, 0, sizeof(int32_t));
+    if (e == hipSuccess) e = pfl::memset_words(st, totals, 0, 2 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = pfl::memset_words(st, adj2, 0, sizeof(uint32_t) * (size_t)nw * WB_ADJ_WORDS);
+    if (e == hipSuccess) e = pfl::memset_words(st, g->px_gh_cnt2, 0, sizeof(int32_t) * nw);
+    if (e == hipSuccess) e = pfl::memset_words(st, g->px_need2, 0, sizeof(int32_t) * nw);
+    if (e == hipSuccess) e = pfl::memset_words(st, g->px_g1_gw, 0, sizeof(int32_t) * nw);
     // one pinned block for everything the host wants back: flag, totals, ring-2 counts, widest ring-1 rows
     const size_t back = sizeof(int32_t) * (2 + 2 * (size_t)nw) + 2 * sizeof(unsigned long long);
     void* pin = nullptr;
     if (e == hipSuccess && pf_pinned_scratch(g->ctx, back, &pin) != PF_OK) e = hipErrorOutOfMemory;
     if (e == hipSuccess) {
-        k_win_rings<<<(unsigned)nw, PF_WIN_THREADS, 0, st>>>(g->slice_ptr, g->scol, g->win_rows, (int32_t)nw, g->px_gh_cnt, g->px_gh_row,
+        pfl::launch<k_win_rings>(dim3((unsigned)nw), dim3(PF_WIN_THREADS), 0, st, g->slice_ptr, g->scol, g->win_rows, (int32_t)nw, g->px_gh_cnt, g->px_gh_row,
                                                              g->px_gh_cnt2, g->px_need2, adj2, g->px_g1_w, g->px_g1_pos, g->px_g1_slot,
                                                              g->px_g1_gw, totals, flags);
-        k_win_rings_check<<<(unsigned)std::min<int64_t>((nw * nw + PF_WIN_THREADS - 1) / PF_WIN_THREADS, 64), PF_WIN_THREADS, 0, st>>>(
-            adj2, (int32_t)nw, flags);
+        pfl::launch<k_win_rings_check>(dim3((unsigned)std::min<int64_t>((nw * nw + PF_WIN_THREADS - 1) / PF_WIN_THREADS, 64)), dim3(PF_WIN_THREADS), 0, st, adj2, (int32_t)nw, flags);
         e = hipGetLastError();
     }
     unsigned long long* p_tot = reinterpret_cast<unsigned long long*>(pin);
     int32_t* p_i = reinterpret_cast<int32_t*>(p_tot + 2);
-    if (e == hipSuccess) e = hipMemcpyAsync(p_tot, totals, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipMemcpyAsync(p_i, flags, sizeof(int32_t), hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipMemcpyAsync(p_i + 2, g->px_gh_cnt2, sizeof(int32_t) * nw, hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipMemcpyAsync(p_i + 2 + nw, g->px_g1_gw, sizeof(int32_t) * nw, hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e == hipSuccess) e = pfl::memcpy_async(st, p_tot, totals, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = pfl::memcpy_async(st, p_i, flags, sizeof(int32_t), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = pfl::memcpy_async(st, p_i + 2, g->px_gh_cnt2, sizeof(int32_t) * nw, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = pfl::memcpy_async(st, p_i + 2 + nw, g->px_g1_gw, sizeof(int32_t) * nw, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = pfl::sync(st);
     pf_free(st, flags);
     pf_free(st, adj2);
     pf_free(st, totals);
