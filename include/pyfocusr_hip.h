@@ -226,7 +226,9 @@ int pf_orth_cheb2(pf_graph* ga, pf_graph* gb, const int32_t* orth, const int32_t
 int pf_orth_redone(pf_graph* g);
 /* on != 0: the second Gram-Schmidt pass runs whenever |w'| < 0.71 |w| (the classical constant) instead of 0.3 |w|: for
  * iterations that come close to exhausting a small space (unfiltered solves of tiny graphs), where the loose criterion
- * loses orthogonality.  Per graph; off by default. */
+ * loses orthogonality.  on = 2: EVERY step takes the second pass (the full steps of Lanczos with partial
+ * reorthogonalisation: one pass against a basis that is orthogonal to 1e-9 only would leave the new vector at that level).
+ * Per graph; off by default. */
 int pf_orth_strict(pf_graph* g, int32_t on);
 /* on != 0: pf_orth_begin / pf_orth_begin2 / pf_orth_cheb2 queue the second pass together with the first; it runs on the
  * device's own verdict (two launches that return at once when the first pass was fine) and reports h1 + h2 itself, so
@@ -235,6 +237,11 @@ int pf_orth_strict(pf_graph* g, int32_t on);
  * the basis (asymmetric W): a repeated filter application costs more than the ~5 us of the two idle launches.  Per graph;
  * off by default. */
 int pf_orth_device_passes(pf_graph* g, int32_t on);
+/* The NEXT pf_orth_begin / pf_orth_begin2 / pf_orth_cheb2 step of this graph - and only that one - takes its basis from TWO
+ * ranges of slots: [first, first + split) and [first2, first2 + count - split), with `first` and `count` as passed to that
+ * call; the coefficients come back in that order.  For Lanczos with partial reorthogonalisation (pf_eigs_smallest on
+ * symmetric W): most steps orthogonalise against the locked null vectors and the last two basis vectors only. */
+int pf_orth_split(pf_graph* g, int32_t first2, int32_t split);
 int pf_scale(pf_graph* g, int32_t slot, double alpha);
 /* slots [dst_first, dst_first+k) = slots [src_first, src_first+m) * Y, Y row-major m x k; ranges must not overlap */
 int pf_combine(pf_graph* g, int32_t src_first, int32_t m, const double* Y, int32_t k, int32_t dst_first);
@@ -363,6 +370,9 @@ typedef struct pf_eigs_stats {
     double max_residual;  /* max ||S x - lambda x||_2 of the returned pairs */
     int32_t second_passes; /* outer steps whose Gram-Schmidt projection cancelled digits (second pass run) */
     int32_t mode;          /* 0: symmetric W (Lanczos on S); 1: asymmetric W, interval filter (Arnoldi on L, complex outliers carried); 2: ellipse filter */
+    int32_t local_steps;   /* symmetric W: outer steps that orthogonalised against the null vectors and the last two basis vectors only
+                              (partial reorthogonalisation; the others were full Gram-Schmidt steps) */
+    int32_t reserved;
 } pf_eigs_stats;
 int pf_eigs_smallest(pf_graph* g, int32_t n_wanted, int32_t minmax, double* vals, double* vecs, int32_t* n_out,
                      pf_eigs_stats* stats);

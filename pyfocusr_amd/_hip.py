@@ -43,7 +43,7 @@ class GraphInfo(C.Structure):
 class EigsStats(C.Structure):
     _fields_ = [("matvecs", C.c_int64), ("outer_steps", C.c_int32), ("restarts", C.c_int32), ("filter_resets", C.c_int32),
                 ("degree", C.c_int32), ("n_null", C.c_int32), ("cut", C.c_double), ("max_residual", C.c_double),
-                ("second_passes", C.c_int32), ("mode", C.c_int32)]
+                ("second_passes", C.c_int32), ("mode", C.c_int32), ("local_steps", C.c_int32), ("reserved", C.c_int32)]
 
 
 class Timing(C.Structure):
@@ -96,6 +96,7 @@ SIGNATURES = {
     "pf_orth": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, _f64p, _f64p]),
     "pf_orth_begin": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "pf_orth_end": (C.c_int, [C.c_void_p, _f64p, _f64p]),
+    "pf_orth_split": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     "pf_orth_begin2": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                  C.c_int32]),
     "pf_orth_cheb2": (C.c_int, [C.c_void_p, C.c_void_p, _i32p, _i32p, _f64p]),
@@ -850,6 +851,11 @@ class DeviceLaplacian(object):
         cd = (C.c_double * 6)(float(req[3]), float(req[4]), float(req[5]), float(req_other[3]), float(req_other[4]), float(req_other[5]))
         _check(self._lib.pf_orth_cheb2(self._h, other._h, o, ci, cd))
         self._orth_count, other._orth_count = int(orth[2]), int(orth_other[2])
+
+    def orth_split(self, first2, split):
+        """The next `orth_begin` / `orth_begin2` / `orth_cheb2` step of this graph takes its basis from the slots
+        [first, first + split) and [first2, first2 + count - split) (`pf_orth_split`)."""
+        _check(self._lib.pf_orth_split(self._h, int(first2), int(split)))
 
     def orth_strict(self, on):
         """Second Gram-Schmidt pass at the classical threshold (|w'| < 0.71 |w|) instead of the loose one (0.3)."""

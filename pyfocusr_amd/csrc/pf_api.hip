@@ -87,7 +87,8 @@ hipStream_t pf_stream_b(pf_ctx* c) {
         // (the least priority, like the copy stream - they are never busy together: the first mesh's kernels, at the main
         // stream's normal priority, keep their pace and the second's fill the gaps: pair assembly 1.17 -> 1.14 ms)
         if (pf_create_side_stream(&s, true) != hipSuccess ||
-            hipEventCreateWithFlags(&c->join_ev, hipEventDisableTiming) != hipSuccess) {
+            hipEventCreateWithFlags(&c->join_ev, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming) != hipSuccess) {
             (void)hipGetLastError();
             if (s) (void)hipStreamDestroy(s);
             return nullptr;
@@ -199,41 +200,39 @@ void pf_free(hipStream_t st, void* p) {
 
 namespace pfl {
 
-void flush(Recorder& a, Recorder* b, hipStream_t st) {
+void flush(Recorder& a, Recorder* b) {
     Recorder* const saved = tl_rec;
     tl_rec = nullptr;  // what runs now is launched, and frees are frees
     size_t i = 0, j = 0;
     const size_t na = a.ops.size(), nb = b ? b->ops.size() : 0;
+    auto alone = [](const Op& o) { o.key ? o.run1(o, o.st) : o.call(o.st); };
     while (i < na && j < nb) {
         const Op& x = a.ops[i];
         const Op& y = b->ops[j];
         if (x.key != y.key) {
             // a copy or an event record that only one mesh has (the first one records the build's start): it runs alone
             if (!x.key) {
-                x.call(st);
+                alone(x);
                 ++i;
                 continue;
             }
             if (!y.key) {
-                y.call(st);
+                alone(y);
                 ++j;
                 continue;
             }
             break;  // different kernels: the two host codes took different turns - the rest one after the other
         }
-        if (x.key && x.block.x == y.block.x && x.block.y == y.block.y && x.block.z == y.block.z) {
-            x.run2(x, y, st);
-        } else if (x.key) {
-            x.run1(x, st);
-            y.run1(y, st);
+        if (x.key && x.st == y.st && x.block.x == y.block.x && x.block.y == y.block.y && x.block.z == y.block.z) {
+            x.run2(x, y, x.st);
         } else {
-            x.call(st);
-            y.call(st);
+            alone(x);
+            alone(y);
         }
         ++i, ++j;
     }
-    for (; i < na; ++i) a.ops[i].key ? a.ops[i].run1(a.ops[i], st) : a.ops[i].call(st);
-    for (; j < nb; ++j) b->ops[j].key ? b->ops[j].run1(b->ops[j], st) : b->ops[j].call(st);
+    for (; i < na; ++i) alone(a.ops[i]);
+    for (; j < nb; ++j) alone(b->ops[j]);
     a.ops.clear();
     for (auto& f : a.frees) pf_free(f.first, f.second);
     a.frees.clear();
@@ -245,8 +244,8 @@ void flush(Recorder& a, Recorder* b, hipStream_t st) {
     tl_rec = saved;
 }
 
-void flush_self(hipStream_t st) {
-    if (tl_rec) flush(*tl_rec, nullptr, st);
+void flush_self() {
+    if (tl_rec) flush(*tl_rec, nullptr);
 }
 
 }  // namespace pfl
@@ -378,6 +377,7 @@ void pf_destroy(pf_ctx* c) {
         hipStreamSynchronize(c->stream_b);
         hipStreamDestroy(c->stream_b);
         hipEventDestroy(c->join_ev);
+        if (c->fork_ev) hipEventDestroy(c->fork_ev);
         c->stream_b = nullptr;
     }
     if (c->pinned_scratch_b) hipHostFree(c->pinned_scratch_b);

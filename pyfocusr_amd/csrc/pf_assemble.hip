@@ -733,12 +733,24 @@ struct FinishJob {
     // and the slice pointers.  `robust`: the second time round, with the general sort.
     int queue_order(bool robust) {
         const int64_t n = g->n;
+        // (g->side_stream, set by a build that has forked: the order chain runs beside the labelling rounds, which it has
+        // nothing to do with; the join comes before the report below)
+        hipStream_t ls = g->side_stream ? g->side_stream : st;
         PF_TRY(pf_compute_order(g, d_pts, robust ? nullptr : flags));  // (flags[0]: free for this; the statistics start at flags + 2)
         if (robust) PF_HIP(pfl::memset_words(st, flags, 0, sizeof(int32_t)));
         if (!g->perm_m) g->perm_m = g->perm, g->iperm_m = g->iperm;  // (no m-space: a graph handed in as a matrix)
-        pfl::launch<k_slice_widths>(dim3(nblk(g->n_pad)), dim3(PF_BLOCK), 0, st, g->rowptr, g->perm_m, n, g->n_slices, width64);
+        pfl::launch<k_slice_widths>(dim3(nblk(g->n_pad)), dim3(PF_BLOCK), 0, ls, g->rowptr, g->perm_m, n, g->n_slices, width64);
         PF_HIP(hipGetLastError());
-        PF_TRY(pf_exclusive_scan_i64(st, width64, g->slice_ptr, g->n_slices + 1));
+        PF_TRY(pf_exclusive_scan_i64(ls, width64, g->slice_ptr, g->n_slices + 1));
+        if (g->side_stream) {  // join: the build stream waits for the side chain
+            hipStream_t side = g->side_stream;
+            hipEvent_t ev = g->ctx->join_ev;
+            pfl::call(st, [=](hipStream_t s) {
+                (void)hipEventRecord(ev, side);
+                (void)hipStreamWaitEvent(s, ev, 0);
+            });
+            g->side_stream = nullptr;
+        }
         if (!report) {
             PF_TRY(dev_alloc(st, &report, PF_REPORT_INTS));
             tmp.push_back(report);
@@ -894,6 +906,7 @@ struct MeshBuild {
     double* b_rw = nullptr;
     double* pts_m = nullptr;     // the points and ...
     int32_t* faces_m = nullptr;  // ... faces renumbered by the Morton rank of the points (m-space)
+    bool fork_ok = false;        // set by the pair build: independent chains of the build may run on the ctx's second stream
     bool robust = false;         // the Morton order by the general sort (second attempt: vertices piled into one cell)
     bool needs_robust = false;   // end(): the counting sort gave up - build once more with robust = true
 
@@ -1004,8 +1017,20 @@ struct MeshBuild {
             PF_HIP(hipGetLastError());
             // the face-by-face bound of the spectrum (k_face_bound); it holds if every undirected edge lies in exactly two
             // triangles: W symmetric and no directed edge listed twice - both known after the read-back
+            // Fork (pair builds: their launches are recorded, so blocks released below go back only after the join has been
+            // queued): the face bound and, in the last phase, the order inside windows have nothing to do with the row
+            // statistics and the 12 labelling rounds - they run beside them on the ctx's second stream.
+            if (fork_ok && pfl::tl_rec && pf_stream_b(ctx) && ctx->fork_ev) {
+                hipStream_t side = ctx->stream_b;
+                hipEvent_t ev = ctx->fork_ev;
+                pfl::call(st, [=](hipStream_t s) {
+                    (void)hipEventRecord(ev, s);
+                    (void)hipStreamWaitEvent(side, ev, 0);
+                });
+                g->side_stream = side;
+            }
             if (face_bound) {
-                pfl::launch<k_face_bound>(dim3(nblk(n_faces)), dim3(PF_BLOCK), 0, st, d_faces, d_pts, n_faces, n, pmin);
+                pfl::launch<k_face_bound>(dim3(nblk(n_faces)), dim3(PF_BLOCK), 0, g->side_stream ? g->side_stream : st, d_faces, d_pts, n_faces, n, pmin);
                 PF_HIP(hipGetLastError());
             }
             fin.g = g, fin.d_pts = d_pts, fin.numeric_symmetry = false, fin.d_extra = b_flags, fin.h_extra = h_flags;
@@ -1217,13 +1242,14 @@ int pf_graph_build_device2(pf_mesh* mesh_a, pf_mesh* mesh_b, pf_graph** out_a, p
         hipStream_t st = ctx->stream;
         rc = a.prepare(mesh_a, 0);
         if (rc == PF_OK) rc = b.prepare(mesh_b, 1, true);
+        a.fork_ok = b.fork_ok = getenv("PF_BUILD_FORK") == nullptr || atoi(getenv("PF_BUILD_FORK")) != 0;
         for (int k = 0; k < MeshBuild::N_PHASES && rc == PF_OK; ++k) {
             pfl::tl_rec = &ra;
             rc = a.phase(k);
             pfl::tl_rec = &rb;
             if (rc == PF_OK) rc = b.phase(k);
             pfl::tl_rec = nullptr;
-            pfl::flush(ra, &rb, st);
+            pfl::flush(ra, &rb);
         }
         // second halves: each waits for the read-back (one wait serves both: one stream), decides, and records its SELL fill
         if (rc == PF_OK) {
@@ -1240,7 +1266,7 @@ int pf_graph_build_device2(pf_mesh* mesh_a, pf_mesh* mesh_b, pf_graph** out_a, p
             }
         }
         pfl::tl_rec = nullptr;
-        pfl::flush(ra, &rb, st);  // (also after an error: the recorded launches are harmless, the held-back frees are due)
+        pfl::flush(ra, &rb);  // (also after an error: the recorded launches are harmless, the held-back frees are due)
         a.release();
         b.release();
         if (rc == PF_OK) {

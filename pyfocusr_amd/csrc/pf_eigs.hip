@@ -33,6 +33,7 @@ struct DeviceOps final : pfk::Ops {
     int ws_ensure(int32_t slots) override { return pf_ws_ensure(g, slots); }
     int lock_nulls(int32_t op, int32_t* locked) override { return pf_lock_null_vectors(g, op, locked); }
     int orth_strict(bool on) override { return pf_orth_strict(g, on ? 1 : 0); }
+    int orth_always_twice(bool on, bool strict_otherwise) override { return pf_orth_strict(g, on ? 2 : (strict_otherwise ? 1 : 0)); }
     int orth_device_passes(bool on) override { return pf_orth_device_passes(g, on ? 1 : 0); }
     int start_vector(int32_t slot, uint64_t seed) override { return pf_start_vector(g, slot, seed); }
     int orth_begin(int32_t w, int32_t first, int32_t count) override { return pf_orth_begin(g, w, first, count, 1); }
@@ -62,9 +63,11 @@ struct DeviceOps final : pfk::Ops {
     int resnorms(int32_t ax_first, int32_t x_first, const double* lam, int32_t count, double* out) override {
         return pf_resnorms(g, ax_first, x_first, lam, count, out);
     }
-    int gram_begin(int32_t first_a, int32_t count_a, int32_t first_b, int32_t count_b) override {
-        return pf_gram_begin(g, first_a, count_a, first_b, count_b);
+    int gram_begin(int32_t first_a, int32_t count_a, int32_t first_b, int32_t count_b, bool self_b) override {
+        PF_TRY(pf_gram_begin(g, first_a, count_a, first_b, count_b, 0));
+        return self_b ? pf_gram_begin(g, first_b, count_b, first_b, count_b, 1) : PF_OK;
     }
+    bool orth_split(int32_t first2, int32_t split) override { return pf_orth_split(g, first2, split) == PF_OK; }
     int gram_end(double* out) override { return pf_small_end(g, out); }
     int resnorms_begin(int32_t ax_first, int32_t x_first, const double* lam, int32_t count) override {
         return pf_resnorms_begin(g, ax_first, x_first, lam, count);

@@ -152,7 +152,7 @@ struct pf_ctx {
     std::condition_variable worker_cv;
     std::function<void()> worker_task;
     bool worker_busy = false, worker_stop = false;
-    hipEvent_t join_ev = nullptr;
+    hipEvent_t join_ev = nullptr, fork_ev = nullptr;
     std::vector<pf_graph*> deferred;  // graphs with a download that is not queued yet ...
     std::mutex deferred_mutex;        // ... guarded: pf_host_free / pf_host_detach walk every ctx's list from whatever thread collects an array
     int64_t alloc_misses = 0;  // allocations the cache could not serve (hipMalloc: 0.1-1 ms each)
@@ -171,6 +171,7 @@ inline uint64_t pf_next_uid() {
 
 struct pf_graph {
     hipStream_t build_stream = nullptr;  // while the graph is being assembled: the stream its kernels and blocks belong to
+    hipStream_t side_stream = nullptr;   // ... and, between a fork and a join of the build, the stream of its independent chain
     uint64_t uid = pf_next_uid();  // never reused (unlike an address): remembered facts about a PAIR of graphs are keyed by it
     pf_ctx* ctx = nullptr;
     int64_t n = 0, n_pad = 0, n_faces = 0;
@@ -275,6 +276,8 @@ struct pf_graph {
     int32_t orth_w = 0, orth_first = 0, orth_normalize = 0;  // arguments of the orth in flight (pf_orth_end's second pass)
     int32_t orth_redone = 0;     // the last pf_orth_end ran the second Gram-Schmidt pass itself
     double orth_serial = 0.0;    // tickets handed to the fused Gram-Schmidt kernels so far
+    int32_t orth_split = -1, orth_first2 = 0;          // pf_orth_split: for the next step ...
+    int32_t orth_split_now = -1, orth_first2_now = 0;  // ... and the step in flight
     double orth_ticket = 0.0;    // ticket of the step in flight (0: that step reports through orth_ev instead)
     double orth_thresh = 0.09;   // second pass when |w'|^2 < orth_thresh |w|^2 (0.5: strict, pf_orth_strict)
     int32_t orth_device_passes = 0;  // 1: the second Gram-Schmidt pass is queued with the first and runs on the device's own verdict
@@ -362,7 +365,7 @@ static inline int32_t pf_window_rows(int64_t n_pad) { return n_pad <= 262144 ? 1
 constexpr int PF_KNN_TREE_MIN_D = 7;
 int pf_knn_tree_run(pf_ctx* c);
 extern "C" {
-int pf_gram_begin(pf_graph* g, int32_t first_a, int32_t count_a, int32_t first_b, int32_t count_b);
+int pf_gram_begin(pf_graph* g, int32_t first_a, int32_t count_a, int32_t first_b, int32_t count_b, int32_t append);
 int pf_resnorms_begin(pf_graph* g, int32_t ax_first, int32_t x_first, const double* lam, int32_t count);
 int pf_small_end(pf_graph* g, double* out);
 int pf_combine2(pf_graph* g, int32_t src_first, int32_t m, const double* Y, int32_t k, int32_t dst_first, int32_t src_first2,

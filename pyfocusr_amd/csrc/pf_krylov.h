@@ -89,9 +89,12 @@ struct Ops {
     virtual int resnorms(int32_t ax_first, int32_t x_first, const double* lam, int32_t count, double* out) = 0;
     // The same in two halves - queue, collect - so that the extractions of the two graphs of a pair overlap (one graph's
     // host algebra and waits beside the other's launches).  Defaults: the synchronous call at the first half.
-    virtual int gram_begin(int32_t first_a, int32_t count_a, int32_t first_b, int32_t count_b) {
-        held.assign((size_t)count_a * count_b, 0.0);
-        return gram(first_a, count_a, first_b, count_b, held.data());
+    // (self_b: the Gram matrix of the b vectors themselves, count_b x count_b, is appended to the result)
+    virtual int gram_begin(int32_t first_a, int32_t count_a, int32_t first_b, int32_t count_b, bool self_b = false) {
+        held.assign((size_t)count_a * count_b + (self_b ? (size_t)count_b * count_b : 0), 0.0);
+        const int rc = gram(first_a, count_a, first_b, count_b, held.data());
+        if (rc || !self_b) return rc;
+        return gram(first_b, count_b, first_b, count_b, held.data() + (size_t)count_a * count_b);
     }
     virtual int gram_end(double* out) {
         std::copy(held.begin(), held.end(), out);
@@ -106,6 +109,18 @@ struct Ops {
         return 0;
     }
     std::vector<double> held;
+    // on: every Gram-Schmidt step from now on takes its second pass; off: back to the criterion orth_strict(strict_otherwise)
+    // names.  (A test double whose steps always take two passes has nothing to do.)
+    virtual int orth_always_twice(bool on, bool strict_otherwise) {
+        (void)on, (void)strict_otherwise;
+        return 0;
+    }
+    // The NEXT orth_begin (alone or in a pair's shared launch) takes its basis from the slots [first, first + split) and
+    // [first2, first2 + count - split) instead of [first, first + count).  false: not supported (every step is a full one).
+    virtual bool orth_split(int32_t first2, int32_t split) {
+        (void)first2, (void)split;
+        return false;
+    }
     // launches that two graphs of a pair share; the defaults run them one after the other
     virtual int orth_begin_pair(Ops& other, const int32_t* orth /*[8]: w, first, count, normalize per graph*/) {
         PFK_TRY(orth_begin(orth[0], orth[1], orth[2]));
@@ -274,6 +289,17 @@ struct Solver {
     // norms | collect them); stepwise_extract: advance() returns between the phases with no request (drive_pair alternates
     // the two graphs' phases), `extracting` says so
     bool stepwise_extract = false, extracting = false;
+    // Lanczos with PARTIAL reorthogonalisation (symmetric graphs; H. Simon 1984): a step orthogonalises against the locked
+    // null vectors and the last two basis vectors only - the three-term recurrence - while a recurrence over the
+    // coefficients estimates w_{j+1,k} = <v_{j+1}, v_k>; when an estimate passes pro_thresh the next TWO steps are full
+    // Gram-Schmidt steps and the estimates start again from the unit roundoff.  The basis stays semi-orthogonal (1e-9),
+    // the tridiagonal matrix is the projection of the operator to working precision, and the extraction orthonormalises
+    // the few Ritz vectors it keeps (generalised Rayleigh-Ritz).  250k blobs: 4 full steps of ~36; a full step reads
+    // the whole basis twice (avg. 18 vectors x 2 MB), a local one three vectors.
+    bool pro = false, pro_local = false;   // enabled for this solve; the step in flight is a local one
+    int pro_force = 0;                     // full steps still owed
+    double pro_thresh = 1e-9;
+    std::vector<double> om_prev, om_cur;   // estimates for v_{j-1}, v_j against v_k (basis index k)
     std::vector<double> ex_Rk;
     int ex_nk = 0;
 
@@ -296,6 +322,7 @@ struct Solver {
         // nearly every step at higher degree): the second pass rides with the first instead of costing a repeated application.
         // Lanczos: only the first two steps of a solve (see step(): the first product with the start vector always cancels).
         PFK_TRY(ops->orth_device_passes(true));
+        pro = sym && (!getenv("PF_EIGS_PRO") || atoi(getenv("PF_EIGS_PRO")) != 0) && n_active >= 4096;
         c0 = ops->n_components();
         want = (int)std::min<int64_t>(n_wanted, std::max<int64_t>(n_active - c0, 0));
         st.mode = sym ? 0 : 1;
@@ -349,6 +376,37 @@ struct Solver {
         return begin_mode(false);
     }
 
+    // The estimates of <v_{j+1}, v_k>, k = c0 .. j, from those of v_j and v_{j-1} (Simon's recurrence; alpha_k, beta_k read
+    // from H; beta_next = the norm the step that produced v_{j+1} found).  Called with j still the index of the vector the
+    // filter was applied to.  A step that was full resets its vector's estimates to the unit roundoff.
+    void pro_update(double beta_next) {
+        const double eps = 1.1e-16;
+        const size_t ld = (size_t)m_max;
+        auto alpha = [&](int k) { return H[(size_t)k * ld + k]; };
+        auto beta_of = [&](int k) { return k > c0 ? H[(size_t)k * ld + k - 1] : 0.0; };  // beta_k couples v_{k-1} and v_k
+        std::vector<double> nw((size_t)m_max + 2, 0.0);
+        double worst = 0.0;
+        if (!pro_local) {
+            for (int k = c0; k <= j; ++k) nw[(size_t)k] = eps;
+        } else if (beta_next > 0.0) {
+            const double aj = alpha(j), bj = beta_of(j);
+            for (int k = c0; k < j; ++k) {
+                double t = beta_of(k + 1) * om_cur[(size_t)k + 1] + (alpha(k) - aj) * om_cur[(size_t)k] - bj * om_prev[(size_t)k];
+                if (k > c0) t += beta_of(k) * om_cur[(size_t)k - 1];
+                t += (t < 0.0 ? -1.0 : 1.0) * 2.0 * eps * (fabs(beta_of(k + 1)) + fabs(beta_next));
+                nw[(size_t)k] = t / beta_next;
+                worst = std::max(worst, fabs(nw[(size_t)k]));
+            }
+            nw[(size_t)j] = eps * sqrt((double)std::max<int64_t>(n_active, 1)) * fabs(beta_of(c0 + 1)) / beta_next;
+            worst = std::max(worst, fabs(nw[(size_t)j]));
+        }
+        nw[(size_t)j + 1] = 1.0;
+        om_prev.swap(om_cur);
+        om_cur.swap(nw);
+        if (pro_local && worst > pro_thresh) pro_force = 2;
+        if (getenv("PF_EIGS_DEBUG")) fprintf(stderr, "pro: step j=%d local=%d estimate %.2e alpha %.3e beta %.3e\n", j, (int)pro_local, worst, alpha(j), beta_next);
+    }
+
     // (re)start the solve with the interval filter, or with the ellipse filter at its next height
     int begin_mode(bool want_ellipse) {
         if (!want_ellipse) {
@@ -385,6 +443,10 @@ struct Solver {
         for (int i = 0; i < c0; ++i) H[(size_t)i * m_max + i] = theta0;
         j = c0;
         hess = true;
+        pro_force = 0;
+        pro_local = false;
+        om_prev.assign((size_t)m_max + 2, 0.0);
+        om_cur.assign((size_t)m_max + 2, 0.0);
         // the null vectors (an earlier attempt's restart or extraction reuses their slots), then the start vector,
         // orthogonal to them and normalised on the device; its coefficients are collected when the first filter
         // application has been queued behind it (no synchronisation at the head of the solve)
@@ -611,7 +673,7 @@ struct Solver {
                     // orth_end AFTER the speculative application had read the vector, cost that application (200 us of a
                     // 10.7 ms step, both graphs).  The first two steps take the device's own second pass; later steps (ratios
                     // 0.35-0.78) the single pass without the two idle launches.
-                    if (sym) PFK_TRY(ops->orth_device_passes(j <= c0 + 1));
+
                     // the Gram-Schmidt step and - to keep the device busy - the NEXT filter application, queued before this
                     // step's coefficients are read (a speculative application after the last step would be wasted)
                     spec = j + 1 < m_max && !near_conv;
@@ -619,6 +681,19 @@ struct Solver {
                     req.orth_w = A0 + j + 1;
                     req.orth_first = A0;
                     req.orth_count = j + 1;
+                    // (local: not before the basis has two Lanczos vectors, never after a restart - the kept Ritz vectors
+                    // are no Lanczos sequence -, not while full steps are owed)
+                    pro_local = pro && hess && restarts == 0 && pro_force == 0 && j >= c0 + 2 && ops->orth_split(A0 + j - 1, c0);
+                    if (pro_local) req.orth_count = c0 + 2;
+                    else if (pro_force > 0) --pro_force;
+                    if (sym) {
+                        // A FULL step of a run with local steps: two passes, always - one pass of classical Gram-Schmidt
+                        // against a basis that is orthogonal to 1e-9 only leaves the new vector at 1e-9, and the estimates
+                        // (which restart from the unit roundoff there) would be wrong from then on.  Both on the device.
+                        const bool pro_full = pro && hess && restarts == 0 && !pro_local && j >= c0 + 2;
+                        PFK_TRY(ops->orth_device_passes(j <= c0 + 1 || pro_full));
+                        if (pro) PFK_TRY(ops->orth_always_twice(pro_full, n_active < 4096));
+                    }
                     if (spec) {
                         req.kind = REQ_ORTH_CHEB;
                         req.cheb_src = A0 + j + 1;
@@ -637,12 +712,25 @@ struct Solver {
                     if (redone || ops->last_twice) st.second_passes += 1;
                     if (redone) spec = false;  // w was refined after the speculative application had read it: apply the filter again
                     bool finite = isfinite(beta);
-                    for (int i = 0; i <= j && finite; ++i) finite = isfinite(h[i]);
+                    for (int i = 0; i < (pro_local ? c0 + 2 : j + 1) && finite; ++i) finite = isfinite(h[i]);
                     if (!finite && !sym) return NEED_ELLIPSE;  // an outlier outside the damped set overflowed at this degree
                     PFK_CHECK(finite, PF_E_DEGENERATE, "pf_eigs_smallest: the Chebyshev filter overflowed (degree %d): the operator has "
                               "eigenvalues above the assumed bound %g", p, hi);
-                    for (int i = 0; i <= j; ++i) H[(size_t)i * m_max + j] = h[i];
+                    if (pro_local) st.local_steps += 1;
+                    if (pro_local) {  // h = [nulls (c0), v_{j-1}, v_j]
+                        for (int i = 0; i <= j; ++i) H[(size_t)i * m_max + j] = 0.0;
+                        for (int i = 0; i < c0; ++i) H[(size_t)i * m_max + j] = h[i];
+                        H[(size_t)(j - 1) * m_max + j] = h[c0];
+                        H[(size_t)j * m_max + j] = h[c0 + 1];
+                    } else {
+                        for (int i = 0; i <= j; ++i) H[(size_t)i * m_max + j] = h[i];
+                        // (partial reorthogonalisation keeps the matrix tridiagonal: what a full step removes from the
+                        // older vectors is the drift the estimates track, not a coefficient of the recurrence)
+                        if (pro && hess && restarts == 0)
+                            for (int i = c0; i + 1 < j; ++i) H[(size_t)i * m_max + j] = 0.0;
+                    }
                     for (int i = 0; i < j; ++i) H[(size_t)j * m_max + i] = b[i];
+                    if (pro && hess && restarts == 0) pro_update(beta);
                     ++j;
                     std::fill(b.begin(), b.end(), 0.0);
                     b[j - 1] = beta;
@@ -771,18 +859,59 @@ struct Solver {
         }
         PFK_TRY(ops->spmv_multi(op, B0, A0, q));  // A Z -> region A (the Krylov basis is no longer needed)
         st.matvecs += q;
-        return ops->gram_begin(A0, q, B0, q);  // G[i][r] = <A z_i, z_r>
+        // G[i][r] = <A z_i, z_r>; after partial reorthogonalisation also <z_i, z_r>: the Ritz vectors of a basis that is
+        // orthogonal to 1e-9 only are orthonormalised by the Rayleigh-Ritz step itself (generalised problem)
+        return ops->gram_begin(A0, q, B0, q, pro);
     }
 
     int extract_b() {
-        std::vector<double> G((size_t)q * q), HA((size_t)q * q), lam;
+        std::vector<double> G((size_t)q * q * (pro ? 2 : 1)), HA((size_t)q * q), lam;
         std::vector<double>& Rk = ex_Rk;
         PFK_TRY(ops->gram_end(G.data()));
         int nk = 0;
         if (sym) {
             for (int a = 0; a < q; ++a)
                 for (int bb = 0; bb < q; ++bb) HA[(size_t)a * q + bb] = 0.5 * (G[(size_t)a * q + bb] + G[(size_t)bb * q + a]);
+            std::vector<double> Lc;  // pro: M = Z^T Z = Lc Lc^T (lower), HA <- Lc^-1 HA Lc^-T
+            if (pro) {
+                const double* M = G.data() + (size_t)q * q;
+                Lc.assign((size_t)q * q, 0.0);
+                for (int a = 0; a < q; ++a)
+                    for (int bb = 0; bb <= a; ++bb) {
+                        double v = 0.5 * (M[(size_t)a * q + bb] + M[(size_t)bb * q + a]);
+                        for (int t = 0; t < bb; ++t) v -= Lc[(size_t)a * q + t] * Lc[(size_t)bb * q + t];
+                        if (a == bb) {
+                            PFK_CHECK(v > 0.25, PF_E_DEGENERATE, "pf_eigs_smallest: the Ritz vectors lost their independence (%g)", v);
+                            Lc[(size_t)a * q + a] = sqrt(v);
+                        } else {
+                            Lc[(size_t)a * q + bb] = v / Lc[(size_t)bb * q + bb];
+                        }
+                    }
+                // C = Lc^-1 HA Lc^-T: forward substitution on the rows, then on the columns
+                for (int col = 0; col < q; ++col)
+                    for (int a = 0; a < q; ++a) {
+                        double v = HA[(size_t)a * q + col];
+                        for (int t = 0; t < a; ++t) v -= Lc[(size_t)a * q + t] * HA[(size_t)t * q + col];
+                        HA[(size_t)a * q + col] = v / Lc[(size_t)a * q + a];
+                    }
+                for (int row = 0; row < q; ++row)
+                    for (int a = 0; a < q; ++a) {
+                        double v = HA[(size_t)row * q + a];
+                        for (int t = 0; t < a; ++t) v -= Lc[(size_t)a * q + t] * HA[(size_t)row * q + t];
+                        HA[(size_t)row * q + a] = v / Lc[(size_t)a * q + a];
+                    }
+                for (int a = 0; a < q; ++a)
+                    for (int bb = 0; bb < a; ++bb) HA[(size_t)a * q + bb] = HA[(size_t)bb * q + a] = 0.5 * (HA[(size_t)a * q + bb] + HA[(size_t)bb * q + a]);
+            }
             pfd::eigh_sym(HA, q, lam);  // HA <- eigenvectors (columns)
+            if (pro) {  // R = Lc^-T Y: back substitution, column by column
+                for (int col = 0; col < q; ++col)
+                    for (int a = q - 1; a >= 0; --a) {
+                        double v = HA[(size_t)a * q + col];
+                        for (int t = a + 1; t < q; ++t) v -= Lc[(size_t)t * q + a] * HA[(size_t)t * q + col];
+                        HA[(size_t)a * q + col] = v / Lc[(size_t)a * q + a];
+                    }
+            }
             std::vector<int> order(q);
             for (int i = 0; i < q; ++i) order[i] = i;
             std::stable_sort(order.begin(), order.end(), [&](int a, int bb) { return lam[a] < lam[bb]; });

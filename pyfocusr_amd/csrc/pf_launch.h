@@ -82,6 +82,7 @@ struct Op {
     const void* key = nullptr;  // what may share a launch: the address of the two-mesh kernel
     dim3 grid, block;
     size_t lds = 0;
+    hipStream_t st = nullptr;  // the stream the host code named (a build forks its independent chains onto a side stream)
     std::vector<unsigned char> args;
     void (*run1)(const Op&, hipStream_t) = nullptr;
     void (*run2)(const Op&, const Op&, hipStream_t) = nullptr;
@@ -107,7 +108,7 @@ void launch(dim3 grid, dim3 block, size_t lds, hipStream_t st, X... x) {
     }
     Op op;
     op.key = reinterpret_cast<const void*>(&k_two<K, P>);
-    op.grid = grid, op.block = block, op.lds = lds;
+    op.grid = grid, op.block = block, op.lds = lds, op.st = st;
     op.args.resize(sizeof(P));
     memcpy(op.args.data(), &p, sizeof(P));
     op.run1 = [](const Op& o, hipStream_t s) {
@@ -134,6 +135,7 @@ inline void call(hipStream_t st, std::function<void(hipStream_t)> f) {
     }
     Op op;
     op.call = std::move(f);
+    op.st = st;
     r->ops.push_back(std::move(op));
 }
 
@@ -162,12 +164,13 @@ inline hipError_t memset_words(hipStream_t st, void* p, int byte_value, size_t b
     return hipSuccess;
 }
 
-// Queue what has been recorded: shared launches where the two lists ask for the same kernel with the same block shape.
-// `b` may be null (one list, as it stands).  Then the held-back frees.  The recorders are left empty.
-void flush(Recorder& a, Recorder* b, hipStream_t st);
+// Queue what has been recorded, every record on the stream it names: shared launches where the two lists ask for the same
+// kernel with the same block shape.  `b` may be null (one list, as it stands).  Then the held-back frees.  The recorders
+// are left empty.
+void flush(Recorder& a, Recorder* b);
 
 // the calling thread's own list, one launch per record (a host-side wait is about to follow)
-void flush_self(hipStream_t st);
+void flush_self();
 
 }  // namespace pfl
 
@@ -187,7 +190,7 @@ inline hipError_t event_record(hipStream_t st, hipEvent_t ev) {
 
 // a host-side wait: whatever the calling thread has recorded goes out first (unshared)
 inline hipError_t sync(hipStream_t st) {
-    flush_self(st);
+    flush_self();
     return hipStreamSynchronize(st);
 }
 

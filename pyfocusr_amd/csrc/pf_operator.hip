@@ -221,6 +221,10 @@ struct OrthArgs {
     double* ws;
     int64_t n_pad, n_chunks;
     int32_t first, count, wslot, normalize;
+    // basis vector b < count lives in slot first + b for b < split and in slot first2 + (b - split) from there on: one range
+    // (split = count), or - the local steps of Lanczos with partial reorthogonalisation, pf_orth_split - the locked null
+    // vectors and the last two basis vectors
+    int32_t split, first2;
     double* partial;   // [count + 1][n_chunks]
     double* hsum;      // device copy of h
     double* nrm2;      // device copy of |w'|^2
@@ -237,6 +241,7 @@ struct OrthArgs {
 struct OrthArgs2 {
     OrthArgs g[2];
 };
+__device__ __forceinline__ int32_t orth_slot(const OrthArgs& a, int b) { return b < a.split ? a.first + b : a.first2 + (b - a.split); }
 
 // partial[b][chunk] = <slot first+b, slot wslot> over the chunk, b < count; partial[count][chunk] = |w|^2 over the chunk
 // (k_dot_partial's sums, in its order)
@@ -264,7 +269,7 @@ __global__ __launch_bounds__(PF_BLOCK) void k_orth_dots(OrthArgs2 a2) {
     for (int u = 0; u < VB; ++u) {
         const int b = b0 + u;
         if (b > a.count) continue;
-        const double* v = a.ws + (int64_t)(b == a.count ? a.wslot : a.first + b) * a.n_pad;
+        const double* v = a.ws + (int64_t)(b == a.count ? a.wslot : orth_slot(a, b)) * a.n_pad;
 #pragma unroll
         for (int it = 0; it < PAIRS; ++it) xs[u][it] = *reinterpret_cast<const double2*>(v + lo + 2 * threadIdx.x + (int64_t)it * (2 * PF_BLOCK));
     }
@@ -354,7 +359,7 @@ __global__ __launch_bounds__(PF_BLOCK) void k_orth_project(OrthArgs2 a2) {
         for (; b + 8 <= count; b += 8) {
             double2 vv[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) vv[u] = *reinterpret_cast<const double2*>(a.ws + (int64_t)(a.first + b + u) * a.n_pad + i);
+            for (int u = 0; u < 8; ++u) vv[u] = *reinterpret_cast<const double2*>(a.ws + (int64_t)orth_slot(a, b + u) * a.n_pad + i);
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const double hb = hs[b + u];
@@ -364,7 +369,7 @@ __global__ __launch_bounds__(PF_BLOCK) void k_orth_project(OrthArgs2 a2) {
         }
         for (; b < count; ++b) {
             const double hb = hs[b];
-            const double2 v = *reinterpret_cast<const double2*>(a.ws + (int64_t)(a.first + b) * a.n_pad + i);
+            const double2 v = *reinterpret_cast<const double2*>(a.ws + (int64_t)orth_slot(a, b) * a.n_pad + i);
             acc.x -= hb * v.x;
             acc.y -= hb * v.y;
         }
@@ -381,7 +386,7 @@ __global__ __launch_bounds__(PF_BLOCK) void k_orth_project(OrthArgs2 a2) {
         int b = 0;
         for (; b + 2 <= count; b += 2) {
             const double h0 = hs[b], h1 = hs[b + 1];
-            const double* v0 = a.ws + (int64_t)(a.first + b) * a.n_pad + i0;
+            const double* v0 = a.ws + (int64_t)orth_slot(a, b) * a.n_pad + i0;
             const double* v1 = v0 + a.n_pad;
             double2 x0[P], x1[P];
 #pragma unroll
@@ -398,7 +403,7 @@ __global__ __launch_bounds__(PF_BLOCK) void k_orth_project(OrthArgs2 a2) {
         }
         for (; b < count; ++b) {
             const double hb = hs[b];
-            const double* vb = a.ws + (int64_t)(a.first + b) * a.n_pad + i0;
+            const double* vb = a.ws + (int64_t)orth_slot(a, b) * a.n_pad + i0;
             double2 vv[P];
 #pragma unroll
             for (int it = 0; it < P; ++it) vv[it] = *reinterpret_cast<const double2*>(vb + (int64_t)it * (2 * PF_BLOCK));
@@ -1309,9 +1314,23 @@ static int orth_launch_pass(const OrthArgs2& a2, int ng, int64_t n_chunks, int64
 // checks, pinned result buffer, event: everything of pf_orth_begin that comes before the launches
 static int orth_prepare(pf_graph* g, int32_t w, int32_t first, int32_t count, int32_t normalize) {
     PF_TRY(check_slots(g, w, 1, "pf_orth_begin"));
-    PF_TRY(check_slots(g, first, count, "pf_orth_begin"));
-    PF_CHECK(w < first || w >= first + count, PF_E_ARG, "pf_orth_begin: w inside the basis range");
+    if (g->orth_split < 0) PF_TRY(check_slots(g, first, count, "pf_orth_begin"));
     PF_CHECK(g->orth_pending < 0, PF_E_STATE, "pf_orth_begin: a previous pf_orth_begin has not been collected");
+    // pf_orth_split (one step only): the basis is slots [first, first + split) and [first2, first2 + count - split)
+    g->orth_split_now = -1;
+    if (g->orth_split >= 0) {
+        const int32_t split = g->orth_split, first2 = g->orth_first2;
+        g->orth_split = -1;
+        PF_CHECK(split <= count && count > 0 && count < PF_ORTH_MAX, PF_E_ARG, "pf_orth_split: %d of %d vectors in the first range", split, count);
+        PF_TRY(check_slots(g, first, split, "pf_orth_begin"));
+        PF_TRY(check_slots(g, first2, count - split, "pf_orth_begin"));
+        PF_CHECK((w < first || w >= first + split) && (w < first2 || w >= first2 + count - split), PF_E_ARG, "pf_orth_begin: w inside the basis ranges");
+        PF_CHECK(first + split <= first2 || first2 + count - split <= first, PF_E_ARG, "pf_orth_split: overlapping ranges");
+        g->orth_split_now = split;
+        g->orth_first2_now = first2;
+    } else {
+        PF_CHECK(w < first || w >= first + count, PF_E_ARG, "pf_orth_begin: w inside the basis range");
+    }
     hipStream_t st = g->ctx->stream;
     PF_TRY(pf_reduce_ensure(g, count + 1));  // (+ the |w|^2 column)
     if (count + 1 > g->orth_host_cap || !g->orth_host) {
@@ -1356,6 +1375,8 @@ static OrthArgs orth_args(pf_graph* g, int32_t w, int32_t first, int32_t count, 
     a.n_pad = g->n_pad;
     a.n_chunks = g->n_chunks;
     a.first = first, a.count = count, a.wslot = w, a.normalize = normalize ? 1 : 0;
+    a.split = g->orth_split_now >= 0 ? g->orth_split_now : count;
+    a.first2 = g->orth_first2_now;
     a.partial = g->partials;
     a.hsum = g->coef + g->coef_cap;
     a.nrm2 = g->coef + 2 * g->coef_cap;
@@ -1492,10 +1513,25 @@ int pf_orth_end(pf_graph* g, double* h, double* nrm) {
         double* hsum = g->coef + g->coef_cap;
         double* nrm2 = g->coef + 2 * g->coef_cap;
         const int32_t w = g->orth_w, first = g->orth_first;
-        k_dot_partial<<<dim3((unsigned)g->n_chunks, (unsigned)count), PF_BLOCK, 0, st>>>(g->ws, g->n_pad, first, w, g->n_chunks, g->partials);
-        PF_HIP(hipGetLastError());
-        k_axpy_finishing<<<nblk(g->n_pad / 2), PF_BLOCK, 0, st>>>(g->ws, g->n_pad, first, count, w, g->partials, g->n_chunks, hsum, 1);
-        PF_HIP(hipGetLastError());
+        const int32_t split = g->orth_split_now >= 0 ? g->orth_split_now : count;  // (two ranges: all dot products first, as in one)
+        if (split > 0) {
+            k_dot_partial<<<dim3((unsigned)g->n_chunks, (unsigned)split), PF_BLOCK, 0, st>>>(g->ws, g->n_pad, first, w, g->n_chunks, g->partials);
+            PF_HIP(hipGetLastError());
+        }
+        if (count > split) {
+            k_dot_partial<<<dim3((unsigned)g->n_chunks, (unsigned)(count - split)), PF_BLOCK, 0, st>>>(g->ws, g->n_pad, g->orth_first2_now, w, g->n_chunks,
+                                                                                                   g->partials + (size_t)split * g->n_chunks);
+            PF_HIP(hipGetLastError());
+        }
+        if (split > 0) {
+            k_axpy_finishing<<<nblk(g->n_pad / 2), PF_BLOCK, 0, st>>>(g->ws, g->n_pad, first, split, w, g->partials, g->n_chunks, hsum, 1);
+            PF_HIP(hipGetLastError());
+        }
+        if (count > split) {
+            k_axpy_finishing<<<nblk(g->n_pad / 2), PF_BLOCK, 0, st>>>(g->ws, g->n_pad, g->orth_first2_now, count - split, w,
+                                                                      g->partials + (size_t)split * g->n_chunks, g->n_chunks, hsum + split, 1);
+            PF_HIP(hipGetLastError());
+        }
         k_dot_partial<<<dim3((unsigned)g->n_chunks, 1u), PF_BLOCK, 0, st>>>(g->ws, g->n_pad, w, w, g->n_chunks, g->partials);
         PF_HIP(hipGetLastError());
         k_scale_finishing<<<nblk(g->n_pad), PF_BLOCK, 0, st>>>(pf_slot(g, w), g->n_pad, g->partials, g->n_chunks, g->orth_normalize,
@@ -1518,13 +1554,22 @@ int pf_orth_end(pf_graph* g, double* h, double* nrm) {
 // above the spectrum), where the second pass costs nothing that matters.  Drivers switch to strict there.
 int pf_orth_strict(pf_graph* g, int32_t on) {
     PF_CHECK(g != nullptr, PF_E_ARG, "pf_orth_strict: NULL graph");
-    g->orth_thresh = on ? 0.5 : 0.09;
+    g->orth_thresh = on >= 2 ? 4.0 : (on ? 0.5 : 0.09);  // (2: |w'|^2 < 4 |w|^2 holds always - every step takes its second pass)
     return PF_OK;
 }
 
 int pf_orth_device_passes(pf_graph* g, int32_t on) {
     PF_CHECK(g != nullptr, PF_E_ARG, "pf_orth_device_passes: NULL graph");
     g->orth_device_passes = on ? 1 : 0;
+    return PF_OK;
+}
+
+// The NEXT pf_orth_begin / _begin2 / pf_orth_cheb2 step of this graph (and only that one) takes its basis from two ranges
+// of slots: [first, first + split) and [first2, first2 + count - split), first / count as passed to that call.
+int pf_orth_split(pf_graph* g, int32_t first2, int32_t split) {
+    PF_CHECK(g != nullptr && split >= 0 && first2 >= 0, PF_E_ARG, "pf_orth_split: bad argument");
+    g->orth_split = split;
+    g->orth_first2 = first2;
     return PF_OK;
 }
 
@@ -1654,17 +1699,21 @@ int pf_gram(pf_graph* g, int32_t first_a, int32_t count_a, int32_t first_b, int3
 // pf_gram / pf_resnorms in two halves: _begin queues the kernels and a copy of the few results into a pinned block of the
 // graph's own, with an event behind it; pf_small_end waits for that event only - what the stream holds behind it (the
 // partner graph's extraction) keeps running.  One collection in flight per graph.
-static int small_begin(pf_graph* g, const double* d_src, size_t count, bool root) {
-    PF_CHECK(g->small_pending == 0, PF_E_STATE, "pf_gram_begin / pf_resnorms_begin: a previous result has not been collected");
+static int small_begin(pf_graph* g, const double* d_src, size_t count, bool root, bool append = false) {
+    PF_CHECK(append ? g->small_pending > 0 && !g->small_root && !root : g->small_pending == 0, PF_E_STATE,
+             "pf_gram_begin / pf_resnorms_begin: a previous result has not been collected");
     pf_ctx* c = g->ctx;
     hipStream_t st = c->stream;
-    if ((int64_t)count > g->small_host_cap || !g->small_host) {
+    const size_t offset = append ? (size_t)g->small_pending : 0;
+    if (append) {
+        PF_CHECK((int64_t)(offset + count) <= g->small_host_cap, PF_E_STATE, "pf_gram_begin: no room to append");
+    } else if ((int64_t)(2 * count) > g->small_host_cap || !g->small_host) {  // (room for an appended block of the same size)
         if (g->small_host) {
             PF_HIP(hipStreamSynchronize(st));
             c->pinned_pool.emplace_back(g->small_host_cap, g->small_host);
             g->small_host = nullptr;
         }
-        const int32_t cap = std::max((int32_t)count, 64);
+        const int32_t cap = std::max((int32_t)(2 * count), 128);
         for (size_t i = 0; i < c->pinned_pool.size(); ++i)
             if (c->pinned_pool[i].first >= cap) {
                 g->small_host_cap = c->pinned_pool[i].first;
@@ -1685,9 +1734,9 @@ static int small_begin(pf_graph* g, const double* d_src, size_t count, bool root
             PF_HIP(hipEventCreateWithFlags(&g->small_ev, hipEventDisableTiming));
         }
     }
-    PF_TRY(pf_copy_by_kernel(st, d_src, g->small_host, sizeof(double) * count));
+    PF_TRY(pf_copy_by_kernel(st, d_src, g->small_host + offset, sizeof(double) * count));
     PF_HIP(hipEventRecord(g->small_ev, st));
-    g->small_pending = (int32_t)count;
+    g->small_pending = (int32_t)(offset + count);
     g->small_root = root;
     return PF_OK;
 }
@@ -1704,7 +1753,8 @@ int pf_small_end(pf_graph* g, double* out) {
     return PF_OK;
 }
 
-int pf_gram_begin(pf_graph* g, int32_t first_a, int32_t count_a, int32_t first_b, int32_t count_b) {
+// (append: the result goes behind the one already waiting - of the same size at most - and pf_small_end returns both)
+int pf_gram_begin(pf_graph* g, int32_t first_a, int32_t count_a, int32_t first_b, int32_t count_b, int32_t append) {
     PF_TRY(check_slots(g, first_a, count_a, "pf_gram"));
     PF_TRY(check_slots(g, first_b, count_b, "pf_gram"));
     PF_CHECK(count_a > 0 && count_b > 0, PF_E_ARG, "pf_gram: bad argument");
@@ -1715,7 +1765,7 @@ int pf_gram_begin(pf_graph* g, int32_t first_a, int32_t count_a, int32_t first_b
     PF_HIP(hipGetLastError());
     k_dot_finish<<<(unsigned)(count_a * count_b), PF_WAVE, 0, st>>>(g->partials, g->n_chunks, g->coef, nullptr, 0);
     PF_HIP(hipGetLastError());
-    return small_begin(g, g->coef, (size_t)count_a * count_b, false);
+    return small_begin(g, g->coef, (size_t)count_a * count_b, false, append != 0);
 }
 
 int pf_resnorms_begin(pf_graph* g, int32_t ax_first, int32_t x_first, const double* lam, int32_t count) {

@@ -390,7 +390,7 @@ int pf_morton_order(pf_graph* g, const double* d_pts, int32_t* d_overflow) {
             if (fail(hipGetLastError())) break;
         } else {
             size_t need = 0;
-            pfl::flush_self(st);  // (a library sort launches at once: whatever this thread has recorded goes first)
+            pfl::flush_self();  // (a library sort launches at once: whatever this thread has recorded goes first)
             if (fail(hipcub::DeviceRadixSort::SortPairs(nullptr, need, k0, k1, v0, g->morder, in, 0, 30, st))) break;
             if (fail(pf_malloc(st, &tmp, need))) break;
             if (fail(hipcub::DeviceRadixSort::SortPairs(tmp, need, k0, k1, v0, g->morder, in, 0, 30, st))) break;
@@ -411,7 +411,8 @@ int pf_morton_order(pf_graph* g, const double* d_pts, int32_t* d_overflow) {
 // m-space; d_pts: the points in that order): boundary rows first, then by degree; g->perm_m / g->iperm_m (solver <-> m),
 // their compositions with morder in g->perm / g->iperm (solver <-> original), g->smooth.
 static int order_in_windows(pf_graph* g, const double* d_pts) {
-    hipStream_t st = g->build_stream ? g->build_stream : g->ctx->stream;
+    hipStream_t st = g->build_stream ? g->build_stream : g->ctx->stream;  // blocks are taken and released on this one ...
+    hipStream_t ls = g->side_stream ? g->side_stream : st;                // ... the kernels may run on the build's side stream
     const int64_t n = g->n;
     const int32_t win_rows = g->win_rows;
     unsigned *bflag = nullptr, *k0 = nullptr, *k1 = nullptr;
@@ -428,30 +429,30 @@ static int order_in_windows(pf_graph* g, const double* d_pts) {
     do {
         if (fail(pf_malloc(st, (void**)&bflag, sizeof(unsigned) * std::max<int64_t>(n, 1)))) break;
         if (fail(pf_malloc(st, (void**)&k0, sizeof(unsigned) * std::max<int64_t>(n, 1)))) break;
-        if (fail(pfl::memset_words(st, bflag, 0, sizeof(unsigned) * std::max<int64_t>(n, 1)))) break;
-        pfl::launch<k_boundary_flags>(dim3(nblk(n)), dim3(PF_BLOCK), 0, st, nullptr, g->rowptr, g->col, nullptr, n, win_rows, bflag);
-        pfl::launch<k_second_ring_flags>(dim3(nblk(n)), dim3(PF_BLOCK), 0, st, nullptr, g->rowptr, g->col, nullptr, n, bflag);
-        pfl::launch<k_degree_keys>(dim3(nblk(n)), dim3(PF_BLOCK), 0, st, nullptr, g->rowptr, bflag, n, win_rows, k0);
+        if (fail(pfl::memset_words(ls, bflag, 0, sizeof(unsigned) * std::max<int64_t>(n, 1)))) break;
+        pfl::launch<k_boundary_flags>(dim3(nblk(n)), dim3(PF_BLOCK), 0, ls, nullptr, g->rowptr, g->col, nullptr, n, win_rows, bflag);
+        pfl::launch<k_second_ring_flags>(dim3(nblk(n)), dim3(PF_BLOCK), 0, ls, nullptr, g->rowptr, g->col, nullptr, n, bflag);
+        pfl::launch<k_degree_keys>(dim3(nblk(n)), dim3(PF_BLOCK), 0, ls, nullptr, g->rowptr, bflag, n, win_rows, k0);
         if (fail(hipGetLastError())) break;
         if (win_rows <= 4096) {
             int32_t n_pow2 = 2;
             while (n_pow2 < win_rows) n_pow2 <<= 1;
-            pfl::launch<k_sort_windows>(dim3((unsigned)((n + win_rows - 1) / win_rows)), dim3(1024), sizeof(unsigned long long) * (size_t)n_pow2, st, k0, nullptr, n, win_rows, n_pow2, g->perm_m);
+            pfl::launch<k_sort_windows>(dim3((unsigned)((n + win_rows - 1) / win_rows)), dim3(1024), sizeof(unsigned long long) * (size_t)n_pow2, ls, k0, nullptr, n, win_rows, n_pow2, g->perm_m);
             if (fail(hipGetLastError())) break;
         } else {
             int bits2 = 12;
             for (int64_t w = (n + win_rows - 1) / win_rows; w > 0; w >>= 1) ++bits2;
             if (fail(pf_malloc(st, (void**)&k1, sizeof(unsigned) * n)) || fail(pf_malloc(st, (void**)&v1, sizeof(int32_t) * n))) break;
-            pfl::launch<k_iota>(dim3(nblk(n)), dim3(PF_BLOCK), 0, st, v1, n);
+            pfl::launch<k_iota>(dim3(nblk(n)), dim3(PF_BLOCK), 0, ls, v1, n);
             size_t need = 0;
-            pfl::flush_self(st);  // (a library sort launches at once: whatever this thread has recorded goes first)
-            if (fail(hipcub::DeviceRadixSort::SortPairs(nullptr, need, k0, k1, v1, g->perm_m, (int)n, 0, bits2, st))) break;
+            pfl::flush_self();  // (a library sort launches at once: whatever this thread has recorded goes first)
+            if (fail(hipcub::DeviceRadixSort::SortPairs(nullptr, need, k0, k1, v1, g->perm_m, (int)n, 0, bits2, ls))) break;
             if (fail(pf_malloc(st, &tmp, need))) break;
-            if (fail(hipcub::DeviceRadixSort::SortPairs(tmp, need, k0, k1, v1, g->perm_m, (int)n, 0, bits2, st))) break;
+            if (fail(hipcub::DeviceRadixSort::SortPairs(tmp, need, k0, k1, v1, g->perm_m, (int)n, 0, bits2, ls))) break;
         }
-        pfl::launch<k_finish_perm>(dim3(nblk(g->n_pad)), dim3(PF_BLOCK), 0, st, g->perm_m, g->iperm_m, n, g->n_pad);
-        pfl::launch<k_compose_perm>(dim3(nblk(g->n_pad)), dim3(PF_BLOCK), 0, st, g->perm_m, g->morder, g->n_pad, g->perm, g->iperm);
-        pfl::launch<k_smooth_start>(dim3(nblk(g->n_pad)), dim3(PF_BLOCK), 0, st, d_pts, g->perm_m, g->order_bbox, g->n_pad, g->smooth);
+        pfl::launch<k_finish_perm>(dim3(nblk(g->n_pad)), dim3(PF_BLOCK), 0, ls, g->perm_m, g->iperm_m, n, g->n_pad);
+        pfl::launch<k_compose_perm>(dim3(nblk(g->n_pad)), dim3(PF_BLOCK), 0, ls, g->perm_m, g->morder, g->n_pad, g->perm, g->iperm);
+        pfl::launch<k_smooth_start>(dim3(nblk(g->n_pad)), dim3(PF_BLOCK), 0, ls, d_pts, g->perm_m, g->order_bbox, g->n_pad, g->smooth);
         if (fail(hipGetLastError())) break;
     } while (0);
     pf_free(st, bflag);
@@ -498,13 +499,13 @@ int pf_compute_order(pf_graph* g, const double* d_pts, int32_t* d_overflow) {
         }
         if (fail(hipGetLastError())) break;
         const bool counting = d_pts != nullptr && d_overflow != nullptr && n >= 4096;  // (else: the general sort)
-        pfl::flush_self(st);  // (a library sort launches at once: whatever this thread has recorded goes first)
+        pfl::flush_self();  // (a library sort launches at once: whatever this thread has recorded goes first)
         if (fail(hipcub::DeviceRadixSort::SortPairs(nullptr, need, k0, k1, v0, v1, in, 0, 30, st))) break;
         tmp_bytes = need;
         const int32_t win_rows = g->win_rows;
         int bits2 = 12;
         for (int64_t w = (n + win_rows - 1) / win_rows; w > 0; w >>= 1) ++bits2;
-        pfl::flush_self(st);  // (a library sort launches at once: whatever this thread has recorded goes first)
+        pfl::flush_self();  // (a library sort launches at once: whatever this thread has recorded goes first)
         if (fail(hipcub::DeviceRadixSort::SortPairs(nullptr, need, k0, k1, v0, v1, in, 0, bits2, st))) break;
         tmp_bytes = need > tmp_bytes ? need : tmp_bytes;
         if (fail(pf_malloc(st, &tmp, tmp_bytes))) break;

@@ -447,7 +447,7 @@ def _c_accept(g, dev, plan, result):
             print("Not enough eigenvalues found, trying again with more eigenvalues!")
             print("Starting!")
     stats = EigsStats()
-    for key in ("matvecs", "outer_steps", "restarts", "filter_resets", "degree", "cut", "n_null", "second_passes", "mode"):
+    for key in ("matvecs", "outer_steps", "restarts", "filter_resets", "degree", "cut", "n_null", "second_passes", "mode", "local_steps"):
         setattr(stats, key, st[key])
     stats.residuals = st["residuals"]
     g._set_spectrum(vals, vecs, stats)

@@ -20,7 +20,7 @@ _ip = C.POINTER(C.c_int32)
 class Stats(C.Structure):  # pf_eigs_stats of include/pyfocusr_hip.h
     _fields_ = [("matvecs", C.c_int64), ("outer_steps", C.c_int32), ("restarts", C.c_int32), ("filter_resets", C.c_int32),
                 ("degree", C.c_int32), ("n_null", C.c_int32), ("cut", C.c_double), ("max_residual", C.c_double),
-                ("second_passes", C.c_int32), ("mode", C.c_int32)]
+                ("second_passes", C.c_int32), ("mode", C.c_int32), ("local_steps", C.c_int32), ("reserved", C.c_int32)]
 
     def as_dict(self):
         return {f: getattr(self, f) for f, _ in self._fields_}

@@ -151,19 +151,39 @@ struct HostOps : pfk::Ops {
         }
         return PF_OK;
     }
+    // the next orth_begin's basis: slots [first, first + split) and [first2, first2 + count - split)
+    int32_t split_next = -1, first2_next = 0;
+    int64_t local_calls = 0;
+    bool always_twice = false;
+    int orth_always_twice(bool on, bool) override {
+        always_twice = on;
+        return PF_OK;
+    }
+    bool orth_split(int32_t first2, int32_t split) override {
+        split_next = split;
+        first2_next = first2;
+        return true;
+    }
     int orth_begin(int32_t wslot, int32_t first, int32_t count) override {
         std::vector<double>& x = ws[wslot];
+        const int32_t split = split_next >= 0 ? split_next : count, first2 = first2_next;
+        if (split_next >= 0) ++local_calls;
+        split_next = -1;
+        auto slot = [&](int b) { return b < split ? first + b : first2 + (b - split); };
         pend_h.assign((size_t)std::max(count, 1), 0.0);
-        for (int pass = 0; pass < 2; ++pass) {
+        // (TD_ONE_PASS: one pass unless the driver asked for two - what the device's steps usually are)
+        const bool one_pass = getenv("TD_ONE_PASS") != nullptr;
+        const int n_pass = one_pass && !always_twice ? 1 : 2;
+        for (int pass = 0; pass < n_pass; ++pass) {
             std::vector<double> hh((size_t)count, 0.0);
             for (int b = 0; b < count; ++b) {
-                const std::vector<double>& v = ws[first + b];
+                const std::vector<double>& v = ws[slot(b)];
                 double d = 0.0;
                 for (int64_t i = 0; i < nn; ++i) d += v[i] * x[i];
                 hh[b] = d;
             }
             for (int b = 0; b < count; ++b) {
-                const std::vector<double>& v = ws[first + b];
+                const std::vector<double>& v = ws[slot(b)];
                 for (int64_t i = 0; i < nn; ++i) x[i] -= hh[b] * v[i];
                 pend_h[b] += hh[b];
             }
@@ -174,6 +194,16 @@ struct HostOps : pfk::Ops {
         if (nrm > 1e-140)
             for (int64_t i = 0; i < nn; ++i) x[i] /= nrm;
         pend_nrm = nrm;
+        if (getenv("TD_DEBUG_ORTH")) {  // the orthogonality the step really left, against every slot in front of w
+            double worst = 0.0;
+            int at = -1;
+            for (int sl = first; sl < wslot; ++sl) {
+                double d = 0.0;
+                for (int64_t i = 0; i < nn; ++i) d += ws[sl][i] * x[i];
+                if (fabs(d) > worst) worst = fabs(d), at = sl;
+            }
+            fprintf(stderr, "orth w=%d count=%d local=%d: max |<w, v>| = %.2e (slot %d), nrm %.3e\n", wslot, count, (int)(split != count), worst, at, nrm);
+        }
         ++orth_calls;
         pend_redone = redone_every > 0 && orth_calls % redone_every == 0;
         return PF_OK;

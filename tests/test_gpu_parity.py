@@ -717,15 +717,27 @@ def test_paired_spectra_equal_single(golden, ctx):
 
 
 def test_pair_build_side_by_side(golden, hip, ctx):
-    """`pf_graph_build_device2` (two meshes assembled on two streams, halves interleaved; blocks of the caching allocator
-    cross between the streams only behind a join): W, deg, L, the statistics and the solver-order operator equal to two
-    single builds bit for bit - for meshes of different size, repeatedly (blocks released on one stream come back on the
+    """`pf_graph_build_device2` (two meshes assembled in shared launches, their independent chains forked onto the second
+    stream): W, deg, L, the statistics and the solver-order operator equal to two single builds bit for bit - for meshes of different size, repeatedly (blocks released on one stream come back on the
     other), with other work queued in between; a bad mesh in either place fails cleanly."""
     from pyfocusr_amd.meshgen import blob_mesh
 
+    from pyfocusr_amd import PolyMesh
+
+    # (round 4: the two builds share their launches - pf_launch.h - where both ask for the same kernel; a torus of quads
+    # beside a triangle mesh and a mesh below the counting sort's size beside a large one make the two lists of launches
+    # part ways: no face bound for quads, the library sort for the small mesh)
+    nu, nv = 180, 60
+    uu, vv = np.meshgrid(np.arange(nu), np.arange(nv), indexing="ij")
+    au, av = 2 * np.pi * uu / nu, 2 * np.pi * vv / nv
+    torus = PolyMesh(np.stack([(3 + np.cos(av)) * np.cos(au), (3 + np.cos(av)) * np.sin(au), np.sin(av)], axis=-1).reshape(-1, 3),
+                     np.stack([uu * nv + vv, ((uu + 1) % nu) * nv + vv, ((uu + 1) % nu) * nv + (vv + 1) % nv, uu * nv + (vv + 1) % nv],
+                              axis=-1).reshape(-1, 4).astype(np.int32))
     cases = [(mesh_of(golden("target_mesh")), mesh_of(golden("source_mesh_15k"))),
              (blob_mesh(60000, seed=41), blob_mesh(20000, seed=42)),
-             (blob_mesh(20000, seed=43), blob_mesh(60000, seed=44))]
+             (blob_mesh(20000, seed=43), blob_mesh(60000, seed=44)),
+             (torus, blob_mesh(20000, seed=47)),
+             (blob_mesh(30000, seed=48), blob_mesh(3000, seed=49))]
     rng = np.random.default_rng(3)
     for rep in range(3):
         for ma, mb in cases:

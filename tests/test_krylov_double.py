@@ -273,3 +273,48 @@ def test_cpp_pair_driver_equals_single_solves(golden):
     for W, k, (vals, vecs, st) in zip(Ws, (6, 9), (ra, rb)):
         v1, x1, s1, _ = kd.solve(W, k)
         assert np.array_equal(vals, v1) and np.array_equal(vecs, x1) and st["matvecs"] == s1["matvecs"]
+
+
+def test_cpp_driver_partial_reorthogonalisation(monkeypatch):
+    """Symmetric graphs of 4096 vertices and more run Lanczos with PARTIAL reorthogonalisation (pf_krylov.h: most steps
+    orthogonalise against the null vectors and the last two basis vectors only, estimates of the drift decide when two
+    full Gram-Schmidt steps are due; the extraction orthonormalises its Ritz vectors): same eigenpairs as with full
+    Gram-Schmidt in every step and as the oracle, most steps local - alone, in a pair, and with several components."""
+    from pyfocusr_amd.meshgen import blob_mesh
+
+    m = blob_mesh(9000, seed=51)
+    W = W_of(m.points, m.faces)
+    vals, vecs, st, res = kd.solve(W, 6)
+    assert st["mode"] == 0 and st["restarts"] == 0
+    assert st["local_steps"] >= 0.6 * st["outer_steps"] > 0, st
+    # the device's steps take ONE Gram-Schmidt pass unless digits cancel; the full steps of such a run ask for two (one pass
+    # against a basis that is orthogonal to 1e-9 only would leave the new vector there and the estimates wrong: seen as
+    # "no convergence" on a two-component mesh of the GPU fuzzer before they did)
+    monkeypatch.setenv("TD_ONE_PASS", "1")
+    vals_1, vecs_1, st_1, res_1 = kd.solve(W, 6)
+    monkeypatch.delenv("TD_ONE_PASS")
+    assert st_1["restarts"] == 0 and st_1["local_steps"] > 0 and st_1["outer_steps"] == st["outer_steps"]
+    np.testing.assert_allclose(vals_1, vals, rtol=1e-11)
+    monkeypatch.setenv("PF_EIGS_PRO", "0")
+    vals_f, vecs_f, st_f, res_f = kd.solve(W, 6)
+    monkeypatch.delenv("PF_EIGS_PRO")
+    assert st_f["local_steps"] == 0 and st_f["outer_steps"] == st["outer_steps"]
+    np.testing.assert_allclose(vals, vals_f, rtol=2e-12)
+    assert np.max(np.abs(np.abs(np.sum(vecs * vecs_f, axis=0)) / (np.linalg.norm(vecs, axis=0) * np.linalg.norm(vecs_f, axis=0)) - 1.0)) < 1e-10
+    assert res.max() < 4 * max(res_f.max(), 1e-13)
+    ref = orc.graph_spectrum(m.points, m.faces, 5)
+    np.testing.assert_allclose(vals[: len(ref["eig_vals"])], ref["eig_vals"][: len(vals)], rtol=1e-9)
+    L = ref["L"]
+    assert np.abs(L @ vecs - vecs * vals[None, :]).max() < 1e-10
+    # two components (two locked null vectors in every local step) beside a single one, as a pair
+    parts = [blob_mesh(n, seed=60 + i) for i, n in enumerate((5000, 4200))]
+    pts = np.concatenate([p.points + 400.0 * i for i, p in enumerate(parts)])
+    faces = np.concatenate([parts[0].faces, parts[1].faces + len(parts[0].points)])
+    W2 = W_of(pts, faces)
+    monkeypatch.setenv("TD_ONE_PASS", "1")
+    (va, xa, sa), (vb, xb, sb), _ = kd.solve_pair(W2, 7, W, 6)
+    monkeypatch.delenv("TD_ONE_PASS")
+    assert sa["n_null"] == 2 and sa["local_steps"] > 0 and sb["local_steps"] > 0
+    np.testing.assert_allclose(vb, vals, rtol=1e-11)
+    L2 = orc.graph_matrices(pts, faces)[3]
+    assert np.abs(L2 @ xa - xa * va[None, :]).max() < 1e-10

@@ -112,29 +112,39 @@ def kernels_of(*files):
     names = set()
     for f in files:
         with open(os.path.join(repo, "pyfocusr_amd", "csrc", f)) as fh:
-            names.update(re.findall(r"__global__[^;{]*?void\s+(\w+)\s*\(", fh.read()))
+            text = fh.read()
+            names.update(re.findall(r"__global__[^;{]*?void\s+(\w+)\s*\(", text))
+            names.update(re.findall(r"struct\s+(\w+)\s*\{\s*static constexpr int BOUNDS", text))  # functors of pf_launch.h
     return names
 
 
-stage_files = dict(assembly=("pf_assemble.hip", "pf_reorder.hip", "pf_scan.hip"), knn=("pf_knn.hip", "pf_knn_tree.hip"))
+def kernel_of(kname):
+    """The kernel's (or, for pfl::k_one / k_two launches, the functor's) plain name, and how many meshes the launch serves."""
+    k = kname.replace("(anonymous namespace)::", "")
+    m = re.search(r"k_(one|two)<(?:pfl::)?(\w+)", k)
+    if m:
+        return m.group(2), (2 if m.group(1) == "two" else 1)
+    m = re.search(r"(\w+)(<[^(]*>)?\(", k)
+    return (m.group(1) if m else None), 1
+
+
+stage_files = dict(assembly=("pf_assemble.hip", "pf_reorder.hip", "pf_scan.hip", "pf_launch.h"), knn=("pf_knn.hip", "pf_knn_tree.hip"))
 stages = {}
 if args.fetch and args.write:
     ftab, wtab = counter_avg(args.fetch, "FETCH_SIZE"), counter_avg(args.write, "WRITE_SIZE")
     # steps the PROFILED command ran (timed + warm-up + any extra untimed step): every step assembles two meshes
-    ce = [calls for kname, (calls, kb) in ftab.items() if "k_count_edges" in kname]
-    n_steps = max(sum(ce) // 2, 1) if ce else max(int(bench.get("steps", 2)) + int(bench.get("warmup", 1)), 1)
+    meshes = sum(calls * kernel_of(kname)[1] for kname, (calls, kb) in ftab.items() if "k_count_edges" in kname)
+    n_steps = max(meshes // 2, 1) if meshes else max(int(bench.get("steps", 2)) + int(bench.get("warmup", 1)), 1)
     for stage, files in stage_files.items():
         names = kernels_of(*files)
         rd = wr = 0.0
         n_disp = 0
         for kname, (calls, kb) in ftab.items():
-            m = re.search(r"(\w+)(<[^(]*>)?\(", kname.replace("(anonymous namespace)::", ""))
-            if m and m.group(1) in names:
+            if kernel_of(kname)[0] in names:
                 rd += 2.0 * kb * 1024.0 * calls
                 n_disp += calls
         for kname, (calls, kb) in wtab.items():
-            m = re.search(r"(\w+)(<[^(]*>)?\(", kname.replace("(anonymous namespace)::", ""))
-            if m and m.group(1) in names:
+            if kernel_of(kname)[0] in names:
                 wr += kb * 1024.0 * calls
         stages[stage] = dict(hbm_read_bytes_per_step=rd / n_steps, hbm_write_bytes_per_step=wr / n_steps,
                              hbm_bytes_per_step=(rd + wr) / n_steps, dispatches_per_step=n_disp / n_steps, steps_counted=n_steps,

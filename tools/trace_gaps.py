@@ -8,6 +8,10 @@ from collections import defaultdict
 
 
 def short(name):
+    # pfl::k_one<K, Pack<...>> / pfl::k_two<...>: the functor's name (x2: one launch for the two meshes of a pair)
+    m = re.search(r"k_(one|two)<(?:\(anonymous namespace\)::|pfl::)?(\w+(?:<\w+>)?)", name)
+    if m:
+        return m.group(2) + (" x2" if m.group(1) == "two" else "")
     m = re.search(r"(k_[a-z0-9_]+(<[^>]*>)?)", name)
     if m:
         return m.group(1)

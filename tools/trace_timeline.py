@@ -1,13 +1,17 @@
 #!/usr/bin/env python3
 """Timeline of the LAST bench step in a rocprofv3 kernel trace (`--kernel-trace --output-format csv`): every dispatch
 with its start offset, duration and the idle gap before it; runs of the same kernel are folded.
-python tools/trace_timeline.py TRACE.csv [first-kernel-of-a-step substring, default k_count_edges]"""
+python tools/trace_timeline.py TRACE.csv [first-kernel-of-a-step substring, default k_bbox]"""
 import csv
 import re
 import sys
 
 
 def short(name):
+    # pfl::k_one<K, Pack<...>> / pfl::k_two<...>: the functor's name (x2: one launch for the two meshes of a pair)
+    m = re.search(r"k_(one|two)<(?:\(anonymous namespace\)::|pfl::)?(\w+(?:<\w+>)?)", name)
+    if m:
+        return m.group(2) + (" x2" if m.group(1) == "two" else "")
     m = re.search(r"(k_[a-z0-9_]+(<[^>]*>)?)", name)
     if m:
         return m.group(1)
@@ -20,10 +24,14 @@ with open(sys.argv[1]) as fh:
     for r in csv.DictReader(fh):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"])))
 rows.sort()
-marker = sys.argv[2] if len(sys.argv) > 2 else "k_count_edges"
+marker = sys.argv[2] if len(sys.argv) > 2 else "k_bbox"
 starts = [i for i, r in enumerate(rows) if marker in r[2] and (i == 0 or marker not in rows[i - 1][2])]
-# a step assembles two meshes: its first dispatch is every second marker
-begin = starts[-2] if len(starts) >= 2 else 0
+# a step assembles two meshes: in one chain of shared launches (the marker once per step, "x2"), or one after / beside the
+# other (twice)
+per_step = 1 if starts and rows[starts[-1]][2].endswith("x2") else 2
+begin = starts[-per_step] if len(starts) >= per_step else 0
+while begin > 0 and rows[begin][0] - rows[begin - 1][1] < 20000 and "fill_words" in rows[begin - 1][2]:
+    begin -= 1
 while begin > 0 and rows[begin][0] - rows[begin - 1][1] < 100000 and "copyBuffer" in rows[begin - 1][2]:
     begin -= 1
 step = rows[begin:]
