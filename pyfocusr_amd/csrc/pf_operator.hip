@@ -367,11 +367,23 @@ __global__ __launch_bounds__(PF_BLOCK) void k_orth_project(OrthArgs2 a2) {
                 acc.y -= hb * vv[u].y;
             }
         }
-        for (; b < count; ++b) {
-            const double hb = hs[b];
-            const double2 v = *reinterpret_cast<const double2*>(a.ws + (int64_t)orth_slot(a, b) * a.n_pad + i);
-            acc.x -= hb * v.x;
-            acc.y -= hb * v.y;
+        if (b < count) {
+            // the last 1-7 vectors (a local step of Lanczos with partial reorthogonalisation has 3-4 in all): their loads in
+            // flight together as well - one round trip instead of one per vector; a vector past the end is the last one
+            // again with coefficient 0 (x - 0 v = x exactly)
+            double2 vv[7];
+            double hh[7];
+#pragma unroll
+            for (int u = 0; u < 7; ++u) {
+                const int bu = b + u < count ? b + u : count - 1;
+                vv[u] = *reinterpret_cast<const double2*>(a.ws + (int64_t)orth_slot(a, bu) * a.n_pad + i);
+                hh[u] = b + u < count ? hs[bu] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 7; ++u) {
+                acc.x -= hh[u] * vv[u].x;
+                acc.y -= hh[u] * vv[u].y;
+            }
         }
         acc.x *= sc;
         acc.y *= sc;
@@ -387,7 +399,7 @@ __global__ __launch_bounds__(PF_BLOCK) void k_orth_project(OrthArgs2 a2) {
         for (; b + 2 <= count; b += 2) {
             const double h0 = hs[b], h1 = hs[b + 1];
             const double* v0 = a.ws + (int64_t)orth_slot(a, b) * a.n_pad + i0;
-            const double* v1 = v0 + a.n_pad;
+            const double* v1 = a.ws + (int64_t)orth_slot(a, b + 1) * a.n_pad + i0;
             double2 x0[P], x1[P];
 #pragma unroll
             for (int it = 0; it < P; ++it) x0[it] = *reinterpret_cast<const double2*>(v0 + (int64_t)it * (2 * PF_BLOCK));

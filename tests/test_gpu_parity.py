@@ -1623,6 +1623,50 @@ def test_hungarian_correspondence_small(golden, ctx):
         Focusr(a, b, icp_register_first=False, initial_correspondence_type="nearest", ctx=ctx)
 
 
+@pytest.mark.parametrize("n", [31250, 420000])
+def test_orth_split_two_ranges(hip, ctx, n):
+    """`pf_orth_split`: one Gram-Schmidt step over TWO ranges of slots (the local steps of Lanczos with partial
+    reorthogonalisation: locked null vectors + the last two basis vectors) against numpy - one pass, the device's second
+    pass, and a step that cancels digits (second pass by pf_orth_end); both kernel shapes (below / from 400k rows)."""
+    from pyfocusr_amd.meshgen import blob_mesh
+
+    rng = np.random.default_rng(1)
+    m = blob_mesh(n, seed=5)
+    g = hip.DeviceLaplacian(m.points, m.faces, ctx=ctx)
+    try:
+        g.ws_ensure(16)
+        Q, _ = np.linalg.qr(rng.standard_normal((n, 8)))
+        for s in range(8):
+            g.upload(s, Q[:, s])
+        B = Q[:, [0, 1, 5, 6]]
+        cancelling = Q[:, 6] * 1e3 + Q[:, 1] * 50 + 1e-3 * rng.standard_normal(n)
+        for wvec, passes, redone, twice in ((rng.standard_normal(n), False, False, False), (rng.standard_normal(n), True, False, False),
+                                            (cancelling, False, True, False), (cancelling, True, False, True)):
+            g.upload(9, wvec)
+            g.orth_device_passes(passes)
+            g.orth_split(5, 2)  # basis: slots 0, 1 and 5, 6
+            g.orth_begin(9, 0, 4, True)
+            h, nrm = g.orth_end()
+            got = g.download_slots(9, 1)[:, 0]
+            href = B.T @ wvec
+            wref = wvec - B @ href
+            h2 = B.T @ wref
+            wref -= B @ h2
+            assert (g.orth_redone, g.orth_twice) == (redone, twice)
+            np.testing.assert_allclose(h, href + h2, rtol=0, atol=1e-12 * np.max(np.abs(href)))
+            assert abs(nrm - np.linalg.norm(wref)) <= 1e-12 * nrm
+            assert np.max(np.abs(got - wref / np.linalg.norm(wref))) < 1e-12
+            assert np.max(np.abs(Q[:, [2, 3, 4, 7]].T @ got)) > 1e-5  # the slots in between were NOT part of the basis
+        # the setting is for one step: the next one takes the plain range again
+        g.upload(9, rng.standard_normal(n))
+        g.orth_device_passes(False)
+        g.orth_begin(9, 0, 8, True)
+        g.orth_end()
+        assert np.max(np.abs(Q.T @ g.download_slots(9, 1)[:, 0])) < 1e-13
+    finally:
+        g.close()
+
+
 def test_resident_kernel_bit_identical(golden, hip, ctx):
     """The whole recurrence in one resident kernel (operator in registers, x in LDS, boundary rows handed over through
     memory, pf_persist.hip) against one step per launch: same bits for both operators, single and paired, equal and
