@@ -269,7 +269,7 @@ def messy_250k_pair(ctx, n=250000, k=5, samples=5000, reps=3, check_cpu=True):
     return out
 
 
-def c5_1m_k10(ctx, n=1000000, k=10, samples=5000, reps=2):
+def c5_1m_k10(ctx, n=1000000, k=10, samples=5000, reps=3):
     """BASELINE config C5 on one GPU (untimed extra, like the bundled 15k pair): a 1M-vertex blob pair, k = 10 -
     stage times of the best of `reps` passes, the largest eigenpair residual, and the correspondence indices of 96
     source rows against a brute-force scan of all 1M target rows (left-to-right squared distances, as the kernel)."""
@@ -280,12 +280,14 @@ def c5_1m_k10(ctx, n=1000000, k=10, samples=5000, reps=2):
     for m in meshes:
         m._pf_device_mesh = _hip.DeviceMesh(m.points, m.faces, ctx=ctx)
     best = None
-    for _ in range(reps):
+    # (one untimed pass first: the ~2 GB of Krylov workspace come fresh from hipMalloc, and the resident kernel's hold-back
+    # calibration runs its trial launches - a first pass took 108 ms where the following ones take 81)
+    for rep in range(reps + 1):
         timers = dict(assembly=0.0, eigensolve=0.0, eigsort=0.0, knn=0.0, matvecs=0)
         t0 = time.perf_counter()
         idx, res, _, (vt, vs, w, _, _) = hot_path_step([ctx, ctx], meshes[0], meshes[1], k, samples, timers)
         dt = time.perf_counter() - t0
-        if best is None or dt < best[0]:
+        if rep > 0 and (best is None or dt < best[0]):
             best = (dt, timers, res)
     tgt, src = vt[:, :k] * w[None, :], vs[:, :k] * w[None, :]
     rows = np.linspace(0, n - 1, 96).astype(np.int64)

@@ -186,7 +186,7 @@ __device__ __forceinline__ double box_d2(const double (&q)[D], const double* __r
     return s;
 }
 
-constexpr int tree_group(int d) { return d <= 8 ? 4 : 2; }
+constexpr int tree_group(int d) { return d <= 12 ? 4 : 2; }
 constexpr int TREE_BATCH = 2;  // leaves scanned between two reductions of the lanes' bests
 
 template <int D>
