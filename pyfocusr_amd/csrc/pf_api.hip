@@ -405,7 +405,6 @@ void pf_destroy(pf_ctx* c) {
     if (c->pinned_scratch) hipHostFree(c->pinned_scratch);
     for (hipEvent_t ev : c->event_pool) hipEventDestroy(ev);
     pf_persist_release(c);
-    if (c->persist_done_ev) hipEventDestroy(c->persist_done_ev);
     if (c->persist_abort) hipHostFree(c->persist_abort);
     hipEventDestroy(c->ev0);
     hipEventDestroy(c->ev1);

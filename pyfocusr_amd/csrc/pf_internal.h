@@ -79,7 +79,6 @@ struct pf_ctx {
     uint32_t* persist_sync = nullptr;  // device word(s) of the resident Chebyshev kernel: its abort flag (pf_persist.hip)
     int32_t* persist_abort = nullptr;  // pinned host word: a barrier wait ran out
     void* persist_cal = nullptr;  // the hold-back calibration of this ctx's resident launches (pf_persist.hip: HoldCalibration)
-    hipEvent_t persist_done_ev = nullptr;  // recorded behind this ctx's latest resident launch (what a would-be owner of the path queries)
     double op_ms = 0.0;
     int64_t op_launches = 0;
     double op_bytes = 0.0;
