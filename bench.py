@@ -770,7 +770,7 @@ def main():
             "traffic_over_algorithmic": None if asm_traffic is None else asm_traffic / asm_bytes,
             "dispatches_per_step": stage_pmc.get("assembly", {}).get("dispatches_per_step"),
             "traffic_source": PMC_SUMMARY if asm_traffic is not None else None,
-            "note": "both meshes of the pair; wall time of the stage (the two builds run side by side on two streams)"}
+            "note": "both meshes of the pair; wall time of the stage (the two builds share their launches: pf_launch.h)"}
         try:
             if args.no_extras:
                 raise LookupError("skipped with --no-extras (one extra untimed step)")
