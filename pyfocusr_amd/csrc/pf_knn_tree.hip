@@ -78,13 +78,15 @@ __global__ __launch_bounds__(PF_BLOCK) void k_tree_keys(const double* __restrict
                                                         unsigned* __restrict__ keys, int32_t* __restrict__ vals) {
     const int64_t i = (int64_t)blockIdx.x * PF_BLOCK + threadIdx.x;
     if (i >= n) return;
-    const TreeGrid g = *gp;
+    // (the grid is read where it lies: a local copy indexed by the run-time axis number k would live in SCRATCH memory -
+    // 0.78 ms per million points instead of ~0.03)
+    const int na = gp->na, bits = gp->bits;
     unsigned key = 0;
-    const int cells = 1 << g.bits;
-    for (int k = 0; k < g.na; ++k) {
-        const double t = (pts[i * d + g.axis[k]] - g.lo[k]) * g.scale[k];
+    const int cells = 1 << bits;
+    for (int k = 0; k < na; ++k) {
+        const double t = (pts[i * d + gp->axis[k]] - gp->lo[k]) * gp->scale[k];
         const unsigned c = t > 0.0 ? (t >= (double)cells ? (unsigned)(cells - 1) : (unsigned)t) : 0u;
-        for (int j = 0; j < g.bits; ++j) key |= ((c >> j) & 1u) << (j * g.na + k);
+        for (int j = 0; j < bits; ++j) key |= ((c >> j) & 1u) << (j * na + k);
     }
     keys[i] = key;
     vals[i] = (int32_t)i;
