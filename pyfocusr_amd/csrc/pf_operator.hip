@@ -1325,14 +1325,16 @@ static int orth_launch_pass(const OrthArgs2& a2, int ng, int64_t n_chunks, int64
 
 // checks, pinned result buffer, event: everything of pf_orth_begin that comes before the launches
 static int orth_prepare(pf_graph* g, int32_t w, int32_t first, int32_t count, int32_t normalize) {
+    // pf_orth_split (this step only, whatever becomes of it): the basis is slots [first, first + split) and
+    // [first2, first2 + count - split)
+    const int32_t split_req = g->orth_split, first2_req = g->orth_first2;
+    g->orth_split = -1;
     PF_TRY(check_slots(g, w, 1, "pf_orth_begin"));
-    if (g->orth_split < 0) PF_TRY(check_slots(g, first, count, "pf_orth_begin"));
+    if (split_req < 0) PF_TRY(check_slots(g, first, count, "pf_orth_begin"));
     PF_CHECK(g->orth_pending < 0, PF_E_STATE, "pf_orth_begin: a previous pf_orth_begin has not been collected");
-    // pf_orth_split (one step only): the basis is slots [first, first + split) and [first2, first2 + count - split)
     g->orth_split_now = -1;
-    if (g->orth_split >= 0) {
-        const int32_t split = g->orth_split, first2 = g->orth_first2;
-        g->orth_split = -1;
+    if (split_req >= 0) {
+        const int32_t split = split_req, first2 = first2_req;
         PF_CHECK(split <= count && count > 0 && count < PF_ORTH_MAX, PF_E_ARG, "pf_orth_split: %d of %d vectors in the first range", split, count);
         PF_TRY(check_slots(g, first, split, "pf_orth_begin"));
         PF_TRY(check_slots(g, first2, count - split, "pf_orth_begin"));
