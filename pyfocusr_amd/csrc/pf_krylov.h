@@ -802,6 +802,22 @@ struct Solver {
                         PFK_TRY(ops->combine(A0, j, Y.data(), n_keep, B0));
                         PFK_TRY(ops->copy(A0 + j, B0 + n_keep, 1));  // the residual vector follows the kept block
                         PFK_TRY(ops->copy(B0, A0, n_keep + 1));
+                        if (pro && st.local_steps > 0 && restarts == 0) {
+                            // the basis of a run with local steps is orthogonal to 1e-9 only, and so are the Ritz vectors
+                            // kept from it: from here on every step is a full one, against a basis that is orthonormal
+                            // again - column by column, two passes each (a rare event: ~20 small steps)
+                            PFK_TRY(ops->orth_device_passes(true));
+                            PFK_TRY(ops->orth_always_twice(true, n_active < 4096));
+                            std::vector<double> hh((size_t)n_keep + 1);
+                            for (int col = 1; col <= n_keep; ++col) {
+                                double nrm_c = 0.0;
+                                bool redone_c = false;
+                                PFK_TRY(ops->orth_begin(A0 + col, A0, col));
+                                PFK_TRY(ops->orth_end(hh.data(), &nrm_c, &redone_c));
+                                PFK_CHECK(nrm_c > 0.5, PF_E_DEGENERATE, "pf_eigs_smallest: the kept Ritz vectors lost their independence (%g)", nrm_c);
+                            }
+                            PFK_TRY(ops->orth_always_twice(false, n_active < 4096));
+                        }
                         for (int col = 0; col < n_keep; ++col) {
                             double r = 0.0;
                             for (int i = 0; i < j; ++i) r += U[(size_t)i * j + col] * b[i];

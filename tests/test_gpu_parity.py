@@ -1623,6 +1623,37 @@ def test_hungarian_correspondence_small(golden, ctx):
         Focusr(a, b, icp_register_first=False, initial_correspondence_type="nearest", ctx=ctx)
 
 
+def test_eigs_partial_reorthogonalisation_on_device(hip, ctx, monkeypatch):
+    """`pf_eigs_smallest` on symmetric graphs runs Lanczos with partial reorthogonalisation (most steps against the null
+    vectors and the last two basis vectors, `stats.local_steps`): same eigenpairs as with full Gram-Schmidt in every step
+    (`PF_EIGS_PRO=0`) on a blob with two components and on a torus grid - every eigenvalue double, one thick restart, the
+    kept Ritz vectors orthonormalised again."""
+    from pyfocusr_amd import Graph, PolyMesh
+    from pyfocusr_amd.meshgen import blob_mesh
+
+    nu, nv = 128, 64
+    uu, vv = np.meshgrid(np.arange(nu), np.arange(nv), indexing="ij")
+    au, av = 2 * np.pi * uu / nu, 2 * np.pi * vv / nv
+    pts = np.stack([(3 + np.cos(av)) * np.cos(au), (3 + np.cos(av)) * np.sin(au), np.sin(av)], axis=-1).reshape(-1, 3)
+    a, b, c, d = uu * nv + vv, ((uu + 1) % nu) * nv + vv, ((uu + 1) % nu) * nv + (vv + 1) % nv, uu * nv + (vv + 1) % nv
+    faces = np.concatenate([np.stack([a, b, c], -1).reshape(-1, 3), np.stack([a, c, d], -1).reshape(-1, 3)]).astype(np.int32)
+    m1, m2 = blob_mesh(25000, seed=40744), blob_mesh(6250, seed=657489)  # (the fuzzer's case that lost its Ritz vectors once)
+    two = PolyMesh(np.concatenate([m1.points, m2.points + 300.0]), np.concatenate([m1.faces, m2.faces + 25000]))
+    for mesh, k, restarts in ((PolyMesh(pts, faces), 9, 1), (two, 4, 0)):
+        g = Graph(mesh, n_spectral_features=k, norm_eig_vecs=False, n_rand_samples=10**9, ctx=ctx, verbose=False)
+        g.get_graph_spectrum()
+        monkeypatch.setenv("PF_EIGS_PRO", "0")
+        vals_f, vecs_f, st_f = g.device.eigs_smallest(k)
+        monkeypatch.delenv("PF_EIGS_PRO")
+        vals, vecs, st = g.device.eigs_smallest(k)
+        assert st_f["local_steps"] == 0 and st["local_steps"] >= 0.5 * st["outer_steps"], (st, st_f)
+        assert st["restarts"] == st_f["restarts"] == restarts and abs(st["outer_steps"] - st_f["outer_steps"]) <= 4
+        np.testing.assert_allclose(vals, vals_f, rtol=1e-12)
+        assert st["max_residual"] < 5e-12
+        np.testing.assert_allclose(g.eig_vals[:k], vals, rtol=1e-12)  # (the public path took the same solver)
+        g.device.close()
+
+
 @pytest.mark.parametrize("n", [31250, 420000])
 def test_orth_split_two_ranges(hip, ctx, n):
     """`pf_orth_split`: one Gram-Schmidt step over TWO ranges of slots (the local steps of Lanczos with partial

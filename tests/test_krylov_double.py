@@ -318,3 +318,29 @@ def test_cpp_driver_partial_reorthogonalisation(monkeypatch):
     np.testing.assert_allclose(vb, vals, rtol=1e-11)
     L2 = orc.graph_matrices(pts, faces)[3]
     assert np.abs(L2 @ xa - xa * va[None, :]).max() < 1e-10
+
+
+def test_cpp_driver_partial_reorthogonalisation_degenerate_and_restart(monkeypatch):
+    """A torus grid (every eigenvalue of its Laplacian twice, by symmetry) needs a thick restart: the Ritz vectors kept from
+    a basis that partial reorthogonalisation left orthogonal to 1e-9 only are orthonormalised again before the iteration
+    goes on with full steps - both copies of every eigenvalue, residuals at the level of a run with full Gram-Schmidt,
+    also when the steps take one Gram-Schmidt pass like the device's (before: 78 instead of 61 steps, residual 3e-10)."""
+    nu, nv, k = 128, 64, 9
+    uu, vv = np.meshgrid(np.arange(nu), np.arange(nv), indexing="ij")
+    au, av = 2 * np.pi * uu / nu, 2 * np.pi * vv / nv
+    pts = np.stack([(3 + np.cos(av)) * np.cos(au), (3 + np.cos(av)) * np.sin(au), np.sin(av)], axis=-1).reshape(-1, 3)
+    a, b, c, d = uu * nv + vv, ((uu + 1) % nu) * nv + vv, ((uu + 1) % nu) * nv + (vv + 1) % nv, uu * nv + (vv + 1) % nv
+    faces = np.concatenate([np.stack([a, b, c], -1).reshape(-1, 3), np.stack([a, c, d], -1).reshape(-1, 3)]).astype(np.int32)
+    W = W_of(pts, faces)
+    monkeypatch.setenv("PF_EIGS_PRO", "0")
+    vals_f, _, st_f, res_f = kd.solve(W, k)
+    monkeypatch.delenv("PF_EIGS_PRO")
+    for one_pass in (False, True):
+        if one_pass:
+            monkeypatch.setenv("TD_ONE_PASS", "1")
+        vals, vecs, st, res = kd.solve(W, k)
+        assert st["restarts"] >= 1 and st["local_steps"] > 0, st
+        assert st["outer_steps"] <= st_f["outer_steps"] + 6, (st, st_f)
+        np.testing.assert_allclose(vals, vals_f, rtol=1e-12)
+        assert res.max() < 1e-11
+        assert np.abs(vals[0] / vals[1] - 1.0) < 1e-9 and np.abs(vals[2] / vals[3] - 1.0) < 1e-9  # the pairs
