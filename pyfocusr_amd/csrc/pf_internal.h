@@ -114,6 +114,8 @@ struct pf_ctx {
     pf_knn_tree knn_tree;
     bool knn_count_on = false;              // pf_knn_count: the counting instantiation of k_knn_coop
     unsigned long long* knn_visited = nullptr;
+    size_t knn_visited_words = 0;
+    int64_t knn_visited_waves = 0;
     int32_t knn_mode = 0;  // 0: by depth (box hierarchy for k = 1, d >= PF_KNN_TREE_MIN_D = 7), 1: always the grid, 2: always the hierarchy
     // operator timing: event pairs recorded around filter applications, resolved lazily in pf_timing_get so
     // that timing never blocks the host (the solver queues the next application while this one runs)

@@ -456,6 +456,8 @@ __global__ __launch_bounds__(PF_BLOCK) void k_knn_coop(const double* __restrict_
                                                        double* __restrict__ d2_out, unsigned long long* __restrict__ visited = nullptr) {
     constexpr int G = knn_group(D);
     unsigned long long seen = 0;  // (wave-uniform)
+    const unsigned long long t_begin = COUNT ? __builtin_amdgcn_s_memrealtime() : 0ull;  // (100 MHz)
+    unsigned long long n_chunks = 0, n_scans = 0, t_scan = 0, t_bounds = 0;  // (COUNT only)
     const KnnGrid g = *gp;
     const int lane = threadIdx.x & (PF_WAVE - 1);
     const int64_t group = (int64_t)blockIdx.x * (PF_BLOCK / PF_WAVE) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x / PF_WAVE));
@@ -500,6 +502,7 @@ __global__ __launch_bounds__(PF_BLOCK) void k_knn_coop(const double* __restrict_
             if (lane >= off) inc += up;
         }
         const int32_t total = __builtin_amdgcn_readlane(inc, PF_WAVE - 1);
+        if constexpr (COUNT) n_chunks += (unsigned long long)total, n_scans += 1ull;
         for (int32_t j = 0; j < total; ++j) {
             const int row = (int)__popcll(__ballot(inc <= j));  // lanes whose rows end before chunk j
             const int32_t first = row > 0 ? __builtin_amdgcn_readlane(inc, row - 1) : 0;
@@ -565,8 +568,12 @@ __global__ __launch_bounds__(PF_BLOCK) void k_knn_coop(const double* __restrict_
     for (int ring = 1; ring <= 4; ++ring) {
         rx0 = max(ux0 - ring, 0), rx1 = min(ux1 + ring, g.r0 - 1);
         ry0 = max(uy0 - ring, 0), ry1 = min(uy1 + ring, g.r1 - 1);
+        unsigned long long ta = COUNT ? __builtin_amdgcn_s_memrealtime() : 0ull;
         for (int yb = ry0; yb <= ry1; yb += PF_WAVE) scan_rows(yb + lane <= ry1 ? yb + lane : -1, rx0, rx1);
-        if (bounds(x0, x1, y0, y1)) break;
+        unsigned long long tb = COUNT ? __builtin_amdgcn_s_memrealtime() : 0ull;
+        const bool all_bounded = bounds(x0, x1, y0, y1);
+        if constexpr (COUNT) t_scan += tb - ta, t_bounds += __builtin_amdgcn_s_memrealtime() - tb;
+        if (all_bounded) break;
     }
     // phase 2: the rows of the rectangle from the group's own row outwards, a few at a time (4 + 4, 8 + 8, ... 32 + 32), and
     // after each batch the rectangle is re-derived from what has been found: bounds only shrink, and when the first one
@@ -577,12 +584,15 @@ __global__ __launch_bounds__(PF_BLOCK) void k_knn_coop(const double* __restrict_
         int w = 4;
         while (lo > y0 || hi < y1) {
             const int na = max(min(w, y1 - hi), 0), nb = max(min(w, lo - y0), 0);  // (a side that is finished may be past its bound)
+            unsigned long long ta = COUNT ? __builtin_amdgcn_s_memrealtime() : 0ull;
             scan_rows(lane < na ? hi + 1 + lane : (lane < na + nb ? lo - 1 - (lane - na) : -1), x0, x1);
+            unsigned long long tb = COUNT ? __builtin_amdgcn_s_memrealtime() : 0ull;
             hi += na;
             lo -= nb;
             w = min(2 * w, PF_WAVE / 2);
             int nx0, nx1, ny0, ny1;
             bounds(nx0, nx1, ny0, ny1);
+            if constexpr (COUNT) t_scan += tb - ta, t_bounds += __builtin_amdgcn_s_memrealtime() - tb;
             x0 = max(x0, nx0), x1 = min(x1, nx1);
             y0 = max(y0, ny0), y1 = min(y1, ny1);
         }
@@ -596,7 +606,18 @@ __global__ __launch_bounds__(PF_BLOCK) void k_knn_coop(const double* __restrict_
         }
     }
     if constexpr (COUNT) {
-        if (lane == 0 && visited) atomicAdd(visited, seen * (unsigned long long)nq);
+        if (lane == 0 && visited) {
+            atomicAdd(visited, seen * (unsigned long long)nq);
+            // the wave's own figures (diagnostics: pf_knn_wave_stats), one record per wave behind the counter - no atomics
+            // (nine of them per wave on one cache line made the counted search six times slower)
+            unsigned long long* rec = visited + 8 + 8 * group;
+            rec[0] = __builtin_amdgcn_s_memrealtime() - t_begin;
+            rec[1] = seen;
+            rec[2] = n_chunks;
+            rec[3] = n_scans;
+            rec[4] = t_scan;
+            rec[5] = t_bounds;
+        }
     }
 }
 
@@ -688,8 +709,18 @@ int launch_knn_k(pf_ctx* c) {
     if constexpr (K == 1 && D <= 9) {
         const int64_t waves = (c->knn_nqry + knn_group(D) - 1) / knn_group(D);
         if (c->knn_count_on) {
-            if (!c->knn_visited) PF_HIP(pf_malloc(c->stream, (void**)&c->knn_visited, sizeof(unsigned long long)));
-            PF_HIP(hipMemsetAsync(c->knn_visited, 0, sizeof(unsigned long long), c->stream));
+            // [0] pairs, then from [8] on eight words per wave (pf_knn_wave_stats)
+            const size_t words = 8 + 8 * (size_t)waves;
+            if (c->knn_visited && c->knn_visited_words < words) {
+                pf_free(c->stream, c->knn_visited);
+                c->knn_visited = nullptr;
+            }
+            if (!c->knn_visited) {
+                PF_HIP(pf_malloc(c->stream, (void**)&c->knn_visited, words * sizeof(unsigned long long)));
+                c->knn_visited_words = words;
+            }
+            c->knn_visited_waves = waves;
+            PF_HIP(hipMemsetAsync(c->knn_visited, 0, words * sizeof(unsigned long long), c->stream));
             k_knn_coop<D, true><<<(unsigned)((waves + PF_BLOCK / PF_WAVE - 1) / (PF_BLOCK / PF_WAVE)), PF_BLOCK, 0, c->stream>>>(
                 c->knn_ref_soa, c->knn_ref_ld, c->knn_ref_orig, c->knn_cell_start, c->knn_qry_s, c->knn_qry_orig, c->knn_nqry,
                 (const KnnGrid*)c->knn_grid, c->knn_idx, c->knn_d2, c->knn_visited);
@@ -984,6 +1015,31 @@ int pf_knn_count(pf_ctx* c, int32_t enable_counting, int64_t* pairs) {
     }
     if (pairs) *pairs = (int64_t)h;
     c->knn_count_on = enable_counting != 0;
+    return PF_OK;
+}
+
+/* Diagnostics of the last COUNTED grid search: the waves' own run times (10 ns ticks of the device's constant clock) -
+ * their sum, the slowest wave, the number of waves - and the candidates of the wave that scanned most. */
+int pf_knn_wave_stats(pf_ctx* c, double* sum_us, double* max_us, int64_t* waves, int64_t* max_candidates, double* detail /* [4]: chunks, scans, scan us, bounds us (sums) */) {
+    PF_CHECK(c != nullptr, PF_E_ARG, "pf_knn_wave_stats: ctx is NULL");
+    const int64_t nw = c->knn_visited ? c->knn_visited_waves : 0;
+    std::vector<unsigned long long> h((size_t)(8 * nw), 0ull);
+    if (nw > 0) {
+        PF_HIP(hipMemcpyAsync(h.data(), c->knn_visited + 8, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost, c->stream));
+        PF_HIP(hipStreamSynchronize(c->stream));
+    }
+    unsigned long long sum = 0, mx = 0, mc = 0, ch = 0, sc = 0, ts = 0, tb = 0;
+    for (int64_t w = 0; w < nw; ++w) {
+        const unsigned long long* r = h.data() + 8 * w;
+        sum += r[0];
+        if (r[0] > mx) mx = r[0], mc = r[1];
+        ch += r[2], sc += r[3], ts += r[4], tb += r[5];
+    }
+    if (sum_us) *sum_us = 0.01 * (double)sum;
+    if (max_us) *max_us = 0.01 * (double)mx;
+    if (waves) *waves = nw;
+    if (max_candidates) *max_candidates = (int64_t)mc;
+    if (detail) detail[0] = (double)ch, detail[1] = (double)sc, detail[2] = 0.01 * (double)ts, detail[3] = 0.01 * (double)tb;
     return PF_OK;
 }
 
