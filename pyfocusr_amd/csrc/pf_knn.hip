@@ -457,7 +457,7 @@ __global__ __launch_bounds__(PF_BLOCK) void k_knn_coop(const double* __restrict_
     constexpr int G = knn_group(D);
     unsigned long long seen = 0;  // (wave-uniform)
     const unsigned long long t_begin = COUNT ? __builtin_amdgcn_s_memrealtime() : 0ull;  // (100 MHz)
-    unsigned long long n_chunks = 0, n_scans = 0, t_scan = 0, t_bounds = 0;  // (COUNT only)
+    unsigned long long n_chunks = 0, n_scans = 0, t_scan = 0, t_bounds = 0, n_pass = 0;  // (COUNT only)
     const KnnGrid g = *gp;
     const int lane = threadIdx.x & (PF_WAVE - 1);
     const int64_t group = (int64_t)blockIdx.x * (PF_BLOCK / PF_WAVE) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x / PF_WAVE));
@@ -513,6 +513,18 @@ __global__ __launch_bounds__(PF_BLOCK) void k_knn_coop(const double* __restrict_
 #pragma unroll
                 for (int c = 0; c < D; ++c) x[c] = soa[(int64_t)c * ld + r];
                 const int32_t o = ref_orig[r];
+                if constexpr (COUNT) {  // how many candidates survive the coordinates OUTSIDE the grid plane, against the bounds at hand
+                    bool pass = false;
+#pragma unroll
+                    for (int i = 0; i < G; ++i) {
+                        double s3 = 0.0;
+#pragma unroll
+                        for (int c = 0; c < D; ++c)
+                            if (c != g.a0 && c != g.a1) s3 += (q[i][c] - x[c]) * (q[i][c] - x[c]);
+                        pass = pass || s3 <= best[i];
+                    }
+                    n_pass += (unsigned long long)__popcll(__ballot(pass));
+                }
 #pragma unroll
                 for (int i = 0; i < G; ++i) {
                     double s = 0.0;
@@ -617,6 +629,7 @@ __global__ __launch_bounds__(PF_BLOCK) void k_knn_coop(const double* __restrict_
             rec[3] = n_scans;
             rec[4] = t_scan;
             rec[5] = t_bounds;
+            rec[6] = n_pass;
         }
     }
 }
@@ -1020,7 +1033,7 @@ int pf_knn_count(pf_ctx* c, int32_t enable_counting, int64_t* pairs) {
 
 /* Diagnostics of the last COUNTED grid search: the waves' own run times (10 ns ticks of the device's constant clock) -
  * their sum, the slowest wave, the number of waves - and the candidates of the wave that scanned most. */
-int pf_knn_wave_stats(pf_ctx* c, double* sum_us, double* max_us, int64_t* waves, int64_t* max_candidates, double* detail /* [4]: chunks, scans, scan us, bounds us (sums) */) {
+int pf_knn_wave_stats(pf_ctx* c, double* sum_us, double* max_us, int64_t* waves, int64_t* max_candidates, double* detail /* [5]: chunks, scans, scan us, bounds us, candidates that pass the off-plane coordinates (sums) */) {
     PF_CHECK(c != nullptr, PF_E_ARG, "pf_knn_wave_stats: ctx is NULL");
     const int64_t nw = c->knn_visited ? c->knn_visited_waves : 0;
     std::vector<unsigned long long> h((size_t)(8 * nw), 0ull);
@@ -1028,18 +1041,18 @@ int pf_knn_wave_stats(pf_ctx* c, double* sum_us, double* max_us, int64_t* waves,
         PF_HIP(hipMemcpyAsync(h.data(), c->knn_visited + 8, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost, c->stream));
         PF_HIP(hipStreamSynchronize(c->stream));
     }
-    unsigned long long sum = 0, mx = 0, mc = 0, ch = 0, sc = 0, ts = 0, tb = 0;
+    unsigned long long sum = 0, mx = 0, mc = 0, ch = 0, sc = 0, ts = 0, tb = 0, np = 0;
     for (int64_t w = 0; w < nw; ++w) {
         const unsigned long long* r = h.data() + 8 * w;
         sum += r[0];
         if (r[0] > mx) mx = r[0], mc = r[1];
-        ch += r[2], sc += r[3], ts += r[4], tb += r[5];
+        ch += r[2], sc += r[3], ts += r[4], tb += r[5], np += r[6];
     }
     if (sum_us) *sum_us = 0.01 * (double)sum;
     if (max_us) *max_us = 0.01 * (double)mx;
     if (waves) *waves = nw;
     if (max_candidates) *max_candidates = (int64_t)mc;
-    if (detail) detail[0] = (double)ch, detail[1] = (double)sc, detail[2] = 0.01 * (double)ts, detail[3] = 0.01 * (double)tb;
+    if (detail) detail[0] = (double)ch, detail[1] = (double)sc, detail[2] = 0.01 * (double)ts, detail[3] = 0.01 * (double)tb, detail[4] = (double)np;
     return PF_OK;
 }
 

@@ -31,7 +31,7 @@ for rep in range(3):
 dt = timers["knn"]
 pairs = ctx.knn_count(False)
 s, m, nw, mc = C.c_double(), C.c_double(), C.c_int64(), C.c_int64()
-det = (C.c_double * 4)()
+det = (C.c_double * 5)()
 lib.pf_knn_wave_stats(ctx._h, C.byref(s), C.byref(m), C.byref(nw), C.byref(mc), det)
 slots = 256 * 4 * 6
 print("counted search %.2f ms wall; %d waves, %.0f pairs per query" % (1e3 * dt, nw.value, pairs / n))
@@ -39,3 +39,4 @@ print("wave run time: average %.1f us, slowest %.1f us (scanned %d candidates x 
     s.value / max(nw.value, 1), m.value, mc.value, 1e-3 * s.value, 1e-3 * s.value / slots, slots))
 print("per wave: %.1f chunks in %.1f scans; scans %.1f us, bounds %.1f us, rest %.1f us" % (det[0] / nw.value, det[1] / nw.value, det[2] / nw.value, det[3] / nw.value,
       (s.value - det[2] - det[3]) / nw.value))
+print("candidates that pass the coordinates outside the grid plane (against the bounds at hand): %.1f per chunk of 64 lanes" % (det[4] / max(det[0], 1)))
