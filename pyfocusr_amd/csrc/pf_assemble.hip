@@ -1120,6 +1120,7 @@ void pf_graph_free(pf_graph* g) {
     pf_free(st, g->ws);
     pf_free(st, g->partials);
     pf_free(st, g->coef);
+    pf_free(st, g->orth_counter);
     if (g->orth_pending >= 0 || g->small_pending > 0 || g->px_state == -2) pfl::sync(st);  // a step or a result nobody collected still writes its pinned buffer
     if (g->orth_host) g->ctx->pinned_pool.emplace_back(g->orth_host_cap, g->orth_host);
     if (g->orth_ev) g->ctx->event_pool.push_back(g->orth_ev);

@@ -277,6 +277,9 @@ struct pf_graph {
     int32_t orth_w = 0, orth_first = 0, orth_normalize = 0;  // arguments of the orth in flight (pf_orth_end's second pass)
     int32_t orth_redone = 0;     // the last pf_orth_end ran the second Gram-Schmidt pass itself
     double orth_serial = 0.0;    // tickets handed to the fused Gram-Schmidt kernels so far
+    unsigned long long* orth_counter = nullptr;  // arrivals at the grid-wide wait of k_orth_local, summed over the graph's life
+    unsigned long long orth_arrivals = 0;        // ... as the host counts them
+    uint64_t orth_epoch = 0;                     // pf_persist_abort_epoch() the counter was last zeroed under
     int32_t orth_split = -1, orth_first2 = 0;          // pf_orth_split: for the next step ...
     int32_t orth_split_now = -1, orth_first2_now = 0;  // ... and the step in flight
     double orth_ticket = 0.0;    // ticket of the step in flight (0: that step reports through orth_ev instead)
@@ -392,5 +395,8 @@ void pf_persist_release(pf_ctx* ctx);  // pf_destroy: another ctx may take the r
 int pf_window_slots_prepare(pf_graph* g);  // px_* of the graph (see pf_graph)
 int pf_window_slots_begin(pf_graph* g);    // ... queued only; _prepare collects
 bool pf_persist_enabled();
+bool pf_persist_trusted();  // kernels with grid-wide waits may be used (enabled, not suspended after a timeout)
+uint64_t pf_persist_abort_epoch();  // bumped by every bounded wait that ran out (device counters of that time are void)
+int pf_persist_sync_ensure(pf_ctx* ctx);  // ctx->persist_sync / persist_abort exist from here on
 int pf_window_rings_prepare(pf_graph* g);  // the second-ring structures on top of them (px2_state)
 void pf_window_slots_free(pf_graph* g);

@@ -13,6 +13,8 @@
 #include <string.h>
 
 #include <algorithm>
+#include <map>
+#include <mutex>
 #include <vector>
 
 #include "pf_internal.h"
@@ -237,6 +239,12 @@ struct OrthArgs {
     // then always reads the final vector - no pf_orth_redone, no repeated application.
     int32_t pass;      // 0: one pass, a raised verdict is the host's business (pf_orth_end); 1 / 2: first / second of two; -1: not this graph
     double* verdict;   // device copy of pass 1's verdict
+    // k_orth_local (the whole step in one launch): arrivals at its grid-wide wait, the count that ends the wait, where a
+    // wait that ran out is reported (the resident filter kernel's abort words)
+    unsigned long long* counter;
+    unsigned long long target;
+    uint32_t* abort_flag;
+    int32_t* host_abort;
 };
 struct OrthArgs2 {
     OrthArgs g[2];
@@ -431,6 +439,132 @@ __global__ __launch_bounds__(PF_BLOCK) void k_orth_project(OrthArgs2 a2) {
             acc[it].y *= sc;
             *reinterpret_cast<double2*>(a.ws + (int64_t)a.wslot * a.n_pad + i0 + (int64_t)it * (2 * PF_BLOCK)) = acc[it];
         }
+    }
+}
+// A LOCAL Gram-Schmidt step (Lanczos with partial reorthogonalisation: the null vectors and the last two basis vectors, 4
+// at most) in ONE launch.  A block owns a 4096-row chunk: it loads w and the basis vectors' pieces once, forms the chunk's
+// partial sums exactly as k_orth_dots does, publishes them, waits until every chunk of the graph has (a counter, bounded),
+// sums the partials exactly as k_orth_project does and projects the rows it still holds in registers - the same
+// operations in the same order on every number: the same bits as the two launches, one kernel boundary less (~5 us of a
+// ~16 us step).  The grid is one block per chunk and graph (122 at 250k, 490 at 1M rows): all resident.
+constexpr int PF_ORTH_LOCAL_MAX = 4;
+__global__ __launch_bounds__(PF_BLOCK) void k_orth_local(OrthArgs2 a2) {
+    __shared__ double red[PF_ORTH_LOCAL_MAX + 1][PF_BLOCK / PF_WAVE];
+    __shared__ double hs[PF_ORTH_LOCAL_MAX + 1];
+    __shared__ double s_scale, s_after, s_redo;
+    __shared__ int s_ok;
+    const OrthArgs& a = a2.g[blockIdx.z];
+    const int64_t chunk = blockIdx.x;
+    if (a.pass < 0 || chunk >= a.n_chunks) return;  // (block-uniform: the grid is sized for the larger graph of a pair)
+    const int32_t count = a.count;
+    const int lane = threadIdx.x & (PF_WAVE - 1);
+    double* w = a.ws + (int64_t)a.wslot * a.n_pad;
+    const int64_t lo = chunk * PF_DOT_CHUNK;
+    constexpr int PAIRS = PF_DOT_CHUNK / (2 * PF_BLOCK);
+    double2 cs[PAIRS], xs[PF_ORTH_LOCAL_MAX][PAIRS];
+#pragma unroll
+    for (int it = 0; it < PAIRS; ++it) cs[it] = *reinterpret_cast<const double2*>(w + lo + 2 * threadIdx.x + (int64_t)it * (2 * PF_BLOCK));
+#pragma unroll
+    for (int u = 0; u < PF_ORTH_LOCAL_MAX; ++u) {
+        const double* v = a.ws + (int64_t)orth_slot(a, u < count ? u : count - 1) * a.n_pad;  // (past the end: the last one again, unused)
+#pragma unroll
+        for (int it = 0; it < PAIRS; ++it) xs[u][it] = *reinterpret_cast<const double2*>(v + lo + 2 * threadIdx.x + (int64_t)it * (2 * PF_BLOCK));
+    }
+    // ---- the chunk's partial sums: k_orth_dots' operations in its order (column `count`: |w|^2)
+#pragma unroll
+    for (int u = 0; u <= PF_ORTH_LOCAL_MAX; ++u) {
+        if (u > count) continue;
+        double s = 0.0;
+#pragma unroll
+        for (int it = 0; it < PAIRS; ++it) {
+            const double2 x = u == count ? cs[it] : xs[u < PF_ORTH_LOCAL_MAX ? u : 0][it];
+            s += x.x * cs[it].x;
+            s += x.y * cs[it].y;
+        }
+#pragma unroll
+        for (int off = PF_WAVE / 2; off > 0; off >>= 1) s += __shfl_down(s, off, PF_WAVE);
+        if (lane == 0) red[u][threadIdx.x / PF_WAVE] = s;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x <= count) {
+        const double p = (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(a.partial) + (int64_t)threadIdx.x * a.n_chunks + chunk,
+                           (unsigned long long)__double_as_longlong(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // in memory before the block says it has arrived
+    }
+    __syncthreads();
+    // ---- every chunk of this graph has published: one arrival per block, a bounded wait
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(a.counter, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        int ok = 1;
+        while (__hip_atomic_load(a.counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < a.target) {
+            if (__builtin_amdgcn_s_memrealtime() - t0 > 20000000ull ||  // 0.2 s of the 100 MHz clock
+                __hip_atomic_load(a.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                __hip_atomic_store(a.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                *a.host_abort = 1;
+                ok = 0;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        s_ok = ok;
+    }
+    __syncthreads();
+    if (!s_ok) return;
+    // ---- the sums of the partials: k_orth_project's operations in its order (read from where the other XCDs wrote them)
+    for (int b = threadIdx.x / PF_WAVE; b < count + 1; b += PF_BLOCK / PF_WAVE) {
+        double s = 0.0;
+        for (int64_t k = lane; k < a.n_chunks; k += PF_WAVE)
+            s += __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<unsigned long long*>(a.partial) + (int64_t)b * a.n_chunks + k,
+                                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+#pragma unroll
+        for (int off = PF_WAVE / 2; off > 0; off >>= 1) s += __shfl_down(s, off, PF_WAVE);
+        if (lane == 0) hs[b] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double sum = 0.0;
+        for (int b = 0; b < count; ++b) sum += hs[b] * hs[b];
+        const double before = hs[count], after = before - sum;
+        // (one pass: a raised verdict is pf_orth_end's business.  The flag goes through a vector register on purpose: this
+        // compiler turned `fine ? 0.0 : 1.0` into an s_cselect on SCC behind a v_cmp that sets VCC - the verdict then was
+        // whatever the last scalar compare had left)
+        int fine = after >= a.thresh * before ? 1 : 0;
+        asm volatile("" : "+v"(fine));
+        s_redo = fine ? 0.0 : 1.0;
+        s_after = after;
+        s_scale = (fine && a.normalize && after > 1e-280) ? 1.0 / sqrt(after) : 1.0;
+    }
+    __syncthreads();
+    if (chunk == 0) {
+        for (int b = threadIdx.x; b < count; b += PF_BLOCK) {
+            a.hsum[b] = hs[b];
+            a.host_out[b] = hs[b];
+        }
+        if (threadIdx.x == 0) {
+            *a.nrm2 = s_after;
+            a.host_out[count] = s_after;
+            a.host_out[count + 1] = s_redo;
+        }
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(a.host_out + count + 2, a.ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    const double sc = s_scale;
+#pragma unroll
+    for (int it = 0; it < PAIRS; ++it) {
+        double2 acc = cs[it];
+#pragma unroll
+        for (int u = 0; u < PF_ORTH_LOCAL_MAX; ++u) {
+            if (u >= count) continue;
+            const double hb = hs[u];
+            acc.x -= hb * xs[u][it].x;
+            acc.y -= hb * xs[u][it].y;
+        }
+        acc.x *= sc;
+        acc.y *= sc;
+        *reinterpret_cast<double2*>(w + lo + 2 * threadIdx.x + (int64_t)it * (2 * PF_BLOCK)) = acc;
     }
 }
 __global__ __launch_bounds__(PF_BLOCK) void k_scale_finishing(double* __restrict__ x, int64_t n_pad, const double* __restrict__ partial,
@@ -1309,7 +1443,54 @@ int pf_dots(pf_graph* g, int32_t w, int32_t first, int32_t count, double* out) {
 
 // the two launches of one Gram-Schmidt pass (of one graph, or of both graphs of a pair: ng = 2); bases beyond the Infinity
 // Cache (>= 400k rows: 1M x 50 vectors = 400 MB) take the shapes with several vectors / a whole chunk per block
-static int orth_launch_pass(const OrthArgs2& a2, int ng, int64_t n_chunks, int64_t n_pad, int32_t count, hipStream_t st) {
+// blocks of k_orth_local the device holds at once (0: the one-launch step is switched off - PF_ORTH_LOCAL=0 - or unknown)
+static int64_t orth_local_capacity(int device) {
+    static std::mutex m;
+    static std::map<int, int64_t> cap;
+    std::lock_guard<std::mutex> lk(m);
+    auto it = cap.find(device);
+    if (it != cap.end()) return it->second;
+    int64_t c = 0;
+    const char* e = getenv("PF_ORTH_LOCAL");
+    if (!(e && e[0] == '0')) {
+        int per_cu = 0;
+        hipDeviceProp_t prop;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(k_orth_local), PF_BLOCK, 0) == hipSuccess &&
+            hipGetDeviceProperties(&prop, device) == hipSuccess)
+            c = (int64_t)per_cu * prop.multiProcessorCount;
+        else
+            (void)hipGetLastError();
+    }
+    cap[device] = c;
+    return c;
+}
+
+static int orth_launch_pass(OrthArgs2& a2, int ng, int64_t n_chunks, int64_t n_pad, int32_t count, hipStream_t st, pf_graph* const* gs = nullptr) {
+    // a local step (4 vectors at most, one pass) of every graph in the launch: the whole step in ONE kernel
+    bool local = gs != nullptr && count <= PF_ORTH_LOCAL_MAX && count >= 1;
+    for (int q = 0; q < ng && local; ++q) local = a2.g[q].pass == 0 && a2.g[q].count <= PF_ORTH_LOCAL_MAX && a2.g[q].count >= 1;
+    if (local && pf_persist_trusted() && n_chunks * ng <= orth_local_capacity(gs[0]->ctx->device)) {
+        pf_ctx* ctx = gs[0]->ctx;
+        PF_TRY(pf_persist_sync_ensure(ctx));
+        for (int q = 0; q < ng; ++q) {
+            pf_graph* g = gs[q];
+            const uint64_t epoch = pf_persist_abort_epoch();
+            if (!g->orth_counter) PF_HIP(pf_malloc(st, (void**)&g->orth_counter, sizeof(unsigned long long)));
+            if (g->orth_epoch != epoch) {  // new, or a bounded wait ran out since: whatever had arrived then is void
+                PF_HIP(hipMemsetAsync(g->orth_counter, 0, sizeof(unsigned long long), st));
+                g->orth_arrivals = 0;
+                g->orth_epoch = epoch;
+            }
+            g->orth_arrivals += (unsigned long long)g->n_chunks;
+            a2.g[q].counter = g->orth_counter;
+            a2.g[q].target = g->orth_arrivals;
+            a2.g[q].abort_flag = ctx->persist_sync;
+            a2.g[q].host_abort = ctx->persist_abort;
+        }
+        k_orth_local<<<dim3((unsigned)n_chunks, 1u, (unsigned)ng), PF_BLOCK, 0, st>>>(a2);
+        PF_HIP(hipGetLastError());
+        return PF_OK;
+    }
     if (n_pad >= 400000) {
         k_orth_dots<4><<<dim3((unsigned)n_chunks, (unsigned)((count + 1 + 3) / 4), (unsigned)ng), PF_BLOCK, 0, st>>>(a2);
         PF_HIP(hipGetLastError());
@@ -1416,7 +1597,8 @@ int pf_orth_begin(pf_graph* g, int32_t w, int32_t first, int32_t count, int32_t 
         // dot products; the second Gram-Schmidt pass is pf_orth_end's business in the rare step that needs it
         OrthArgs2 a2{};
         a2.g[0] = orth_args(g, w, first, count, normalize);
-        PF_TRY(orth_launch_pass(a2, 1, g->n_chunks, g->n_pad, count, st));
+        pf_graph* const one[1] = {g};
+        PF_TRY(orth_launch_pass(a2, 1, g->n_chunks, g->n_pad, count, st, one));
         if (a2.g[0].pass == 1) {  // the second pass, on the device's own verdict
             a2.g[0].pass = 2;
             PF_TRY(orth_launch_pass(a2, 1, g->n_chunks, g->n_pad, count, st));
@@ -1464,7 +1646,8 @@ int pf_orth_begin2(pf_graph* ga, int32_t w_a, int32_t first_a, int32_t count_a, 
     a2.g[1] = orth_args(gb, w_b, first_b, count_b, normalize_b);
     const int64_t chunks2 = std::max(ga->n_chunks, gb->n_chunks), pad2 = std::max(ga->n_pad, gb->n_pad);
     const int32_t count2 = std::max(count_a, count_b);
-    PF_TRY(orth_launch_pass(a2, 2, chunks2, pad2, count2, st));
+    pf_graph* const two[2] = {ga, gb};
+    PF_TRY(orth_launch_pass(a2, 2, chunks2, pad2, count2, st, two));
     if (a2.g[0].pass == 1 || a2.g[1].pass == 1) {  // the second pass of the graph(s) that asked for it, on the device's own verdict
         for (int q = 0; q < 2; ++q) a2.g[q].pass = a2.g[q].pass == 1 ? 2 : -1;
         PF_TRY(orth_launch_pass(a2, 2, chunks2, pad2, count2, st));

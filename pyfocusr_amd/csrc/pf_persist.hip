@@ -963,6 +963,8 @@ bool persist_enabled() {
 
 }  // namespace
 bool pf_persist_enabled() { return persist_enabled(); }
+uint64_t pf_persist_abort_epoch() { return g_abort_epoch.load(); }
+bool pf_persist_trusted() { return persist_enabled() && g_suspended.load() <= 0; }  // (no bounded wait has run out lately)
 namespace {
 
 // a filter application is about to run: false while a suspension lasts (counted down here, once per application:
@@ -1140,12 +1142,7 @@ int persist_cheb2(const pf_persist_args* a, const pf_persist_args* b, int64_t gr
     OwnerGuard own(ctx);
     if (!own.ok) return PF_OK;
     hipStream_t st = ctx->stream;
-    if (!ctx->persist_sync) {
-        PF_HIP(pf_malloc(st, (void**)&ctx->persist_sync, sizeof(uint32_t) * 32));
-        PF_HIP(hipMemsetAsync(ctx->persist_sync, 0, sizeof(uint32_t) * 32, st));
-        PF_HIP(hipHostMalloc((void**)&ctx->persist_abort, sizeof(int32_t), hipHostMallocDefault));
-        *ctx->persist_abort = 0;
-    }
+    PF_TRY(pf_persist_sync_ensure(ctx));
     const uint64_t epoch = g_abort_epoch.load();
     const pf_persist_args* in[2] = {a, b};
     const int ng = gb ? 2 : 1;
@@ -1537,12 +1534,7 @@ int pf_persist_cheb(const pf_persist_args* a, const pf_persist_args* b, int* don
         if (most <= RX_THREADS / 2) kernel = k_cheb_resident<2, 1, rx_jr(2, 1), true>;
     }
     hipStream_t st = ctx->stream;
-    if (!ctx->persist_sync) {
-        PF_HIP(pf_malloc(st, (void**)&ctx->persist_sync, sizeof(uint32_t) * 32));
-        PF_HIP(hipMemsetAsync(ctx->persist_sync, 0, sizeof(uint32_t) * 32, st));
-        PF_HIP(hipHostMalloc((void**)&ctx->persist_abort, sizeof(int32_t), hipHostMallocDefault));
-        *ctx->persist_abort = 0;
-    }
+    PF_TRY(pf_persist_sync_ensure(ctx));
     const uint64_t epoch = g_abort_epoch.load();
     const pf_persist_args* in[2] = {a, b};
     RxArgs args{};
@@ -1636,6 +1628,19 @@ void pf_persist_release(pf_ctx* ctx) {
         delete cal;
         ctx->persist_cal = nullptr;
     }
+}
+
+// the abort word on the device and its pinned twin (also raised by the one-launch Gram-Schmidt step of pf_operator.hip,
+// whose grid-wide wait is bounded like the resident kernels')
+int pf_persist_sync_ensure(pf_ctx* ctx) {
+    if (!ctx->persist_sync) {
+        hipStream_t st = ctx->stream;
+        PF_HIP(pf_malloc(st, (void**)&ctx->persist_sync, sizeof(uint32_t) * 32));
+        PF_HIP(hipMemsetAsync(ctx->persist_sync, 0, sizeof(uint32_t) * 32, st));
+        PF_HIP(hipHostMalloc((void**)&ctx->persist_abort, sizeof(int32_t), hipHostMallocDefault));
+        *ctx->persist_abort = 0;
+    }
+    return PF_OK;
 }
 
 // Called wherever the library has just synchronised with the stream.  If a resident launch gave up: drain the stream
