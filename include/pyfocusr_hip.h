@@ -242,6 +242,12 @@ int pf_orth_device_passes(pf_graph* g, int32_t on);
  * call; the coefficients come back in that order.  For Lanczos with partial reorthogonalisation (pf_eigs_smallest on
  * symmetric W): most steps orthogonalise against the locked null vectors and the last two basis vectors only. */
 int pf_orth_split(pf_graph* g, int32_t first2, int32_t split);
+/* Process-wide: the LOCAL Gram-Schmidt steps (four vectors at most, one pass: Lanczos with partial reorthogonalisation) as
+ * ONE launch (k_orth_local: the blocks of a graph meet at a counter between the dot products and the projection) where
+ * the device holds the whole grid at once and the resident path is trusted (pf_persist_state).  0: dot products and
+ * projection as two launches, like every other step; 1 / -1: one launch (the default; PF_ORTH_LOCAL=0 in the
+ * environment switches it off for the whole process).  The results are bit-identical either way. */
+int pf_orth_one_launch(int32_t on);
 int pf_scale(pf_graph* g, int32_t slot, double alpha);
 /* slots [dst_first, dst_first+k) = slots [src_first, src_first+m) * Y, Y row-major m x k; ranges must not overlap */
 int pf_combine(pf_graph* g, int32_t src_first, int32_t m, const double* Y, int32_t k, int32_t dst_first);

@@ -97,6 +97,7 @@ SIGNATURES = {
     "pf_orth_begin": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "pf_orth_end": (C.c_int, [C.c_void_p, _f64p, _f64p]),
     "pf_orth_split": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
+    "pf_orth_one_launch": (C.c_int, [C.c_int32]),
     "pf_orth_begin2": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                  C.c_int32]),
     "pf_orth_cheb2": (C.c_int, [C.c_void_p, C.c_void_p, _i32p, _i32p, _f64p]),
@@ -280,6 +281,12 @@ def persist_enable(on=True):
     """Process-wide switch of the resident Chebyshev kernel (operator in registers, x in LDS, one kernel per filter
     application; on by default, see csrc/pf_persist.hip).  Results are bit-identical either way."""
     _check(load_library().pf_persist_enable(int(bool(on))))
+
+
+def orth_one_launch(on=True):
+    """Process-wide switch of the one-launch local Gram-Schmidt step (csrc/pf_operator.hip: k_orth_local); off: dot
+    products and projection as two launches, like every other step.  Results are bit-identical either way."""
+    _check(load_library().pf_orth_one_launch(int(bool(on))))
 
 
 def persist_two_step(level=1):
@@ -858,8 +865,9 @@ class DeviceLaplacian(object):
         _check(self._lib.pf_orth_split(self._h, int(first2), int(split)))
 
     def orth_strict(self, on):
-        """Second Gram-Schmidt pass at the classical threshold (|w'| < 0.71 |w|) instead of the loose one (0.3)."""
-        _check(self._lib.pf_orth_strict(self._h, int(bool(on))))
+        """Second Gram-Schmidt pass at the classical threshold (|w'| < 0.71 |w|) instead of the loose one (0.3); on = 2:
+        every step takes its second pass."""
+        _check(self._lib.pf_orth_strict(self._h, 2 if on == 2 and on is not True else int(bool(on))))
 
     def orth_device_passes(self, on):
         """The second Gram-Schmidt pass queued with the first, run on the device's own verdict (`pf_orth_device_passes`):

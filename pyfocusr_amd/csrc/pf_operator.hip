@@ -13,6 +13,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <vector>
@@ -441,6 +442,26 @@ __global__ __launch_bounds__(PF_BLOCK) void k_orth_project(OrthArgs2 a2) {
         }
     }
 }
+// One lane per block: arrival at the meeting of the blocks of a graph inside a launch, then a bounded wait until the counter
+// has reached `want`.  What the blocks exchange travels in 8-byte agent-scope atomic stores and loads (the partial sums):
+// performed at the memory side, the stores waited for before the arrival, the loads issued behind the poll that matched -
+// no release in front and no acquire behind (an L2 write-back and an invalidation: ~3 us of a 14 us step), and the poll
+// itself is a relaxed load.  0: the wait ran out (abort words raised).
+__device__ __forceinline__ int orth_meet(const OrthArgs& a, unsigned long long want) {
+    __hip_atomic_fetch_add(a.counter, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__hip_atomic_load(a.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+        if (__builtin_amdgcn_s_memrealtime() - t0 > 20000000ull ||  // 0.2 s of the 100 MHz clock
+            __hip_atomic_load(a.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+            __hip_atomic_store(a.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *a.host_abort = 1;
+            return 0;
+        }
+        __builtin_amdgcn_s_sleep(2);
+    }
+    return 1;
+}
+
 // A LOCAL Gram-Schmidt step (Lanczos with partial reorthogonalisation: the null vectors and the last two basis vectors, 4
 // at most) in ONE launch.  A block owns a 4096-row chunk: it loads w and the basis vectors' pieces once, forms the chunk's
 // partial sums exactly as k_orth_dots does, publishes them, waits until every chunk of the graph has (a counter, bounded),
@@ -494,33 +515,32 @@ __global__ __launch_bounds__(PF_BLOCK) void k_orth_local(OrthArgs2 a2) {
     }
     __syncthreads();
     // ---- every chunk of this graph has published: one arrival per block, a bounded wait
-    if (threadIdx.x == 0) {
-        __hip_atomic_fetch_add(a.counter, 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-        int ok = 1;
-        while (__hip_atomic_load(a.counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < a.target) {
-            if (__builtin_amdgcn_s_memrealtime() - t0 > 20000000ull ||  // 0.2 s of the 100 MHz clock
-                __hip_atomic_load(a.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
-                __hip_atomic_store(a.abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                *a.host_abort = 1;
-                ok = 0;
-                break;
-            }
-            __builtin_amdgcn_s_sleep(2);
-        }
-        s_ok = ok;
-    }
+    if (threadIdx.x == 0) s_ok = orth_meet(a, a.target);
     __syncthreads();
     if (!s_ok) return;
     // ---- the sums of the partials: k_orth_project's operations in its order (read from where the other XCDs wrote them)
-    for (int b = threadIdx.x / PF_WAVE; b < count + 1; b += PF_BLOCK / PF_WAVE) {
-        double s = 0.0;
-        for (int64_t k = lane; k < a.n_chunks; k += PF_WAVE)
-            s += __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<unsigned long long*>(a.partial) + (int64_t)b * a.n_chunks + k,
-                                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    {  // (the two vectors of a wave - b and b + 4 - with their loads in flight together; per vector the order of the sum is kept)
+        const int b0 = threadIdx.x / PF_WAVE, b1 = b0 + PF_BLOCK / PF_WAVE;
+        double s0 = 0.0, s1 = 0.0;
+        for (int64_t k = lane; k < a.n_chunks; k += PF_WAVE) {
+            const double x0 = b0 < count + 1 ? __longlong_as_double((long long)__hip_atomic_load(
+                                                   reinterpret_cast<unsigned long long*>(a.partial) + (int64_t)b0 * a.n_chunks + k, __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_AGENT))
+                                             : 0.0;
+            const double x1 = b1 < count + 1 ? __longlong_as_double((long long)__hip_atomic_load(
+                                                   reinterpret_cast<unsigned long long*>(a.partial) + (int64_t)b1 * a.n_chunks + k, __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_AGENT))
+                                             : 0.0;
+            s0 += x0;
+            s1 += x1;
+        }
 #pragma unroll
-        for (int off = PF_WAVE / 2; off > 0; off >>= 1) s += __shfl_down(s, off, PF_WAVE);
-        if (lane == 0) hs[b] = s;
+        for (int off = PF_WAVE / 2; off > 0; off >>= 1) {
+            s0 += __shfl_down(s0, off, PF_WAVE);
+            s1 += __shfl_down(s1, off, PF_WAVE);
+        }
+        if (lane == 0 && b0 < count + 1) hs[b0] = s0;
+        if (lane == 0 && b1 < count + 1) hs[b1] = s1;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -1444,6 +1464,9 @@ int pf_dots(pf_graph* g, int32_t w, int32_t first, int32_t count, double* out) {
 // the two launches of one Gram-Schmidt pass (of one graph, or of both graphs of a pair: ng = 2); bases beyond the Infinity
 // Cache (>= 400k rows: 1M x 50 vectors = 400 MB) take the shapes with several vectors / a whole chunk per block
 // blocks of k_orth_local the device holds at once (0: the one-launch step is switched off - PF_ORTH_LOCAL=0 - or unknown)
+// pf_orth_one_launch: -1 as the environment says (PF_ORTH_LOCAL; on by default), 0 the separate launches, 1 on
+static std::atomic<int> g_orth_one_launch{-1};
+
 static int64_t orth_local_capacity(int device) {
     static std::mutex m;
     static std::map<int, int64_t> cap;
@@ -1465,28 +1488,31 @@ static int64_t orth_local_capacity(int device) {
     return c;
 }
 
+// the counter of the meeting inside k_orth_local: `arrivals` more per launch
+static int orth_meetings_prepare(pf_graph* g, OrthArgs& a, unsigned long long arrivals, hipStream_t st) {
+    pf_ctx* ctx = g->ctx;
+    const uint64_t epoch = pf_persist_abort_epoch();
+    if (!g->orth_counter) PF_HIP(pf_malloc(st, (void**)&g->orth_counter, sizeof(unsigned long long)));
+    if (g->orth_epoch != epoch) {  // new, or a bounded wait ran out since: whatever had arrived then is void
+        PF_HIP(hipMemsetAsync(g->orth_counter, 0, sizeof(unsigned long long), st));
+        g->orth_arrivals = 0;
+        g->orth_epoch = epoch;
+    }
+    g->orth_arrivals += arrivals;
+    a.counter = g->orth_counter;
+    a.target = g->orth_arrivals;
+    a.abort_flag = ctx->persist_sync;
+    a.host_abort = ctx->persist_abort;
+    return PF_OK;
+}
+
 static int orth_launch_pass(OrthArgs2& a2, int ng, int64_t n_chunks, int64_t n_pad, int32_t count, hipStream_t st, pf_graph* const* gs = nullptr) {
     // a local step (4 vectors at most, one pass) of every graph in the launch: the whole step in ONE kernel
     bool local = gs != nullptr && count <= PF_ORTH_LOCAL_MAX && count >= 1;
     for (int q = 0; q < ng && local; ++q) local = a2.g[q].pass == 0 && a2.g[q].count <= PF_ORTH_LOCAL_MAX && a2.g[q].count >= 1;
-    if (local && pf_persist_trusted() && n_chunks * ng <= orth_local_capacity(gs[0]->ctx->device)) {
-        pf_ctx* ctx = gs[0]->ctx;
-        PF_TRY(pf_persist_sync_ensure(ctx));
-        for (int q = 0; q < ng; ++q) {
-            pf_graph* g = gs[q];
-            const uint64_t epoch = pf_persist_abort_epoch();
-            if (!g->orth_counter) PF_HIP(pf_malloc(st, (void**)&g->orth_counter, sizeof(unsigned long long)));
-            if (g->orth_epoch != epoch) {  // new, or a bounded wait ran out since: whatever had arrived then is void
-                PF_HIP(hipMemsetAsync(g->orth_counter, 0, sizeof(unsigned long long), st));
-                g->orth_arrivals = 0;
-                g->orth_epoch = epoch;
-            }
-            g->orth_arrivals += (unsigned long long)g->n_chunks;
-            a2.g[q].counter = g->orth_counter;
-            a2.g[q].target = g->orth_arrivals;
-            a2.g[q].abort_flag = ctx->persist_sync;
-            a2.g[q].host_abort = ctx->persist_abort;
-        }
+    if (local && g_orth_one_launch.load() != 0 && pf_persist_trusted() && n_chunks * ng <= orth_local_capacity(gs[0]->ctx->device)) {
+        PF_TRY(pf_persist_sync_ensure(gs[0]->ctx));
+        for (int q = 0; q < ng; ++q) PF_TRY(orth_meetings_prepare(gs[q], a2.g[q], (unsigned long long)gs[q]->n_chunks, st));
         k_orth_local<<<dim3((unsigned)n_chunks, 1u, (unsigned)ng), PF_BLOCK, 0, st>>>(a2);
         PF_HIP(hipGetLastError());
         return PF_OK;
@@ -1763,6 +1789,11 @@ int pf_orth_device_passes(pf_graph* g, int32_t on) {
 
 // The NEXT pf_orth_begin / _begin2 / pf_orth_cheb2 step of this graph (and only that one) takes its basis from two ranges
 // of slots: [first, first + split) and [first2, first2 + count - split), first / count as passed to that call.
+int pf_orth_one_launch(int32_t on) {
+    g_orth_one_launch.store(on < 0 ? -1 : (on ? 1 : 0));
+    return PF_OK;
+}
+
 int pf_orth_split(pf_graph* g, int32_t first2, int32_t split) {
     PF_CHECK(g != nullptr && split >= 0 && first2 >= 0, PF_E_ARG, "pf_orth_split: bad argument");
     g->orth_split = split;

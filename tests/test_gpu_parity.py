@@ -1698,6 +1698,74 @@ def test_orth_split_two_ranges(hip, ctx, n):
         g.close()
 
 
+def test_orth_local_one_launch_bit_identical(hip, ctx):
+    """A local Gram-Schmidt step in ONE launch (`k_orth_local`: dot products, the meeting of the graph's blocks at a
+    counter, projection of the rows still held in registers) against the two launches of every other step
+    (`pf_orth_one_launch(0)`): the same bits in w, h, the norm and the verdict.  One to four vectors, one and two slot
+    ranges, a step that cancels digits (the host's second pass), with and without normalisation; a pair with unequal sizes
+    and counts (the smaller graph's blocks leave the shared grid early)."""
+    from pyfocusr_amd.meshgen import blob_mesh
+
+    rng = np.random.default_rng(21)
+    graphs = {}
+    try:
+        for n in (20000, 250000, 420000):
+            m = blob_mesh(n, seed=3)
+            g = hip.DeviceLaplacian(m.points, m.faces, ctx=ctx)
+            graphs[n] = g
+            g.ws_ensure(32)
+            Q, _ = np.linalg.qr(rng.standard_normal((n, 10)))
+            for s_ in range(10):
+                g.upload(s_, Q[:, s_])
+            g._Q = Q
+            g.orth_device_passes(False)
+            g.orth_strict(0)
+        noise = {n: rng.standard_normal(n) for n in graphs}
+
+        def vectors(n):
+            Q = graphs[n]._Q
+            return (("random", noise[n]), ("cancelling", 3.0 * Q[:, 0] - 2.0 * Q[:, 8] + 1e-7 * noise[n]),
+                    ("mild", Q @ np.linspace(0.5, -0.4, 10) + 0.9 * noise[n] / np.linalg.norm(noise[n])))
+
+        seen = set()
+        for n, g in graphs.items():
+            for label, wvec in vectors(n):
+                for split, count, normalize in ((False, 4, True), (True, 4, True), (True, 3, False), (False, 1, True), (False, 2, False)):
+                    out = []
+                    for fused in (False, True):
+                        hip.orth_one_launch(fused)
+                        g.upload(20, wvec)
+                        if split:
+                            g.orth_split(7, 1)  # slot 0 and slots 7, 8, ...
+                        g.orth_begin(20, 0, count, normalize)
+                        h, nrm = g.orth_end()
+                        out.append((h.copy(), nrm, g.download_slots(20, 1), bool(g.orth_redone)))
+                    (h0, n0, w0, r0), (h1, n1, w1, r1) = out
+                    what = (n, label, split, count, normalize)
+                    assert r0 == r1 and n0 == n1 and np.array_equal(h0, h1) and np.array_equal(w0, w1), what
+                    seen.add(r1)
+        assert seen == {False, True}  # single passes, and steps whose verdict sent pf_orth_end into the second pass
+        for na, nb in ((250000, 20000), (420000, 250000)):
+            ga, gb = graphs[na], graphs[nb]
+            for (la, wa), (lb, wb) in zip(vectors(na), reversed(vectors(nb))):
+                out = []
+                for fused in (False, True):
+                    hip.orth_one_launch(fused)
+                    ga.upload(20, wa)
+                    gb.upload(20, wb)
+                    gb.orth_split(7, 1)
+                    ga.orth_begin2((20, 0, 4, True), gb, (20, 0, 3, True))
+                    ha, nrma = ga.orth_end()
+                    hb, nrmb = gb.orth_end()
+                    out.append((ha.copy(), nrma, ga.download_slots(20, 1), bool(ga.orth_redone), hb.copy(), nrmb, gb.download_slots(20, 1), bool(gb.orth_redone)))
+                for x, y in zip(*out):
+                    assert np.array_equal(np.asarray(x), np.asarray(y)), (na, nb, la, lb)
+    finally:
+        hip.orth_one_launch(True)
+        for g in graphs.values():
+            g.close()
+
+
 def test_resident_kernel_bit_identical(golden, hip, ctx):
     """The whole recurrence in one resident kernel (operator in registers, x in LDS, boundary rows handed over through
     memory, pf_persist.hip) against one step per launch: same bits for both operators, single and paired, equal and
