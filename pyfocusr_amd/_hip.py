@@ -225,7 +225,10 @@ class _PinnedBlock(object):
 _pinned_free = {}  # nbytes -> [ptr]: blocks of collected arrays, reused by the next result of the same size
 _pinned_cached = [0]
 _pinned_lock = threading.Lock()  # (compute_spectra runs one host thread per context; arrays are collected on any thread)
-_PINNED_CACHE_BYTES = 256 << 20  # page-locked memory kept for reuse: four 250k x 5 result pairs and their remapped images
+# page-locked memory kept for reuse.  A 1M-vertex pair with k = 10 turns over four 84 MB blocks per pipeline step: with the
+# 256 MiB of round 3 whether they fitted beside what smaller workloads had left behind decided between 80 and 90 ms per
+# step (two hipHostMalloc / hipHostFree of 84 MB each) - 1 GiB, and blocks of OTHER sizes make room first.
+_PINNED_CACHE_BYTES = 1 << 30
 
 
 def _pinned_release(ptr, nbytes):
@@ -234,17 +237,29 @@ def _pinned_release(ptr, nbytes):
     # a download the library still OWES to this block (pf_finalize_vectors_begin holds downloads back; a failed call may
     # have left one behind) must never be queued once the block can be handed out again; one in flight is waited for
     _lib.pf_host_detach(C.c_void_p(ptr))
+    evicted = []
     with _pinned_lock:
+        if nbytes <= _PINNED_CACHE_BYTES:
+            # the sizes in use now are the ones worth keeping: blocks of other sizes go first (largest first)
+            while _pinned_cached[0] + nbytes > _PINNED_CACHE_BYTES:
+                others = [sz for sz, ptrs in _pinned_free.items() if ptrs and sz != nbytes]
+                if not others:
+                    break
+                sz = max(others)
+                evicted.append(_pinned_free[sz].pop())
+                _pinned_cached[0] -= sz
         keep = _pinned_cached[0] + nbytes <= _PINNED_CACHE_BYTES
         if keep:
             _pinned_free.setdefault(nbytes, []).append(ptr)
             _pinned_cached[0] += nbytes
+    for other in evicted:
+        _lib.pf_host_free(C.c_void_p(other))
     if not keep:
         _lib.pf_host_free(C.c_void_p(ptr))
 
 
 def pinned_trim():
-    """Give the cached page-locked blocks back to the system (they are kept for reuse otherwise, up to 256 MiB)."""
+    """Give the cached page-locked blocks back to the system (they are kept for reuse otherwise, up to 1 GiB)."""
     with _pinned_lock:
         blocks = [p for ptrs in _pinned_free.values() for p in ptrs]
         _pinned_free.clear()
