@@ -791,7 +791,7 @@ def test_pair_driver_in_c(golden, hip, ctx):
                   for n in ("target_mesh", "source_mesh")]
             before = hip.persist_state(ctx)["launches"]
             compute_spectra(gs)
-            assert hip.persist_state(ctx)["launches"] > before
+            assert hip.persist_state(ctx)["launches"] > before or not hip.persist_state(ctx)["enabled"]  # (PF_PERSIST=0: tools/check_fallbacks.sh)
             results[driver] = [(g.eig_vals.copy(), g.eig_vecs.copy(), g.eigs_stats) for g in gs]
             for g in gs:
                 g.device.close()
@@ -2122,7 +2122,7 @@ def test_eigs_c_call_asymmetric_w(golden, hip, ctx):
     dt, ds = devs["target_mesh_15k"], devs["source_mesh_15k"]
     before = hip.persist_state(ctx)["launches"]
     (vt, xt, stt), (vs, xs, sts) = dt.eigs_smallest2(ds, 5, 9, minmax=True, wait=False)
-    assert hip.persist_state(ctx)["launches"] > before  # the resident filter kernel serves L = G (D - W) too
+    assert hip.persist_state(ctx)["launches"] > before or not hip.persist_state(ctx)["enabled"]  # the resident filter kernel serves L = G (D - W) too
     dt.finalize_wait()
     ds.finalize_wait()
     for dev, vals, vecs, m_out in ((dt, vt, xt, 5), (ds, vs, xs, 9)):
