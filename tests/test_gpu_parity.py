@@ -1698,6 +1698,44 @@ def test_orth_split_two_ranges(hip, ctx, n):
         g.close()
 
 
+def test_pinned_cache_keeps_the_sizes_in_use(hip, ctx, monkeypatch):
+    """The cache of page-locked result blocks (`_hip.pinned_empty`): collected blocks are reused by the next request of their
+    size; when the cache is full, blocks of OTHER sizes make room (a pipeline that has moved on to larger meshes keeps
+    the blocks it turns over now - with the round-3 rule a 1M-vertex step paid two 84 MB hipHostMalloc per pass in half of
+    the bench processes); a block larger than the whole cache goes back to the system."""
+    import gc
+
+    hip.pinned_trim()
+    monkeypatch.setattr(hip, "_PINNED_CACHE_BYTES", 64 << 20)
+    try:
+        small = [hip.pinned_empty((1 << 20,)) for _ in range(6)]  # 6 x 8 MB
+        ptrs_small = {a.ctypes.data for a in small}
+        del small
+        gc.collect()
+        assert hip._pinned_cached[0] == 6 * (8 << 20)
+        again = hip.pinned_empty((1 << 20,))
+        assert again.ctypes.data in ptrs_small and hip._pinned_cached[0] == 5 * (8 << 20)  # reused, not allocated
+        del again
+        gc.collect()
+        big = [hip.pinned_empty((3 << 20,)) for _ in range(2)]  # 2 x 24 MB: 48 + 48 > 64
+        ptrs_big = {a.ctypes.data for a in big}
+        del big
+        gc.collect()
+        # both large blocks are kept; small ones made room, largest-first among the OTHER sizes (all 8 MB here)
+        assert len(hip._pinned_free.get(24 << 20, [])) == 2 and hip._pinned_cached[0] <= 64 << 20
+        assert len(hip._pinned_free.get(8 << 20, [])) == 2
+        b2 = [hip.pinned_empty((3 << 20,)) for _ in range(2)]
+        assert {a.ctypes.data for a in b2} == ptrs_big
+        del b2
+        huge = hip.pinned_empty((9 << 20,))  # 72 MB > the whole cache: never kept
+        del huge
+        gc.collect()
+        assert hip._pinned_free.get(72 << 20, []) == [] and hip._pinned_cached[0] <= 64 << 20
+    finally:
+        hip.pinned_trim()
+    assert hip._pinned_cached[0] == 0
+
+
 def test_orth_local_one_launch_bit_identical(hip, ctx):
     """A local Gram-Schmidt step in ONE launch (`k_orth_local`: dot products, the meeting of the graph's blocks at a
     counter, projection of the rows still held in registers) against the two launches of every other step
